@@ -1,0 +1,359 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ by RUNNING THE
+REFERENCE'S OWN CODE in this container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+/root/reference is imported read-only with its missing third-party modules
+stubbed (torch_geometric, torchvision, torchsummary, imageio, cv2).  The stub
+for ``torch_geometric.nn.GCNConv`` / ``Sequential`` is the oracle's restatement
+(oracle/gnn_oracle.py) because PyG 2.0.2 is not installable here; everything
+else that executes — ``DummyDataset.create_graphs`` (datasets.py:1441-1584),
+``HierarchicalPatchModel.__init__/forward/create_node_pixels/
+bilinear_interpolation`` (models.py:286-553), the criteria (criterion.py) — is
+the reference's own code.  Only OUTPUT DATA is written to the repo; no
+reference source text or bytecode is copied.
+
+Outputs
+  topology.json        per config: N, E, sha256 of sorted undirected edge list, degree histogram
+  topo_f8_a2_edges.npy full undirected edge list for F=8 / naux=2
+  kat_f16_a3.npz       layer KAT: inputs, weights seed, per-layer outputs, logits (eval)
+  cfg1_f64_a2.npz      BASELINE config 1 (64x64, 2 aux, L=2, B=1): sampled rows, digests, argmax
+  coord_f32_a4.npz     coordinate-graph path (B=2): coords per layer, logits, train-mode grad norms
+  mainonly_f16.npz     use_main_graph_only ablation
+  losses_f16_a3.npz    WeightedBCEWithLogits + ExpectedLandmarkMSE values on the KAT logits
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from oracle import gnn_oracle as O
+from fixtures_util import fill_state_dict, synthetic_frames, initial_coords
+
+
+# ----------------------------------------------------------------- stubs
+def _from_networkx(G):
+    """PyG 2.0.2 ``from_networkx`` semantics: relabel to 0..N-1 in node order,
+    directed copy, edges in adjacency order."""
+    import networkx as nx
+    G = nx.convert_node_labels_to_integers(G)
+    G = G.to_directed() if not nx.is_directed(G) else G
+    ei = torch.tensor(list(G.edges), dtype=torch.long).t().contiguous().view(2, -1)
+    data = types.SimpleNamespace()
+    data.edge_index = ei
+    data.num_nodes = G.number_of_nodes()
+    return data
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Dataset:
+        def __init__(self, *a, **k):
+            pass
+
+    tg = mod("torch_geometric")
+    tg.nn = mod("torch_geometric.nn", GCNConv=O.OracleGCNConv, Sequential=O.OracleSequential,
+                global_add_pool=lambda *a, **k: None, JumpingKnowledge=O.OracleJumpingKnowledge)
+    tg.data = mod("torch_geometric.data", Dataset=_Dataset)
+    tg.utils = mod("torch_geometric.utils", from_networkx=_from_networkx)
+    tv = mod("torchvision")
+    tv.models = mod("torchvision.models")
+    tv.models._utils = mod("torchvision.models._utils", IntermediateLayerGetter=object)
+    tv.transforms = mod("torchvision.transforms")
+    tv.transforms.functional = mod("torchvision.transforms.functional", hflip=lambda x: x)
+    mod("torchsummary", summary=lambda *a, **k: None)
+    mod("imageio")
+    mod("cv2")
+    try:
+        import matplotlib  # noqa: F401
+    except Exception:
+        mp = mod("matplotlib")
+        mp.pyplot = mod("matplotlib.pyplot", new_figure_manager=None)
+
+
+install_stubs()
+sys.path.insert(0, REF)
+from src.core import models as RM            # noqa: E402  (reference code, executed not copied)
+from src.core import datasets as RD          # noqa: E402
+from src.core import criterion as RC         # noqa: E402
+
+from echoglad_amd.topology import TopologySpec, HierTopology   # noqa: E402
+
+
+def digest(arr: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+# ------------------------------------------------------------ topology
+TOPO_CONFIGS = [
+    # (frame, naux, main_only, coord, conn, main_type, aux_type)
+    (8, 2, False, False, False, "grid", "grid"),
+    (16, 3, False, False, False, "grid", "grid"),
+    (16, 3, False, True, False, "grid", "grid"),
+    (16, 3, False, False, True, "grid", "grid"),
+    (16, 3, False, True, True, "grid", "grid"),
+    (16, 3, False, False, False, "grid-diagonal", "grid-diagonal"),
+    (16, 2, True, False, False, "grid", "grid"),
+    (32, 4, False, True, False, "grid", "grid"),
+    (64, 2, False, False, False, "grid", "grid"),          # BASELINE cfg 1 (slice-clamp quirk)
+    (30, 3, False, False, False, "grid", "grid"),          # odd crop
+    (17, 3, False, False, False, "grid", "grid"),          # odd frame
+    (8, 1, False, False, False, "grid", "grid"),           # negative centre -> wraps to last row
+    (48, 5, False, False, False, "grid", "grid-diagonal"),
+    (64, 6, False, False, False, "grid", "grid"),
+    (224, 7, False, False, False, "grid", "grid"),         # BASELINE cfg 2 (default.yml)
+    (224, 7, True, False, False, "grid", "grid"),          # BASELINE cfg 3
+    (224, 7, False, True, False, "grid", "grid"),          # BASELINE cfg 4
+]
+
+
+def reference_graph(frame, naux, main_only, coord, conn, main_type, aux_type):
+    ds = RD.DummyDataset(data_dir=None, data_info_file=None, mode="train", num_aux_graphs=naux,
+                         frame_size=frame, main_graph_type=main_type, aux_graph_type=aux_type,
+                         use_coordinate_graph=coord, use_connection_nodes=conn, use_main_graph_only=main_only)
+    g = _from_networkx(ds.graphs)
+    return g.edge_index.numpy(), np.asarray(ds.node_type, dtype=np.float64), g.num_nodes
+
+
+def topo_entry(ei, node_type, n):
+    lo, hi = np.minimum(ei[0], ei[1]), np.maximum(ei[0], ei[1])
+    und = np.unique(np.stack([lo, hi], axis=1), axis=0)          # sorted lexicographically
+    deg = np.bincount(ei[1], minlength=n)
+    vals, cnt = np.unique(deg, return_counts=True)
+    return {
+        "num_nodes": int(n),
+        "num_directed_edges": int(ei.shape[1]),
+        "num_undirected_edges": int(und.shape[0]),
+        "edge_sha256": digest(und.astype("<i8")),
+        "degree_hist": {str(int(v)): int(c) for v, c in zip(vals, cnt)},
+        "node_type_sha256": digest(node_type.astype("<f8")),
+        "num_valid": int((node_type == 0).sum()),
+    }, und
+
+
+def make_topology():
+    out = {}
+    for cfg in TOPO_CONFIGS:
+        frame, naux, main_only, coord, conn, mt, at = cfg
+        if frame == 224 and os.environ.get("GOLDEN_SKIP_224"):
+            continue
+        ei, nt, n = reference_graph(*cfg)
+        entry, und = topo_entry(ei, nt, n)
+        key = f"F{frame}_A{naux}_mo{int(main_only)}_co{int(coord)}_cn{int(conn)}_{mt}_{at}"
+        out[key] = entry
+        # cross-check the closed form right here
+        topo = HierTopology(TopologySpec(frame, naux, main_only, coord, conn, mt, at))
+        assert topo.num_nodes == n, (key, topo.num_nodes, n)
+        assert topo.edge_set_digest() == entry["edge_sha256"], key
+        assert np.array_equal(topo.node_type(), nt), key
+        print("topology ok", key, entry["num_nodes"], entry["num_undirected_edges"], flush=True)
+        if (frame, naux) == (8, 2) and not (coord or conn or main_only) and mt == "grid":
+            np.save(os.path.join(HERE, "topo_f8_a2_edges.npy"), und.astype(np.int64))
+    with open(os.path.join(HERE, "topology.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+# ------------------------------------------------------------ model fixtures
+def build_ref_model(frame, naux, layers, coord=False, main_only=False, C=128, hidden=128, clf=32):
+    m = RM.HierarchicalPatchModel(frame_size=frame, gnn_dropout_p=0.5, classifier_dropout_p=0.5,
+                                  node_embedding_dim=C, node_hidden_dim=hidden, num_output_channels=4,
+                                  num_gnn_layers=layers, num_aux_graphs=naux, gnn_jk_mode="last",
+                                  classifier_hidden_dim=clf, residual=True, use_coordinate_graph=coord,
+                                  output_activation="logit", use_connection_nodes=False,
+                                  use_main_graph_only=main_only)
+    return m
+
+
+def collate(ei, nt, n, batch):
+    """PyG Batch collate: per-sample node offset on edge_index, cat on dim 0."""
+    eis = [torch.from_numpy(ei) + b * n for b in range(batch)]
+    edge_index = torch.cat(eis, dim=1)
+    node_type = torch.from_numpy(np.tile(nt, batch))
+    batch_idx = torch.arange(batch).repeat_interleave(n)
+    return edge_index, node_type, batch_idx
+
+
+def run_ref(model, frames, edge_index, node_type, batch_idx, coords=None):
+    layer_out = []
+    hooks = [l.register_forward_hook(lambda m, i, o: layer_out.append(o.detach().clone())) for l in model.gnn_layers]
+    node_feats = []
+    orig = model.create_node_pixels
+
+    def wrapped(*a, **k):
+        r = orig(*a, **k)
+        node_feats.append(r.detach().clone())
+        return r
+    model.create_node_pixels = wrapped
+    c = coords.clone() if coords is not None else None       # reference mutates it in place (models.py:450)
+    logits, out_coords = model(x=frames, node_coords=c, edge_index=edge_index, node_type=node_type,
+                               batch_idx=batch_idx)
+    for h in hooks:
+        h.remove()
+    model.create_node_pixels = orig
+    return logits, out_coords, node_feats[0], layer_out
+
+
+def make_kat():
+    frame, naux, L, B = 16, 3, 3, 2
+    ei, nt, n = reference_graph(frame, naux, False, False, False, "grid", "grid")
+    edge_index, node_type, batch_idx = collate(ei, nt, n, B)
+    model = build_ref_model(frame, naux, L)
+    fill_state_dict(model, seed=1234)
+    model.eval()
+    frames = synthetic_frames(B, 128, frame, seed=200)
+    with torch.no_grad():
+        logits, _, node_feats, layer_out = run_ref(model, frames, edge_index, node_type, batch_idx)
+        # dense fp64 cross-check of the first GCN layer output (pre-BN)
+        conv = model.gnn_layers[0].module_0
+        d64 = O.gcn_conv_dense64(node_feats, edge_index, conv.lin.weight, conv.bias)
+        s32 = O.gcn_conv_sparse(node_feats, edge_index, conv.lin.weight, conv.bias)
+        assert (d64 - s32.double()).abs().max() < 1e-5
+    np.savez_compressed(os.path.join(HERE, "kat_f16_a3.npz"),
+                        frame=frame, naux=naux, layers=L, batch=B, weight_seed=1234, frame_seed=200,
+                        edge_index=edge_index.numpy(), node_type=node_type.numpy(),
+                        node_feats=node_feats.numpy(),
+                        layer0=layer_out[0].numpy(), layer1=layer_out[1].numpy(), layer2=layer_out[2].numpy(),
+                        gcn0_dense64=d64.numpy(),
+                        logits=logits.numpy())
+    print("kat", logits.shape, float(logits.abs().max()))
+    return model, logits, B, frame, naux
+
+
+def make_cfg1():
+    frame, naux, L, B = 64, 2, 2, 1
+    ei, nt, n = reference_graph(frame, naux, False, False, False, "grid", "grid")
+    edge_index, node_type, batch_idx = collate(ei, nt, n, B)
+    model = build_ref_model(frame, naux, L)
+    fill_state_dict(model, seed=4321)
+    model.eval()
+    frames = synthetic_frames(B, 128, frame, seed=200)
+    with torch.no_grad():
+        logits, _, node_feats, layer_out = run_ref(model, frames, edge_index, node_type, batch_idx)
+    rows = np.linspace(0, n - 1, 64).astype(np.int64)
+    arg = O.landmark_argmax(logits, B, frame)
+    np.savez_compressed(os.path.join(HERE, "cfg1_f64_a2.npz"),
+                        frame=frame, naux=naux, layers=L, batch=B, weight_seed=4321, frame_seed=200,
+                        num_nodes=n, sample_rows=rows, logits_rows=logits.numpy()[rows],
+                        node_feats_rows=node_feats.numpy()[rows],
+                        layer1_rows=layer_out[1].numpy()[rows],
+                        logits_sum=np.float64(logits.double().sum().item()),
+                        logits_abs_sum=np.float64(logits.double().abs().sum().item()),
+                        argmax=arg.numpy())
+    print("cfg1", logits.shape, arg.tolist())
+
+
+def make_coord():
+    frame, naux, L, B = 32, 4, 3, 2
+    ei, nt, n = reference_graph(frame, naux, False, True, False, "grid", "grid")
+    edge_index, node_type, batch_idx = collate(ei, nt, n, B)
+    model = build_ref_model(frame, naux, L, coord=True)
+    fill_state_dict(model, seed=777)
+    frames = synthetic_frames(B, 128, frame, seed=201)
+    coords0 = initial_coords(B, frame)
+    # eval forward; capture coordinates after every layer through the coordinate MLP hook
+    model.eval()
+    deltas = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: deltas.append(o.detach().clone()))
+             for m in model.node_coordinate_mlp]
+    with torch.no_grad():
+        logits, out_coords, node_feats, layer_out = run_ref(model, frames, edge_index, node_type, batch_idx, coords0)
+    for h in hooks:
+        h.remove()
+    # train-mode (dropout p=0 so it is deterministic) forward+backward: gradient fixtures
+    model_t = build_ref_model(frame, naux, L, coord=True)
+    for mod in model_t.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    fill_state_dict(model_t, seed=777)
+    model_t.train()
+    logits_t, coords_t, _, _ = run_ref(model_t, frames, edge_index, node_type, batch_idx, coords0)
+    loss = (logits_t ** 2).mean() + (coords_t ** 2).mean() * 1e-3
+    loss.backward()
+    gn = {k: float(p.grad.double().norm()) for k, p in model_t.named_parameters() if p.grad is not None}
+    keys = sorted(gn)
+    np.savez_compressed(os.path.join(HERE, "coord_f32_a4.npz"),
+                        frame=frame, naux=naux, layers=L, batch=B, weight_seed=777, frame_seed=201,
+                        coords0=coords0.numpy(), deltas=np.stack([d.numpy() for d in deltas]),
+                        out_coords=out_coords.numpy(), logits=logits.numpy(),
+                        node_feats=node_feats.numpy(),
+                        layer2=layer_out[2].numpy(),
+                        train_logits=logits_t.detach().numpy(), train_coords=coords_t.detach().numpy(),
+                        train_loss=np.float64(loss.item()),
+                        grad_keys=np.array(keys), grad_norms=np.array([gn[k] for k in keys], dtype=np.float64))
+    print("coord", logits.shape, out_coords.tolist())
+
+
+def make_mainonly():
+    frame, naux, L, B = 16, 2, 3, 2
+    ei, nt, n = reference_graph(frame, naux, True, False, False, "grid", "grid")
+    edge_index, node_type, batch_idx = collate(ei, nt, n, B)
+    model = build_ref_model(frame, naux, L, main_only=True)
+    fill_state_dict(model, seed=99)
+    model.eval()
+    frames = synthetic_frames(B, 128, frame, seed=202)
+    with torch.no_grad():
+        logits, _, node_feats, layer_out = run_ref(model, frames, edge_index, node_type, batch_idx)
+    np.savez_compressed(os.path.join(HERE, "mainonly_f16.npz"),
+                        frame=frame, naux=naux, layers=L, batch=B, weight_seed=99, frame_seed=202,
+                        node_feats=node_feats.numpy(), logits=logits.numpy())
+    print("mainonly", logits.shape)
+
+
+def make_losses(model, logits, B, frame, naux):
+    """criterion.py:13-27 and :93-151 evaluated by the reference's own classes."""
+    rs = np.random.RandomState(5)
+    topo = HierTopology(TopologySpec(frame, naux))
+    n = topo.num_nodes
+    y = np.zeros((B, n, 4), dtype=np.float32)
+    # one-hot per level per channel, like create_node_labels (datasets.py:1586-1612)
+    levels = [(lv.base, lv.side) for lv in topo.aux_levels] + [(topo.main.base, topo.main.side)]
+    for b in range(B):
+        for ch in range(4):
+            hh, ww = rs.randint(0, frame, size=2)
+            for base, side in levels:
+                r, c = hh * side // frame, ww * side // frame
+                y[b, base + r * side + c, ch] = 1.0
+    y_t = torch.from_numpy(y).view(B * n, 4)
+    valid = torch.ones_like(y_t)
+    bce = RC.WeightedBCEWithLogitsLoss(reduction="none", ones_weight=9000, loss_weight=1)
+    elm = RC.ExpectedLandmarkMSE(loss_weight=10, batch_size=B, frame_size=frame, num_aux_graphs=naux,
+                                 use_main_graph_only=False, num_output_channels=4)
+    with torch.no_grad():
+        l_bce = bce.compute(logits.view(B, n, 4), y_t.view(B, n, 4), valid)
+        l_elm = elm.compute(logits, y_t, valid)
+    np.savez_compressed(os.path.join(HERE, "losses_f16_a3.npz"), labels=y.reshape(B * n, 4),
+                        bce=np.float64(l_bce.item()), elm=np.float64(l_elm.item()))
+    print("losses", float(l_bce), float(l_elm))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["topology", "models"]
+    if "topology" in which:
+        make_topology()
+    if "models" in which:
+        model, logits, B, frame, naux = make_kat()
+        make_losses(model, logits, B, frame, naux)
+        make_cfg1()
+        make_coord()
+        make_mainonly()
+    assert not os.path.exists(os.path.join(REF, "src", "__pycache__")), "bytecode leaked into the reference"
