@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Throughput of the EchoGLAD GNN hot path on MI355X: echo frames/s through the full GNN stack.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (3 fused GCN layers + the 4 classifier heads, eval mode,
+reference src/core/models.py:428-490) over one batch of synthetic node features already
+resident in HBM -> logits resident in HBM.  Workload = BASELINE.json configs[1]
+(default.yml: 224x224 frame, 7 aux levels, 3 GNN layers, batch 8 per GPU).  Frames are
+independent units, so ranks shard the batch with no data-path collective (weak scaling).
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, measured live with HIP events on
+the launch stream) and `cpu_baseline` (the CPU oracle = port of the reference PyG op sequence,
+timed on this box's host cores on a bounded sample)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import numpy as np
+import torch
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_F32_MFMA_TF = 157.3       # MI355X_MICROARCH.md: dense fp32 MFMA peak
+C = 128
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    p.add_argument("--frame", type=int, default=224)
+    p.add_argument("--naux", type=int, default=7)
+    p.add_argument("--layers", type=int, default=3)
+    p.add_argument("--main-only", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample")
+    p.add_argument("--kernel-iters", type=int, default=30)
+    return p.parse_args()
+
+
+def build_model(args, device):
+    from echoglad_amd import nn as egnn
+    from fixtures_util import fill_state_dict
+    kw = dict(frame_size=args.frame, gnn_dropout_p=0.5, classifier_dropout_p=0.5, node_embedding_dim=C,
+              node_hidden_dim=C, num_output_channels=4, num_gnn_layers=args.layers, num_aux_graphs=args.naux,
+              gnn_jk_mode="last", classifier_hidden_dim=32, residual=True, use_coordinate_graph=False,
+              output_activation="logit", use_main_graph_only=args.main_only)
+    model = egnn.HierarchicalPatchModel(**kw)
+    fill_state_dict(model, seed=200)          # glorot-like weights, trained-like BN stats (seed: default.yml:24)
+    return model.to(device).eval(), kw
+
+
+def cpu_baseline(args, kw, state_dict):
+    """The oracle (a port of the reference's PyG op sequence: gcn_norm recomputed per layer,
+    x W^T, index_select gather, scale, index_add_ scatter, BN, ReLU, residual, 4 classifier MLPs)
+    on the host cores, on a bounded sample of the same workload."""
+    from oracle import gnn_oracle as O
+    from echoglad_amd.topology import TopologySpec, get_topology
+    from fixtures_util import synthetic_node_feats
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ref = O.OracleHierarchicalPatchModel(**kw)
+    ref.load_state_dict({k: v.cpu() for k, v in state_dict.items()}, strict=True)
+    ref.eval()
+    topo = get_topology(TopologySpec(args.frame, args.naux, args.main_only))
+    B = args.cpu_frames
+    ei = torch.from_numpy(topo.batched_edge_index(B))
+    nt = torch.from_numpy(np.tile(topo.node_type(), B))
+    feats = synthetic_node_feats(B * topo.num_nodes, C, seed=200)
+    times = []
+    with torch.no_grad():
+        ref.forward_nodes(feats, ei, nt, B)                      # warm-up
+        t_end = time.perf_counter() + 20.0
+        while len(times) < 5 and (time.perf_counter() < t_end or len(times) < 2):
+            t0 = time.perf_counter()
+            out, _ = ref.forward_nodes(feats, ei, nt, B)
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(B / best, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{B} frames of the same workload (F={args.frame}, naux={args.naux}, L={args.layers}), "
+                      f"min of {len(times)} runs after 1 warm-up, torch CPU fp32 {cores} threads"}, out, feats, ei
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+
+    from echoglad_amd import ops
+    from echoglad_amd.topology import TopologySpec, get_topology
+    from fixtures_util import synthetic_node_feats
+
+    model, kw = build_model(args, device)
+    topo = get_topology(TopologySpec(args.frame, args.naux, args.main_only))
+    B, N = args.batch, topo.num_nodes
+    # this rank's shard of the global batch: frames [rank*B, (rank+1)*B) — synthetic N(0,1) node features
+    feats = synthetic_node_feats(B * N, C, seed=200 + rank).to(device)
+    edge_index = torch.from_numpy(topo.batched_edge_index(B)).to(device)
+
+    def step():
+        with torch.no_grad():
+            return model.forward_nodes(feats, edge_index, B)[0]
+
+    for _ in range(args.warmup):
+        out = step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames_per_s = world * B * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # ---- dominant kernel: the fused GCN layer, timed with HIP events on the launch stream
+        graph, gb = model._resolver.resolve(edge_index, feats.shape[0])
+        w, scale, shift = model._folded_layers()[0]
+        buf = torch.empty_like(feats)
+        for _ in range(3):
+            ops.gcn_layer_fwd(graph, gb, feats, w, scale, shift, feats, relu=True, out=buf)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(args.kernel_iters):
+            ops.gcn_layer_fwd(graph, gb, feats, w, scale, shift, feats, relu=True, out=buf)
+        ev1.record()
+        torch.cuda.synchronize()
+        layer_ms = ev0.elapsed_time(ev1) / args.kernel_iters
+        e_dir = 2 * topo.num_undirected_edges
+        flops = B * (N * 2 * C * C + (e_dir + N) * 2 * C)             # SURVEY §8(d) per-layer FLOPs
+        bytes_alg = B * N * 2 * C * 4                                  # read x once + write out once
+        tf = flops / (layer_ms * 1e-3) / 1e12
+        gbs = bytes_alg / (layer_ms * 1e-3) / 1e9
+        roofline = {"bound": "mfma", "kernel": "k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>",
+                    "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                    "frac": round(tf / PEAK_F32_MFMA_TF, 4), "traffic": None,
+                    "avg_launch_ms": round(layer_ms, 4),
+                    "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": bytes_alg}}
+        # whole-stack algorithmic bytes: N * (L*1024 + 528) per frame
+        stack_bytes = N * (args.layers * 1024 + 528)
+        result = {
+            "metric": "echo frames/sec through full GNN stack (224x224 default hier-graph); MAE parity",
+            "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1] default.yml: {args.frame}x{args.frame} frame, "
+                                   f"{'main grid only' if args.main_only else str(args.naux) + ' aux levels'}, "
+                                   f"num_gnn_layers={args.layers}, batch={B} per GPU, eval mode, "
+                                   "node features [B*N,128] in HBM -> logits [B*N_valid,4] in HBM",
+                       "nodes_per_frame": N, "directed_edges_per_frame": e_dir, "global_batch": B * world,
+                       "parallelism": f"dp{world} (batch-sharded frames, no data-path collective)"},
+            "stack_hbm_frac": round(frames_per_s / world * stack_bytes / 1e9 / PEAK_HBM_GBS, 4),
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            cb, cpu_out, cpu_feats, cpu_ei = cpu_baseline(args, kw, model.state_dict())
+            result["cpu_baseline"] = cb
+            # parity of the measured path on the CPU sample (same inputs): logits + landmark indices
+            from oracle import gnn_oracle as O
+            with torch.no_grad():
+                got = model.forward_nodes(cpu_feats.to(device), cpu_ei.to(device), args.cpu_frames)[0].cpu()
+            result["parity"] = {"max_abs_err_vs_oracle": float((got - cpu_out).abs().max()),
+                                "landmark_argmax_equal": bool(torch.equal(
+                                    O.landmark_argmax(got, args.cpu_frames, args.frame),
+                                    O.landmark_argmax(cpu_out, args.cpu_frames, args.frame)))}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""ctypes binding of the C-ABI library (include/echoglad_hip.h).
+
+There is no CPU fallback: if the shared object is missing or does not load,
+``load()`` raises and every op that needs it fails loudly."""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+import re
+from pathlib import Path
+from typing import Dict, List, Optional
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libechoglad_hip.so"
+HEADER_PATH = _PKG.parent / "include" / "echoglad_hip.h"
+
+EG_OK, EG_ERR_ARG, EG_ERR_UNSUPPORTED, EG_ERR_HIP = 0, -1, -2, -3
+
+_lib: Optional[ct.CDLL] = None
+
+_p = ct.c_void_p
+_i = ct.c_int
+_i64 = ct.c_int64
+
+# name -> (restype, argtypes); must list every symbol the header declares
+SIGNATURES: Dict[str, tuple] = {
+    "eg_version": (_i, []),
+    "eg_last_error": (ct.c_char_p, []),
+    "eg_topo_create": (_i, [_i, _i, _i, _i, ct.POINTER(_p)]),
+    "eg_csr_create": (_i, [_p, _i64, _i64, _p, ct.POINTER(_p)]),
+    "eg_graph_destroy": (_i, [_p]),
+    "eg_graph_num_nodes": (_i64, [_p]),
+    "eg_graph_is_structured": (_i, [_p]),
+    "eg_graph_deg_inv_sqrt": (_i, [_p, _p, _p]),
+    "eg_edge_hash": (_i, [_p, _i64, _p, _p]),
+    "eg_gcn_layer_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "eg_gcn_aggregate": (_i, [_p, _i, _p, _p, _p]),
+    "eg_linear128_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "eg_classifier_fwd": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "eg_bn_stats": (_i, [_p, _i64, _p, _p, _p]),
+    "eg_bn_act_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _i, _p, _p]),
+    "eg_bn_act_bwd": (_i, [_p, _p, _p, _i64, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "eg_dweight128": (_i, [_p, _p, _i64, _p, _p, _p]),
+    "eg_bilinear4_fwd": (_i, [_p, _p, _i, _i64, _i64, _i, _p, _p]),
+    "eg_bilinear4_bwd": (_i, [_p, _p, _p, _i, _i64, _i64, _i, _p, _p, _p]),
+    "eg_scatter_rows": (_i, [_p, _p, _i, _i64, _i64, _i, _p]),
+}
+
+
+def header_symbols() -> List[str]:
+    """Every function name declared in include/echoglad_hip.h."""
+    text = HEADER_PATH.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(eg_[a-z0-9_]+)\s*\(", text)))
+
+
+def load() -> ct.CDLL:
+    """Load the library (after torch, so both share one HIP runtime instance)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  — must come first: libamdhip64.so.7 resolves to the copy torch loaded
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -m echoglad_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
+    lib = ct.CDLL(str(LIB_PATH), mode=ct.RTLD_GLOBAL if hasattr(ct, "RTLD_GLOBAL") else 0)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue          # checked by check_exports(); ops fail on use
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check_exports() -> List[str]:
+    """Names declared in the header that the library does not export."""
+    lib = load()
+    return [n for n in header_symbols() if not hasattr(lib, n)]
+
+
+def last_error() -> str:
+    msg = load().eg_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc: int, what: str) -> None:
+    if rc != EG_OK:
+        kind = {EG_ERR_ARG: "bad argument", EG_ERR_UNSUPPORTED: "unsupported", EG_ERR_HIP: "HIP error"}.get(rc, str(rc))
+        raise RuntimeError(f"{what} failed ({kind}): {last_error()}")

@@ -1,0 +1,138 @@
+// Shared declarations of the gfx950 hot-path library (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/echoglad_hip.h"
+
+namespace eg {
+
+constexpr int C = EG_CHANNELS;     // 128 channels per node row (512 B)
+constexpr int TILE = 64;           // node rows per workgroup tile
+constexpr int LDA = C + 4;         // LDS row stride (floats): 132 -> ds_read_b128 of 16 rows is conflict-free
+constexpr int MAX_LEVELS = 14;     // aux levels + main grid
+constexpr int MAX_SLOTS = 10;      // self + 4 in-level + parent + 4 children
+
+int set_error(int code, const std::string& msg);
+#define EG_HIP_TRY(expr)                                                                         \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return ::eg::set_error(EG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// Closed-form hierarchical topology.  Kernels read a device copy through a const
+// pointer: every field is wave-uniform, so the accesses are scalar loads (a by-value
+// kernel argument would be spilled to scratch by the dynamic level indexing).
+struct Topo {
+    int n_nodes;             // nodes per frame, incl. coordinate nodes
+    int n_levels;            // aux levels + 1
+    int n_aux;               // 0 when use_main_graph_only
+    int frame;               // F
+    int crop0, ncrop;        // run of rows/cols of the last aux level wired to the main grid
+    int coord_base;          // first coordinate node id (== n_nodes when there are none)
+    int base[MAX_LEVELS];    // first node id of each level (aux 1..naux, then main)
+    int side[MAX_LEVELS];    // grid side of each level
+    unsigned long long magic;// floor(2^40 / F) + 1 : idx / F == (idx * magic) >> 40 for idx < 2^24
+};
+
+// One node's neighbourhood: ids[0] is the node itself; slots beyond the real
+// neighbours repeat the node with valid=0 so the caller can issue all loads
+// unconditionally.  Follows reference src/core/datasets.py:1441-1584.
+struct Nbrs {
+    int id[MAX_SLOTS];
+    int valid[MAX_SLOTS];
+    int count;      // slots to visit: 6 for main-grid and coordinate nodes, 10 for aux nodes
+    int degree;     // real neighbours, excluding self
+};
+
+__host__ __device__ inline int level_of(const Topo& T, int n) {
+    int l = 0;
+#pragma unroll 1
+    for (int k = 1; k < T.n_levels; ++k) l += (n >= T.base[k]) ? 1 : 0;
+    return l;
+}
+
+__host__ __device__ inline void neighbours(const Topo& T, int n, Nbrs& nb) {
+#pragma unroll
+    for (int s = 0; s < MAX_SLOTS; ++s) { nb.id[s] = n; nb.valid[s] = 0; }
+    nb.valid[0] = 1;
+    if (n >= T.coord_base) {                          // isolated K4 (datasets.py:1517-1523)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                 // slots 1..4 = the four coordinate nodes, self masked out
+            const int o = T.coord_base + j;
+            nb.id[1 + j] = o;
+            nb.valid[1 + j] = (o != n);
+        }
+        nb.count = 6; nb.degree = 3;
+        return;
+    }
+    const int l = level_of(T, n);
+    const int side = T.side[l];
+    const int idx = n - T.base[l];
+    const bool is_main = (l == T.n_levels - 1);
+    int r, c;
+    if (is_main) {
+        r = (int)(((unsigned long long)(unsigned)idx * T.magic) >> 40);
+        c = idx - r * side;
+    } else {                                          // aux sides are powers of two
+        const int lg = l + 1;
+        r = idx >> lg;
+        c = idx & (side - 1);
+    }
+    int deg = 0;
+    // in-level 4-neighbourhood (nx.grid_graph, datasets.py:1465,1490)
+    nb.valid[1] = r > 0;            nb.id[1] = nb.valid[1] ? n - side : n;
+    nb.valid[2] = r < side - 1;     nb.id[2] = nb.valid[2] ? n + side : n;
+    nb.valid[3] = c > 0;            nb.id[3] = nb.valid[3] ? n - 1 : n;
+    nb.valid[4] = c < side - 1;     nb.id[4] = nb.valid[4] ? n + 1 : n;
+    deg += nb.valid[1] + nb.valid[2] + nb.valid[3] + nb.valid[4];
+    // parent
+    if (is_main) {
+        if (T.n_aux > 0 && r < 2 * T.ncrop && c < 2 * T.ncrop) {       // datasets.py:1558-1584
+            const int pl = T.n_levels - 2;
+            nb.id[5] = T.base[pl] + (T.crop0 + (r >> 1)) * T.side[pl] + T.crop0 + (c >> 1);
+            nb.valid[5] = 1; ++deg;
+        }
+        nb.count = 6;
+    } else {
+        if (l > 0) {                                                   // datasets.py:1534-1556
+            nb.id[5] = T.base[l - 1] + (r >> 1) * T.side[l - 1] + (c >> 1);
+            nb.valid[5] = 1; ++deg;
+        }
+        // children
+        const int cl = l + 1;
+        int cr = -1, cc = -1;
+        if (cl < T.n_levels - 1) { cr = 2 * r; cc = 2 * c; }
+        else if (r >= T.crop0 && r < T.crop0 + T.ncrop && c >= T.crop0 && c < T.crop0 + T.ncrop) {
+            cr = 2 * (r - T.crop0); cc = 2 * (c - T.crop0);
+        }
+        if (cr >= 0) {
+            const int cs = T.side[cl];
+            const int b = T.base[cl] + cr * cs + cc;
+            nb.id[6] = b;          nb.id[7] = b + 1;
+            nb.id[8] = b + cs;     nb.id[9] = b + cs + 1;
+            nb.valid[6] = nb.valid[7] = nb.valid[8] = nb.valid[9] = 1;
+            deg += 4;
+        }
+        nb.count = 10;
+    }
+    nb.degree = deg;
+}
+
+enum GraphKind { GRAPH_TOPO = 1, GRAPH_CSR = 2 };
+
+}  // namespace eg
+
+// The opaque handle of the public ABI.
+struct eg_graph {
+    int kind;
+    int64_t n_nodes;          // per frame (topo) / total (csr)
+    eg::Topo topo;            // kind == GRAPH_TOPO (host copy)
+    eg::Topo* topo_dev;       // device copy read by the kernels through scalar loads
+    float* dis;               // device [n_nodes]   (deg+1)^-1/2
+    int* rowptr;              // device [n_nodes+1] kind == GRAPH_CSR
+    int* colidx;              // device [nnz]
+    int64_t nnz;
+};

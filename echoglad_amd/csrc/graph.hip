@@ -1,0 +1,250 @@
+// Graph handles of the gfx950 hot-path library: closed-form topology, generic CSR, edge digest.
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace eg {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+// Python floor division
+static inline int floordiv(int a, int b) {
+    int q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+    return q;
+}
+
+// Python `range(len)[start:stop]` with step 1 -> [lo, hi)
+static inline void py_slice(int len, int start, int stop, int& lo, int& hi) {
+    lo = start < 0 ? (len + start < 0 ? 0 : len + start) : (start > len ? len : start);
+    hi = stop < 0 ? (len + stop < 0 ? 0 : len + stop) : (stop > len ? len : stop);
+    if (hi < lo) hi = lo;
+}
+
+static int build_topo(int frame, int naux, int main_only, int coord_nodes, Topo& T) {
+    if (frame < 2 || frame > 4096) return set_error(EG_ERR_ARG, "frame must be in [2, 4096]");
+    if (!main_only && (naux < 1 || naux + 1 > MAX_LEVELS)) return set_error(EG_ERR_ARG, "naux out of range");
+    T = Topo{};
+    int nid = 0;
+    T.n_aux = main_only ? 0 : naux;
+    for (int k = 1; k <= T.n_aux; ++k) {
+        T.base[k - 1] = nid;
+        T.side[k - 1] = 1 << k;
+        nid += (1 << k) * (1 << k);
+    }
+    T.n_levels = T.n_aux + 1;
+    T.base[T.n_levels - 1] = nid;
+    T.side[T.n_levels - 1] = frame;
+    nid += frame * frame;
+    T.coord_base = nid;
+    if (!main_only && coord_nodes) nid += 4;       // datasets.py:1508-1523: only inside `if not use_main_graph_only`
+    T.n_nodes = nid;
+    T.frame = frame;
+    T.magic = ((1ull << 40) / (unsigned long long)frame) + 1ull;
+    if ((long long)frame * frame >= (1ll << 24)) return set_error(EG_ERR_UNSUPPORTED, "frame too large");
+    T.crop0 = 0; T.ncrop = 0;
+    if (T.n_aux > 0) {                             // datasets.py:1565-1567, Python slice semantics
+        const int p = 1 << T.n_aux;
+        const int half = frame / 2;
+        const int c0 = floordiv(p - half, 2);
+        int lo, hi;
+        py_slice(p, c0, c0 + half, lo, hi);
+        T.crop0 = lo; T.ncrop = hi - lo;
+    }
+    return EG_OK;
+}
+
+// ---------------------------------------------------------------- CSR build
+__global__ void k_edge_keys(const int64_t* __restrict__ ei, int64_t n_edges, int n_nodes, int* __restrict__ keys,
+                            int* __restrict__ vals, int* __restrict__ counts) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const int64_t src = ei[e], dst = ei[n_edges + e];
+    const bool drop = (src == dst) || src < 0 || dst < 0 || src >= n_nodes || dst >= n_nodes;
+    keys[e] = drop ? n_nodes : (int)dst;          // dropped edges sort behind every real row
+    vals[e] = (int)src;
+    if (!drop) atomicAdd(&counts[dst], 1);        // integer: order-independent
+}
+
+__global__ void k_dis_from_counts(const int* __restrict__ counts, int n, float* __restrict__ dis) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dis[i] = 1.0f / sqrtf((float)(counts[i] + 1));
+}
+
+// ---------------------------------------------------------------- edge digest
+__device__ inline unsigned long long mix64(unsigned long long r, unsigned long long c) {
+    unsigned long long h = r * 0x9E3779B97F4A7C15ull + c * 0xC2B2AE3D27D4EB4Full + 0x165667B19E3779F9ull;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return h;
+}
+
+__global__ void k_edge_hash(const int64_t* __restrict__ ei, int64_t n_edges, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * blockDim.x)
+        acc += mix64((unsigned long long)ei[e], (unsigned long long)ei[n_edges + e]);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[1], acc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (unsigned long long)n_edges;
+}
+
+}  // namespace eg
+
+using namespace eg;
+
+extern "C" {
+
+int eg_version(void) { return 100; }
+
+const char* eg_last_error(void) { return g_last_error.c_str(); }
+
+int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph** out) {
+    if (!out) return set_error(EG_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    Topo T;
+    int rc = build_topo(frame, naux, main_only, coord_nodes, T);
+    if (rc != EG_OK) return rc;
+    std::vector<float> dis(T.n_nodes);
+    Nbrs nb;
+    for (int n = 0; n < T.n_nodes; ++n) {
+        neighbours(T, n, nb);
+        dis[n] = (float)(1.0 / std::sqrt((double)(nb.degree + 1)));
+    }
+    eg_graph* g = new eg_graph{};
+    g->kind = GRAPH_TOPO;
+    g->n_nodes = T.n_nodes;
+    g->topo = T;
+    hipError_t e = hipMalloc((void**)&g->dis, sizeof(float) * T.n_nodes);
+    if (e == hipSuccess) e = hipMemcpy(g->dis, dis.data(), sizeof(float) * T.n_nodes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->topo_dev, sizeof(Topo));
+    if (e == hipSuccess) e = hipMemcpy(g->topo_dev, &T, sizeof(Topo), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (g->dis) (void)hipFree(g->dis);
+        if (g->topo_dev) (void)hipFree(g->topo_dev);
+        delete g;
+        return set_error(EG_ERR_HIP, std::string("eg_topo_create: ") + hipGetErrorString(e));
+    }
+    *out = g;
+    return EG_OK;
+}
+
+int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream_t stream_, eg_graph** out) {
+    if (!out) return set_error(EG_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_nodes <= 0 || n_nodes >= (1ll << 31) - 1 || n_edges < 0 || n_edges >= (1ll << 31) - 1)
+        return set_error(EG_ERR_ARG, "n_nodes / n_edges out of int32 range");
+    if (n_edges > 0 && !ei) return set_error(EG_ERR_ARG, "edge_index is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int n = (int)n_nodes;
+    const int m = (int)n_edges;
+    eg_graph* g = new eg_graph{};
+    g->kind = GRAPH_CSR;
+    g->n_nodes = n_nodes;
+    int *keys = nullptr, *vals = nullptr, *keys_out = nullptr, *counts = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0, tmp2 = 0;
+    auto cleanup = [&](bool all) {
+        if (keys) (void)hipFree(keys);
+        if (vals) (void)hipFree(vals);
+        if (keys_out) (void)hipFree(keys_out);
+        if (counts) (void)hipFree(counts);
+        if (tmp) (void)hipFree(tmp);
+        if (all) {
+            if (g->dis) (void)hipFree(g->dis);
+            if (g->rowptr) (void)hipFree(g->rowptr);
+            if (g->colidx) (void)hipFree(g->colidx);
+            delete g;
+        }
+    };
+#define CSR_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            cleanup(true);                                                                         \
+            return set_error(EG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+        }                                                                                          \
+    } while (0)
+    const size_t mm = (size_t)(m > 0 ? m : 1);
+    CSR_TRY(hipMalloc((void**)&keys, sizeof(int) * mm));
+    CSR_TRY(hipMalloc((void**)&vals, sizeof(int) * mm));
+    CSR_TRY(hipMalloc((void**)&keys_out, sizeof(int) * mm));
+    CSR_TRY(hipMalloc((void**)&counts, sizeof(int) * ((size_t)n + 1)));
+    CSR_TRY(hipMalloc((void**)&g->colidx, sizeof(int) * mm));
+    CSR_TRY(hipMalloc((void**)&g->rowptr, sizeof(int) * ((size_t)n + 1)));
+    CSR_TRY(hipMalloc((void**)&g->dis, sizeof(float) * (size_t)n));
+    CSR_TRY(hipMemsetAsync(counts, 0, sizeof(int) * ((size_t)n + 1), stream));
+    if (m > 0) {
+        hipLaunchKernelGGL(k_edge_keys, dim3((m + 255) / 256), dim3(256), 0, stream, ei, n_edges, n, keys, vals, counts);
+        CSR_TRY(hipGetLastError());
+        // stable LSD radix sort by target: neighbours keep their edge_index order
+        int end_bit = 1;
+        while ((1ll << end_bit) <= n_nodes && end_bit < 32) ++end_bit;
+        CSR_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_out, vals, g->colidx, m, 0, end_bit, stream));
+    }
+    CSR_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, counts, g->rowptr, n + 1, stream));
+    if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
+    CSR_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    if (m > 0) {
+        size_t tb = tmp_bytes;
+        int end_bit = 1;
+        while ((1ll << end_bit) <= n_nodes && end_bit < 32) ++end_bit;
+        CSR_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, keys_out, vals, g->colidx, m, 0, end_bit, stream));
+    }
+    {
+        size_t tb = tmp_bytes;
+        CSR_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, counts, g->rowptr, n + 1, stream));
+    }
+    hipLaunchKernelGGL(k_dis_from_counts, dim3((n + 255) / 256), dim3(256), 0, stream, counts, n, g->dis);
+    CSR_TRY(hipGetLastError());
+    int nnz = 0;
+    CSR_TRY(hipMemcpyAsync(&nnz, g->rowptr + n, sizeof(int), hipMemcpyDeviceToHost, stream));
+    CSR_TRY(hipStreamSynchronize(stream));
+    g->nnz = nnz;
+    cleanup(false);
+#undef CSR_TRY
+    *out = g;
+    return EG_OK;
+}
+
+int eg_graph_destroy(eg_graph* g) {
+    if (!g) return EG_OK;
+    if (g->dis) (void)hipFree(g->dis);
+    if (g->topo_dev) (void)hipFree(g->topo_dev);
+    if (g->rowptr) (void)hipFree(g->rowptr);
+    if (g->colidx) (void)hipFree(g->colidx);
+    delete g;
+    return EG_OK;
+}
+
+int64_t eg_graph_num_nodes(const eg_graph* g) { return g ? g->n_nodes : -1; }
+
+int eg_graph_is_structured(const eg_graph* g) { return g && g->kind == GRAPH_TOPO; }
+
+int eg_graph_deg_inv_sqrt(const eg_graph* g, float* out_dev, eg_stream_t stream) {
+    if (!g || !out_dev) return set_error(EG_ERR_ARG, "NULL argument");
+    EG_HIP_TRY(hipMemcpyAsync(out_dev, g->dis, sizeof(float) * g->n_nodes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return EG_OK;
+}
+
+int eg_edge_hash(const int64_t* ei, int64_t n_edges, uint64_t* out_dev, eg_stream_t stream_) {
+    if (!out_dev || (n_edges > 0 && !ei) || n_edges < 0) return set_error(EG_ERR_ARG, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    EG_HIP_TRY(hipMemsetAsync(out_dev, 0, 2 * sizeof(uint64_t), stream));
+    int blocks = (int)((n_edges + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_edge_hash, dim3(blocks), dim3(256), 0, stream, ei, n_edges, (unsigned long long*)out_dev);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+}  // extern "C"

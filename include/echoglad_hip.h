@@ -1,0 +1,117 @@
+/*
+ * echoglad_hip.h — C ABI of the MI355X (gfx950) hierarchical-GNN hot path.
+ *
+ * Drop-in boundary for the EchoGLAD GNN stack.  The reference has no FFI of
+ * its own (it is pure Python on top of torch_geometric); the entry points
+ * below are what a ctypes binding on the reference side would call in place of
+ *   - torch_geometric GCNConv.forward            (call site src/core/models.py:330-332, :431)
+ *   - BatchNorm1d / Dropout / ReLU / residual     (src/core/models.py:333-335, :434-435)
+ *   - node-type filter + 4 classifier MLPs + cat  (src/core/models.py:485-490)
+ *   - bilinear_interpolation                      (src/core/models.py:539-553)
+ *   - create_graphs / from_networkx               (src/core/datasets.py:1441-1584, :1392)
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer, 16-byte aligned, row-major
+ *     contiguous fp32 [rows, 128] unless stated otherwise;
+ *   - the caller owns every data buffer; the library allocates nothing on the
+ *     hot path; opaque handles own small device tables and are freed by
+ *     *_destroy;
+ *   - all work is enqueued on the caller's stream (a hipStream_t passed as
+ *     void*), no internal synchronisation, no host reads of device data
+ *     (except in *_create, which are set-up calls);
+ *   - return 0 on success, <0 on failure: EG_ERR_ARG bad argument,
+ *     EG_ERR_UNSUPPORTED shape/topology outside what the kernels cover,
+ *     EG_ERR_HIP a HIP runtime error; text via eg_last_error() (thread local).
+ *   - functions are re-entrant; no global mutable state besides the
+ *     thread-local error string.
+ */
+#ifndef ECHOGLAD_HIP_H
+#define ECHOGLAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EG_OK 0
+#define EG_ERR_ARG (-1)
+#define EG_ERR_UNSUPPORTED (-2)
+#define EG_ERR_HIP (-3)
+
+#define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
+
+typedef void* eg_stream_t; /* hipStream_t */
+
+/* Graph handle: either the implicit (closed-form) hierarchical topology or a
+ * generic CSR built from an edge_index.  Both feed the same layer kernels. */
+typedef struct eg_graph eg_graph;
+
+int eg_version(void);
+const char* eg_last_error(void);
+
+/* ---- graph handles -------------------------------------------------------
+ * Closed form of DummyDataset.create_graphs (src/core/datasets.py:1441-1584):
+ * aux levels 2^k x 2^k (k = 1..naux), main grid frame x frame, 4-neighbour
+ * edges, parent<->child edges, centre-crop link with Python slice semantics,
+ * optional isolated K4 of coordinate nodes.  Connection nodes and
+ * 'grid-diagonal' are not covered (EG_ERR_UNSUPPORTED -> use eg_csr_create). */
+int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph** out);
+
+/* Generic CSR (by target node) from a device edge_index [2, n_edges] int64 in
+ * PyG layout (row 0 = source, row 1 = target).  Deterministic: neighbours keep
+ * their edge_index order.  Self loops in the input are dropped and one self
+ * loop per node is implied (gcn_norm / add_remaining_self_loops).
+ * Set-up call: allocates and synchronises the stream. */
+int eg_csr_create(const int64_t* edge_index_dev, int64_t n_nodes, int64_t n_edges, eg_stream_t stream,
+                  eg_graph** out);
+
+int eg_graph_destroy(eg_graph* g);
+int64_t eg_graph_num_nodes(const eg_graph* g);      /* nodes per frame (topo) or total (csr) */
+int eg_graph_is_structured(const eg_graph* g);
+/* copies the (deg+1)^-1/2 table [num_nodes] to a device buffer (tests / diagnostics) */
+int eg_graph_deg_inv_sqrt(const eg_graph* g, float* out_dev, eg_stream_t stream);
+
+/* Order-independent digest of an edge_index [2, n_edges] int64 on the device:
+ * out_dev[0] = n_edges, out_dev[1] = sum over edges of mix64(src, dst) (mod 2^64).
+ * Used to verify an incoming PyG edge_index against the closed form once. */
+int eg_edge_hash(const int64_t* edge_index_dev, int64_t n_edges, uint64_t* out_dev, eg_stream_t stream);
+
+/* ---- fused GCN layer, inference form -------------------------------------
+ * out[i,:] = act( (sum_{j in N(i) u {i}} d_i^-1/2 d_j^-1/2 x[j,:]) W^T * scale + shift ) + residual[i,:]
+ * i.e. GCNConv -> (bias, eval-mode BatchNorm folded into scale/shift) -> ReLU|Identity -> +residual
+ * in one kernel (src/core/models.py:328-335, :431-435).  rows = batch * num_nodes.
+ *   W        [128,128] row-major [out,in] (GCNConv.lin.weight)
+ *   scale    [128] or NULL (=1), shift [128] or NULL (=0)
+ *   residual [rows,128] or NULL; may alias x; must not alias out
+ *   relu     0|1
+ *   transpose_w  0: x W^T ; 1: x W  (the backward dX form) */
+int eg_gcn_layer_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
+                     const float* shift, const float* residual, int relu, int transpose_w, float* out,
+                     eg_stream_t stream);
+
+/* out = A_hat x  (aggregation only; training / backward building block) */
+int eg_gcn_aggregate(const eg_graph* g, int batch, const float* x, float* out, eg_stream_t stream);
+
+/* out = act((x W^T) * scale + shift) + residual   for rows x 128 (no graph) */
+int eg_linear128_fwd(const float* x, int64_t rows, const float* W, const float* scale, const float* shift,
+                     const float* residual, int relu, int transpose_w, float* out, eg_stream_t stream);
+
+/* ---- node-type filter + 4 classifier heads, inference form ----------------
+ * For every frame f and every valid row r in [row_lo, row_lo + n_valid):
+ *   logits[f*n_valid + r - row_lo, c] = head_c(h[f*n_per_frame + r, :])
+ * head_c = Linear(128,32)-BN-ReLU-Linear(32,16)-BN-ReLU-Linear(16,1) [-Sigmoid]
+ * (src/core/models.py:363-377, :485-490) with eval-mode BN folded by the caller:
+ *   w1 [128,128] = 4 heads' [32,128] stacked, s1/t1 [128]
+ *   w2 [4,16,32], s2/t2 [64];  w3 [4,16], b3 [4]
+ * logits [batch*n_valid, 4]. */
+int eg_classifier_fwd(const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                      const float* w1, const float* s1, const float* t1, const float* w2, const float* s2,
+                      const float* t2, const float* w3, const float* b3, int sigmoid, float* logits,
+                      eg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECHOGLAD_HIP_H */

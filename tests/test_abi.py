@@ -1,0 +1,37 @@
+"""The C-ABI library: builds with hipcc, loads, and exports every symbol the header declares.
+No compute is launched here (no GPU in this container)."""
+import ctypes
+import os
+import subprocess
+
+from echoglad_amd import _lib
+
+
+def test_library_builds_and_loads(built_lib):
+    assert os.path.exists(built_lib)
+    lib = _lib.load()
+    assert lib.eg_version() >= 100
+    assert _lib.last_error() == "" or isinstance(_lib.last_error(), str)
+
+
+def test_every_header_symbol_is_exported(built_lib):
+    names = _lib.header_symbols()
+    assert "eg_gcn_layer_fwd" in names and "eg_classifier_fwd" in names and "eg_topo_create" in names
+    assert _lib.check_exports() == []
+    for n in names:
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+
+
+def test_code_object_targets_gfx950(built_lib):
+    out = subprocess.run(["strings", "-a", str(built_lib)], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_bad_arguments_return_error_codes(built_lib):
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.eg_topo_create(1, 7, 0, 0, ctypes.byref(h)) == _lib.EG_ERR_ARG          # frame < 2
+    assert "frame" in _lib.last_error()
+    assert lib.eg_topo_create(224, 40, 0, 0, ctypes.byref(h)) == _lib.EG_ERR_ARG        # naux too large
+    assert lib.eg_gcn_layer_fwd(None, 1, None, None, None, None, None, 0, 0, None, None) == _lib.EG_ERR_ARG
+    assert lib.eg_graph_destroy(None) == _lib.EG_OK

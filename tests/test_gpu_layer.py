@@ -1,0 +1,161 @@
+"""-m gpu: the HIP kernels, called through the C-ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, dense_ahat, graph_tensors, rand_rows
+from oracle import gnn_oracle as O
+from echoglad_amd import _lib, ops
+from echoglad_amd.topology import HierTopology, TopologySpec, commutative_edge_hash
+
+pytestmark = pytest.mark.gpu
+
+TOPO_CASES = [  # frame, naux, main_only, coord
+    (8, 2, False, False), (16, 3, False, False), (16, 3, False, True), (16, 2, True, False),
+    (64, 2, False, False), (30, 3, False, False), (17, 3, False, False), (8, 1, False, False),
+    (32, 4, False, True), (64, 6, False, False),
+]
+
+
+def test_library_is_loaded_and_not_a_fallback():
+    lib = _lib.load()
+    assert lib.eg_version() >= 100
+    assert torch.cuda.is_available()
+    with pytest.raises(RuntimeError):
+        ops.gcn_aggregate(ops.Graph.topo(8, 2), 1, torch.zeros(84, 128))      # CPU tensor: loud failure
+
+
+@pytest.mark.parametrize("frame,naux,main_only,coord", TOPO_CASES + [(224, 7, False, False), (224, 7, True, False),
+                                                                      (224, 7, False, True)])
+def test_closed_form_degree_table(frame, naux, main_only, coord):
+    topo = HierTopology(TopologySpec(frame, naux, main_only, coord))
+    g = ops.Graph.topo(frame, naux, main_only, coord)
+    assert g.num_nodes == topo.num_nodes
+    dis = g.deg_inv_sqrt().cpu().numpy()
+    assert np.allclose(dis, topo.deg_inv_sqrt(), rtol=1e-7, atol=0)
+
+
+@pytest.mark.parametrize("frame,naux,main_only,coord", TOPO_CASES)
+def test_csr_degree_table_and_edge_hash(frame, naux, main_only, coord):
+    topo = HierTopology(TopologySpec(frame, naux, main_only, coord))
+    ei = torch.from_numpy(topo.batched_edge_index(2)).to(DEV)
+    g = ops.Graph.csr(ei, 2 * topo.num_nodes)
+    dis = g.deg_inv_sqrt().cpu().numpy()
+    assert np.allclose(dis, np.tile(topo.deg_inv_sqrt(), 2), rtol=1e-6)
+    assert ops.edge_hash(ei) == commutative_edge_hash(topo.batched_edge_index(2))
+
+
+@pytest.mark.parametrize("frame,naux,main_only,coord", TOPO_CASES)
+def test_aggregate_stencil_vs_csr_vs_dense(frame, naux, main_only, coord):
+    B = 3
+    topo, ei, _, _ = graph_tensors(frame, naux, B, coord, main_only)
+    x = rand_rows(B * topo.num_nodes, seed=frame + naux)
+    xg = x.to(DEV)
+    s = ops.gcn_aggregate(ops.Graph.topo(frame, naux, main_only, coord), B, xg).cpu()
+    c = ops.gcn_aggregate(ops.Graph.csr(ei.to(DEV), B * topo.num_nodes), 1, xg).cpu()
+    # per-frame CSR handle replicated over the batch
+    c1 = ops.gcn_aggregate(ops.Graph.csr(torch.from_numpy(topo.edge_index()).to(DEV), topo.num_nodes), B, xg).cpu()
+    assert torch.isfinite(s).all()
+    assert (s - c).abs().max() < 2e-6
+    assert (c1 - c).abs().max() < 2e-6
+    if topo.num_nodes <= 4200:
+        a = dense_ahat(topo)
+        want = torch.cat([a @ x[b * topo.num_nodes:(b + 1) * topo.num_nodes].double() for b in range(B)])
+        assert (s.double() - want).abs().max() < 5e-6
+
+
+def test_aggregate_csr_generic_graphs():
+    """connection nodes (huge degree), diagonal grids, self loops and duplicate-free random graphs."""
+    for spec in (TopologySpec(16, 3, use_connection_nodes=True), TopologySpec(16, 3, main_graph_type="grid-diagonal",
+                                                                              aux_graph_type="grid-diagonal")):
+        topo = HierTopology(spec)
+        ei = torch.from_numpy(topo.edge_index())
+        x = rand_rows(topo.num_nodes, seed=5)
+        got = ops.gcn_aggregate(ops.Graph.csr(ei.to(DEV), topo.num_nodes), 1, x.to(DEV)).cpu()
+        want = O.gcn_conv_sparse(x, ei, torch.eye(128), None)
+        assert (got - want).abs().max() < 5e-6
+    # explicit self loops must be replaced, isolated nodes keep x_i
+    ei = torch.tensor([[0, 0, 1, 2, 2], [0, 1, 0, 2, 1]])
+    x = rand_rows(5, seed=6)
+    got = ops.gcn_aggregate(ops.Graph.csr(ei.to(DEV), 5), 1, x.to(DEV)).cpu()
+    want = O.gcn_conv_sparse(x, ei, torch.eye(128), None)
+    assert (got - want).abs().max() < 1e-6
+    assert torch.allclose(got[3:], x[3:])
+
+
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 64, 65, 200, 4116])
+@pytest.mark.parametrize("transpose", [False, True])
+def test_linear128(rows, transpose):
+    rs = np.random.RandomState(rows)
+    x = rand_rows(rows, seed=rows)
+    w = torch.from_numpy(rs.uniform(-0.2, 0.2, (128, 128)).astype(np.float32))
+    scale = torch.from_numpy(rs.uniform(0.5, 1.5, 128).astype(np.float32))
+    shift = torch.from_numpy(rs.standard_normal(128).astype(np.float32))
+    res = rand_rows(rows, seed=rows + 1)
+    got = ops.linear128_fwd(x.to(DEV), w.to(DEV), scale.to(DEV), shift.to(DEV), res.to(DEV), relu=True,
+                            transpose_w=transpose).cpu()
+    wm = w if transpose else w.t()
+    want = torch.relu((x.double() @ wm.double()) * scale.double() + shift.double()) + res.double()
+    assert (got.double() - want).abs().max() < 2e-5
+    plain = ops.linear128_fwd(x.to(DEV), w.to(DEV)).cpu()
+    assert (plain.double() - x.double() @ (w.double() if transpose is None else w.t().double())).abs().max() < 2e-5
+
+
+def test_linear128_distinguishes_rows_and_columns():
+    """A = I check with an asymmetric weight (catches a transposed accumulator map)."""
+    w = torch.arange(128 * 128, dtype=torch.float32).reshape(128, 128) / 1000.0
+    x = torch.eye(128)
+    got = ops.linear128_fwd(x.to(DEV), w.to(DEV)).cpu()
+    assert torch.equal(got, w.t())
+    got_t = ops.linear128_fwd(x.to(DEV), w.to(DEV), transpose_w=True).cpu()
+    assert torch.equal(got_t, w)
+
+
+@pytest.mark.parametrize("frame,naux,main_only,coord", TOPO_CASES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_fused_layer_vs_oracle(frame, naux, main_only, coord, relu):
+    B = 2
+    topo, ei, _, _ = graph_tensors(frame, naux, B, coord, main_only)
+    rows = B * topo.num_nodes
+    rs = np.random.RandomState(frame * 7 + naux)
+    x = rand_rows(rows, seed=11)
+    w = torch.from_numpy(rs.uniform(-0.15, 0.15, (128, 128)).astype(np.float32))
+    b = torch.from_numpy((0.1 * rs.standard_normal(128)).astype(np.float32))
+    bn = torch.nn.BatchNorm1d(128).eval()
+    O.randomize_bn_stats(bn, seed=frame)
+    with torch.no_grad():
+        want = bn(O.gcn_conv_sparse(x, ei, w, b))
+        want = (torch.relu(want) if relu else want) + x
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale + b * scale
+    xg = x.to(DEV)
+    for graph, gb in ((ops.Graph.topo(frame, naux, main_only, coord), B),
+                      (ops.Graph.csr(ei.to(DEV), rows), 1)):
+        got = ops.gcn_layer_fwd(graph, gb, xg, w.to(DEV), scale.to(DEV), shift.to(DEV), xg, relu=relu).cpu()
+        assert (got - want).abs().max() < 3e-5, (graph.structured, float((got - want).abs().max()))
+
+
+def test_fused_layer_is_run_to_run_deterministic():
+    topo, ei, _, _ = graph_tensors(64, 6, 2)
+    x = rand_rows(2 * topo.num_nodes, seed=1).to(DEV)
+    w = rand_rows(128, seed=2).to(DEV) * 0.1
+    g = ops.Graph.topo(64, 6)
+    a = ops.gcn_layer_fwd(g, 2, x, w, None, None, x, relu=True)
+    for _ in range(3):
+        assert torch.equal(a, ops.gcn_layer_fwd(g, 2, x, w, None, None, x, relu=True))
+
+
+@pytest.mark.parametrize("rows_per_frame,row_lo,n_valid,batch", [(340, 0, 340, 2), (344, 0, 340, 3), (348, 4, 340, 2),
+                                                                  (100, 3, 1, 1), (4116, 0, 4116, 1)])
+@pytest.mark.parametrize("sigmoid", [False, True])
+def test_classifier_heads(rows_per_frame, row_lo, n_valid, batch, sigmoid):
+    from gpu_util import model_pair
+    hip, ref = model_pair(16, 3, 1, seed=21, output_activation="sigmoid" if sigmoid else "logit")
+    h = rand_rows(batch * rows_per_frame, seed=3)
+    got = ops.classifier_fwd(h.to(DEV), batch, rows_per_frame, row_lo, n_valid, hip._packed_classifier(),
+                             sigmoid=sigmoid).cpu()
+    hv = h.view(batch, rows_per_frame, 128)[:, row_lo:row_lo + n_valid].reshape(-1, 128)
+    with torch.no_grad():
+        want = torch.cat([c(hv) for c in ref.node_classifiers], dim=1)
+    assert got.shape == want.shape
+    assert (got - want).abs().max() < 2e-5

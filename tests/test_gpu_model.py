@@ -1,0 +1,131 @@
+"""-m gpu: the whole GNN stack through the reference-shaped model API vs golden fixtures and the oracle.
+Bar (BASELINE.json north_star): logits within 1e-4 fp32, landmark argmax indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fixtures_util import initial_coords, synthetic_frames, synthetic_node_feats
+from gpu_util import DEV, graph_tensors, model_pair
+from oracle import gnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run_both(hip, ref, frames, ei, nt, bi, coords=None):
+    with torch.no_grad():
+        want, wc = ref(x=frames, node_coords=None if coords is None else coords.clone(), edge_index=ei,
+                       node_type=nt, batch_idx=bi)
+        got, gc = hip(x=frames.to(DEV), node_coords=None if coords is None else coords.clone().to(DEV),
+                      edge_index=ei.to(DEV), node_type=nt.to(DEV), batch_idx=bi.to(DEV))
+    return got.cpu(), want, (None if gc is None else gc.cpu()), wc
+
+
+def test_kat_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_f16_a3.npz"))
+    hip, ref = model_pair(16, 3, 3, seed=int(g["weight_seed"]))
+    topo, ei, nt, bi = graph_tensors(16, 3, int(g["batch"]))
+    frames = synthetic_frames(int(g["batch"]), 128, 16, int(g["frame_seed"]))
+    got, want, _, _ = _run_both(hip, ref, frames, ei, nt, bi)
+    assert np.abs(got.numpy() - g["logits"]).max() < TOL
+    assert (got - want).abs().max() < TOL
+    # the reference's own (from_networkx) edge order must resolve to the same implicit topology
+    with torch.no_grad():
+        got2, _ = hip(x=frames.to(DEV), edge_index=torch.from_numpy(g["edge_index"]).to(DEV), node_type=nt.to(DEV),
+                      batch_idx=bi.to(DEV))
+    assert torch.equal(got2.cpu(), got)
+    assert hip._resolver.resolve(torch.from_numpy(g["edge_index"]).to(DEV), nt.numel())[0].structured
+
+
+def test_cfg1_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "cfg1_f64_a2.npz"))
+    hip, ref = model_pair(64, 2, 2, seed=int(g["weight_seed"]))
+    topo, ei, nt, bi = graph_tensors(64, 2, 1)
+    frames = synthetic_frames(1, 128, 64, int(g["frame_seed"]))
+    got, want, _, _ = _run_both(hip, ref, frames, ei, nt, bi)
+    assert np.abs(got.numpy()[g["sample_rows"]] - g["logits_rows"]).max() < TOL
+    assert (got - want).abs().max() < TOL
+    assert np.array_equal(O.landmark_argmax(got, 1, 64).numpy(), g["argmax"])
+
+
+def test_main_only_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mainonly_f16.npz"))
+    hip, ref = model_pair(16, 2, 3, main_only=True, seed=int(g["weight_seed"]))
+    topo, ei, nt, bi = graph_tensors(16, 2, int(g["batch"]), main_only=True)
+    frames = synthetic_frames(int(g["batch"]), 128, 16, int(g["frame_seed"]))
+    got, want, _, _ = _run_both(hip, ref, frames, ei, nt, bi)
+    assert np.abs(got.numpy() - g["logits"]).max() < TOL
+
+
+@pytest.mark.parametrize("frame,naux,layers,batch,main_only", [
+    (224, 7, 3, 2, False),      # BASELINE cfg 2 shape (default.yml), reduced batch so the oracle takes seconds
+    (224, 7, 3, 2, True),       # BASELINE cfg 3 shape
+    (64, 6, 3, 3, False), (30, 3, 2, 2, False), (17, 3, 1, 2, False),
+])
+def test_stack_vs_oracle_from_node_features(frame, naux, layers, batch, main_only):
+    hip, ref = model_pair(frame, naux, layers, main_only=main_only, seed=frame + layers)
+    topo, ei, nt, bi = graph_tensors(frame, naux, batch, main_only=main_only)
+    feats = synthetic_node_feats(batch * topo.num_nodes, 128, seed=200)
+    with torch.no_grad():
+        want, _ = ref.forward_nodes(feats, ei, nt, batch)
+        got, _ = hip.forward_nodes(feats.to(DEV), ei.to(DEV), batch)
+    got = got.cpu()
+    err = (got - want).abs().max().item()
+    assert err < TOL, err
+    assert torch.equal(O.landmark_argmax(got, batch, frame), O.landmark_argmax(want, batch, frame))
+    assert (O.landmark_expected_coords(got, batch, frame) - O.landmark_expected_coords(want, batch, frame)).abs().max() < 1e-3
+
+
+def test_generic_edge_index_falls_back_to_csr_kernel():
+    """grid-diagonal graphs are not the closed form the model implies -> CSR path, same answer."""
+    hip, ref = model_pair(16, 3, 2, seed=8)
+    topo, ei, nt, bi = graph_tensors(16, 3, 2, main_type="grid-diagonal", aux_type="grid-diagonal")
+    feats = synthetic_node_feats(2 * topo.num_nodes, 128, seed=9)
+    with torch.no_grad():
+        want, _ = ref.forward_nodes(feats, ei, nt, 2)
+        got, _ = hip.forward_nodes(feats.to(DEV), ei.to(DEV), 2)
+    assert not hip._resolver.resolve(ei.to(DEV), feats.shape[0])[0].structured
+    assert (got.cpu() - want).abs().max() < TOL
+
+
+def test_empty_and_ragged_batches():
+    hip, ref = model_pair(8, 2, 2, seed=4)
+    topo, ei, nt, bi = graph_tensors(8, 2, 1)
+    feats = synthetic_node_feats(topo.num_nodes, 128, seed=1)
+    with torch.no_grad():
+        got, _ = hip.forward_nodes(feats.to(DEV), ei.to(DEV), 1)
+        want, _ = ref.forward_nodes(feats, ei, nt, 1)
+    assert (got.cpu() - want).abs().max() < TOL
+    with pytest.raises(RuntimeError):
+        hip.forward_nodes(feats[:-1].to(DEV), ei.to(DEV), 1)
+
+
+def test_round_trip_properties_at_full_size():
+    """BASELINE cfg 2 at full batch 8: size-independent checks (linearity of the aggregation,
+    frame independence, determinism) instead of an oracle run."""
+    from echoglad_amd import ops
+    B = 8
+    g = ops.Graph.topo(224, 7)
+    n = g.num_nodes
+    x = synthetic_node_feats(B * n, 128, seed=3).to(DEV)
+    y = synthetic_node_feats(B * n, 128, seed=4).to(DEV)
+    ax, ay = ops.gcn_aggregate(g, B, x), ops.gcn_aggregate(g, B, y)
+    axy = ops.gcn_aggregate(g, B, 2.0 * x - 0.5 * y)
+    assert (axy - (2.0 * ax - 0.5 * ay)).abs().max() < 1e-4
+    # A_hat is symmetric: <A x, y> == <x, A y>
+    lhs, rhs = (ax.double() * y.double()).sum(), (x.double() * ay.double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6
+    # frames are independent units: frame 3 alone == frame 3 inside the batch
+    one = ops.gcn_aggregate(g, 1, x[3 * n:4 * n].contiguous())
+    assert torch.equal(one, ax[3 * n:4 * n])
+    hip, _ = model_pair(224, 7, 3, seed=5)
+    topo, ei, nt, bi = graph_tensors(224, 7, B)
+    with torch.no_grad():
+        a, _ = hip.forward_nodes(x, ei.to(DEV), B)
+        b, _ = hip.forward_nodes(x, ei.to(DEV), B)
+        c, _ = hip.forward_nodes(x[3 * n:4 * n].contiguous(), torch.from_numpy(topo.edge_index()).to(DEV), 1)
+    assert torch.equal(a, b)
+    nv = topo.num_valid_nodes
+    assert torch.equal(a[3 * nv:4 * nv], c)

@@ -1,0 +1,169 @@
+"""The CPU oracle against the golden vectors produced by the reference's own models.py
+(tests/golden/make_golden.py) and against its independent dense fp64 restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fixtures_util import fill_state_dict, initial_coords, synthetic_frames
+from oracle import gnn_oracle as O
+from echoglad_amd.topology import HierTopology, TopologySpec
+
+
+def _oracle_model(frame, naux, layers, coord=False, main_only=False, seed=0):
+    m = O.OracleHierarchicalPatchModel(frame_size=frame, gnn_dropout_p=0.5, classifier_dropout_p=0.5,
+                                       node_embedding_dim=128, node_hidden_dim=128, num_output_channels=4,
+                                       num_gnn_layers=layers, num_aux_graphs=naux, classifier_hidden_dim=32,
+                                       use_coordinate_graph=coord, output_activation="logit",
+                                       use_main_graph_only=main_only)
+    fill_state_dict(m, seed)
+    return m.eval()
+
+
+def _graph(frame, naux, batch, coord=False, main_only=False):
+    topo = HierTopology(TopologySpec(frame, naux, main_only, coord))
+    ei = torch.from_numpy(topo.batched_edge_index(batch))
+    nt = torch.from_numpy(np.tile(topo.node_type(), batch))
+    bi = torch.arange(batch).repeat_interleave(topo.num_nodes)
+    return topo, ei, nt, bi
+
+
+def test_kat_layers_and_logits(golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_f16_a3.npz"))
+    frame, naux, L, B = int(g["frame"]), int(g["naux"]), int(g["layers"]), int(g["batch"])
+    m = _oracle_model(frame, naux, L, seed=int(g["weight_seed"]))
+    topo, ei, nt, bi = _graph(frame, naux, B)
+    frames = synthetic_frames(B, 128, frame, int(g["frame_seed"]))
+    with torch.no_grad():
+        feats = m.create_node_pixels(frames, B)
+        assert torch.allclose(feats, torch.from_numpy(g["node_feats"]), atol=1e-6)
+        logits, _, hidden = m.forward_nodes(feats, ei, nt, B, return_hidden=True)
+        # the reference's own edge order (from_networkx) vs the closed form's sorted order: fp noise only
+        logits_ref_order, _ = m.forward_nodes(feats, torch.from_numpy(g["edge_index"]), nt, B)
+    assert np.abs(logits.numpy() - g["logits"]).max() < 2e-5
+    assert np.abs(logits_ref_order.numpy() - g["logits"]).max() < 1e-6
+    for i in range(L):
+        pre_res = hidden[i + 1] - hidden[i]
+        assert np.abs(pre_res.numpy() - g[f"layer{i}"]).max() < 5e-5
+
+
+def test_gcn_sparse_vs_dense64(golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_f16_a3.npz"))
+    x = torch.from_numpy(g["node_feats"])
+    ei = torch.from_numpy(g["edge_index"])
+    rs = np.random.RandomState(3)
+    w = torch.from_numpy(rs.uniform(-0.15, 0.15, (128, 128)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(128).astype(np.float32))
+    s = O.gcn_conv_sparse(x, ei, w, b)
+    d = O.gcn_conv_dense64(x, ei, w, b)
+    assert (s.double() - d).abs().max() < 1e-5
+    m = _oracle_model(16, 3, 3, seed=int(g["weight_seed"]))
+    conv = m.gnn_layers[0].module_0
+    d0 = O.gcn_conv_dense64(x, ei, conv.lin.weight.detach(), conv.bias.detach())
+    assert np.abs(d0.numpy() - g["gcn0_dense64"]).max() < 1e-12
+
+
+def test_gcn_norm_known_answer():
+    # path graph 0-1-2: deg+1 = [2,3,2]
+    ei = torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]])
+    ei2, w = O.gcn_norm(ei, 3)
+    assert ei2.shape[1] == 7
+    dis = torch.tensor([2.0, 3.0, 2.0]).pow(-0.5)
+    assert torch.allclose(w, dis[ei2[0]] * dis[ei2[1]])
+    # existing self loops are replaced, not doubled
+    ei3, w3 = O.gcn_norm(torch.tensor([[0, 0, 1], [0, 1, 0]]), 2)
+    assert ei3.shape[1] == 4 and torch.allclose(w3, torch.full((4,), 0.5))
+
+
+def test_cfg1_plumbing(golden_dir):
+    """BASELINE config 1: single 64x64 frame, 2 aux levels, 2 GNN layers, batch 1."""
+    g = np.load(os.path.join(golden_dir, "cfg1_f64_a2.npz"))
+    frame, naux, L, B = int(g["frame"]), int(g["naux"]), int(g["layers"]), int(g["batch"])
+    m = _oracle_model(frame, naux, L, seed=int(g["weight_seed"]))
+    topo, ei, nt, bi = _graph(frame, naux, B)
+    assert topo.num_nodes == int(g["num_nodes"]) == 4116
+    frames = synthetic_frames(B, 128, frame, int(g["frame_seed"]))
+    with torch.no_grad():
+        logits, _ = m(x=frames, edge_index=ei, node_type=nt, batch_idx=bi)
+    rows = g["sample_rows"]
+    assert np.abs(logits.numpy()[rows] - g["logits_rows"]).max() < 2e-5
+    assert abs(logits.double().sum().item() - float(g["logits_sum"])) < 1e-2
+    assert np.array_equal(O.landmark_argmax(logits, B, frame).numpy(), g["argmax"])
+
+
+def test_coordinate_graph_path(golden_dir):
+    g = np.load(os.path.join(golden_dir, "coord_f32_a4.npz"))
+    frame, naux, L, B = int(g["frame"]), int(g["naux"]), int(g["layers"]), int(g["batch"])
+    m = _oracle_model(frame, naux, L, coord=True, seed=int(g["weight_seed"]))
+    topo, ei, nt, bi = _graph(frame, naux, B, coord=True)
+    frames = synthetic_frames(B, 128, frame, int(g["frame_seed"]))
+    coords0 = initial_coords(B, frame)
+    assert np.allclose(coords0.numpy(), g["coords0"])
+    with torch.no_grad():
+        logits, coords = m(x=frames, node_coords=coords0.clone(), edge_index=ei, node_type=nt, batch_idx=bi)
+    assert np.abs(coords.numpy() - g["out_coords"]).max() < 1e-4
+    assert np.abs(logits.numpy() - g["logits"]).max() < 5e-5
+    assert torch.equal(coords0, initial_coords(B, frame)), "the oracle must not mutate the caller's coords"
+
+
+def test_coordinate_graph_train_gradients(golden_dir):
+    g = np.load(os.path.join(golden_dir, "coord_f32_a4.npz"))
+    frame, naux, L, B = int(g["frame"]), int(g["naux"]), int(g["layers"]), int(g["batch"])
+    m = _oracle_model(frame, naux, L, coord=True, seed=int(g["weight_seed"]))
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.train()
+    topo, ei, nt, bi = _graph(frame, naux, B, coord=True)
+    frames = synthetic_frames(B, 128, frame, int(g["frame_seed"]))
+    logits, coords = m(x=frames, node_coords=initial_coords(B, frame), edge_index=ei, node_type=nt, batch_idx=bi)
+    assert np.abs(logits.detach().numpy() - g["train_logits"]).max() < 2e-4
+    loss = (logits ** 2).mean() + (coords ** 2).mean() * 1e-3
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-4 * max(1.0, abs(float(g["train_loss"])))
+    loss.backward()
+    gn = {k: float(p.grad.double().norm()) for k, p in m.named_parameters() if p.grad is not None}
+    for k, ref in zip(g["grad_keys"], g["grad_norms"]):
+        assert abs(gn[str(k)] - ref) <= 2e-3 * max(ref, 1e-6) + 1e-7, (k, gn[str(k)], ref)
+
+
+def test_main_graph_only(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mainonly_f16.npz"))
+    frame, naux, L, B = int(g["frame"]), int(g["naux"]), int(g["layers"]), int(g["batch"])
+    m = _oracle_model(frame, naux, L, main_only=True, seed=int(g["weight_seed"]))
+    topo, ei, nt, bi = _graph(frame, naux, B, main_only=True)
+    frames = synthetic_frames(B, 128, frame, int(g["frame_seed"]))
+    with torch.no_grad():
+        logits, _ = m(x=frames, edge_index=ei, node_type=nt, batch_idx=bi)
+    assert np.abs(logits.numpy() - g["logits"]).max() < 2e-5
+
+
+def test_dense_bilinear_equals_four_taps():
+    """models.py:539-553 is a 4-tap bilinear sample incl. the clamped edges 0 and F-1."""
+    rs = np.random.RandomState(0)
+    S = 12
+    frame = torch.from_numpy(rs.standard_normal((5, S, S)).astype(np.float32))
+    coords = torch.tensor([[0.0, 0.0], [S - 1.0, S - 1.0], [3.25, 7.75], [10.999, 0.001], [5.0, 11.0]])
+    dense = O.bilinear_interpolation_dense(coords, frame)
+    for p, (h, w) in enumerate(coords.tolist()):
+        h0, w0 = int(np.floor(h)), int(np.floor(w))
+        acc = torch.zeros(5)
+        for hh, wh in ((h0, 1 - (h - h0)), (h0 + 1, h - h0)):
+            for ww, wwt in ((w0, 1 - (w - w0)), (w0 + 1, w - w0)):
+                if hh < S and ww < S:
+                    acc += wh * wwt * frame[:, hh, ww]
+        assert torch.allclose(dense[p], acc, atol=1e-5)
+
+
+def test_argmax_fixture_with_near_ties():
+    B, F = 2, 8
+    rs = np.random.RandomState(1)
+    logits = torch.from_numpy(rs.standard_normal((B * (4 + 16 + F * F), 4)).astype(np.float32))
+    per = logits.view(B, -1, 4)
+    per[0, -1, 0] = 50.0
+    per[0, -2, 0] = 50.0 - 1e-5          # near tie: the larger one must win
+    per[1, 20 + 7, 3] = 60.0
+    idx = O.landmark_argmax(logits, B, F)
+    assert idx[0, 0].item() == F * F - 1 and idx[1, 3].item() == 7
+    e = O.landmark_expected_coords(logits, B, F)
+    assert e.shape == (B, 4, 2) and (e >= 0).all() and (e <= F - 1).all()
