@@ -68,8 +68,7 @@ def cpu_baseline(args, kw, state_dict):
     from oracle import gnn_oracle as O
     from echoglad_amd.topology import TopologySpec, get_topology
     from fixtures_util import synthetic_node_feats
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    avail = os.cpu_count() or 1
     ref = O.OracleHierarchicalPatchModel(**kw)
     ref.load_state_dict({k: v.cpu() for k, v in state_dict.items()}, strict=True)
     ref.eval()
@@ -78,18 +77,32 @@ def cpu_baseline(args, kw, state_dict):
     ei = torch.from_numpy(topo.batched_edge_index(B))
     nt = torch.from_numpy(np.tile(topo.node_type(), B))
     feats = synthetic_node_feats(B * topo.num_nodes, C, seed=200)
-    times = []
+    # torch's CPU index_add_/index_select stop scaling (and regress) with very many threads, so a few
+    # thread counts are probed once and the fastest is used for the timed runs
+    probe = {}
     with torch.no_grad():
-        ref.forward_nodes(feats, ei, nt, B)                      # warm-up
-        t_end = time.perf_counter() + 20.0
-        while len(times) < 5 and (time.perf_counter() < t_end or len(times) < 2):
+        for th in sorted({min(avail, t) for t in (8, 16, 32, 64)}):
+            torch.set_num_threads(th)
+            ref.forward_nodes(feats, ei, nt, B)                  # warm-up at this thread count
+            t0 = time.perf_counter()
+            ref.forward_nodes(feats, ei, nt, B)
+            probe[th] = time.perf_counter() - t0
+            if sum(probe.values()) > 25.0:
+                break
+        cores = min(probe, key=probe.get)
+        torch.set_num_threads(cores)
+        times = [probe[cores]]
+        t_end = time.perf_counter() + 10.0
+        while len(times) < 5 and time.perf_counter() < t_end:
             t0 = time.perf_counter()
             out, _ = ref.forward_nodes(feats, ei, nt, B)
             times.append(time.perf_counter() - t0)
+        out, _ = ref.forward_nodes(feats, ei, nt, B)
     best = min(times)
     return {"value": round(B / best, 3), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{B} frames of the same workload (F={args.frame}, naux={args.naux}, L={args.layers}), "
-                      f"min of {len(times)} runs after 1 warm-up, torch CPU fp32 {cores} threads"}, out, feats, ei
+                      f"min of {len(times)} runs after warm-up, torch CPU fp32, {cores} threads "
+                      f"(fastest of the probed thread counts {sorted(probe)} on {avail} host cores)"}, out, feats, ei
 
 
 def main():

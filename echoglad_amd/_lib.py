@@ -11,7 +11,7 @@ from pathlib import Path
 from typing import Dict, List, Optional
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libechoglad_hip.so"
+LIB_PATH = Path(os.environ.get("ECHOGLAD_LIB", _PKG / "lib" / "libechoglad_hip.so"))
 HEADER_PATH = _PKG.parent / "include" / "echoglad_hip.h"
 
 EG_OK, EG_ERR_ARG, EG_ERR_UNSUPPORTED, EG_ERR_HIP = 0, -1, -2, -3

@@ -38,13 +38,15 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: str = "") -> Path:
+    """variant != "": an experiment build (extra -D flags) written to lib/libechoglad_hip.<variant>.so;
+    select it at run time with ECHOGLAD_LIB=<path>."""
     LIBDIR.mkdir(exist_ok=True)
-    objdir = LIBDIR / "obj"
+    objdir = LIBDIR / ("obj" + ("_" + variant if variant else ""))
     objdir.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.h")) + [PKG.parent / "include" / "echoglad_hip.h"]
     cc = hipcc()
-    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", *extra_flags]
     if verbose:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     objs = []
@@ -66,7 +68,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             print(out, flush=True)
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    target = lib_path()
+    target = lib_path() if not variant else LIBDIR / f"libechoglad_hip.{variant}.so"
     if force or _stale(target, objs):
         cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(target), *map(str, objs)]
         if verbose:
@@ -76,5 +78,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    p = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+    var = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")]
+    p = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, extra_flags=extra,
+              variant=var[0] if var else "")
     print(p)

@@ -25,7 +25,21 @@ int set_error(int code, const std::string& msg);
 // Closed-form hierarchical topology.  Kernels read a device copy through a const
 // pointer: every field is wave-uniform, so the accesses are scalar loads (a by-value
 // kernel argument would be spilled to scratch by the dynamic level indexing).
+// Per-level constants of the implicit stencil, 16 ints so one s_load_dwordx16 fetches a level.
+//   parent of (r,c):   pbase + (poff + (r>>1))*pside + poff + (c>>1)      iff r < plim && c < plim
+//   children of (r,c): cbase + 2(r-clo)*cside + 2(c-clo) (+1, +cside, +cside+1) iff clo <= r,c < chi
+struct LevelDesc {
+    int base, end, side, kind;        // node ids [base, end); kind: 0 aux, 1 main, 2 coordinate nodes
+    int lg;                           // log2(side) for aux levels
+    int pbase, pside, poff, plim;
+    int cbase, cside, clo, chi;
+    int pad0, pad1, pad2;
+};
+
 struct Topo {
+    int n_desc;              // aux levels + main (+ coordinate pseudo-level)
+    int pad_[3];
+    LevelDesc desc[MAX_LEVELS + 1];
     int n_nodes;             // nodes per frame, incl. coordinate nodes
     int n_levels;            // aux levels + 1
     int n_aux;               // 0 when use_main_graph_only

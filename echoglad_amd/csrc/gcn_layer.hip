@@ -45,6 +45,13 @@ __device__ inline f32x2 produce_row(const float* __restrict__ dis, const int* __
     else return load_row2(xf, n, lane);
 }
 
+// One workgroup = 4 waves walks 64-row tiles (persistent, XCD-aware order).  Per tile:
+//   phase 1  each wave aggregates its 16 rows (natural layout: one row = one 512-B wave access) -> LDS
+//   phase 2  each wave: its 32 output channels x 64 rows on the fp32 MFMA (W slice in registers)
+//   phase 3  accumulators go back through the same LDS tile so the epilogue runs in the natural
+//            layout again: per-lane scale/shift, ReLU, residual, and full-row (512 B) coalesced
+//            residual loads / output stores.  A wave touches only its own 16 rows in phases 3 and 1,
+//            so no barrier separates a tile's phase 3 from the next tile's phase 1.
 template <int AGG>
 __global__ __launch_bounds__(256) void k_gcn_layer(const float* __restrict__ x, const float* __restrict__ W,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
@@ -53,19 +60,16 @@ __global__ __launch_bounds__(256) void k_gcn_layer(const float* __restrict__ x, 
                                                    const int* __restrict__ colidx, const Topo* __restrict__ T,
                                                    const LayerDims a) {
     __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA];
-    __shared__ __attribute__((aligned(16))) float s_scale[C];
-    __shared__ __attribute__((aligned(16))) float s_shift[C];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = wave_id();
+    const int j = lane & 31, h = lane >> 5;
 
     float wreg[64];
     load_w_slice(W, wave, lane, a.transpose_w, wreg);
-    if (tid < C) {
-        s_scale[tid] = scale ? scale[tid] : 1.0f;
-        s_shift[tid] = shift ? shift[tid] : 0.0f;
-    }
+    const f32x2 sc = scale ? *reinterpret_cast<const f32x2*>(scale + 2 * lane) : f32x2{1.f, 1.f};
+    const f32x2 sh = shift ? *reinterpret_cast<const f32x2*>(shift + 2 * lane) : f32x2{0.f, 0.f};
 
     TileWalk walk(a.tiles_per_frame * a.batch);
     int tile;
@@ -74,44 +78,46 @@ __global__ __launch_bounds__(256) void k_gcn_layer(const float* __restrict__ x, 
         const int n0 = (tile - frame * a.tiles_per_frame) * TILE;
         const size_t frame_row0 = (size_t)frame * a.n_per_frame;
         const float* __restrict__ xf = x + frame_row0 * C;
+        const int rows_here = (a.n_per_frame - n0) < TILE ? (a.n_per_frame - n0) : TILE;
+        const int rl0 = wave * (TILE / 4);
+        const int rl1 = (rl0 + TILE / 4) < rows_here ? (rl0 + TILE / 4) : rows_here;
 
-        // ---- phase 1: this wave's 16 rows of the aggregated tile -> LDS
+        // ---- phase 1
+        if constexpr (AGG == AGG_STENCIL) {
+            stencil_run_to_lds(T, xf, dis, n0 + rl0, rl0, rl1, lane, s_a);
+        } else {
 #pragma unroll 2
-        for (int q = 0; q < TILE / 4; ++q) {
-            const int rl = wave * (TILE / 4) + q;
-            int n = n0 + rl;
-            n = n < a.n_per_frame ? n : a.n_per_frame - 1;       // ragged last tile: recompute the last row
-            const f32x2 v = produce_row<AGG>(dis, rowptr, colidx, T, xf, n, lane);
-            *reinterpret_cast<f32x2*>(&s_a[rl * LDA + 2 * lane]) = v;
-        }
-        __syncthreads();
-
-        // ---- phase 2: two 32-row blocks, this wave's 32 output channels
-        const int j = lane & 31, h = lane >> 5;
-#pragma unroll 1
-        for (int rb = 0; rb < TILE / 32; ++rb) {
-            if (n0 + rb * 32 >= a.n_per_frame) break;           // uniform
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            mfma_rowblock(s_a, rb * 32, lane, wreg, acc);
-            const int n = n0 + rb * 32 + j;
-            if (n < a.n_per_frame) {
-                const size_t off = (frame_row0 + n) * C;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch0 = 32 * wave + 8 * g + 4 * h;
-                    f32x4 v = {acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(&s_scale[ch0]);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(&s_shift[ch0]);
-                    v = v * sc + sh;
-                    if (a.relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                    if (residual) v += *reinterpret_cast<const f32x4*>(residual + off + ch0);
-                    *reinterpret_cast<f32x4*>(out + off + ch0) = v;
-                }
+            for (int rl = rl0; rl < rl1; ++rl) {
+                const f32x2 v = produce_row<AGG>(dis, rowptr, colidx, T, xf, n0 + rl, lane);
+                *reinterpret_cast<f32x2*>(&s_a[rl * LDA + 2 * lane]) = v;
             }
         }
         __syncthreads();
+
+        // ---- phase 2 (rows beyond rows_here hold stale data; their accumulator columns are never read back)
+        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc1 = acc0;
+        mfma_rowblock(s_a, 0, lane, wreg, acc0);
+        if (rows_here > 32) mfma_rowblock(s_a, 32, lane, wreg, acc1);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch0 = 32 * wave + 8 * g + 4 * h;
+            *reinterpret_cast<f32x4*>(&s_a[j * LDA + ch0]) = f32x4{acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(&s_a[(32 + j) * LDA + ch0]) = f32x4{acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+        }
+        __syncthreads();
+
+        // ---- phase 3
+        const size_t tile_off = (frame_row0 + n0) * C + 2 * lane;
+#pragma unroll 8
+        for (int rl = rl0; rl < rl1; ++rl) {
+            f32x2 v = *reinterpret_cast<const f32x2*>(&s_a[rl * LDA + 2 * lane]);
+            v = v * sc + sh;
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+            if (residual) v += *reinterpret_cast<const f32x2*>(residual + tile_off + (size_t)rl * C);
+            *reinterpret_cast<f32x2*>(out + tile_off + (size_t)rl * C) = v;
+        }
     }
 }
 

@@ -59,6 +59,31 @@ static int build_topo(int frame, int naux, int main_only, int coord_nodes, Topo&
         py_slice(p, c0, c0 + half, lo, hi);
         T.crop0 = lo; T.ncrop = hi - lo;
     }
+    // per-level descriptors for the run-based stencil
+    T.n_desc = T.n_levels + (T.coord_base < T.n_nodes ? 1 : 0);
+    for (int l = 0; l < T.n_levels; ++l) {
+        LevelDesc& d = T.desc[l];
+        d = LevelDesc{};
+        const bool is_main = (l == T.n_levels - 1);
+        d.base = T.base[l];
+        d.side = T.side[l];
+        d.end = is_main ? T.coord_base : T.base[l + 1];
+        d.kind = is_main ? 1 : 0;
+        d.lg = is_main ? 0 : l + 1;
+        if (is_main) {
+            if (T.n_aux > 0) { d.pbase = T.base[l - 1]; d.pside = T.side[l - 1]; d.poff = T.crop0; d.plim = 2 * T.ncrop; }
+        } else {
+            if (l > 0) { d.pbase = T.base[l - 1]; d.pside = T.side[l - 1]; d.poff = 0; d.plim = d.side; }
+            d.cbase = T.base[l + 1]; d.cside = T.side[l + 1];
+            if (l + 1 < T.n_levels - 1) { d.clo = 0; d.chi = d.side; }
+            else { d.clo = T.crop0; d.chi = T.crop0 + T.ncrop; }
+        }
+    }
+    if (T.n_desc > T.n_levels) {
+        LevelDesc& d = T.desc[T.n_levels];
+        d = LevelDesc{};
+        d.base = T.coord_base; d.end = T.n_nodes; d.side = 4; d.kind = 2;
+    }
     return EG_OK;
 }
 

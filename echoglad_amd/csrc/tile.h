@@ -29,8 +29,11 @@ enum Agg { AGG_NONE = 0, AGG_CSR = 1, AGG_STENCIL = 2 };
 __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---- phase 1: one aggregated row (channels 2*lane, 2*lane+1) ---------------------
+// 32-bit element offset from a wave-uniform base: lets the compiler use the SGPR-base + VGPR-offset
+// addressing form (one VGPR per load instead of a 64-bit address pair).  rows * 128 < 2^31 is checked on the host.
 __device__ inline f32x2 load_row2(const float* __restrict__ base, int row, int lane) {
-    return *reinterpret_cast<const f32x2*>(base + (size_t)row * C + 2 * lane);
+    const unsigned off = (unsigned)row * (unsigned)C + 2u * (unsigned)lane;
+    return *reinterpret_cast<const f32x2*>(base + off);
 }
 
 // out_i = d_i * sum_{j in N(i) u {i}} d_j x_j   — implicit topology, no index loads
@@ -57,6 +60,108 @@ __device__ inline f32x2 agg_stencil(const Topo* __restrict__ Tp, const float* __
 #pragma unroll
     for (int s = 5; s >= 0; --s) acc += w[s] * v[s];
     return acc * w[0];
+}
+
+// ---- run-based implicit stencil -------------------------------------------------------
+// A wave aggregates a run of consecutive node ids.  The level lookup and the (row, col)
+// decode (one s_load_dwordx16 of the level descriptor, one magic division) happen once per
+// run or level change; after that the position advances incrementally on the scalar unit.
+// Loads of several nodes are issued together so one wave keeps ~20 row loads (512 B each)
+// in flight.
+enum { KIND_AUX = 0, KIND_MAIN = 1, KIND_COORD = 2 };
+#ifndef EG_MAIN_U
+#define EG_MAIN_U 2      // main-grid nodes aggregated per batch of loads (2 keeps the kernel at 3 waves/SIMD)
+#endif
+
+struct RunPos { int n, r, c; };
+
+__device__ inline LevelDesc run_decode(const Topo* __restrict__ T, int n, RunPos& p) {
+    const int nd = T->n_desc;
+    int l = 0;
+#pragma unroll 1
+    for (int q = 1; q < nd; ++q) l += (n >= T->desc[q].base) ? 1 : 0;
+    const LevelDesc d = T->desc[l];
+    const int idx = n - d.base;
+    const int r_main = (int)(((unsigned long long)(unsigned)idx * T->magic) >> 40);
+    const int r_aux = idx >> d.lg;
+    const int r = d.kind == KIND_MAIN ? r_main : (d.kind == KIND_AUX ? r_aux : 0);
+    p.n = n; p.r = r; p.c = idx - r * d.side;
+    return d;
+}
+
+__device__ inline void run_advance(const LevelDesc& d, RunPos& p) {
+    ++p.n; ++p.c;
+    const bool wrap = (p.c == d.side);
+    p.c = wrap ? 0 : p.c;
+    p.r = wrap ? p.r + 1 : p.r;
+}
+
+// slots: 0 self, 1 up, 2 down, 3 left, 4 right, 5 parent, 6..9 children.  Invalid slots point at the node itself.
+template <int NS>
+__device__ inline void run_slots(const LevelDesc& d, const RunPos& p, int (&id)[NS], int (&valid)[NS]) {
+    const int n = p.n, r = p.r, c = p.c;
+    const bool grid = d.kind != KIND_COORD;
+    id[0] = n; valid[0] = 1;
+    // coordinate pseudo-level: slots 1..4 are the four coordinate nodes (self masked), no parent / children
+    valid[1] = grid ? (r > 0) : (d.base + 0 != n);            id[1] = grid ? (valid[1] ? n - d.side : n) : d.base + 0;
+    valid[2] = grid ? (r < d.side - 1) : (d.base + 1 != n);   id[2] = grid ? (valid[2] ? n + d.side : n) : d.base + 1;
+    valid[3] = grid ? (c > 0) : (d.base + 2 != n);            id[3] = grid ? (valid[3] ? n - 1 : n) : d.base + 2;
+    valid[4] = grid ? (c < d.side - 1) : (d.base + 3 != n);   id[4] = grid ? (valid[4] ? n + 1 : n) : d.base + 3;
+    valid[5] = (r < d.plim) && (c < d.plim);
+    id[5] = valid[5] ? d.pbase + (d.poff + (r >> 1)) * d.pside + d.poff + (c >> 1) : n;
+    if constexpr (NS > 6) {
+        const int has = (r >= d.clo) && (r < d.chi) && (c >= d.clo) && (c < d.chi);
+        const int b = has ? d.cbase + 2 * (r - d.clo) * d.cside + 2 * (c - d.clo) : n;
+        const int cs = has ? d.cside : 0;
+        id[6] = b; id[7] = b + has; id[8] = b + cs; id[9] = b + cs + has;
+        valid[6] = valid[7] = valid[8] = valid[9] = has;
+    }
+}
+
+// U consecutive nodes of one level, NS slots each; results to LDS rows rl .. rl+U-1
+template <int U, int NS>
+__device__ inline void run_group(const LevelDesc& d, RunPos& p, const float* __restrict__ xf,
+                                 const float* __restrict__ dis, int lane, float* s_a, int rl) {
+    float w[U][NS];
+    f32x2 v[U][NS];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int id[NS], valid[NS];
+        run_slots<NS>(d, p, id, valid);
+        run_advance(d, p);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float dd = dis[id[s]];
+            w[u][s] = valid[s] ? dd : 0.0f;
+            v[u][s] = load_row2(xf, id[s], lane);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int s = NS - 1; s >= 0; --s) acc += w[u][s] * v[u][s];
+        *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = acc * w[u][0];
+    }
+}
+
+// rows [rl, rl_end) of the LDS tile <- aggregated rows of nodes n_first, n_first+1, ...
+__device__ inline void stencil_run_to_lds(const Topo* __restrict__ T, const float* __restrict__ xf,
+                                          const float* __restrict__ dis, int n_first, int rl, int rl_end, int lane,
+                                          float* s_a) {
+    if (rl >= rl_end) return;
+    RunPos p;
+    LevelDesc d = run_decode(T, n_first, p);
+    while (rl < rl_end) {
+        if (p.n >= d.end) d = run_decode(T, p.n, p);
+        const int left = rl_end - rl, in_level = d.end - p.n;
+        const int avail = left < in_level ? left : in_level;
+        if (d.kind == KIND_MAIN && avail >= EG_MAIN_U) { run_group<EG_MAIN_U, 6>(d, p, xf, dis, lane, s_a, rl); rl += EG_MAIN_U; }
+#ifndef EG_NO_GEN2
+        else if (avail >= 2) { run_group<2, MAX_SLOTS>(d, p, xf, dis, lane, s_a, rl); rl += 2; }
+#endif
+        else { run_group<1, MAX_SLOTS>(d, p, xf, dis, lane, s_a, rl); rl += 1; }
+    }
 }
 
 // generic CSR (by target).  rowptr/colidx/dis are wave-uniform reads.
@@ -102,18 +207,39 @@ __device__ inline void load_w_slice(const float* __restrict__ W, int wave, int l
     }
 }
 
-// acc[m][n]: n = lane&31 = row (row0 + n), m = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel within the wave's 32
+// acc[m][n]: n = lane&31 = row (row0 + n), m = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel within the wave's 32.
+// The 16 ds_read_b128 are software-pipelined in chunks of 4 (two named fragment sets) so that at most
+// 32 VGPRs hold A fragments while the 64-cycle MFMAs of the previous chunk cover the LDS latency.
+__device__ inline void mfma_chunk(const f32x4 (&av)[4], const float (&wreg)[64], int t0, f32x16& acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 0], av[t].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 1], av[t].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 2], av[t].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 3], av[t].w, acc, 0, 0, 0);
+    }
+}
+
 __device__ inline void mfma_rowblock(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc) {
     const int j = lane & 31, h = lane >> 5;
     const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
+    f32x4 a0[4], a1[4];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const f32x4 av = ap[t];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * t + 0], av.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * t + 1], av.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * t + 2], av.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * t + 3], av.w, acc, 0, 0, 0);
-    }
+    for (int t = 0; t < 4; ++t) a0[t] = ap[t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a0, wreg, 0, acc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a1, wreg, 4, acc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a0, wreg, 8, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a1, wreg, 12, acc);
 }
 
 // XCD-aware persistent tile walk: workgroups with equal blockIdx % 8 share an XCD (and its
