@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k_classifier(const ClsArgs a) {
     __shared__ __attribute__((aligned(16))) float s_t2[64];
     __shared__ __attribute__((aligned(16))) float s_w3[64];
     __shared__ __attribute__((aligned(16))) float s_out[TILE * 4];
+    __shared__ int s_slot;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void k_classifier(const ClsArgs a) {
     }
     const float b3 = a.b3[wave];
 
-    TileWalk walk(a.tiles_per_frame * a.batch);
+    TileWalk walk(WALK_MOD8, a.tiles_per_frame * a.batch, nullptr, &s_slot);
     int tile;
     while (walk.next(tile)) {
         const int frame = tile / a.tiles_per_frame;

@@ -149,4 +149,5 @@ struct eg_graph {
     int* rowptr;              // device [n_nodes+1] kind == GRAPH_CSR
     int* colidx;              // device [nnz]
     int64_t nnz;
+    int* walk_counters;       // device [8 x 32] per-XCD tile queue heads, zeroed before every launch
 };

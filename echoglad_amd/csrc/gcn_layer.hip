@@ -3,6 +3,8 @@
 // Replaces torch_geometric GCNConv + BatchNorm1d + ReLU + residual as used at
 // reference src/core/models.py:328-335, :431-435.  A_hat (X W^T) == (A_hat X) W^T, so the
 // aggregation runs first on the layer input and its result never leaves LDS.
+#include <stdlib.h>
+
 #include "tile.h"
 
 namespace eg {
@@ -23,6 +25,7 @@ struct LayerDims {
     int tiles_per_frame;
     int relu;
     int transpose_w;
+    int walk_mode;
 };
 
 struct LayerArgs {         // host-side bundle only
@@ -34,6 +37,7 @@ struct LayerArgs {         // host-side bundle only
     float* out;
     GraphPtrs gp;
     LayerDims d;
+    int* walk_counters;
 };
 
 template <int AGG>
@@ -58,8 +62,8 @@ __global__ __launch_bounds__(256) void k_gcn_layer(const float* __restrict__ x, 
                                                    const float* __restrict__ residual, float* __restrict__ out,
                                                    const float* __restrict__ dis, const int* __restrict__ rowptr,
                                                    const int* __restrict__ colidx, const Topo* __restrict__ T,
-                                                   const LayerDims a) {
-    __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA];
+                                                   int* __restrict__ walk_counters, const LayerDims a) {
+    __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA + 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void k_gcn_layer(const float* __restrict__ x, 
     const f32x2 sc = scale ? *reinterpret_cast<const f32x2*>(scale + 2 * lane) : f32x2{1.f, 1.f};
     const f32x2 sh = shift ? *reinterpret_cast<const f32x2*>(shift + 2 * lane) : f32x2{0.f, 0.f};
 
-    TileWalk walk(a.tiles_per_frame * a.batch);
+    TileWalk walk(a.walk_mode, a.tiles_per_frame * a.batch, walk_counters, reinterpret_cast<int*>(&s_a[TILE * LDA]));
     int tile;
     while (walk.next(tile)) {
         const int frame = tile / a.tiles_per_frame;
@@ -139,19 +143,30 @@ __global__ __launch_bounds__(256) void k_aggregate(const float* __restrict__ x, 
     }
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// Persistent grid: what is resident at once (256 CUs x 3 workgroups at this kernel's register
+// budget).  A larger grid would run a second, under-occupied round.
 static int grid_for_tiles(long long n_tiles) {
-    long long g = n_tiles < 1024 ? n_tiles : 1024;          // 256 CUs x 4 resident workgroups
-    g = (g + 7) / 8 * 8;                                     // TileWalk groups of 8
+    const long long cap = env_int("EG_GRID", 768);
+    long long g = n_tiles < cap ? n_tiles : cap;
+    g = (g + 7) / 8 * 8;                                     // static walk modes use groups of 8
     return (int)g;
 }
 
-#define LAYER_KARGS a.x, a.W, a.scale, a.shift, a.residual, a.out, a.gp.dis, a.gp.rowptr, a.gp.colidx, a.gp.topo, a.d
+#define LAYER_KARGS a.x, a.W, a.scale, a.shift, a.residual, a.out, a.gp.dis, a.gp.rowptr, a.gp.colidx, a.gp.topo, a.walk_counters, a.d
 
 static int launch_layer(int agg, LayerArgs& a, hipStream_t stream) {
     const long long n_tiles = (long long)a.d.tiles_per_frame * a.d.batch;
     if (n_tiles <= 0) return EG_OK;
     if (n_tiles >= (1ll << 31)) return set_error(EG_ERR_ARG, "too many tiles");
     const dim3 grid(grid_for_tiles(n_tiles)), block(256);
+    a.d.walk_mode = a.walk_counters ? env_int("EG_WALK_MODE", WALK_QUEUE) : WALK_MOD8;
+    if (a.d.walk_mode == WALK_QUEUE)
+        EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * WALK_GROUPS * WALK_CTR_STRIDE, stream));
     switch (agg) {
         case AGG_NONE: hipLaunchKernelGGL(k_gcn_layer<AGG_NONE>, grid, block, 0, stream, LAYER_KARGS); break;
         case AGG_CSR: hipLaunchKernelGGL(k_gcn_layer<AGG_CSR>, grid, block, 0, stream, LAYER_KARGS); break;
@@ -169,6 +184,7 @@ static int fill_graph_args(const eg_graph* g, int batch, LayerArgs& a, int& agg)
     a.gp.rowptr = g->rowptr;
     a.gp.colidx = g->colidx;
     a.gp.topo = g->topo_dev;
+    a.walk_counters = g->walk_counters;
     a.d.n_per_frame = (int)g->n_nodes;
     a.d.batch = batch;
     a.d.tiles_per_frame = (int)((g->n_nodes + TILE - 1) / TILE);

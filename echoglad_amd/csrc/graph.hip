@@ -150,11 +150,13 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
     g->topo = T;
     hipError_t e = hipMalloc((void**)&g->dis, sizeof(float) * T.n_nodes);
     if (e == hipSuccess) e = hipMemcpy(g->dis, dis.data(), sizeof(float) * T.n_nodes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->walk_counters, sizeof(int) * 8 * 32);
     if (e == hipSuccess) e = hipMalloc((void**)&g->topo_dev, sizeof(Topo));
     if (e == hipSuccess) e = hipMemcpy(g->topo_dev, &T, sizeof(Topo), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (g->dis) (void)hipFree(g->dis);
         if (g->topo_dev) (void)hipFree(g->topo_dev);
+        if (g->walk_counters) (void)hipFree(g->walk_counters);
         delete g;
         return set_error(EG_ERR_HIP, std::string("eg_topo_create: ") + hipGetErrorString(e));
     }
@@ -187,6 +189,7 @@ int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream
             if (g->dis) (void)hipFree(g->dis);
             if (g->rowptr) (void)hipFree(g->rowptr);
             if (g->colidx) (void)hipFree(g->colidx);
+            if (g->walk_counters) (void)hipFree(g->walk_counters);
             delete g;
         }
     };
@@ -206,6 +209,7 @@ int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream
     CSR_TRY(hipMalloc((void**)&g->colidx, sizeof(int) * mm));
     CSR_TRY(hipMalloc((void**)&g->rowptr, sizeof(int) * ((size_t)n + 1)));
     CSR_TRY(hipMalloc((void**)&g->dis, sizeof(float) * (size_t)n));
+    CSR_TRY(hipMalloc((void**)&g->walk_counters, sizeof(int) * 8 * 32));
     CSR_TRY(hipMemsetAsync(counts, 0, sizeof(int) * ((size_t)n + 1), stream));
     if (m > 0) {
         hipLaunchKernelGGL(k_edge_keys, dim3((m + 255) / 256), dim3(256), 0, stream, ei, n_edges, n, keys, vals, counts);
@@ -244,6 +248,7 @@ int eg_graph_destroy(eg_graph* g) {
     if (!g) return EG_OK;
     if (g->dis) (void)hipFree(g->dis);
     if (g->topo_dev) (void)hipFree(g->topo_dev);
+    if (g->walk_counters) (void)hipFree(g->walk_counters);
     if (g->rowptr) (void)hipFree(g->rowptr);
     if (g->colidx) (void)hipFree(g->colidx);
     delete g;

@@ -242,24 +242,69 @@ __device__ inline void mfma_rowblock(const float* s_a, int row0, int lane, const
     mfma_chunk(a1, wreg, 12, acc);
 }
 
-// XCD-aware persistent tile walk: workgroups with equal blockIdx % 8 share an XCD (and its
-// L2) under round-robin dispatch, so each such group walks one contiguous chunk of tiles —
-// vertically adjacent grid rows are then served from the same L2.  Pure speed choice.
+// ---- persistent tile walk ------------------------------------------------------------------
+// Tiles that are neighbours in the node order share halo rows (grid rows +-1, parents), so they
+// should be processed on the SAME XCD (same L2) at about the same time.  Three modes:
+//   WALK_QUEUE   (default) each XCD owns one contiguous chunk of tiles; a workgroup reads the XCD it
+//                really runs on (HW_REG_XCC_ID) and claims the next tile of that chunk from a
+//                per-XCD device counter (stealing from other chunks once its own is drained).
+//                Placement-independent for correctness, load-balanced, no assumption on dispatch order.
+//   WALK_MOD8    static: blockIdx % 8 labels the chunk (round-robin dispatch heuristic)
+//   WALK_STRIDE  static: tile = blockIdx + k * gridDim
+enum { WALK_QUEUE = 0, WALK_MOD8 = 1, WALK_STRIDE = 2 };
+constexpr int WALK_GROUPS = 8;
+constexpr int WALK_CTR_STRIDE = 32;     // ints between counters: one 128-B line each
+
+__device__ inline int xcc_id() {
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): id 20, offset 0, size 4
+    return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;
+}
+
 struct TileWalk {
-    int chunk, base, local, stride, n_tiles;
-    __device__ TileWalk(int n_tiles_) : n_tiles(n_tiles_) {
-        const int groups = 8;
-        const int g = blockIdx.x % groups, slot = blockIdx.x / groups;
-        stride = (gridDim.x + groups - 1 - g) / groups;      // workgroups in this group
-        chunk = (n_tiles + groups - 1) / groups;
-        base = g * chunk;
-        local = slot;
+    int mode, n_tiles, chunk;
+    int base, local, stride;        // static modes
+    int group;                      // queue mode: home chunk
+    int* counters;
+    int* s_slot;                    // one int of LDS, written by thread 0
+
+    __device__ TileWalk(int mode_, int n_tiles_, int* counters_, int* s_slot_)
+        : mode(mode_), n_tiles(n_tiles_), counters(counters_), s_slot(s_slot_) {
+        chunk = (n_tiles + WALK_GROUPS - 1) / WALK_GROUPS;
+        if (mode == WALK_MOD8) {
+            const int g = blockIdx.x % WALK_GROUPS;
+            stride = (gridDim.x + WALK_GROUPS - 1 - g) / WALK_GROUPS;
+            base = g * chunk; local = blockIdx.x / WALK_GROUPS;
+        } else if (mode == WALK_STRIDE) {
+            stride = gridDim.x; base = 0; local = blockIdx.x; chunk = n_tiles;
+        } else {
+            group = xcc_id(); base = local = stride = 0;
+        }
     }
+
+    // All threads of the workgroup must call this together (it contains a barrier in queue mode).
     __device__ bool next(int& tile) {
-        if (local >= chunk) return false;
-        tile = base + local;
-        local += stride;
-        return tile < n_tiles;
+        if (mode != WALK_QUEUE) {
+            if (local >= chunk) return false;
+            tile = base + local;
+            local += stride;
+            return tile < n_tiles;
+        }
+        if (threadIdx.x == 0) {
+            int t = -1;
+            for (int k = 0; k < WALK_GROUPS && t < 0; ++k) {
+                const int q = (group + k) % WALK_GROUPS;
+                const int lo = q * chunk;
+                const int size = (n_tiles - lo) < chunk ? (n_tiles - lo) : chunk;
+                if (size <= 0) continue;
+                const int got = atomicAdd(&counters[q * WALK_CTR_STRIDE], 1);
+                if (got < size) t = lo + got;
+            }
+            *s_slot = t;
+        }
+        __syncthreads();
+        tile = *s_slot;
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        return tile >= 0;
     }
 };
 
