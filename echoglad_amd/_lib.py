@@ -31,8 +31,11 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_graph_destroy": (_i, [_p]),
     "eg_graph_num_nodes": (_i64, [_p]),
     "eg_graph_is_structured": (_i, [_p]),
+    "eg_graph_num_tiles": (_i64, [_p]),
     "eg_graph_deg_inv_sqrt": (_i, [_p, _p, _p]),
     "eg_edge_hash": (_i, [_p, _i64, _p, _p]),
+    "eg_debug_xcc": (_i, [_p, _i, _p]),
+    "eg_debug_phase_cycles": (_i, [_p, ct.POINTER(ct.c_uint64), _i]),
     "eg_gcn_layer_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "eg_gcn_aggregate": (_i, [_p, _i, _p, _p, _p]),
     "eg_linear128_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _i, _i, _p, _p]),

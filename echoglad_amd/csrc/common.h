@@ -36,6 +36,12 @@ struct LevelDesc {
     int pad0, pad1, pad2;
 };
 
+// One 8x8 (or smaller, at level edges) patch of one level: the unit of work of the fused layer kernel.
+// LDS row rl = 8*tr + u  <->  node id  desc[level].base + (r0 + tr) * side + c0 + u,  tr < nrows, u < ncols.
+struct TileDesc {
+    int level, r0, c0, nrows, ncols, pad0, pad1, pad2;
+};
+
 struct Topo {
     int n_desc;              // aux levels + main (+ coordinate pseudo-level)
     int pad_[3];
@@ -145,6 +151,8 @@ struct eg_graph {
     int64_t n_nodes;          // per frame (topo) / total (csr)
     eg::Topo topo;            // kind == GRAPH_TOPO (host copy)
     eg::Topo* topo_dev;       // device copy read by the kernels through scalar loads
+    eg::TileDesc* tiles_dev;  // device [n_tiles] 2-D patch table of one frame (kind == GRAPH_TOPO)
+    int n_tiles;
     float* dis;               // device [n_nodes]   (deg+1)^-1/2
     int* rowptr;              // device [n_nodes+1] kind == GRAPH_CSR
     int* colidx;              // device [nnz]

@@ -17,6 +17,7 @@ struct GraphPtrs {
     const int* rowptr;
     const int* colidx;
     const Topo* topo;
+    const TileDesc* tiles;
 };
 
 struct LayerDims {
@@ -40,6 +41,15 @@ struct LayerArgs {         // host-side bundle only
     int* walk_counters;
 };
 
+// Diagnostic build only (-DEG_STAMP): per-wave cycle sums per phase, added to a stats area behind the
+// queue counters.  Never enabled in the shipped library; its run time is not representative.
+#ifdef EG_STAMP
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+                      __builtin_amdgcn_s_waitcnt(0xC07F); st[i] += _t - t_prev; t_prev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 template <int AGG>
 __device__ inline f32x2 produce_row(const float* __restrict__ dis, const int* __restrict__ rowptr,
                                     const int* __restrict__ colidx, const Topo* __restrict__ T,
@@ -49,80 +59,163 @@ __device__ inline f32x2 produce_row(const float* __restrict__ dis, const int* __
     else return load_row2(xf, n, lane);
 }
 
-// One workgroup = 4 waves walks 64-row tiles (persistent, XCD-aware order).  Per tile:
-//   phase 1  each wave aggregates its 16 rows (natural layout: one row = one 512-B wave access) -> LDS
-//   phase 2  each wave: its 32 output channels x 64 rows on the fp32 MFMA (W slice in registers)
+// One workgroup = 8 waves walks 64-row tiles (persistent, XCD-aware dynamic queue).  A tile is an
+// 8x8 patch of one level (implicit topology: neighbour reuse stays inside the workgroup / its L2) or
+// 64 consecutive rows (CSR / plain linear).  Wave w owns LDS rows 8w..8w+7 (one patch row) in the
+// memory phases and output channels 16w..16w+15 in the MFMA phase.  Per tile:
+//   phase 1  each wave aggregates its 8 rows (natural layout: one row = one 512-B wave access) -> LDS
+//   phase 2  each wave: its 16 output channels x 64 rows on the fp32 MFMA (W slice in 32 registers)
 //   phase 3  accumulators go back through the same LDS tile so the epilogue runs in the natural
 //            layout again: per-lane scale/shift, ReLU, residual, and full-row (512 B) coalesced
-//            residual loads / output stores.  A wave touches only its own 16 rows in phases 3 and 1,
+//            residual loads / output stores.  A wave touches only its own 8 LDS rows in phases 3 and 1,
 //            so no barrier separates a tile's phase 3 from the next tile's phase 1.
+constexpr int LAYER_THREADS = 512;
+
 template <int AGG>
-__global__ __launch_bounds__(256) void k_gcn_layer(const float* __restrict__ x, const float* __restrict__ W,
+__global__ __launch_bounds__(LAYER_THREADS) void k_gcn_layer(const float* __restrict__ x, const float* __restrict__ W,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    const float* __restrict__ residual, float* __restrict__ out,
                                                    const float* __restrict__ dis, const int* __restrict__ rowptr,
                                                    const int* __restrict__ colidx, const Topo* __restrict__ T,
+                                                   const TileDesc* __restrict__ tiles,
                                                    int* __restrict__ walk_counters, const LayerDims a) {
     __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA + 4];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane_k = tid & 63;
     const int wave = wave_id();
-    const int j = lane & 31, h = lane >> 5;
 
-    float wreg[64];
-    load_w_slice(W, wave, lane, a.transpose_w, wreg);
-    const f32x2 sc = scale ? *reinterpret_cast<const f32x2*>(scale + 2 * lane) : f32x2{1.f, 1.f};
-    const f32x2 sh = shift ? *reinterpret_cast<const f32x2*>(shift + 2 * lane) : f32x2{0.f, 0.f};
+    float wreg[32];
+    load_w_slice16(W, wave, lane_k, a.transpose_w, wreg);
+    const f32x2 sc = scale ? *reinterpret_cast<const f32x2*>(scale + 2 * lane_k) : f32x2{1.f, 1.f};
+    const f32x2 sh = shift ? *reinterpret_cast<const f32x2*>(shift + 2 * lane_k) : f32x2{0.f, 0.f};
 
     TileWalk walk(a.walk_mode, a.tiles_per_frame * a.batch, walk_counters, reinterpret_cast<int*>(&s_a[TILE * LDA]));
     int tile;
+#ifdef EG_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     while (walk.next(tile)) {
+        STAMP(0);
+        // lane index made opaque per tile: keeps LLVM from hoisting dozens of lane-derived loop invariants
+        // (slot masks = 2 SGPRs each, address pieces) out of the tile loop and pinning registers kernel-wide
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
         const int frame = tile / a.tiles_per_frame;
-        const int n0 = (tile - frame * a.tiles_per_frame) * TILE;
+        const int t_in = tile - frame * a.tiles_per_frame;
         const size_t frame_row0 = (size_t)frame * a.n_per_frame;
         const float* __restrict__ xf = x + frame_row0 * C;
-        const int rows_here = (a.n_per_frame - n0) < TILE ? (a.n_per_frame - n0) : TILE;
-        const int rl0 = wave * (TILE / 4);
-        const int rl1 = (rl0 + TILE / 4) < rows_here ? (rl0 + TILE / 4) : rows_here;
+        const int rl0 = 8 * wave;
+        int seg_first, seg_rows;          // this wave's 8 LDS rows = seg_rows consecutive node rows from seg_first
+        int blocks;                       // 16-row blocks of the tile that hold nodes
 
         // ---- phase 1
         if constexpr (AGG == AGG_STENCIL) {
-            stencil_run_to_lds(T, xf, dis, n0 + rl0, rl0, rl1, lane, s_a);
+            const TileDesc td = tiles[t_in];
+            const LevelDesc d = T->desc[td.level];
+            seg_first = d.base + (td.r0 + wave) * d.side + td.c0;
+            seg_rows = wave < td.nrows ? td.ncols : 0;
+            blocks = (td.nrows + 1) >> 1;
+            stencil_patch_rows(T, d, td, T->magic, xf, dis, a.n_per_frame, wave, 1, lane, s_a);
         } else {
+            const int n0 = t_in * TILE;
+            const int rows_here = (a.n_per_frame - n0) < TILE ? (a.n_per_frame - n0) : TILE;
+            seg_first = n0 + rl0;
+            const int left = rows_here - rl0;
+            seg_rows = left < 0 ? 0 : (left > 8 ? 8 : left);
+            blocks = (rows_here + 15) >> 4;
+            const int last = a.n_per_frame - 1;
+            if constexpr (AGG == AGG_NONE) {
+                f32x2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = load_row2(xf, seg_first + u < last ? seg_first + u : last, lane);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]) = v[u];
+            } else {
 #pragma unroll 2
-            for (int rl = rl0; rl < rl1; ++rl) {
-                const f32x2 v = produce_row<AGG>(dis, rowptr, colidx, T, xf, n0 + rl, lane);
-                *reinterpret_cast<f32x2*>(&s_a[rl * LDA + 2 * lane]) = v;
+                for (int u = 0; u < 8; ++u) {
+                    const int n = seg_first + u < last ? seg_first + u : last;
+                    *reinterpret_cast<f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]) =
+                        produce_row<AGG>(dis, rowptr, colidx, T, xf, n, lane);
+                }
             }
         }
+        STAMP(1);
         __syncthreads();
+        STAMP(2);
 
-        // ---- phase 2 (rows beyond rows_here hold stale data; their accumulator columns are never read back)
-        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f32x16 acc1 = acc0;
-        mfma_rowblock(s_a, 0, lane, wreg, acc0);
-        if (rows_here > 32) mfma_rowblock(s_a, 32, lane, wreg, acc1);
-        __syncthreads();
+        // ---- phase 2 (LDS rows without a node hold stale data; their accumulator columns are never read back)
+        f32x4v acc[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch0 = 32 * wave + 8 * g + 4 * h;
-            *reinterpret_cast<f32x4*>(&s_a[j * LDA + ch0]) = f32x4{acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
-            *reinterpret_cast<f32x4*>(&s_a[(32 + j) * LDA + ch0]) = f32x4{acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+        for (int b = 0; b < 4; ++b) acc[b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#ifndef EG_ABL_NO_MFMA         // timing-only ablation
+        mfma16_pair(s_a, 0, lane, wreg, acc[0], acc[1]);
+        if (blocks > 2) mfma16_pair(s_a, 32, lane, wreg, acc[2], acc[3]);
+#else
+        acc[0][0] = wreg[lane & 63 ? 1 : 0] + s_a[lane]; acc[1][0] = wreg[31];
+#endif
+        // residual rows of this wave's segment: issued now so their latency hides behind the barriers and the
+        // accumulator round trip through LDS.  NULL residual reads x and is ignored below.
+        f32x2 res[8];
+        const bool full = (seg_rows == 8);                                    // uniform
+        const size_t seg_off = (frame_row0 + seg_first) * C + 2 * lane;
+        {
+            const float* rp = (residual ? residual : x) + seg_off;
+#ifndef EG_ABL_NO_P3
+            if (full) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) res[u] = *reinterpret_cast<const f32x2*>(rp + u * C);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    res[u] = f32x2{0.f, 0.f};
+                    if (u < seg_rows) res[u] = *reinterpret_cast<const f32x2*>(rp + u * C);
+                }
+            }
+#else
+#pragma unroll
+            for (int u = 0; u < 8; ++u) res[u] = f32x2{0.f, 0.f};
+#endif
         }
+        STAMP(3);
         __syncthreads();
+        STAMP(4);
+        {
+            const int j = lane & 15, q4 = lane >> 4;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                *reinterpret_cast<f32x4v*>(&s_a[(16 * b + j) * LDA + 16 * wave + 4 * q4]) = acc[b];
+        }
+        STAMP(5);
+        __syncthreads();
+        STAMP(6);
 
         // ---- phase 3
-        const size_t tile_off = (frame_row0 + n0) * C + 2 * lane;
-#pragma unroll 8
-        for (int rl = rl0; rl < rl1; ++rl) {
-            f32x2 v = *reinterpret_cast<const f32x2*>(&s_a[rl * LDA + 2 * lane]);
+        float* op = out + seg_off;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            f32x2 v = *reinterpret_cast<const f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]);
             v = v * sc + sh;
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-            if (residual) v += *reinterpret_cast<const f32x2*>(residual + tile_off + (size_t)rl * C);
-            *reinterpret_cast<f32x2*>(out + tile_off + (size_t)rl * C) = v;
+            if (residual) v += res[u];
+#ifndef EG_ABL_NO_P3
+            if (full) *reinterpret_cast<f32x2*>(op + u * C) = v;
+            else if (u < seg_rows) *reinterpret_cast<f32x2*>(op + u * C) = v;
+#else
+            if (v.x == 1234.5678f) *reinterpret_cast<f32x2*>(op + u * C) = v;
+#endif
         }
+        STAMP(7);
     }
+#ifdef EG_STAMP
+    if (lane_k == 0) {
+        unsigned long long* stats = reinterpret_cast<unsigned long long*>(walk_counters + WALK_GROUPS * WALK_CTR_STRIDE);
+        for (int i = 0; i < 8; ++i) atomicAdd(&stats[i], st[i]);
+        atomicAdd(&stats[8], 1ull);
+    }
+#endif
 }
 
 // aggregation only: out = A_hat x, one wave per node row, no LDS
@@ -143,27 +236,34 @@ __global__ __launch_bounds__(256) void k_aggregate(const float* __restrict__ x, 
     }
 }
 
+__global__ void k_debug_xcc(int* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = xcc_id();
+        out[gridDim.x + blockIdx.x] = (int)(__builtin_amdgcn_s_memtime() & 0x7fffffff);
+    }
+}
+
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
 }
 
-// Persistent grid: what is resident at once (256 CUs x 3 workgroups at this kernel's register
+// Persistent grid: what is resident at once (256 CUs x 2 workgroups of 8 waves at this kernel's register
 // budget).  A larger grid would run a second, under-occupied round.
 static int grid_for_tiles(long long n_tiles) {
-    const long long cap = env_int("EG_GRID", 768);
+    const long long cap = env_int("EG_GRID", 512);
     long long g = n_tiles < cap ? n_tiles : cap;
     g = (g + 7) / 8 * 8;                                     // static walk modes use groups of 8
     return (int)g;
 }
 
-#define LAYER_KARGS a.x, a.W, a.scale, a.shift, a.residual, a.out, a.gp.dis, a.gp.rowptr, a.gp.colidx, a.gp.topo, a.walk_counters, a.d
+#define LAYER_KARGS a.x, a.W, a.scale, a.shift, a.residual, a.out, a.gp.dis, a.gp.rowptr, a.gp.colidx, a.gp.topo, a.gp.tiles, a.walk_counters, a.d
 
 static int launch_layer(int agg, LayerArgs& a, hipStream_t stream) {
     const long long n_tiles = (long long)a.d.tiles_per_frame * a.d.batch;
     if (n_tiles <= 0) return EG_OK;
     if (n_tiles >= (1ll << 31)) return set_error(EG_ERR_ARG, "too many tiles");
-    const dim3 grid(grid_for_tiles(n_tiles)), block(256);
+    const dim3 grid(grid_for_tiles(n_tiles)), block(LAYER_THREADS);
     a.d.walk_mode = a.walk_counters ? env_int("EG_WALK_MODE", WALK_QUEUE) : WALK_MOD8;
     if (a.d.walk_mode == WALK_QUEUE)
         EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * WALK_GROUPS * WALK_CTR_STRIDE, stream));
@@ -187,8 +287,10 @@ static int fill_graph_args(const eg_graph* g, int batch, LayerArgs& a, int& agg)
     a.walk_counters = g->walk_counters;
     a.d.n_per_frame = (int)g->n_nodes;
     a.d.batch = batch;
-    a.d.tiles_per_frame = (int)((g->n_nodes + TILE - 1) / TILE);
+    a.gp.tiles = g->tiles_dev;
     agg = g->kind == GRAPH_TOPO ? AGG_STENCIL : AGG_CSR;
+    // implicit topology: one tile per 8x8 patch of a level; CSR: 64 consecutive rows
+    a.d.tiles_per_frame = agg == AGG_STENCIL ? g->n_tiles : (int)((g->n_nodes + TILE - 1) / TILE);
     return EG_OK;
 }
 
@@ -197,6 +299,13 @@ static int fill_graph_args(const eg_graph* g, int batch, LayerArgs& a, int& agg)
 using namespace eg;
 
 extern "C" {
+
+int eg_debug_xcc(int* out_dev, int nblocks, eg_stream_t stream) {
+    if (!out_dev || nblocks < 1) return set_error(EG_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_debug_xcc, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, out_dev);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
 
 int eg_gcn_layer_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                      const float* shift, const float* residual, int relu, int transpose_w, float* out,

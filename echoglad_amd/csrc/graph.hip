@@ -144,18 +144,84 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
         neighbours(T, n, nb);
         dis[n] = (float)(1.0 / std::sqrt((double)(nb.degree + 1)));
     }
+    // 2-D patch table.  Order = depth-first post-order over the pyramid of 8x8 patches: the patches under a
+    // coarse patch are emitted (recursively, 2x2 blocks) before it, so vertical neighbours, parents and
+    // children are worked on close in time by the workgroups of one XCD and meet in its L2.  Patches that
+    // the pyramid does not reach (outside the centre crop, or a main-only graph) follow in 2x2-block order.
+    std::vector<TileDesc> tiles;
+    {
+        std::vector<std::vector<char>> seen(T.n_levels);
+        std::vector<int> tside(T.n_levels);
+        for (int l = 0; l < T.n_levels; ++l) {
+            tside[l] = (T.desc[l].side + 7) / 8;
+            seen[l].assign((size_t)tside[l] * tside[l], 0);
+        }
+        auto push = [&](int l, int ty, int tx) {
+            const LevelDesc& d = T.desc[l];
+            const int r0 = ty * 8, c0 = tx * 8;
+            tiles.push_back(TileDesc{l, r0, c0, d.side - r0 < 8 ? d.side - r0 : 8, d.side - c0 < 8 ? d.side - c0 : 8, 0, 0, 0});
+        };
+        // explicit stack: (level, ty, tx, state)
+        struct Item { int l, ty, tx, expanded; };
+        auto visit = [&](int l0, int ty0, int tx0) {
+            std::vector<Item> st;
+            st.push_back(Item{l0, ty0, tx0, 0});
+            while (!st.empty()) {
+                Item it = st.back();
+                st.pop_back();
+                if (it.l < 0 || it.l >= T.n_levels || it.ty < 0 || it.tx < 0 || it.ty >= tside[it.l] || it.tx >= tside[it.l]) continue;
+                char& sn = seen[it.l][(size_t)it.ty * tside[it.l] + it.tx];
+                if (it.expanded) { push(it.l, it.ty, it.tx); continue; }
+                if (sn) continue;
+                sn = 1;
+                st.push_back(Item{it.l, it.ty, it.tx, 1});
+                const LevelDesc& d = T.desc[it.l];
+                if (d.kind != 0) continue;                        // main grid: leaf
+                // node range of the children of this patch, in the child level's coordinates
+                const int rlo = 2 * (it.ty * 8 - d.clo), rhi = 2 * (it.ty * 8 + 8 - d.clo);
+                const int clo = 2 * (it.tx * 8 - d.clo), chi = 2 * (it.tx * 8 + 8 - d.clo);
+                const int cl = it.l + 1;
+                const int climit = 2 * (d.chi - d.clo);
+                const int r_a = rlo < 0 ? 0 : rlo, r_b = rhi > climit ? climit : rhi;
+                const int c_a = clo < 0 ? 0 : clo, c_b = chi > climit ? climit : chi;
+                if (r_a >= r_b || c_a >= c_b) continue;
+                for (int ty = (r_b - 1) / 8; ty >= r_a / 8; --ty)        // reversed: the stack pops them in order
+                    for (int tx = (c_b - 1) / 8; tx >= c_a / 8; --tx) st.push_back(Item{cl, ty, tx, 0});
+            }
+        };
+        if (T.n_aux > 0) visit(0, 0, 0);
+        for (int l = 0; l < T.n_levels; ++l) {                    // whatever the pyramid did not reach: 2x2-block order
+            const int ts = tside[l];
+            for (int by = 0; by < ts; by += 2)
+                for (int bx = 0; bx < ts; bx += 2)
+                    for (int dy = 0; dy < 2; ++dy)
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int ty = by + dy, tx = bx + dx;
+                            if (ty < ts && tx < ts && !seen[l][(size_t)ty * ts + tx]) { seen[l][(size_t)ty * ts + tx] = 1; push(l, ty, tx); }
+                        }
+        }
+        if (T.n_desc > T.n_levels) {
+            const LevelDesc& d = T.desc[T.n_levels];
+            tiles.push_back(TileDesc{T.n_levels, 0, 0, 1, d.end - d.base, 0, 0, 0});
+        }
+    }
     eg_graph* g = new eg_graph{};
     g->kind = GRAPH_TOPO;
     g->n_nodes = T.n_nodes;
     g->topo = T;
+    g->n_tiles = (int)tiles.size();
     hipError_t e = hipMalloc((void**)&g->dis, sizeof(float) * T.n_nodes);
     if (e == hipSuccess) e = hipMemcpy(g->dis, dis.data(), sizeof(float) * T.n_nodes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->walk_counters, sizeof(int) * 8 * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->walk_counters, sizeof(int) * (8 * 32 + 64));
+    if (e == hipSuccess) e = hipMemset(g->walk_counters, 0, sizeof(int) * (8 * 32 + 64));
     if (e == hipSuccess) e = hipMalloc((void**)&g->topo_dev, sizeof(Topo));
     if (e == hipSuccess) e = hipMemcpy(g->topo_dev, &T, sizeof(Topo), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->tiles_dev, sizeof(TileDesc) * tiles.size());
+    if (e == hipSuccess) e = hipMemcpy(g->tiles_dev, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (g->dis) (void)hipFree(g->dis);
         if (g->topo_dev) (void)hipFree(g->topo_dev);
+        if (g->tiles_dev) (void)hipFree(g->tiles_dev);
         if (g->walk_counters) (void)hipFree(g->walk_counters);
         delete g;
         return set_error(EG_ERR_HIP, std::string("eg_topo_create: ") + hipGetErrorString(e));
@@ -209,7 +275,8 @@ int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream
     CSR_TRY(hipMalloc((void**)&g->colidx, sizeof(int) * mm));
     CSR_TRY(hipMalloc((void**)&g->rowptr, sizeof(int) * ((size_t)n + 1)));
     CSR_TRY(hipMalloc((void**)&g->dis, sizeof(float) * (size_t)n));
-    CSR_TRY(hipMalloc((void**)&g->walk_counters, sizeof(int) * 8 * 32));
+    CSR_TRY(hipMalloc((void**)&g->walk_counters, sizeof(int) * (8 * 32 + 64)));
+    CSR_TRY(hipMemsetAsync(g->walk_counters, 0, sizeof(int) * (8 * 32 + 64), stream));
     CSR_TRY(hipMemsetAsync(counts, 0, sizeof(int) * ((size_t)n + 1), stream));
     if (m > 0) {
         hipLaunchKernelGGL(k_edge_keys, dim3((m + 255) / 256), dim3(256), 0, stream, ei, n_edges, n, keys, vals, counts);
@@ -248,6 +315,7 @@ int eg_graph_destroy(eg_graph* g) {
     if (!g) return EG_OK;
     if (g->dis) (void)hipFree(g->dis);
     if (g->topo_dev) (void)hipFree(g->topo_dev);
+    if (g->tiles_dev) (void)hipFree(g->tiles_dev);
     if (g->walk_counters) (void)hipFree(g->walk_counters);
     if (g->rowptr) (void)hipFree(g->rowptr);
     if (g->colidx) (void)hipFree(g->colidx);
@@ -259,9 +327,19 @@ int64_t eg_graph_num_nodes(const eg_graph* g) { return g ? g->n_nodes : -1; }
 
 int eg_graph_is_structured(const eg_graph* g) { return g && g->kind == GRAPH_TOPO; }
 
+int64_t eg_graph_num_tiles(const eg_graph* g) { return g ? (g->kind == GRAPH_TOPO ? g->n_tiles : (g->n_nodes + TILE - 1) / TILE) : -1; }
+
 int eg_graph_deg_inv_sqrt(const eg_graph* g, float* out_dev, eg_stream_t stream) {
     if (!g || !out_dev) return set_error(EG_ERR_ARG, "NULL argument");
     EG_HIP_TRY(hipMemcpyAsync(out_dev, g->dis, sizeof(float) * g->n_nodes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return EG_OK;
+}
+
+int eg_debug_phase_cycles(eg_graph* g, uint64_t* out_host, int reset) {
+    if (!g || !out_host) return set_error(EG_ERR_ARG, "NULL argument");
+    EG_HIP_TRY(hipDeviceSynchronize());
+    EG_HIP_TRY(hipMemcpy(out_host, g->walk_counters + 8 * 32, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) EG_HIP_TRY(hipMemset(g->walk_counters + 8 * 32, 0, 16 * sizeof(uint64_t)));
     return EG_OK;
 }
 

@@ -70,7 +70,7 @@ __device__ inline f32x2 agg_stencil(const Topo* __restrict__ Tp, const float* __
 // in flight.
 enum { KIND_AUX = 0, KIND_MAIN = 1, KIND_COORD = 2 };
 #ifndef EG_MAIN_U
-#define EG_MAIN_U 2      // main-grid nodes aggregated per batch of loads (2 keeps the kernel at 3 waves/SIMD)
+#define EG_MAIN_U 4      // main-grid nodes per burst of row loads (24 loads in flight per wave)
 #endif
 
 struct RunPos { int n, r, c; };
@@ -133,7 +133,11 @@ __device__ inline void run_group(const LevelDesc& d, RunPos& p, const float* __r
         for (int s = 0; s < NS; ++s) {
             const float dd = dis[id[s]];
             w[u][s] = valid[s] ? dd : 0.0f;
+#ifdef EG_ABL_NO_NBR          // timing-only ablation: neighbour rows are not loaded (results wrong)
+            v[u][s] = s == 0 ? load_row2(xf, id[0], lane) : v[u][0];
+#else
             v[u][s] = load_row2(xf, id[s], lane);
+#endif
         }
     }
 #pragma unroll
@@ -145,22 +149,207 @@ __device__ inline void run_group(const LevelDesc& d, RunPos& p, const float* __r
     }
 }
 
-// rows [rl, rl_end) of the LDS tile <- aggregated rows of nodes n_first, n_first+1, ...
-__device__ inline void stencil_run_to_lds(const Topo* __restrict__ T, const float* __restrict__ xf,
-                                          const float* __restrict__ dis, int n_first, int rl, int rl_end, int lane,
-                                          float* s_a) {
-    if (rl >= rl_end) return;
-    RunPos p;
-    LevelDesc d = run_decode(T, n_first, p);
-    while (rl < rl_end) {
-        if (p.n >= d.end) d = run_decode(T, p.n, p);
-        const int left = rl_end - rl, in_level = d.end - p.n;
-        const int avail = left < in_level ? left : in_level;
-        if (d.kind == KIND_MAIN && avail >= EG_MAIN_U) { run_group<EG_MAIN_U, 6>(d, p, xf, dis, lane, s_a, rl); rl += EG_MAIN_U; }
-#ifndef EG_NO_GEN2
-        else if (avail >= 2) { run_group<2, MAX_SLOTS>(d, p, xf, dis, lane, s_a, rl); rl += 2; }
-#endif
-        else { run_group<1, MAX_SLOTS>(d, p, xf, dis, lane, s_a, rl); rl += 1; }
+// ---- lane-parallel stencil decode ------------------------------------------------------------
+// The neighbourhood of several nodes is decoded at once on the VALU: lane L handles
+// (node u = L / LPN, slot s = L % LPN) of a batch whose nodes all lie in one level (descriptor d
+// is wave-uniform).  One vector gather fetches every normalisation weight of the batch; ids and
+// weights are then broadcast with v_readlane as the row loads / FMAs are issued.  The scalar unit
+// only walks levels.  slots: 0 self, 1 up, 2 down, 3 left, 4 right, 5 parent, 6..9 children.
+__device__ inline void lane_slot(const LevelDesc& d, unsigned long long magic, int n, int s, int& id, int& valid) {
+    const int idx = n - d.base;
+    const int r_main = (int)(((unsigned long long)(unsigned)idx * magic) >> 40);
+    const int r = d.kind == KIND_MAIN ? r_main : (d.kind == KIND_AUX ? (idx >> d.lg) : 0);
+    const int c = idx - r * d.side;
+    const bool par_ok = (r < d.plim) && (c < d.plim);
+    const int par_id = d.pbase + (d.poff + (r >> 1)) * d.pside + d.poff + (c >> 1);
+    const bool ch_ok = (r >= d.clo) && (r < d.chi) && (c >= d.clo) && (c < d.chi);
+    const int ch_b = d.cbase + 2 * (r - d.clo) * d.cside + 2 * (c - d.clo);
+    int cand = n;
+    bool ok = (s == 0);
+    cand = s == 1 ? n - d.side : cand;  ok = s == 1 ? (r > 0) : ok;
+    cand = s == 2 ? n + d.side : cand;  ok = s == 2 ? (r < d.side - 1) : ok;
+    cand = s == 3 ? n - 1 : cand;       ok = s == 3 ? (c > 0) : ok;
+    cand = s == 4 ? n + 1 : cand;       ok = s == 4 ? (c < d.side - 1) : ok;
+    cand = s == 5 ? par_id : cand;      ok = s == 5 ? par_ok : ok;
+    const int q = s - 6;                                    // children 6..9
+    const int ch_id = ch_b + (q & 1) + ((q >> 1) & 1) * d.cside;
+    cand = (s >= 6 && s <= 9) ? ch_id : cand;
+    ok = (s >= 6 && s <= 9) ? ch_ok : ok;
+    if (d.kind == KIND_COORD) {                             // isolated K4: slots 1..4 = the four coordinate nodes
+        cand = (s >= 1 && s <= 4) ? d.base + s - 1 : n;
+        ok = (s == 0) || (s >= 1 && s <= 4 && cand != n);
+    }
+    valid = ok ? 1 : 0;
+    id = ok ? cand : n;
+}
+
+__device__ inline float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// An SGPR zero the optimiser cannot see through.  Added to a lane index it ties a v_readlane to this program
+// point: without it LLVM hoists all weight broadcasts of a batch to where the weights are produced and then
+// spills dozens of SGPRs around the loads.
+__device__ inline int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}
+
+// ---- one grid-row segment of up to 8 consecutive nodes ("row-run stencil") -----------------------
+// For 8 consecutive nodes of one grid row every neighbour class is a run of consecutive node rows:
+//   S  the 8 nodes themselves (also each other's left / right neighbours), L / R the two edge rows,
+//   U / D the 8 rows above / below, P the 4 parents (nodes 2k, 2k+1 share one),
+//   C0 / C1 the 16 + 16 children (aux levels only).
+// 30 row loads per 8 main-grid nodes (62 on an aux level) instead of 8 x 6 (8 x 10).  Run bases are
+// scalar; weights come from the lane-parallel decode above (one vector gather per batch).
+// Out-of-grid neighbours have weight 0 and a clamped (in-frame) address.
+__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Forces the accumulator updates of a stage to be complete at this program point and keeps later loads
+// below it ("memory"): ISel otherwise sinks every FMA of a batch to the end, which keeps all 30-62 row
+// loads of the batch live in registers at once.
+__device__ inline void pin_acc(f32x2 (&acc)[8]) {
+    asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y),
+                      "+v"(acc[3].x), "+v"(acc[3].y), "+v"(acc[4].x), "+v"(acc[4].y), "+v"(acc[5].x), "+v"(acc[5].y),
+                      "+v"(acc[6].x), "+v"(acc[6].y), "+v"(acc[7].x), "+v"(acc[7].y) :: "memory");
+}
+
+__device__ inline const float* run_ptr(const float* __restrict__ xf, int row0, int lane) {
+    return xf + ((unsigned)row0 * (unsigned)C + 2u * (unsigned)lane);     // rows row0+k are at imm offsets k*512 B
+}
+__device__ inline f32x2 ld2(const float* p, int k) { return *reinterpret_cast<const f32x2*>(p + k * C); }
+
+template <bool AUX>
+__device__ inline void stencil_row8(const Topo* __restrict__ T, const LevelDesc& d, unsigned long long magic,
+                                    const float* __restrict__ xf, const float* __restrict__ dis, int n_first, int cnt,
+                                    int n_frame, int lane, float* s_a, int rl) {
+    // run bases from the position of the first node (scalar)
+    const int idx = n_first - d.base;
+    const int r_main = (int)(((unsigned long long)(unsigned)idx * magic) >> 40);
+    const int r = d.kind == KIND_MAIN ? r_main : (idx >> d.lg);
+    const int c0 = idx - r * d.side;
+    const int cb = d.cbase + 2 * (r - d.clo) * d.cside + 2 * (c0 - d.clo);
+    const bool kids = AUX && r >= d.clo && r < d.chi;
+    // Rare per-node scalar path: coordinate K4, and segments so close to the end of the frame that a run of 8
+    // rows (self / below / children) would have to be clamped while some of its rows are real neighbours.
+    if (d.kind == KIND_COORD || n_first + d.side + 8 > n_frame || (kids && cb + d.cside + 16 > n_frame)) {
+        for (int u = 0; u < cnt; ++u)
+            *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = agg_stencil(T, xf, dis, n_first + u, lane);
+        return;
+    }
+    // weights: lane (u = lane>>3, s = lane&7) -> slot s of node u; aux levels also need slots 8, 9
+    int u_l = lane >> 3, s_l = lane & 7;
+    // opaque to the optimiser: otherwise the dozen (slot == k) lane masks of lane_slot are hoisted out of the
+    // tile loop as loop invariants and pin ~30 SGPRs (2 per mask) for the whole kernel
+    asm volatile("" : "+v"(u_l), "+v"(s_l));
+    const int n_l = n_first + (u_l < cnt ? u_l : cnt - 1);
+    int id, valid;
+    lane_slot(d, magic, n_l, s_l, id, valid);
+    const float dwa = dis[id];
+    const float wa = valid ? dwa : 0.0f;
+    float wb = 0.0f;
+    if constexpr (AUX) {
+        lane_slot(d, magic, n_l, 8 + (s_l & 1), id, valid);
+        const float dwb = dis[id];
+        wb = valid ? dwb : 0.0f;
+    }
+    const int hi8 = n_frame - 8, last = n_frame - 1;
+    const float* ps = run_ptr(xf, n_first, lane);
+    const float* pl = run_ptr(xf, clampi(n_first - 1, 0, last), lane);
+    const float* pr = run_ptr(xf, clampi(n_first + 8, 0, last), lane);
+    const float* pu = run_ptr(xf, clampi(n_first - d.side, 0, hi8), lane);
+    const float* pd = run_ptr(xf, clampi(n_first + d.side, 0, hi8), lane);
+    const float* pp = run_ptr(xf, clampi(d.pbase + (d.poff + (r >> 1)) * d.pside + d.poff + (c0 >> 1), 0, hi8), lane);
+
+    // Loads are issued one stage ahead of the FMAs that consume them; sched_barriers pin that order so at
+    // most two stages (<= 18 rows) are live in registers while ~16-18 row loads stay in flight.
+    f32x2 S[8], L, R, U[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) S[k] = ld2(ps, k);
+    L = ld2(pl, 0);
+    R = ld2(pr, 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) U[k] = ld2(pu, k);
+    __builtin_amdgcn_sched_barrier(0);
+    int zz = opaque_zero();
+    f32x2 acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        f32x2 a = readlane_f(wa, u * 8 + 4 + zz) * (u < 7 ? S[u < 7 ? u + 1 : 7] : R);
+        a += readlane_f(wa, u * 8 + 3 + zz) * (u > 0 ? S[u > 0 ? u - 1 : 0] : L);
+        a += readlane_f(wa, u * 8 + 0 + zz) * S[u];
+        acc[u] = a;
+    }
+    pin_acc(acc);
+    f32x2 D[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) D[k] = ld2(pd, k);
+    __builtin_amdgcn_sched_barrier(0);
+    zz = opaque_zero();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += readlane_f(wa, u * 8 + 1 + zz) * U[u];
+    pin_acc(acc);
+    f32x2 P[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) P[k] = ld2(pp, k);
+    __builtin_amdgcn_sched_barrier(0);
+    zz = opaque_zero();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += readlane_f(wa, u * 8 + 2 + zz) * D[u];
+    pin_acc(acc);
+    __builtin_amdgcn_sched_barrier(0);
+    zz = opaque_zero();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += readlane_f(wa, u * 8 + 5 + zz) * P[u >> 1];
+    pin_acc(acc);
+    if constexpr (AUX) {
+        // children: rows 2r and 2r+1 of the next level, 16 consecutive node rows each, consumed in four
+        // quarter stages of 8 rows (children of nodes 4h..4h+3), each issued one stage ahead
+        const float* pc[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            pc[st] = run_ptr(xf, clampi(cb + (st >> 1) * d.cside + 8 * (st & 1), 0, hi8), lane);
+        f32x2 Ca[8], Cb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Ca[k] = ld2(pc[0], k);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            if (st < 3) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { if (st & 1) Ca[k] = ld2(pc[st + 1], k); else Cb[k] = ld2(pc[st + 1], k); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            zz = opaque_zero();
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int u = 4 * (st & 1) + uu;
+                const float w0 = (st >> 1) == 0 ? readlane_f(wa, u * 8 + 6 + zz) : readlane_f(wb, u * 8 + 0 + zz);
+                const float w1 = (st >> 1) == 0 ? readlane_f(wa, u * 8 + 7 + zz) : readlane_f(wb, u * 8 + 1 + zz);
+                if (st & 1) acc[u] += w0 * Cb[2 * uu] + w1 * Cb[2 * uu + 1];
+                else acc[u] += w0 * Ca[2 * uu] + w1 * Ca[2 * uu + 1];
+            }
+            pin_acc(acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    zz = opaque_zero();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const f32x2 o = acc[u] * readlane_f(wa, u * 8 + zz);
+        if (u < cnt) *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = o;
+    }
+}
+
+// patch rows tr0 .. tr0+ntr-1 of patch td -> LDS rows 8*tr .. 8*tr+7
+__device__ inline void stencil_patch_rows(const Topo* __restrict__ T, const LevelDesc& d, const TileDesc& td, unsigned long long magic,
+                                          const float* __restrict__ xf, const float* __restrict__ dis, int n_frame,
+                                          int tr0, int ntr, int lane, float* s_a) {
+#pragma unroll 1
+    for (int tr = tr0; tr < tr0 + ntr; ++tr) {
+        if (tr >= td.nrows) break;
+        const int n_first = d.base + (td.r0 + tr) * d.side + td.c0;
+        if (d.kind == KIND_AUX) stencil_row8<true>(T, d, magic, xf, dis, n_first, td.ncols, n_frame, lane, s_a, tr * 8);
+        else stencil_row8<false>(T, d, magic, xf, dis, n_first, td.ncols, n_frame, lane, s_a, tr * 8);
     }
 }
 
@@ -240,6 +429,68 @@ __device__ inline void mfma_rowblock(const float* s_a, int row0, int lane, const
     mfma_chunk(a0, wreg, 8, acc);
     __builtin_amdgcn_sched_barrier(0);
     mfma_chunk(a1, wreg, 12, acc);
+}
+
+// ---- 8-wave layout: wave w owns 16 output channels, v_mfma_f32_16x16x4_f32 ------------------------
+// A operand = W slice (32 VGPRs for the lifetime of the workgroup): lane (i = l&15, kq = l>>4) holds
+// W[16w+i][koff(kq) + s], s = 0..31.  B operand = LDS tile: lane (j = l&15, kq) reads a[row0+j][koff(kq)+s]
+// as 8 ds_read_b128.  koff = {0, 64, 32, 96}: the two kq values that share a ds_read_b128 lane group
+// are 64 floats apart, which keeps the 16 lanes of a group on disjoint banks at LDS row stride 132.
+// D: lane (j, q = l>>4), reg i  ->  out[row0 + j][16w + 4q + i].
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ inline int koff16(int kq) { return ((kq & 1) << 6) | ((kq & 2) << 4); }
+
+__device__ inline void load_w_slice16(const float* __restrict__ W, int wave, int lane, int transpose, float (&wreg)[32]) {
+    const int i = lane & 15, k0 = koff16(lane >> 4);
+    if (!transpose) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(W + (size_t)(16 * wave + i) * C + k0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f32x4 q = p[t];
+            wreg[4 * t + 0] = q.x; wreg[4 * t + 1] = q.y; wreg[4 * t + 2] = q.z; wreg[4 * t + 3] = q.w;
+        }
+    } else {
+        const float* p = W + (size_t)k0 * C + 16 * wave + i;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) wreg[s] = p[(size_t)s * C];
+    }
+}
+
+// two 16-row blocks (row0, row0+16) with independent accumulators: the 40-cycle dependent latency of one
+// chain is covered by the other chain's 32-cycle issue slot.
+__device__ inline void mfma16_pair(const float* s_a, int row0, int lane, const float (&wreg)[32], f32x4v& accA, f32x4v& accB) {
+    const int j = lane & 15, k0 = koff16(lane >> 4);
+    const f32x4* pa = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + k0);
+    const f32x4* pb = reinterpret_cast<const f32x4*>(s_a + (row0 + 16 + j) * LDA + k0);
+    f32x4 fa[4], fb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { fa[t] = pa[t]; fb[t] = pb[t]; }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        f32x4 ga[4], gb[4];
+        if (c == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ga[t] = pa[4 + t]; gb[t] = pb[4 + t]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int w0 = 16 * c + 4 * t;
+            accA = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[w0 + 0], fa[t].x, accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[w0 + 0], fb[t].x, accB, 0, 0, 0);
+            accA = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[w0 + 1], fa[t].y, accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[w0 + 1], fb[t].y, accB, 0, 0, 0);
+            accA = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[w0 + 2], fa[t].z, accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[w0 + 2], fb[t].z, accB, 0, 0, 0);
+            accA = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[w0 + 3], fa[t].w, accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[w0 + 3], fb[t].w, accB, 0, 0, 0);
+        }
+        if (c == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { fa[t] = ga[t]; fb[t] = gb[t]; }
+        }
+    }
 }
 
 // ---- persistent tile walk ------------------------------------------------------------------

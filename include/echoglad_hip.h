@@ -70,8 +70,17 @@ int eg_csr_create(const int64_t* edge_index_dev, int64_t n_nodes, int64_t n_edge
 int eg_graph_destroy(eg_graph* g);
 int64_t eg_graph_num_nodes(const eg_graph* g);      /* nodes per frame (topo) or total (csr) */
 int eg_graph_is_structured(const eg_graph* g);
+int64_t eg_graph_num_tiles(const eg_graph* g);      /* 64-row work tiles per frame (8x8 patches for a topo handle) */
 /* copies the (deg+1)^-1/2 table [num_nodes] to a device buffer (tests / diagnostics) */
 int eg_graph_deg_inv_sqrt(const eg_graph* g, float* out_dev, eg_stream_t stream);
+
+/* Diagnostic (stamp builds only, -DEG_STAMP): per-phase cycle sums of the layer kernel accumulated in
+ * the handle since the last reset: out_host[0..7] = phase sums over all waves, out_host[8] = waves.
+ * Synchronises the device. */
+int eg_debug_phase_cycles(eg_graph* g, uint64_t* out_host, int reset);
+
+/* Diagnostic: out_dev[b] = XCC (XCD) id workgroup b ran on, out_dev[nblocks + b] = its start time stamp. */
+int eg_debug_xcc(int* out_dev, int nblocks, eg_stream_t stream);
 
 /* Order-independent digest of an edge_index [2, n_edges] int64 on the device:
  * out_dev[0] = n_edges, out_dev[1] = sum over edges of mix64(src, dst) (mod 2^64).

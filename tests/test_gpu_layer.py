@@ -33,6 +33,9 @@ def test_closed_form_degree_table(frame, naux, main_only, coord):
     assert g.num_nodes == topo.num_nodes
     dis = g.deg_inv_sqrt().cpu().numpy()
     assert np.allclose(dis, topo.deg_inv_sqrt(), rtol=1e-7, atol=0)
+    # the 8x8 patch table must hold every patch of every level exactly once (+1 for the coordinate nodes)
+    want = sum(((lv.side + 7) // 8) ** 2 for lv in topo.aux_levels + [topo.main]) + (1 if topo.n_coord else 0)
+    assert _lib.load().eg_graph_num_tiles(g._h) == want
 
 
 @pytest.mark.parametrize("frame,naux,main_only,coord", TOPO_CASES)

@@ -1,0 +1,24 @@
+"""Diagnostic: per-phase cycle shares of the fused layer kernel (needs the -DEG_STAMP variant)."""
+import ctypes as ct, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+import torch
+from echoglad_amd import ops, _lib
+from fixtures_util import synthetic_node_feats
+B = 8
+g = ops.Graph.topo(224, 7)
+x = synthetic_node_feats(B * g.num_nodes, 128, 1).cuda()
+w = (synthetic_node_feats(128, 128, 2) * 0.1).cuda()
+out = torch.empty_like(x)
+buf = (ct.c_uint64 * 9)()
+lib = _lib.load()
+for it in range(3):
+    ops.gcn_layer_fwd(g, B, x, w, None, None, x, relu=True, out=out)
+    lib.eg_debug_phase_cycles(g._h, buf, 1)
+    v = list(buf)
+names = ["next_tile", "phase1", "barrier1", "mfma", "barrier2", "dwrite", "barrier3", "phase3"]
+tot = sum(v[:8]); waves = max(v[8], 1)
+tiles = 1128 * B
+print(f"waves={waves} tiles={tiles} cycles/wave={tot/waves:.0f} cycles/tile/wave={tot/waves/(tiles/ (waves/8)):.0f}")
+for n, c in zip(names, v[:8]):
+    print(f"{n:10s} {100*c/tot:6.2f}%  {c/waves/(tiles/(waves/8)):9.0f} cyc/tile")
