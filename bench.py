@@ -46,6 +46,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample")
     p.add_argument("--kernel-iters", type=int, default=30)
+    p.add_argument("--no-hip-graph", action="store_true", help="launch the 4 kernels of a step eagerly from Python")
     return p.parse_args()
 
 
@@ -126,6 +127,7 @@ def main():
     from fixtures_util import synthetic_node_feats
 
     model, kw = build_model(args, device)
+    model.enable_hip_graph(not args.no_hip_graph)
     topo = get_topology(TopologySpec(args.frame, args.naux, args.main_only))
     B, N = args.batch, topo.num_nodes
     # this rank's shard of the global batch: frames [rank*B, (rank+1)*B) — synthetic N(0,1) node features
@@ -195,7 +197,8 @@ def main():
                                    f"num_gnn_layers={args.layers}, batch={B} per GPU, eval mode, "
                                    "node features [B*N,128] in HBM -> logits [B*N_valid,4] in HBM",
                        "nodes_per_frame": N, "directed_edges_per_frame": e_dir, "global_batch": B * world,
-                       "parallelism": f"dp{world} (batch-sharded frames, no data-path collective)"},
+                       "parallelism": f"dp{world} (batch-sharded frames, no data-path collective)",
+                       "launch": "eager" if args.no_hip_graph else "hipGraph replay of the step's kernels"},
             "stack_hbm_frac": round(frames_per_s / world * stack_bytes / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": roofline,
         }

@@ -72,7 +72,7 @@ __device__ inline f32x2 produce_row(const float* __restrict__ dis, const int* __
 constexpr int LAYER_THREADS = 512;
 
 template <int AGG>
-__global__ __launch_bounds__(LAYER_THREADS) void k_gcn_layer(const float* __restrict__ x, const float* __restrict__ W,
+__global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __restrict__ x, const float* __restrict__ W,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    const float* __restrict__ residual, float* __restrict__ out,
                                                    const float* __restrict__ dis, const int* __restrict__ rowptr,
@@ -157,27 +157,22 @@ __global__ __launch_bounds__(LAYER_THREADS) void k_gcn_layer(const float* __rest
         acc[0][0] = wreg[lane & 63 ? 1 : 0] + s_a[lane]; acc[1][0] = wreg[31];
 #endif
         // residual rows of this wave's segment: issued now so their latency hides behind the barriers and the
-        // accumulator round trip through LDS.  NULL residual reads x and is ignored below.
+        // accumulator round trip through LDS.  NULL residual reads x and is ignored below.  Everything in
+        // phase 3 is branch-free: a conditional store becomes its own basic block that starts with
+        // s_waitcnt vmcnt(0) (8 serialised store round trips per tile).  Rows without a node therefore
+        // re-load / re-store row 0 of the segment (same address, same value: harmless).
         f32x2 res[8];
-        const bool full = (seg_rows == 8);                                    // uniform
         const size_t seg_off = (frame_row0 + seg_first) * C + 2 * lane;
         {
             const float* rp = (residual ? residual : x) + seg_off;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
 #ifndef EG_ABL_NO_P3
-            if (full) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) res[u] = *reinterpret_cast<const f32x2*>(rp + u * C);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    res[u] = f32x2{0.f, 0.f};
-                    if (u < seg_rows) res[u] = *reinterpret_cast<const f32x2*>(rp + u * C);
-                }
-            }
+                res[u] = *reinterpret_cast<const f32x2*>(rp + (u < seg_rows ? u : 0) * C);
 #else
-#pragma unroll
-            for (int u = 0; u < 8; ++u) res[u] = f32x2{0.f, 0.f};
+                res[u] = f32x2{0.f, 0.f};
 #endif
+            }
         }
         STAMP(3);
         __syncthreads();
@@ -193,19 +188,27 @@ __global__ __launch_bounds__(LAYER_THREADS) void k_gcn_layer(const float* __rest
         STAMP(6);
 
         // ---- phase 3
-        float* op = out + seg_off;
+        if (seg_rows > 0) {                                                    // uniform; false only on ragged tiles
+            float* op = out + seg_off;
+            f32x2 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            f32x2 v = *reinterpret_cast<const f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]);
-            v = v * sc + sh;
-            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-            if (residual) v += res[u];
+            for (int u = 0; u < 8; ++u) {
+                f32x2 t = *reinterpret_cast<const f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]);
+                t = t * sc + sh;
+                if (a.relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); }
+                if (residual) t += res[u];
+                v[u] = t;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = u < seg_rows;                                   // uniform
+                const f32x2 val = ok ? v[u] : v[0];
 #ifndef EG_ABL_NO_P3
-            if (full) *reinterpret_cast<f32x2*>(op + u * C) = v;
-            else if (u < seg_rows) *reinterpret_cast<f32x2*>(op + u * C) = v;
+                *reinterpret_cast<f32x2*>(op + (ok ? u : 0) * C) = val;
 #else
-            if (v.x == 1234.5678f) *reinterpret_cast<f32x2*>(op + u * C) = v;
+                if (val.x == 1234.5678f) *reinterpret_cast<f32x2*>(op + (ok ? u : 0) * C) = val;
 #endif
+            }
         }
         STAMP(7);
     }

@@ -336,7 +336,7 @@ __device__ inline void stencil_row8(const Topo* __restrict__ T, const LevelDesc&
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const f32x2 o = acc[u] * readlane_f(wa, u * 8 + zz);
-        if (u < cnt) *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = o;
+        *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = o;   // rows >= cnt are padding rows of the tile
     }
 }
 
@@ -459,6 +459,7 @@ __device__ inline void load_w_slice16(const float* __restrict__ W, int wave, int
 
 // two 16-row blocks (row0, row0+16) with independent accumulators: the 40-cycle dependent latency of one
 // chain is covered by the other chain's 32-cycle issue slot.
+template <bool PREFETCH = true>
 __device__ inline void mfma16_pair(const float* s_a, int row0, int lane, const float (&wreg)[32], f32x4v& accA, f32x4v& accB) {
     const int j = lane & 15, k0 = koff16(lane >> 4);
     const f32x4* pa = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + k0);
@@ -469,7 +470,7 @@ __device__ inline void mfma16_pair(const float* s_a, int row0, int lane, const f
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         f32x4 ga[4], gb[4];
-        if (c == 0) {
+        if (PREFETCH && c == 0) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) { ga[t] = pa[4 + t]; gb[t] = pb[4 + t]; }
         }
@@ -487,6 +488,10 @@ __device__ inline void mfma16_pair(const float* s_a, int row0, int lane, const f
             accB = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[w0 + 3], fb[t].w, accB, 0, 0, 0);
         }
         if (c == 0) {
+            if (!PREFETCH) {                      // register-lean form: second half is read after the first is consumed
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { ga[t] = pa[4 + t]; gb[t] = pb[4 + t]; }
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) { fa[t] = ga[t]; fb[t] = gb[t]; }
         }

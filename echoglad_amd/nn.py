@@ -276,6 +276,17 @@ class HierarchicalPatchModel(nn.Module):
                                           use_connection_nodes=bool(use_connection_nodes))
         self._resolver = GraphResolver(self.topology_spec)
         self._fold_cache: Dict[str, tuple] = {}
+        self._hip_graphs: Dict[tuple, tuple] = {}
+        self.use_hip_graph = False
+
+    def enable_hip_graph(self, flag: bool = True) -> "HierarchicalPatchModel":
+        """Inference only: capture the kernel sequence of ``forward_nodes`` (3 fused layers + classifier
+        + queue resets) into a HIP graph the first time a given input buffer is seen and replay it on
+        later calls with the same buffers (same data_ptr / shape / weights).  The returned logits
+        tensor is owned by the graph and overwritten by the next replay."""
+        self.use_hip_graph = bool(flag)
+        self._hip_graphs.clear()
+        return self
 
     # ---- static row ranges (replace the reference's node_type host syncs, models.py:447,456,473,485)
     def _row_ranges(self):
@@ -351,6 +362,8 @@ class HierarchicalPatchModel(nn.Module):
         fused = (not self.training) and (not torch.is_grad_enabled() or not node_feats.requires_grad)
         fused = fused and self.jk is None and not any(p.requires_grad and torch.is_grad_enabled()
                                                       for p in self.parameters())
+        if fused and self.use_hip_graph and not self.use_coordinate_graph and not torch.cuda.is_current_stream_capturing():
+            return self._forward_nodes_graphed(node_feats, edge_index, B), None
         hidden = [node_feats.contiguous()]
         if fused:
             folded = self._folded_layers()
@@ -377,6 +390,31 @@ class HierarchicalPatchModel(nn.Module):
         if self.use_coordinate_graph:
             node_coords = node_coords.reshape(B * 4, -1)
         return out.squeeze(1), node_coords
+
+    def _forward_nodes_graphed(self, node_feats, edge_index, B):
+        key = (node_feats.data_ptr(), tuple(node_feats.shape), edge_index.data_ptr(), int(edge_index.shape[1]), B,
+               tuple(_versions(l) for l in self.gnn_layers), tuple(_versions(c) for c in self.node_classifiers))
+        hit = self._hip_graphs.get(key)
+        if hit is None:
+            was = self.use_hip_graph
+            self.use_hip_graph = False
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                     # warm-up outside capture (allocations, caches)
+                    self.forward_nodes(node_feats, edge_index, B)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out, _ = self.forward_nodes(node_feats, edge_index, B)
+            finally:
+                self.use_hip_graph = was
+            if len(self._hip_graphs) > 8:
+                self._hip_graphs.clear()
+            hit = (g, out)
+            self._hip_graphs[key] = hit
+        hit[0].replay()
+        return hit[1]
 
     # ---- avg-pool node features (models.py:498-537): the step in front of the hot path ---------
     def create_node_pixels(self, echo_frames: torch.Tensor, num_samples_per_batch: int, node_coords=None):
