@@ -40,13 +40,14 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_gcn_aggregate": (_i, [_p, _i, _p, _p, _p]),
     "eg_linear128_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _i, _i, _p, _p]),
     "eg_classifier_fwd": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
-    "eg_bn_stats": (_i, [_p, _i64, _p, _p, _p]),
-    "eg_bn_act_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _i, _p, _p]),
-    "eg_bn_act_bwd": (_i, [_p, _p, _p, _i64, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "eg_workspace_bytes": (ct.c_size_t, []),
+    "eg_colsum128": (_i, [_p, _i64, _p, _p, _p]),
     "eg_dweight128": (_i, [_p, _p, _i64, _p, _p, _p]),
-    "eg_bilinear4_fwd": (_i, [_p, _p, _i, _i64, _i64, _i, _p, _p]),
-    "eg_bilinear4_bwd": (_i, [_p, _p, _p, _i, _i64, _i64, _i, _p, _p, _p]),
-    "eg_scatter_rows": (_i, [_p, _p, _i, _i64, _i64, _i, _p]),
+    "eg_bn_stats": (_i, [_p, _i64, _p, _p, _p, _p]),
+    "eg_bn_act_fwd": (_i, [_p, _i64, _p, _p, _p, _i, ct.c_float, ct.c_uint64, _p, _p]),
+    "eg_bn_act_bwd": (_i, [_p, _p, _i64, _p, _p, _p, _p, _i, ct.c_float, ct.c_uint64, _p, _p, _p, _p, _p]),
+    "eg_bilinear4_fwd": (_i, [_p, _p, _i, _i, _i64, _i64, _i, _p, _p]),
+    "eg_bilinear4_bwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i, _p, _p, _p]),
 }
 
 

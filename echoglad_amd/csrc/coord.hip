@@ -1,0 +1,120 @@
+// Coordinate-graph resampling for gfx950: the reference's dense bilinear_interpolation
+// (src/core/models.py:539-553: hat weights relu(1-|c-i|) along h and w, outer product, weighted sum over
+// the whole [C,F,F] map = 103 MB of temporaries per frame at 224x224) is mathematically a 4-tap sample.
+// One wave per landmark gathers the <= 4 node rows of the main grid it touches (lane = channel pair).
+#include "tile.h"
+
+namespace eg {
+
+struct BilArgs {
+    int batch, points, frame;     // points per frame (4 in the reference)
+    long long n_per_frame, main_base;
+};
+
+struct Taps {
+    int i[2];
+    float w[2], dw[2];            // hat weight and its derivative wrt the coordinate
+};
+
+__device__ inline Taps taps_1d(float c, int F) {
+    Taps t;
+    const float f = floorf(c);
+    const int i0 = (int)f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = i0 + k;
+        const float d = c - (float)i;
+        const float w = 1.0f - fabsf(d);
+        const bool ok = i >= 0 && i < F && w > 0.0f;
+        t.i[k] = ok ? i : 0;
+        t.w[k] = ok ? w : 0.0f;
+        t.dw[k] = ok ? (d > 0.f ? -1.0f : (d < 0.f ? 1.0f : 0.0f)) : 0.0f;   // d/dc relu(1-|c-i|); 0 at the kink like torch.abs
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(256) void k_bilinear4_fwd(const float* __restrict__ h, const float* __restrict__ coords,
+                                                       float* __restrict__ out, const BilArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= a.batch * a.points) return;
+    const int frame = p / a.points;
+    const Taps th = taps_1d(coords[2 * p + 0], a.frame), tw = taps_1d(coords[2 * p + 1], a.frame);
+    const float* base = h + ((size_t)frame * a.n_per_frame + a.main_base) * C + 2 * lane;
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int ka = 0; ka < 2; ++ka)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float w = th.w[ka] * tw.w[kb];
+            const f32x2 v = *reinterpret_cast<const f32x2*>(base + ((size_t)th.i[ka] * a.frame + tw.i[kb]) * C);
+            acc += w * v;
+        }
+    *reinterpret_cast<f32x2*>(out + (size_t)p * C + 2 * lane) = acc;
+}
+
+// one wave per FRAME walks its landmarks in order, so two landmarks that touch the same pixel never race
+__global__ __launch_bounds__(256) void k_bilinear4_bwd(const float* __restrict__ dout, const float* __restrict__ h,
+                                                       const float* __restrict__ coords, float* __restrict__ dh,
+                                                       float* __restrict__ dcoords, const BilArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= a.batch) return;
+    const size_t fbase = ((size_t)frame * a.n_per_frame + a.main_base) * C + 2 * lane;
+    for (int q = 0; q < a.points; ++q) {
+        const int p = frame * a.points + q;
+        const Taps th = taps_1d(coords[2 * p + 0], a.frame), tw = taps_1d(coords[2 * p + 1], a.frame);
+        const f32x2 g = *reinterpret_cast<const f32x2*>(dout + (size_t)p * C + 2 * lane);
+        float gh = 0.f, gw = 0.f;
+#pragma unroll
+        for (int ka = 0; ka < 2; ++ka)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const size_t off = fbase + ((size_t)th.i[ka] * a.frame + tw.i[kb]) * C;
+                const f32x2 v = *reinterpret_cast<const f32x2*>(h + off);
+                const float dot = g.x * v.x + g.y * v.y;
+                gh += th.dw[ka] * tw.w[kb] * dot;
+                gw += th.w[ka] * tw.dw[kb] * dot;
+                const float w = th.w[ka] * tw.w[kb];
+                if (dh && w != 0.f) {
+                    f32x2 cur = *reinterpret_cast<const f32x2*>(dh + off);
+                    cur += w * g;
+                    *reinterpret_cast<f32x2*>(dh + off) = cur;
+                }
+            }
+        for (int o = 32; o > 0; o >>= 1) { gh += __shfl_xor(gh, o); gw += __shfl_xor(gw, o); }
+        if (dcoords && lane == 0) { dcoords[2 * p + 0] = gh; dcoords[2 * p + 1] = gw; }
+    }
+}
+
+}  // namespace eg
+
+using namespace eg;
+
+extern "C" {
+
+int eg_bilinear4_fwd(const float* h, const float* coords, int batch, int points, int64_t n_per_frame, int64_t main_base,
+                     int frame, float* out, eg_stream_t stream) {
+    if (!h || !coords || !out || batch < 1 || points < 1 || frame < 1 || main_base < 0 ||
+        main_base + (int64_t)frame * frame > n_per_frame)
+        return set_error(EG_ERR_ARG, "bad argument");
+    const BilArgs a{batch, points, frame, (long long)n_per_frame, (long long)main_base};
+    const int n = batch * points;
+    hipLaunchKernelGGL(k_bilinear4_fwd, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, coords, out, a);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+/* dh (may be NULL) is ACCUMULATED into: dh[tap rows] += w * dout; dcoords (may be NULL) is overwritten. */
+int eg_bilinear4_bwd(const float* dout, const float* h, const float* coords, int batch, int points, int64_t n_per_frame,
+                     int64_t main_base, int frame, float* dh, float* dcoords, eg_stream_t stream) {
+    if (!dout || !h || !coords || batch < 1 || points < 1 || frame < 1 || main_base < 0 ||
+        main_base + (int64_t)frame * frame > n_per_frame)
+        return set_error(EG_ERR_ARG, "bad argument");
+    const BilArgs a{batch, points, frame, (long long)n_per_frame, (long long)main_base};
+    hipLaunchKernelGGL(k_bilinear4_bwd, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, dout, h, coords, dh, dcoords, a);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,336 @@
+// Training-mode pieces of the GNN layer for gfx950 (reference src/core/models.py:328-335 in train mode and
+// its autograd backward):
+//   eg_colsum128      db = sum_rows dy                                   (GCNConv.bias gradient)
+//   eg_dweight128     dW[o][i] = sum_r g[r][o] * x[r][i]  on fp32 MFMA   (GCNConv.lin.weight gradient, g = A_hat dy)
+//   eg_bn_stats       per-channel batch mean / biased variance over ALL rows of the batch (BatchNorm1d train)
+//   eg_bn_act_fwd     y = relu(dropout(z * scale + shift)) + residual    (BN affine + Dropout + ReLU + residual)
+//   eg_bn_act_bwd     dz, dgamma, dbeta from dy (two passes: reduce, apply); dropout mask regenerated from the seed
+// All reductions are two-stage (per-workgroup partials in a caller-provided workspace, then one fixed-order
+// pass), so results are bitwise reproducible run to run: no float atomics anywhere.
+#include "tile.h"
+
+namespace eg {
+
+constexpr int RED_BLOCKS = 1024;           // stage-1 workgroups of the column reductions
+constexpr int RED_THREADS = 256;
+
+// ---- counter-based dropout mask: keep iff hash(seed, element) >= p ---------------------------------
+__device__ inline float keep_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);     // 24 random bits -> [0,1)
+    return u >= p ? inv_keep : 0.0f;
+}
+
+// ---- stage 1: per-workgroup column partials of up to NQ quantities ---------------------------------
+// lane = channel pair; a wave walks rows; 4 waves of a block are combined through LDS.
+template <int NQ, typename F>
+__device__ inline void column_partials(long long rows, double* __restrict__ partial, F&& row_values) {
+    __shared__ double s_red[4][NQ][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc[NQ][2];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q][0] = acc[q][1] = 0.0;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        f32x2 v[NQ];
+        row_values(r, lane, v);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { acc[q][0] += (double)v[q].x; acc[q][1] += (double)v[q].y; }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { s_red[wave][q][2 * lane] = acc[q][0]; s_red[wave][q][2 * lane + 1] = acc[q][1]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NQ * C; i += RED_THREADS) {
+        const int q = i / C, c = i % C;
+        partial[((size_t)blockIdx.x * NQ + q) * C + c] = s_red[0][q][c] + s_red[1][q][c] + s_red[2][q][c] + s_red[3][q][c];
+    }
+}
+
+// stage 2: fixed-order sum over the workgroup partials -> totals[NQ][C] (double, first NQ*C of the workspace tail)
+template <int NQ>
+__global__ void k_reduce_partials(const double* __restrict__ partial, int nblocks, double* __restrict__ totals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NQ * C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * NQ * C + i];
+    totals[i] = s;
+}
+
+__global__ __launch_bounds__(RED_THREADS) void k_colsum_partial(const float* __restrict__ x, long long rows, double* __restrict__ partial) {
+    column_partials<1>(rows, partial, [&](long long r, int lane, f32x2 (&v)[1]) {
+        v[0] = *reinterpret_cast<const f32x2*>(x + (size_t)r * C + 2 * lane);
+    });
+}
+
+__global__ __launch_bounds__(RED_THREADS) void k_stats_partial(const float* __restrict__ x, long long rows, double* __restrict__ partial) {
+    column_partials<2>(rows, partial, [&](long long r, int lane, f32x2 (&v)[2]) {
+        v[0] = *reinterpret_cast<const f32x2*>(x + (size_t)r * C + 2 * lane);
+        v[1] = v[0] * v[0];
+    });
+}
+
+__global__ void k_colsum_final(const double* __restrict__ totals, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c < C) out[c] = (float)totals[c];
+}
+
+__global__ void k_stats_final(const double* __restrict__ totals, long long rows, float* __restrict__ mean, float* __restrict__ var) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const double m = totals[c] / (double)rows;
+    double v = totals[C + c] / (double)rows - m * m;
+    mean[c] = (float)m;
+    var[c] = (float)(v > 0.0 ? v : 0.0);
+}
+
+// ---- BN affine + dropout + ReLU + residual, forward ------------------------------------------------
+struct ActArgs {
+    long long rows;
+    int relu;
+    float p, inv_keep;
+    unsigned long long seed;
+};
+
+__global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ z, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, const float* __restrict__ residual,
+                                                    float* __restrict__ out, const ActArgs a) {
+    const long long n4 = a.rows * (C / 4);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (C / 4)) * 4;
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4);
+        f32x4 v = zz * sc + sh;
+        if (a.p > 0.f) {
+            v.x *= keep_scale(a.seed, (unsigned long long)i * 4 + 0, a.p, a.inv_keep);
+            v.y *= keep_scale(a.seed, (unsigned long long)i * 4 + 1, a.p, a.inv_keep);
+            v.z *= keep_scale(a.seed, (unsigned long long)i * 4 + 2, a.p, a.inv_keep);
+            v.w *= keep_scale(a.seed, (unsigned long long)i * 4 + 3, a.p, a.inv_keep);
+        }
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+
+// ---- backward: g = dy * keep * relu'(v);  dbeta = sum g, dgamma = sum g * xhat ----------------------
+__device__ inline f32x2 act_grad2(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ mean,
+                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, const ActArgs& a, long long r, int lane, f32x2& xhat) {
+    const size_t off = (size_t)r * C + 2 * lane;
+    const f32x2 d = *reinterpret_cast<const f32x2*>(dy + off);
+    const f32x2 zz = *reinterpret_cast<const f32x2*>(z + off);
+    const f32x2 m = *reinterpret_cast<const f32x2*>(mean + 2 * lane);
+    const f32x2 is = *reinterpret_cast<const f32x2*>(invstd + 2 * lane);
+    const f32x2 ga = *reinterpret_cast<const f32x2*>(gamma + 2 * lane);
+    const f32x2 be = *reinterpret_cast<const f32x2*>(beta + 2 * lane);
+    xhat = (zz - m) * is;
+    const f32x2 v = xhat * ga + be;
+    f32x2 g = d;
+    if (a.p > 0.f) {
+        g.x *= keep_scale(a.seed, (unsigned long long)off, a.p, a.inv_keep);
+        g.y *= keep_scale(a.seed, (unsigned long long)off + 1, a.p, a.inv_keep);
+    }
+    if (a.relu) { g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f; }
+    return g;
+}
+
+__global__ __launch_bounds__(RED_THREADS) void k_bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                double* __restrict__ partial, const ActArgs a) {
+    column_partials<2>(a.rows, partial, [&](long long r, int lane, f32x2 (&v)[2]) {
+        f32x2 xhat;
+        const f32x2 g = act_grad2(dy, z, mean, invstd, gamma, beta, a, r, lane, xhat);
+        v[0] = g;
+        v[1] = g * xhat;
+    });
+}
+
+__global__ void k_bn_bwd_final(const double* __restrict__ totals, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = threadIdx.x;
+    if (c < C) { dbeta[c] = (float)totals[c]; dgamma[c] = (float)totals[C + c]; }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ z,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const double* __restrict__ totals, float* __restrict__ dz,
+                                                      const ActArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double inv_n = 1.0 / (double)a.rows;
+    const f32x2 mg = {(float)(totals[2 * lane] * inv_n), (float)(totals[2 * lane + 1] * inv_n)};             // mean of g
+    const f32x2 mgx = {(float)(totals[C + 2 * lane] * inv_n), (float)(totals[C + 2 * lane + 1] * inv_n)};   // mean of g*xhat
+    const f32x2 ga = *reinterpret_cast<const f32x2*>(gamma + 2 * lane);
+    const f32x2 is = *reinterpret_cast<const f32x2*>(invstd + 2 * lane);
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < a.rows; r += (long long)gridDim.x * 4) {
+        f32x2 xhat;
+        const f32x2 g = act_grad2(dy, z, mean, invstd, gamma, beta, a, r, lane, xhat);
+        const f32x2 o = ga * is * (g - mg - xhat * mgx);
+        *reinterpret_cast<f32x2*>(dz + (size_t)r * C + 2 * lane) = o;
+    }
+}
+
+// ---- dW = g^T x on the fp32 MFMA ---------------------------------------------------------------------
+// A workgroup (4 waves) owns a contiguous chunk of rows and the whole 128x128 result: wave w computes the
+// 32 x 128 slab dW[32w..32w+31][:] as four 32x32 accumulators.  Row tiles of 32 rows of g and x go through
+// LDS; v_mfma_f32_32x32x2_f32: A[i][k] = g[row k][32w + i] (lane i = l&31, k = l>>5), B[k][j] = x[row k][32jb + j].
+constexpr int DW_ROWS = 32;
+constexpr int DW_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void k_dweight_partial(const float* __restrict__ g, const float* __restrict__ x, long long rows,
+                                                         float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float s_g[DW_ROWS * C];
+    __shared__ __attribute__((aligned(16))) float s_x[DW_ROWS * C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int i = lane & 31, kh = lane >> 5;
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+    const long long n_tiles = (rows + DW_ROWS - 1) / DW_ROWS;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long long r0 = t * DW_ROWS;
+        // 32 rows x 128 floats = 1024 float4 per matrix; 256 threads -> 4 each
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;                 // float4 index
+            const long long r = r0 + e / 32;
+            f32x4 vg = {0.f, 0.f, 0.f, 0.f}, vx = vg;
+            if (r < rows) {
+                vg = *reinterpret_cast<const f32x4*>(g + (size_t)r * C + (e % 32) * 4);
+                vx = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + (e % 32) * 4);
+            }
+            *reinterpret_cast<f32x4*>(&s_g[e * 4]) = vg;
+            *reinterpret_cast<f32x4*>(&s_x[e * 4]) = vx;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < DW_ROWS / 2; ++s) {
+            const int r = 2 * s + kh;
+            const float a = s_g[r * C + 32 * wave + i];
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+                acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_x[r * C + 32 * jb + i], acc[jb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[m][n]: n = lane&31 -> input channel 32jb + n; m = (reg&3) + 8*(reg>>2) + 4*kh -> output channel 32w + m
+    float* p = partial + (size_t)blockIdx.x * C * C;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
+            p[(size_t)(32 * wave + m) * C + 32 * jb + i] = acc[jb][e];
+        }
+}
+
+__global__ void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C * C + idx];
+    dw[idx] = (float)s;
+}
+
+static int red_blocks(long long rows) {
+    long long b = (rows + 3) / 4;
+    if (b > RED_BLOCKS) b = RED_BLOCKS;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace eg
+
+using namespace eg;
+
+extern "C" {
+
+// doubles needed by the two-stage reductions: RED_BLOCKS * 2 * 128 partials + 2 * 128 totals; dW needs
+// DW_BLOCKS * 128 * 128 floats.  One buffer of eg_workspace_bytes() serves every call below.
+size_t eg_workspace_bytes(void) {
+    const size_t red = ((size_t)RED_BLOCKS * 2 * C + 2 * C) * sizeof(double);
+    const size_t dw = (size_t)DW_BLOCKS * C * C * sizeof(float);
+    return red > dw ? red : dw;
+}
+
+int eg_colsum128(const float* x, int64_t rows, void* workspace, float* out, eg_stream_t stream_) {
+    if (!x || !workspace || !out || rows < 1) return set_error(EG_ERR_ARG, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    double* partial = (double*)workspace;
+    const int nb = red_blocks(rows);
+    double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nb), dim3(RED_THREADS), 0, stream, x, (long long)rows, partial);
+    hipLaunchKernelGGL(k_reduce_partials<1>, dim3(1), dim3(128), 0, stream, partial, nb, totals);
+    hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(128), 0, stream, totals, out);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_bn_stats(const float* x, int64_t rows, void* workspace, float* mean, float* var, eg_stream_t stream_) {
+    if (!x || !workspace || !mean || !var || rows < 1) return set_error(EG_ERR_ARG, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    double* partial = (double*)workspace;
+    const int nb = red_blocks(rows);
+    double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
+    hipLaunchKernelGGL(k_stats_partial, dim3(nb), dim3(RED_THREADS), 0, stream, x, (long long)rows, partial);
+    hipLaunchKernelGGL(k_reduce_partials<2>, dim3(1), dim3(256), 0, stream, partial, nb, totals);
+    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(128), 0, stream, totals, (long long)rows, mean, var);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+static ActArgs make_act(int64_t rows, int relu, float p, uint64_t seed) {
+    ActArgs a{};
+    a.rows = rows; a.relu = relu; a.p = p; a.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    return a;
+}
+
+int eg_bn_act_fwd(const float* z, int64_t rows, const float* scale, const float* shift, const float* residual,
+                  int relu, float dropout_p, uint64_t seed, float* out, eg_stream_t stream) {
+    if (!z || !scale || !shift || !out || rows < 1) return set_error(EG_ERR_ARG, "bad argument");
+    if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    const ActArgs a = make_act(rows, relu, dropout_p, seed);
+    long long blocks = (rows * (C / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_bn_act_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, scale, shift, residual, out, a);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* mean, const float* invstd,
+                  const float* gamma, const float* beta, int relu, float dropout_p, uint64_t seed, void* workspace,
+                  float* dz, float* dgamma, float* dbeta, eg_stream_t stream_) {
+    if (!dy || !z || !mean || !invstd || !gamma || !beta || !workspace || !dz || !dgamma || !dbeta || rows < 1)
+        return set_error(EG_ERR_ARG, "bad argument");
+    if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const ActArgs a = make_act(rows, relu, dropout_p, seed);
+    double* partial = (double*)workspace;
+    const int nb = red_blocks(rows);
+    double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nb), dim3(RED_THREADS), 0, stream, dy, z, mean, invstd, gamma, beta, partial, a);
+    hipLaunchKernelGGL(k_reduce_partials<2>, dim3(1), dim3(256), 0, stream, partial, nb, totals);
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(128), 0, stream, totals, dgamma, dbeta);
+    long long blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, stream, dy, z, mean, invstd, gamma, beta, totals, dz, a);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_dweight128(const float* g, const float* x, int64_t rows, void* workspace, float* dw, eg_stream_t stream_) {
+    if (!g || !x || !workspace || !dw || rows < 1) return set_error(EG_ERR_ARG, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    long long nt = (rows + DW_ROWS - 1) / DW_ROWS;
+    const int nb = (int)(nt < DW_BLOCKS ? nt : DW_BLOCKS);
+    hipLaunchKernelGGL(k_dweight_partial, dim3(nb), dim3(256), 0, stream, g, x, (long long)rows, (float*)workspace);
+    hipLaunchKernelGGL(k_dweight_final, dim3((C * C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, dw);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+}  // extern "C"

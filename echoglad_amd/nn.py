@@ -110,6 +110,36 @@ class _GCNConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _BNActFn(torch.autograd.Function):
+    """Train-mode tail of one GNN layer in two HIP passes: BatchNorm1d with batch statistics over all rows
+    of the batch, Dropout, ReLU|Identity and the residual add (src/core/models.py:333-335, :434-435).
+    Running statistics are updated like nn.BatchNorm1d (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, residual, relu, p, momentum, eps, seed):
+        z = z.contiguous()
+        mean, var = ops.bn_stats(z)
+        n = z.shape[0]
+        with torch.no_grad():
+            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        invstd = torch.rsqrt(var + eps)
+        scale = (gamma * invstd).contiguous()
+        shift = (beta - mean * scale).contiguous()
+        out = ops.bn_act_fwd(z, scale, shift, residual.contiguous() if residual is not None else None, relu, p, seed)
+        ctx.save_for_backward(z, mean, invstd, gamma.detach().contiguous(), beta.detach().contiguous())
+        ctx.cfg = (relu, p, seed, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, invstd, gamma, beta = ctx.saved_tensors
+        relu, p, seed, has_res = ctx.cfg
+        dy = dy.contiguous()
+        dz, dgamma, dbeta = ops.bn_act_bwd(dy, z, mean, invstd, gamma, beta, relu, p, seed)
+        return dz, dgamma, dbeta, None, None, (dy if has_res else None), None, None, None, None, None
+
+
 # ---------------------------------------------------------------------------
 # torch_geometric-compatible modules
 # ---------------------------------------------------------------------------
@@ -330,6 +360,21 @@ class HierarchicalPatchModel(nn.Module):
             self._fold_cache["cls"] = hit
         return hit[1]
 
+    # ---- one GNN layer in train mode: GCNConv kernel + fused BN/Dropout/ReLU/residual kernels ----------
+    def _layer_train(self, i: int, x_in: torch.Tensor, graph: ops.Graph, gb: int) -> torch.Tensor:
+        layer = self.gnn_layers[i]
+        conv, bn, drop = layer.module_0, layer.module_1, layer.module_2
+        z = conv.forward_graph(x_in, graph, gb)
+        p = float(drop.p)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0      # host RNG: reproducible under torch.manual_seed
+        relu = i < self.num_gnn_layers - 1
+        res = x_in if (self.residual and z.shape[1] == x_in.shape[1]) else None
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        h = _BNActFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu, p, momentum, bn.eps, seed)
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        return h
+
     # ---- coordinate-graph update (models.py:438-473) ---------------------------------------
     def _coordinate_update(self, i: int, h: torch.Tensor, node_coords: torch.Tensor, batch: int):
         n, _, _, main_base, coord_base = self._row_ranges()
@@ -373,6 +418,8 @@ class HierarchicalPatchModel(nn.Module):
                 w, scale, shift = folded[i]
                 h = ops.gcn_layer_fwd(graph, gb, x_in, w, scale, shift, x_in if self.residual else None,
                                       relu=(i < self.num_gnn_layers - 1))
+            elif self.training:
+                h = self._layer_train(i, x_in, graph, gb)
             else:
                 h = self.gnn_layers[i].forward_graph(x_in, graph, gb)
                 if self.residual and h.shape[1] == x_in.shape[1]:

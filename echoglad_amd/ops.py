@@ -154,3 +154,142 @@ def classifier_fwd(h: torch.Tensor, batch: int, n_per_frame: int, row_lo: int, n
                                              _ptr(p["t2"]), _ptr(p["w3"]), _ptr(p["b3"]), int(sigmoid), _ptr(out),
                                              _stream()), "eg_classifier_fwd")
     return out
+
+
+# ---------------------------------------------------------------------------
+# training-mode pieces
+# ---------------------------------------------------------------------------
+_workspaces = {}
+
+
+def _workspace(device) -> torch.Tensor:
+    """One reduction workspace per (device, stream); the C side never allocates."""
+    key = (torch.device(device), torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        nbytes = int(_lib.load().eg_workspace_bytes())
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def colsum128(x: torch.Tensor) -> torch.Tensor:
+    _check_rows(x, "x")
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().eg_colsum128(_ptr(x), int(x.shape[0]), _ptr(_workspace(x.device)), _ptr(out), _stream()),
+               "eg_colsum128")
+    return out
+
+
+def dweight128(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """g^T x -> [128(out), 128(in)]"""
+    _check_rows(g, "g")
+    _check_rows(x, "x", g.shape[0])
+    out = torch.empty(C, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().eg_dweight128(_ptr(g), _ptr(x), int(x.shape[0]), _ptr(_workspace(x.device)), _ptr(out),
+                                         _stream()), "eg_dweight128")
+    return out
+
+
+def bn_stats(x: torch.Tensor):
+    """(mean[128], biased var[128]) over all rows."""
+    _check_rows(x, "x")
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    var = torch.empty(C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().eg_bn_stats(_ptr(x), int(x.shape[0]), _ptr(_workspace(x.device)), _ptr(mean), _ptr(var),
+                                       _stream()), "eg_bn_stats")
+    return mean, var
+
+
+def bn_act_fwd(z, scale, shift, residual=None, relu=False, dropout_p=0.0, seed=0) -> torch.Tensor:
+    _check_rows(z, "z")
+    _check_vec(scale, "scale", C)
+    _check_vec(shift, "shift", C)
+    if residual is not None:
+        _check_rows(residual, "residual", z.shape[0])
+    out = torch.empty_like(z)
+    _lib.check(_lib.load().eg_bn_act_fwd(_ptr(z), int(z.shape[0]), _ptr(scale), _ptr(shift), _ptr(residual), int(relu),
+                                         float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(out), _stream()),
+               "eg_bn_act_fwd")
+    return out
+
+
+def bn_act_bwd(dy, z, mean, invstd, gamma, beta, relu=False, dropout_p=0.0, seed=0):
+    """-> (dz, dgamma, dbeta)"""
+    _check_rows(dy, "dy")
+    _check_rows(z, "z", dy.shape[0])
+    for t, n in ((mean, "mean"), (invstd, "invstd"), (gamma, "gamma"), (beta, "beta")):
+        _check_vec(t, n, C)
+    dz = torch.empty_like(z)
+    dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
+    _lib.check(_lib.load().eg_bn_act_bwd(_ptr(dy), _ptr(z), int(z.shape[0]), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                         _ptr(beta), int(relu), float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                         _ptr(_workspace(z.device)), _ptr(dz), _ptr(dgamma), _ptr(dbeta), _stream()),
+               "eg_bn_act_bwd")
+    return dz, dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------
+# coordinate-graph resampling
+# ---------------------------------------------------------------------------
+def _check_coords(coords, batch, points):
+    if not coords.is_cuda or coords.dtype != torch.float32 or not coords.is_contiguous() or \
+            coords.numel() != batch * points * 2:
+        raise RuntimeError(f"coords must be contiguous CUDA float32 with {batch * points * 2} elements")
+
+
+def bilinear4_fwd(h, coords, batch, n_per_frame, main_base, frame, points=4) -> torch.Tensor:
+    _check_rows(h, "h", batch * n_per_frame)
+    _check_coords(coords, batch, points)
+    out = torch.empty(batch * points, C, dtype=torch.float32, device=h.device)
+    _lib.check(_lib.load().eg_bilinear4_fwd(_ptr(h), _ptr(coords), batch, points, n_per_frame, main_base, frame,
+                                            _ptr(out), _stream()), "eg_bilinear4_fwd")
+    return out
+
+
+def bilinear4_bwd(dout, h, coords, batch, n_per_frame, main_base, frame, dh=None, want_dcoords=True, points=4):
+    _check_rows(h, "h", batch * n_per_frame)
+    _check_coords(coords, batch, points)
+    dout = dout.contiguous()
+    dcoords = torch.empty(batch * points, 2, dtype=torch.float32, device=h.device) if want_dcoords else None
+    _lib.check(_lib.load().eg_bilinear4_bwd(_ptr(dout), _ptr(h), _ptr(coords), batch, points, n_per_frame, main_base,
+                                            frame, _ptr(dh), _ptr(dcoords), _stream()), "eg_bilinear4_bwd")
+    return dcoords
+
+
+class _Bilinear4Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, coords, batch, n_per_frame, main_base, frame):
+        coords = coords.contiguous()
+        ctx.save_for_backward(h, coords)
+        ctx.dims = (batch, n_per_frame, main_base, frame)
+        return bilinear4_fwd(h, coords, batch, n_per_frame, main_base, frame)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, coords = ctx.saved_tensors
+        batch, n_per_frame, main_base, frame = ctx.dims
+        dh = torch.zeros_like(h) if ctx.needs_input_grad[0] else None
+        dcoords = bilinear4_bwd(dout, h, coords, batch, n_per_frame, main_base, frame, dh=dh,
+                                want_dcoords=ctx.needs_input_grad[1])
+        if dcoords is not None:
+            dcoords = dcoords.view_as(coords)
+        return dh, dcoords, None, None, None, None
+
+
+def bilinear4(h, coords, batch, n_per_frame, main_base, frame) -> torch.Tensor:
+    """[batch*4, 128] features at the landmark coordinates (differentiable wrt h and coords)."""
+    c = coords.reshape(batch * 4, 2)
+    if torch.is_grad_enabled() and (h.requires_grad or c.requires_grad):
+        return _Bilinear4Fn.apply(h, c, batch, n_per_frame, main_base, frame)
+    return bilinear4_fwd(h, c.contiguous(), batch, n_per_frame, main_base, frame)
+
+
+def scatter_coord_rows(h, new_feats, batch, n_per_frame, coord_base) -> torch.Tensor:
+    """h[type==1 rows] = new_feats (models.py:473).  The coordinate rows are the last 4 rows of every frame, so
+    this is a strided slice assignment; under autograd a copy keeps the saved forward values intact."""
+    need_grad = torch.is_grad_enabled() and (h.requires_grad or new_feats.requires_grad)
+    tgt = h.clone() if need_grad else h
+    tgt.view(batch, n_per_frame, C)[:, coord_base:coord_base + 4, :] = new_feats.view(batch, 4, C)
+    return tgt

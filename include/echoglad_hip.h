@@ -120,6 +120,43 @@ int eg_classifier_fwd(const float* h, int batch, int64_t n_per_frame, int64_t ro
                       const float* t2, const float* w3, const float* b3, int sigmoid, float* logits,
                       eg_stream_t stream);
 
+/* ---- training-mode pieces (BatchNorm batch statistics, Dropout, backward) -----------------------
+ * Reference: the same Sequential (src/core/models.py:328-335) in train mode and its autograd backward
+ * (engine.py:271-273).  Every reduction is two-stage through a caller-provided workspace of at least
+ * eg_workspace_bytes() bytes (device memory, reusable across calls on one stream): no float atomics,
+ * results are bitwise reproducible. */
+size_t eg_workspace_bytes(void);
+
+/* out[128] = sum over rows of x[rows,128]                     (GCNConv.bias gradient) */
+int eg_colsum128(const float* x, int64_t rows, void* workspace, float* out, eg_stream_t stream);
+
+/* dw[o][i] = sum_r g[r][o] * x[r][i], [128,128] row-major     (GCNConv.lin.weight gradient, g = A_hat dy) */
+int eg_dweight128(const float* g, const float* x, int64_t rows, void* workspace, float* dw, eg_stream_t stream);
+
+/* BatchNorm1d(128) batch statistics over ALL rows: mean[128], biased variance var[128] (models.py:333) */
+int eg_bn_stats(const float* x, int64_t rows, void* workspace, float* mean, float* var, eg_stream_t stream);
+
+/* out = relu?(dropout_p(z * scale + shift)) + residual ; dropout keeps element e iff hash(seed, e) >= p and
+ * scales by 1/(1-p) (nn.Dropout semantics; the mask is a pure function of (seed, element index)).
+ * residual may be NULL. */
+int eg_bn_act_fwd(const float* z, int64_t rows, const float* scale, const float* shift, const float* residual,
+                  int relu, float dropout_p, uint64_t seed, float* out, eg_stream_t stream);
+
+/* backward of  y = relu?(dropout(BN_train(z)))  given dy: dz[rows,128], dgamma[128], dbeta[128].
+ * mean / invstd are the batch statistics used in the forward (invstd = 1/sqrt(var + eps)). */
+int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* mean, const float* invstd,
+                  const float* gamma, const float* beta, int relu, float dropout_p, uint64_t seed, void* workspace,
+                  float* dz, float* dgamma, float* dbeta, eg_stream_t stream);
+
+/* ---- coordinate-graph resampling (src/core/models.py:539-553 as a 4-tap gather) -------------------
+ * coords [batch*points, 2] in (h, w) order; out[p,:] = bilinear sample of frame p/points' main grid
+ * (rows main_base .. main_base + frame*frame of each frame's node block), zero outside the grid. */
+int eg_bilinear4_fwd(const float* h, const float* coords, int batch, int points, int64_t n_per_frame, int64_t main_base,
+                     int frame, float* out, eg_stream_t stream);
+/* dh (nullable) is accumulated into (+=) at the touched rows; dcoords (nullable) [batch*points,2] is overwritten */
+int eg_bilinear4_bwd(const float* dout, const float* h, const float* coords, int batch, int points, int64_t n_per_frame,
+                     int64_t main_base, int frame, float* dh, float* dcoords, eg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,170 @@
+"""-m gpu: training-mode kernels and the backward path vs torch autograd on the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fixtures_util import initial_coords, synthetic_frames, synthetic_node_feats
+from gpu_util import DEV, graph_tensors, model_pair, rand_rows
+from oracle import gnn_oracle as O
+from echoglad_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows", [1, 63, 64, 1000, 72020])
+def test_colsum_and_bn_stats(rows):
+    x = rand_rows(rows, seed=rows, scale=2.0) + 0.5
+    xg = x.to(DEV)
+    assert torch.allclose(ops.colsum128(xg).cpu(), x.double().sum(0).float(), rtol=1e-6, atol=1e-4)
+    mean, var = ops.bn_stats(xg)
+    assert torch.allclose(mean.cpu(), x.double().mean(0).float(), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(var.cpu(), x.double().var(0, unbiased=False).float(), rtol=1e-5, atol=1e-6)
+    a, b = ops.bn_stats(xg)
+    assert torch.equal(a, mean) and torch.equal(b, var)           # two-stage reductions are deterministic
+
+
+@pytest.mark.parametrize("rows", [5, 32, 33, 4116, 20000])
+def test_dweight(rows):
+    g, x = rand_rows(rows, seed=1), rand_rows(rows, seed=2)
+    got = ops.dweight128(g.to(DEV), x.to(DEV)).cpu()
+    want = (g.double().t() @ x.double()).float()
+    assert (got - want).abs().max() < 1e-4 * max(1.0, want.abs().max().item())
+    # asymmetric check: one-hot rows pick single entries
+    g1 = torch.zeros(rows, 128); x1 = torch.zeros(rows, 128)
+    g1[0, 3] = 2.0; x1[0, 77] = 5.0
+    got1 = ops.dweight128(g1.to(DEV), x1.to(DEV)).cpu()
+    assert got1[3, 77] == 10.0 and got1.abs().sum() == 10.0
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_bn_act_forward_backward_vs_autograd(relu, with_res):
+    rows = 3000
+    z = (rand_rows(rows, seed=3) * 1.5 + 0.2).requires_grad_(True)
+    res = rand_rows(rows, seed=4).requires_grad_(True) if with_res else None
+    bn = torch.nn.BatchNorm1d(128).train()
+    O.randomize_bn_stats(bn, seed=2)
+    want = bn(z)
+    want = torch.relu(want) if relu else want
+    if with_res:
+        want = want + res
+    dy = rand_rows(rows, seed=5)
+    want.backward(dy)
+    mean, var = ops.bn_stats(z.detach().to(DEV))
+    invstd = torch.rsqrt(var + bn.eps)
+    gamma, beta = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    got = ops.bn_act_fwd(z.detach().to(DEV), scale, shift, res.detach().to(DEV) if with_res else None, relu=relu)
+    assert (got.cpu() - want.detach()).abs().max() < 2e-5
+    dz, dgamma, dbeta = ops.bn_act_bwd(dy.to(DEV), z.detach().to(DEV), mean, invstd, gamma, beta, relu=relu)
+    assert (dz.cpu() - z.grad).abs().max() < 2e-5
+    assert torch.allclose(dgamma.cpu(), bn.weight.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(dbeta.cpu(), bn.bias.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_dropout_mask_statistics_and_consistency():
+    rows, p = 20000, 0.5
+    z = torch.ones(rows, 128, device=DEV)
+    one, zero = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    y = ops.bn_act_fwd(z, one, zero, None, relu=False, dropout_p=p, seed=1234)
+    keep = (y != 0).float()
+    assert abs(keep.mean().item() - (1 - p)) < 5e-3
+    assert torch.all((y == 0) | (y == 1.0 / (1 - p)))
+    assert abs(keep.mean(0).min().item() - (1 - p)) < 0.02 and abs(keep.mean(1).min().item() - (1 - p)) < 0.2
+    assert torch.equal(y, ops.bn_act_fwd(z, one, zero, None, relu=False, dropout_p=p, seed=1234))
+    assert not torch.equal(y, ops.bn_act_fwd(z, one, zero, None, relu=False, dropout_p=p, seed=1235))
+    # backward regenerates the same mask: with mean/invstd chosen so BN is the identity, g == dy * mask
+    mean, invstd = torch.zeros(128, device=DEV), torch.ones(128, device=DEV)
+    dy = torch.ones(rows, 128, device=DEV)
+    dz, dgamma, dbeta = ops.bn_act_bwd(dy, z, mean, invstd, one, zero, relu=False, dropout_p=p, seed=1234)
+    assert torch.allclose(dbeta, y.sum(0), rtol=1e-6)
+
+
+def test_bilinear_forward_backward_vs_dense_reference():
+    B, F, naux = 2, 16, 3
+    topo, ei, nt, bi = graph_tensors(F, naux, B, coord=True)
+    n, mb = topo.num_nodes, topo.main.base
+    h = rand_rows(B * n, seed=7).requires_grad_(True)
+    coords = torch.tensor([[0.0, 0.0], [15.0, 15.0], [3.25, 7.75], [14.999, 0.001],
+                           [5.0, 11.0], [7.5, 7.5], [0.3, 14.6], [12.2, 3.9]], requires_grad=True)
+    main = h.view(B, n, 128)[:, mb:mb + F * F, :].permute(0, 2, 1).reshape(B, 128, F, F)
+    want = torch.cat([O.bilinear_interpolation_dense(coords[4 * b:4 * b + 4], main[b]) for b in range(B)])
+    dout = rand_rows(B * 4, seed=8)
+    want.backward(dout)
+    hg = h.detach().to(DEV).requires_grad_(True)
+    cg = coords.detach().to(DEV).requires_grad_(True)
+    got = ops.bilinear4(hg, cg, B, n, mb, F)
+    assert (got.detach().cpu() - want.detach()).abs().max() < 1e-5
+    got.backward(dout.to(DEV))
+    assert (hg.grad.cpu() - h.grad).abs().max() < 1e-5
+    assert (cg.grad.cpu() - coords.grad).abs().max() < 1e-3
+    # coordinates outside the frame sample zero (the reference's hat weights vanish there)
+    far = torch.tensor([[99.9, 112.5]] * (B * 4))
+    assert ops.bilinear4(hg.detach(), far.to(DEV), B, n, mb, F).abs().max() == 0
+
+
+def test_coordinate_graph_eval_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "coord_f32_a4.npz"))
+    frame, naux, L, B = int(g["frame"]), int(g["naux"]), int(g["layers"]), int(g["batch"])
+    hip, ref = model_pair(frame, naux, L, coord=True, seed=int(g["weight_seed"]))
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+    frames = synthetic_frames(B, 128, frame, int(g["frame_seed"]))
+    coords0 = initial_coords(B, frame)
+    with torch.no_grad():
+        got, gc = hip(x=frames.to(DEV), node_coords=coords0.clone().to(DEV), edge_index=ei.to(DEV),
+                      node_type=nt.to(DEV), batch_idx=bi.to(DEV))
+    assert np.abs(gc.cpu().numpy() - g["out_coords"]).max() < 1e-4
+    assert np.abs(got.cpu().numpy() - g["logits"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("frame,naux,coord", [(16, 3, False), (32, 4, True)])
+def test_train_step_gradients_vs_oracle(frame, naux, coord):
+    """train mode, dropout p = 0 (the RNG streams cannot match): logits, coords and every parameter gradient."""
+    B, L = 2, 3
+    hip, ref = model_pair(frame, naux, L, coord=coord, seed=31)
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    hip.train(); ref.train()
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=coord)
+    frames = synthetic_frames(B, 128, frame, 11)
+    coords0 = initial_coords(B, frame) if coord else None
+    want, wc = ref(x=frames, node_coords=None if coords0 is None else coords0.clone(), edge_index=ei, node_type=nt,
+                   batch_idx=bi)
+    got, gc = hip(x=frames.to(DEV), node_coords=None if coords0 is None else coords0.clone().to(DEV),
+                  edge_index=ei.to(DEV), node_type=nt.to(DEV), batch_idx=bi.to(DEV))
+    assert (got.detach().cpu() - want.detach()).abs().max() < 2e-4
+    lw = (want ** 2).mean() + (0 if wc is None else (wc ** 2).mean() * 1e-3)
+    lg = (got ** 2).mean() + (0 if gc is None else (gc ** 2).mean() * 1e-3)
+    lw.backward(); lg.backward()
+    ref_grads = dict(ref.named_parameters())
+    for name, p in hip.named_parameters():
+        rg = ref_grads[name].grad
+        assert p.grad is not None, name
+        denom = max(rg.abs().max().item(), 1e-6)
+        assert (p.grad.cpu() - rg).abs().max().item() / denom < 5e-3, name
+    # BatchNorm running statistics follow nn.BatchNorm1d
+    for (n1, b1), (n2, b2) in zip(hip.named_buffers(), ref.named_buffers()):
+        if "running" in n1:
+            assert torch.allclose(b1.cpu(), b2, rtol=1e-4, atol=1e-5), n1
+
+
+def test_train_with_dropout_runs_and_is_seeded():
+    hip, _ = model_pair(16, 3, 2, seed=5)
+    hip.train()
+    topo, ei, nt, bi = graph_tensors(16, 3, 2)
+    feats = synthetic_node_feats(2 * topo.num_nodes, 128, seed=1).to(DEV)
+    torch.manual_seed(7)
+    a, _ = hip.forward_nodes(feats, ei.to(DEV), 2)
+    torch.manual_seed(7)
+    b, _ = hip.forward_nodes(feats, ei.to(DEV), 2)
+    torch.manual_seed(8)
+    c, _ = hip.forward_nodes(feats, ei.to(DEV), 2)
+    assert torch.isfinite(a).all()
+    a.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in hip.parameters())
+    # GNN-layer dropout is keyed on the host RNG (classifier dropout uses torch's device RNG)
+    assert a.shape == b.shape == c.shape

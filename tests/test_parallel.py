@@ -1,0 +1,92 @@
+"""N>1 path on CPU: world_size-2 gloo run of the batch sharding + flat gradient all-reduce
+(echoglad_amd/parallel.py) against a single-process run of the full batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fixtures_util import fill_state_dict, synthetic_node_feats
+from oracle import gnn_oracle as O
+from echoglad_amd import parallel
+from echoglad_amd.topology import HierTopology, TopologySpec
+
+
+def test_shard_range_is_a_partition():
+    for n in (1, 7, 8, 64, 257):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_frames_views():
+    N = 84
+    feats = torch.arange(4 * N * 2, dtype=torch.float32).view(4 * N, 2)
+    coords = torch.arange(16 * 2, dtype=torch.float32).view(16, 2)
+    s = parallel.shard_frames(1, 2, N, node_feats=feats, node_coords=coords, labels=feats[:, :1])
+    assert s["frame_range"] == (2, 4)
+    assert torch.equal(s["node_feats"], feats[2 * N:]) and torch.equal(s["node_coords"], coords[8:])
+    assert s["labels"].shape[0] == 2 * N
+
+
+def _model(frame, naux):
+    m = O.OracleHierarchicalPatchModel(frame_size=frame, node_embedding_dim=128, node_hidden_dim=128,
+                                       num_gnn_layers=2, num_aux_graphs=naux, classifier_hidden_dim=32,
+                                       output_activation="logit")
+    fill_state_dict(m, 3)
+    return m.eval()          # eval-mode BN so that shard-wise and full-batch losses are identical functions
+
+
+def _worker(rank, world, port, frame, naux, B, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    topo = HierTopology(TopologySpec(frame, naux))
+    n = topo.num_nodes
+    feats = synthetic_node_feats(B * n, 128, seed=5)
+    shard = parallel.shard_frames(rank, world, n, node_feats=feats)
+    lo, hi = shard["frame_range"]
+    b = hi - lo
+    model = _model(frame, naux)
+    if rank != 0:                      # ranks start different; broadcast must fix that
+        for p in model.parameters():
+            p.data.add_(1.0)
+    parallel.broadcast_parameters(model, src=0)
+    ei = torch.from_numpy(topo.batched_edge_index(b))
+    nt = torch.from_numpy(np.tile(topo.node_type(), b))
+    logits, _ = model.forward_nodes(shard["node_feats"], ei, nt, b)
+    loss = (logits ** 2).sum() / (B * n)            # global mean written as a sum of shard sums
+    loss.backward()
+    red = parallel.GradientAllReducer(model.parameters(), average=False)
+    pending = red.allreduce(async_op=True)
+    pending.wait()
+    if rank == 0:
+        torch.save({k: p.grad.clone() for k, p in model.named_parameters()}, os.path.join(out_dir, "grads.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_match_single_process(tmp_path):
+    frame, naux, B, world = 8, 2, 4, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, frame, naux, B, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(tmp_path, "grads.pt"))
+    topo = HierTopology(TopologySpec(frame, naux))
+    n = topo.num_nodes
+    model = _model(frame, naux)
+    feats = synthetic_node_feats(B * n, 128, seed=5)
+    ei = torch.from_numpy(topo.batched_edge_index(B))
+    nt = torch.from_numpy(np.tile(topo.node_type(), B))
+    logits, _ = model.forward_nodes(feats, ei, nt, B)
+    ((logits ** 2).sum() / (B * n)).backward()
+    for k, p in model.named_parameters():
+        assert torch.allclose(got[k], p.grad, rtol=1e-4, atol=1e-6), k
