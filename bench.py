@@ -179,9 +179,20 @@ def main():
         bytes_alg = B * N * 2 * C * 4                                  # read x once + write out once
         tf = flops / (layer_ms * 1e-3) / 1e12
         gbs = bytes_alg / (layer_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes of the same command (tools/profile_round.sh), committed under profiles/
+        traffic, traffic_src = None, None
+        for cand in sorted([f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")], reverse=True) \
+                if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if args.frame == 224 and args.naux == 7 and B == 8 and not args.main_only:
+                    traffic, traffic_src = int(pm["k_gcn_layer"]["hbm_bytes_per_launch"]), "profiles/" + cand
+                break
+            except Exception:
+                continue
         roofline = {"bound": "mfma", "kernel": "k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>",
                     "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_F32_MFMA_TF, 4), "traffic": None,
+                    "frac": round(tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(layer_ms, 4),
                     "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": bytes_alg}}

@@ -144,8 +144,9 @@ def test_train_step_gradients_vs_oracle(frame, naux, coord):
     for name, p in hip.named_parameters():
         rg = ref_grads[name].grad
         assert p.grad is not None, name
-        denom = max(rg.abs().max().item(), 1e-6)
-        assert (p.grad.cpu() - rg).abs().max().item() / denom < 5e-3, name
+        # (a bias in front of a train-mode BatchNorm has an exactly-zero gradient: both sides are rounding noise)
+        err = (p.grad.cpu() - rg).abs().max().item()
+        assert err < 5e-3 * rg.abs().max().item() + 1e-6, (name, err, rg.abs().max().item())
     # BatchNorm running statistics follow nn.BatchNorm1d
     for (n1, b1), (n2, b2) in zip(hip.named_buffers(), ref.named_buffers()):
         if "running" in n1:
