@@ -71,7 +71,10 @@ __device__ inline f32x2 produce_row(const float* __restrict__ dis, const int* __
 //            so no barrier separates a tile's phase 3 from the next tile's phase 1.
 constexpr int LAYER_THREADS = 512;
 
-template <int AGG>
+// RES_GLOBAL: the residual rows are fetched from global memory in the epilogue (any pointer).  The hot
+// instantiation <AGG_STENCIL, false> instead reuses the self rows that phase 1 stashed in LDS (residual == x)
+// or has no residual at all, and carries no registers for the residual.
+template <int AGG, bool RES_GLOBAL>
 __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __restrict__ x, const float* __restrict__ W,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    const float* __restrict__ residual, float* __restrict__ out,
@@ -80,6 +83,9 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
                                                    const TileDesc* __restrict__ tiles,
                                                    int* __restrict__ walk_counters, const LayerDims a) {
     __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA + 4];
+    // raw self rows of the tile (implicit-topology path with residual == x): the epilogue's residual source
+    __shared__ __attribute__((aligned(16))) float s_xbuf[(AGG == AGG_STENCIL && !RES_GLOBAL) ? TILE * C : 4];
+    float* const s_x = (AGG == AGG_STENCIL && !RES_GLOBAL && residual) ? s_xbuf : nullptr;
 
     const int tid = threadIdx.x;
     const int lane_k = tid & 63;
@@ -87,8 +93,9 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
 
     float wreg[32];
     load_w_slice16(W, wave, lane_k, a.transpose_w, wreg);
-    const f32x2 sc = scale ? *reinterpret_cast<const f32x2*>(scale + 2 * lane_k) : f32x2{1.f, 1.f};
-    const f32x2 sh = shift ? *reinterpret_cast<const f32x2*>(shift + 2 * lane_k) : f32x2{0.f, 0.f};
+    // epilogue constants for this lane's 4 channels in the paired-row layout (row parity lane>>5, channels 4*(lane&31)..)
+    const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + 4 * (lane_k & 31)) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sh = shift ? *reinterpret_cast<const f32x4*>(shift + 4 * (lane_k & 31)) : f32x4{0.f, 0.f, 0.f, 0.f};
 
     TileWalk walk(a.walk_mode, a.tiles_per_frame * a.batch, walk_counters, reinterpret_cast<int*>(&s_a[TILE * LDA]));
     int tile;
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
             seg_first = d.base + (td.r0 + wave) * d.side + td.c0;
             seg_rows = wave < td.nrows ? td.ncols : 0;
             blocks = (td.nrows + 1) >> 1;
-            stencil_patch_rows(T, d, td, T->magic, xf, dis, a.n_per_frame, wave, 1, lane, s_a);
+            stencil_patch_rows(T, d, td, T->magic, xf, dis, a.n_per_frame, wave, 1, lane, s_a, s_x);
         } else {
             const int n0 = t_in * TILE;
             const int rows_here = (a.n_per_frame - n0) < TILE ? (a.n_per_frame - n0) : TILE;
@@ -128,11 +135,15 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
             blocks = (rows_here + 15) >> 4;
             const int last = a.n_per_frame - 1;
             if constexpr (AGG == AGG_NONE) {
-                f32x2 v[8];
+                const PairLane pl{lane >> 5, lane & 31};
+                f32x4 v[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = load_row2(xf, seg_first + u < last ? seg_first + u : last, lane);
+                for (int k = 0; k < 4; ++k) {
+                    const int n = seg_first + 2 * k + pl.h;
+                    v[k] = *reinterpret_cast<const f32x4*>(xf + ((unsigned)(n < last ? n : last) * (unsigned)C + 4u * pl.q));
+                }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]) = v[u];
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(&s_a[(rl0 + 2 * k + pl.h) * LDA + 4 * pl.q]) = v[k];
             } else {
 #pragma unroll 2
                 for (int u = 0; u < 8; ++u) {
@@ -156,21 +167,24 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
 #else
         acc[0][0] = wreg[lane & 63 ? 1 : 0] + s_a[lane]; acc[1][0] = wreg[31];
 #endif
-        // residual rows of this wave's segment: issued now so their latency hides behind the barriers and the
-        // accumulator round trip through LDS.  NULL residual reads x and is ignored below.  Everything in
-        // phase 3 is branch-free: a conditional store becomes its own basic block that starts with
-        // s_waitcnt vmcnt(0) (8 serialised store round trips per tile).  Rows without a node therefore
-        // re-load / re-store row 0 of the segment (same address, same value: harmless).
-        f32x2 res[8];
-        const size_t seg_off = (frame_row0 + seg_first) * C + 2 * lane;
-        {
+        // residual rows of this wave's segment (when they are not already in LDS): issued now so their latency
+        // hides behind the barriers and the accumulator round trip through LDS.  Paired-row layout: this lane
+        // handles rows 2k + h of the segment.  Everything in phase 3 is branch-free: a conditional store becomes
+        // its own basic block that starts with s_waitcnt vmcnt(0) (serialised store round trips).  A lane whose
+        // row holds no node re-loads / re-stores a row that does (row h if it exists, else row 0; same value).
+        const PairLane pl{lane >> 5, lane & 31};
+        const int fix_row = pl.h < seg_rows ? pl.h : 0;
+        f32x4 res[RES_GLOBAL ? 4 : 1];
+        const size_t seg_off = (frame_row0 + seg_first) * C + 4 * pl.q;
+        if constexpr (RES_GLOBAL) {
             const float* rp = (residual ? residual : x) + seg_off;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int k = 0; k < 4; ++k) {
 #ifndef EG_ABL_NO_P3
-                res[u] = *reinterpret_cast<const f32x2*>(rp + (u < seg_rows ? u : 0) * C);
+                const int row = (2 * k + pl.h) < seg_rows ? 2 * k + pl.h : fix_row;
+                res[k] = *reinterpret_cast<const f32x4*>(rp + (size_t)row * C);
 #else
-                res[u] = f32x2{0.f, 0.f};
+                res[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
             }
         }
@@ -190,23 +204,25 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
         // ---- phase 3
         if (seg_rows > 0) {                                                    // uniform; false only on ragged tiles
             float* op = out + seg_off;
-            f32x2 v[8];
+            f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                f32x2 t = *reinterpret_cast<const f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]);
+            for (int k = 0; k < 4; ++k) {
+                // rows that hold no node compute on row fix_row's data so the duplicate store writes the same value
+                const int row = (2 * k + pl.h) < seg_rows ? 2 * k + pl.h : fix_row;
+                f32x4 t = *reinterpret_cast<const f32x4*>(&s_a[(rl0 + row) * LDA + 4 * pl.q]);
                 t = t * sc + sh;
-                if (a.relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); }
-                if (residual) t += res[u];
-                v[u] = t;
+                if (a.relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+                if constexpr (RES_GLOBAL) { if (residual) t += res[k]; }
+                else { if (s_x) t += *reinterpret_cast<const f32x4*>(&s_x[(rl0 + row) * C + 4 * pl.q]); }
+                v[k] = t;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool ok = u < seg_rows;                                   // uniform
-                const f32x2 val = ok ? v[u] : v[0];
+            for (int k = 0; k < 4; ++k) {
+                const int row = (2 * k + pl.h) < seg_rows ? 2 * k + pl.h : fix_row;
 #ifndef EG_ABL_NO_P3
-                *reinterpret_cast<f32x2*>(op + (ok ? u : 0) * C) = val;
+                *reinterpret_cast<f32x4*>(op + (size_t)row * C) = v[k];
 #else
-                if (val.x == 1234.5678f) *reinterpret_cast<f32x2*>(op + (ok ? u : 0) * C) = val;
+                if (v[k].x == 1234.5678f) *reinterpret_cast<f32x4*>(op + (size_t)row * C) = v[k];
 #endif
             }
         }
@@ -270,10 +286,14 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream) {
     a.d.walk_mode = a.walk_counters ? env_int("EG_WALK_MODE", WALK_QUEUE) : WALK_MOD8;
     if (a.d.walk_mode == WALK_QUEUE)
         EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * WALK_GROUPS * WALK_CTR_STRIDE, stream));
+    const bool res_lds = (a.residual == nullptr) || (a.residual == a.x);     // epilogue residual from the LDS stash / none
     switch (agg) {
-        case AGG_NONE: hipLaunchKernelGGL(k_gcn_layer<AGG_NONE>, grid, block, 0, stream, LAYER_KARGS); break;
-        case AGG_CSR: hipLaunchKernelGGL(k_gcn_layer<AGG_CSR>, grid, block, 0, stream, LAYER_KARGS); break;
-        default: hipLaunchKernelGGL(k_gcn_layer<AGG_STENCIL>, grid, block, 0, stream, LAYER_KARGS); break;
+        case AGG_NONE: hipLaunchKernelGGL((k_gcn_layer<AGG_NONE, true>), grid, block, 0, stream, LAYER_KARGS); break;
+        case AGG_CSR: hipLaunchKernelGGL((k_gcn_layer<AGG_CSR, true>), grid, block, 0, stream, LAYER_KARGS); break;
+        default:
+            if (res_lds) hipLaunchKernelGGL((k_gcn_layer<AGG_STENCIL, false>), grid, block, 0, stream, LAYER_KARGS);
+            else hipLaunchKernelGGL((k_gcn_layer<AGG_STENCIL, true>), grid, block, 0, stream, LAYER_KARGS);
+            break;
     }
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;

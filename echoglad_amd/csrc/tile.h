@@ -219,10 +219,62 @@ __device__ inline const float* run_ptr(const float* __restrict__ xf, int row0, i
 }
 __device__ inline f32x2 ld2(const float* p, int k) { return *reinterpret_cast<const f32x2*>(p + k * C); }
 
+// ---- paired-row layout ---------------------------------------------------------------------------
+// One wave access moves TWO consecutive node rows (1 KB): lane l -> row parity h = l >> 5, channels
+// 4q .. 4q+3 with q = l & 31 (16 B per lane).  The L1/TA pipeline handles 16-B lanes at twice the byte rate
+// of 8-B lanes, and a segment of 8 nodes needs 18 such loads instead of 30 (46 instead of 62 on aux levels).
+// Node u of the segment lives in half h = u & 1 of pair k = u >> 1.
+struct PairLane { int h, q; };
+
+// 32-bit element offsets from the wave-uniform frame base (SGPR base + one VGPR offset + immediate)
+__device__ inline unsigned pair_off(int row0, const PairLane& pl) {
+    return (unsigned)row0 * (unsigned)C + (unsigned)(pl.h * C + 4 * pl.q);              // rows row0+2k+h at imm offsets k*1 KB
+}
+__device__ inline unsigned bcast_off(int row, const PairLane& pl) {
+    return (unsigned)row * (unsigned)C + (unsigned)(4 * pl.q);                          // the same row in both halves
+}
+__device__ inline f32x4 ld4(const float* __restrict__ xf, unsigned off, int k) {
+    return *reinterpret_cast<const f32x4*>(xf + (off + (unsigned)(k * 2 * C)));
+}
+// [a.upper | b.lower]: the node before / after a pair boundary, in the half that needs it
+__device__ inline f32x4 seam(const f32x4& a, const f32x4& b, bool upper_half) {
+    f32x4 m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[i]), __float_as_uint(b[i]), false, false);
+        // r[0] = [a.lo | b.lo], r[1] = [a.up | b.up]
+        m[i] = upper_half ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+    }
+    return m;
+}
+
+// lower / upper half of v broadcast to both halves (one v_permlane32_swap per register, no LDS)
+__device__ inline void halves(const f32x4& v, f32x4& lo, f32x4& up) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned x = __float_as_uint(v[i]);
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        lo[i] = __uint_as_float(r[0]);
+        up[i] = __uint_as_float(r[1]);
+    }
+}
+__device__ inline f32x4 sel(bool upper_half, const f32x4& if_lower, const f32x4& if_upper) {
+    return upper_half ? if_upper : if_lower;
+}
+// weight of (node 2k + h, slot) for this lane: lane index (2k+h)*8 + slot of the decode vector
+__device__ inline float pair_w(float w, int hb4, int k, int slot) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(hb4 + ((2 * k) * 8 + slot) * 4, __float_as_int(w)));
+}
+__device__ inline void pin_acc4(f32x4 (&acc)[4]) {
+    asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[0].z), "+v"(acc[0].w), "+v"(acc[1].x), "+v"(acc[1].y),
+                      "+v"(acc[1].z), "+v"(acc[1].w), "+v"(acc[2].x), "+v"(acc[2].y), "+v"(acc[2].z), "+v"(acc[2].w),
+                      "+v"(acc[3].x), "+v"(acc[3].y), "+v"(acc[3].z), "+v"(acc[3].w) :: "memory");
+}
+
 template <bool AUX>
 __device__ inline void stencil_row8(const Topo* __restrict__ T, const LevelDesc& d, unsigned long long magic,
                                     const float* __restrict__ xf, const float* __restrict__ dis, int n_first, int cnt,
-                                    int n_frame, int lane, float* s_a, int rl) {
+                                    int n_frame, int lane, float* s_a, float* s_x, int rl) {
     // run bases from the position of the first node (scalar)
     const int idx = n_first - d.base;
     const int r_main = (int)(((unsigned long long)(unsigned)idx * magic) >> 40);
@@ -233,8 +285,10 @@ __device__ inline void stencil_row8(const Topo* __restrict__ T, const LevelDesc&
     // Rare per-node scalar path: coordinate K4, and segments so close to the end of the frame that a run of 8
     // rows (self / below / children) would have to be clamped while some of its rows are real neighbours.
     if (d.kind == KIND_COORD || n_first + d.side + 8 > n_frame || (kids && cb + d.cside + 16 > n_frame)) {
-        for (int u = 0; u < cnt; ++u)
+        for (int u = 0; u < cnt; ++u) {
             *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = agg_stencil(T, xf, dis, n_first + u, lane);
+            if (s_x) *reinterpret_cast<f32x2*>(&s_x[(rl + u) * C + 2 * lane]) = load_row2(xf, n_first + u, lane);
+        }
         return;
     }
     // weights: lane (u = lane>>3, s = lane&7) -> slot s of node u; aux levels also need slots 8, 9
@@ -253,103 +307,123 @@ __device__ inline void stencil_row8(const Topo* __restrict__ T, const LevelDesc&
         const float dwb = dis[id];
         wb = valid ? dwb : 0.0f;
     }
+    const PairLane pl{lane >> 5, lane & 31};
+    const bool up_half = pl.h != 0;
+    const int hb4 = pl.h * 32;                                   // byte offset of "+1 node" in the decode vector (8 lanes * 4 B)
     const int hi8 = n_frame - 8, last = n_frame - 1;
-    const float* ps = run_ptr(xf, n_first, lane);
-    const float* pl = run_ptr(xf, clampi(n_first - 1, 0, last), lane);
-    const float* pr = run_ptr(xf, clampi(n_first + 8, 0, last), lane);
-    const float* pu = run_ptr(xf, clampi(n_first - d.side, 0, hi8), lane);
-    const float* pd = run_ptr(xf, clampi(n_first + d.side, 0, hi8), lane);
-    const float* pp = run_ptr(xf, clampi(d.pbase + (d.poff + (r >> 1)) * d.pside + d.poff + (c0 >> 1), 0, hi8), lane);
+    const unsigned os = pair_off(n_first, pl);
+    const unsigned ou = pair_off(clampi(n_first - d.side, 0, hi8), pl);
+    const unsigned od = pair_off(clampi(n_first + d.side, 0, hi8), pl);
+    const unsigned op = pair_off(clampi(d.pbase + (d.poff + (r >> 1)) * d.pside + d.poff + (c0 >> 1), 0, hi8), pl);
+    const unsigned oL = bcast_off(clampi(n_first - 1, 0, last), pl);
+    const unsigned oR = bcast_off(clampi(n_first + 8, 0, last), pl);
 
-    // Loads are issued one stage ahead of the FMAs that consume them; sched_barriers pin that order so at
-    // most two stages (<= 18 rows) are live in registers while ~16-18 row loads stay in flight.
-    f32x2 S[8], L, R, U[8];
+    // stage A loads: self pairs and the two edge rows (6 wave loads = 5 KB in flight)
+    f32x4 S[4], Le, Re;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) S[k] = ld2(ps, k);
-    L = ld2(pl, 0);
-    R = ld2(pr, 0);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) U[k] = ld2(pu, k);
+    for (int k = 0; k < 4; ++k) S[k] = ld4(xf, os, k);
+    Le = *reinterpret_cast<const f32x4*>(xf + oL);
+    Re = *reinterpret_cast<const f32x4*>(xf + oR);
     __builtin_amdgcn_sched_barrier(0);
-    int zz = opaque_zero();
-    f32x2 acc[8];
+
+    f32x4 acc[4];
+    {   // self + left + right.  M[j] = [node 2j-1 | node 2j] is the left neighbour vector of pair j and the right
+        // neighbour vector of pair j-1 (edge rows Le / Re are already in both halves)
+        f32x4 Mk = seam(Le, S[0], up_half);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        f32x2 a = readlane_f(wa, u * 8 + 4 + zz) * (u < 7 ? S[u < 7 ? u + 1 : 7] : R);
-        a += readlane_f(wa, u * 8 + 3 + zz) * (u > 0 ? S[u > 0 ? u - 1 : 0] : L);
-        a += readlane_f(wa, u * 8 + 0 + zz) * S[u];
-        acc[u] = a;
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 Mn = seam(S[k], k < 3 ? S[k < 3 ? k + 1 : 3] : Re, up_half);
+            f32x4 a = pair_w(wa, hb4, k, 4) * Mn;
+            a += pair_w(wa, hb4, k, 3) * Mk;
+            a += pair_w(wa, hb4, k, 0) * S[k];
+            acc[k] = a;
+            Mk = Mn;
+        }
+        if (s_x) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(&s_x[(rl + 2 * k + pl.h) * C + 4 * pl.q]) = S[k];
+        }
     }
-    pin_acc(acc);
-    f32x2 D[8];
+    pin_acc4(acc);
+    // stage B loads: rows above, rows below and the two parent pairs (10 wave loads = 10 KB in flight)
+    f32x4 U[4], D[4], P[2];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) D[k] = ld2(pd, k);
+    for (int k = 0; k < 4; ++k) U[k] = ld4(xf, ou, k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) D[k] = ld4(xf, od, k);
+    P[0] = ld4(xf, op, 0);
+    P[1] = ld4(xf, op, 1);
+    pin_acc4(acc);
     __builtin_amdgcn_sched_barrier(0);
-    zz = opaque_zero();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] += readlane_f(wa, u * 8 + 1 + zz) * U[u];
-    pin_acc(acc);
-    f32x2 P[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) P[k] = ld2(pp, k);
+    for (int k = 0; k < 4; ++k) acc[k] += pair_w(wa, hb4, k, 1) * U[k];
+    pin_acc4(acc);
     __builtin_amdgcn_sched_barrier(0);
-    zz = opaque_zero();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] += readlane_f(wa, u * 8 + 2 + zz) * D[u];
-    pin_acc(acc);
+    for (int k = 0; k < 4; ++k) acc[k] += pair_w(wa, hb4, k, 2) * D[k];
+    pin_acc4(acc);
     __builtin_amdgcn_sched_barrier(0);
-    zz = opaque_zero();
+    {   // parents: nodes 2k and 2k+1 share parent k = half (k & 1) of parent pair (k >> 1)
+        f32x4 plo[2], pup[2];
+        halves(P[0], plo[0], pup[0]);
+        halves(P[1], plo[1], pup[1]);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] += readlane_f(wa, u * 8 + 5 + zz) * P[u >> 1];
-    pin_acc(acc);
+        for (int k = 0; k < 4; ++k) acc[k] += pair_w(wa, hb4, k, 5) * ((k & 1) ? pup[k >> 1] : plo[k >> 1]);
+    }
+    pin_acc4(acc);
     if constexpr (AUX) {
-        // children: rows 2r and 2r+1 of the next level, 16 consecutive node rows each, consumed in four
-        // quarter stages of 8 rows (children of nodes 4h..4h+3), each issued one stage ahead
-        const float* pc[4];
+        // children of node u: the two halves of child pair u in child row 2r (slots 6, 7) and in child row 2r+1
+        // (slots 8, 9).  Weighted lane-wise, then the two halves are added and routed to node u's half of acc[u>>1].
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned oc0 = pair_off(clampi(cb, 0, hi8), pl);
+        const unsigned oc1 = pair_off(clampi(cb + 8, 0, hi8), pl);
+        const unsigned oc2 = pair_off(clampi(cb + d.cside, 0, hi8), pl);
+        const unsigned oc3 = pair_off(clampi(cb + d.cside + 8, 0, hi8), pl);
+        const int hs4 = pl.h * 4;                                  // slot 6 -> 7 / 8 -> 9 for the upper half
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
-            pc[st] = run_ptr(xf, clampi(cb + (st >> 1) * d.cside + 8 * (st & 1), 0, hi8), lane);
-        f32x2 Ca[8], Cb[8];
+        for (int half = 0; half < 2; ++half) {                     // nodes 4*half .. 4*half+3
+            f32x4 Ca[4], Cb[4];
+            const unsigned qa = half ? oc1 : oc0;
+            const unsigned qb = half ? oc3 : oc2;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) Ca[k] = ld2(pc[0], k);
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            if (st < 3) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { if (st & 1) Ca[k] = ld2(pc[st + 1], k); else Cb[k] = ld2(pc[st + 1], k); }
-            }
+            for (int k = 0; k < 4; ++k) { Ca[k] = ld4(xf, qa, k); Cb[k] = ld4(xf, qb, k); }
             __builtin_amdgcn_sched_barrier(0);
-            zz = opaque_zero();
 #pragma unroll
-            for (int uu = 0; uu < 4; ++uu) {
-                const int u = 4 * (st & 1) + uu;
-                const float w0 = (st >> 1) == 0 ? readlane_f(wa, u * 8 + 6 + zz) : readlane_f(wb, u * 8 + 0 + zz);
-                const float w1 = (st >> 1) == 0 ? readlane_f(wa, u * 8 + 7 + zz) : readlane_f(wb, u * 8 + 1 + zz);
-                if (st & 1) acc[u] += w0 * Cb[2 * uu] + w1 * Cb[2 * uu + 1];
-                else acc[u] += w0 * Ca[2 * uu] + w1 * Ca[2 * uu + 1];
+            for (int kk = 0; kk < 2; ++kk) {
+                f32x4 red[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int u = 4 * half + 2 * kk + e;
+                    const float w67 = __int_as_float(__builtin_amdgcn_ds_bpermute(hs4 + (u * 8 + 6) * 4, __float_as_int(wa)));
+                    const float w89 = __int_as_float(__builtin_amdgcn_ds_bpermute(hs4 + (u * 8 + 0) * 4, __float_as_int(wb)));
+                    const f32x4 t = w67 * Ca[2 * kk + e] + w89 * Cb[2 * kk + e];
+                    f32x4 tl, tu;
+                    halves(t, tl, tu);
+                    red[e] = tl + tu;
+                }
+                acc[2 * half + kk] += sel(up_half, red[0], red[1]);
             }
-            pin_acc(acc);
+            pin_acc4(acc);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    zz = opaque_zero();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const f32x2 o = acc[u] * readlane_f(wa, u * 8 + zz);
-        *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = o;   // rows >= cnt are padding rows of the tile
+    for (int k = 0; k < 4; ++k) {
+        const f32x4 o = acc[k] * pair_w(wa, hb4, k, 0);
+        *reinterpret_cast<f32x4*>(&s_a[(rl + 2 * k + pl.h) * LDA + 4 * pl.q]) = o;       // rows >= cnt are padding rows of the tile
     }
 }
 
 // patch rows tr0 .. tr0+ntr-1 of patch td -> LDS rows 8*tr .. 8*tr+7
 __device__ inline void stencil_patch_rows(const Topo* __restrict__ T, const LevelDesc& d, const TileDesc& td, unsigned long long magic,
                                           const float* __restrict__ xf, const float* __restrict__ dis, int n_frame,
-                                          int tr0, int ntr, int lane, float* s_a) {
+                                          int tr0, int ntr, int lane, float* s_a, float* s_x) {
 #pragma unroll 1
     for (int tr = tr0; tr < tr0 + ntr; ++tr) {
         if (tr >= td.nrows) break;
         const int n_first = d.base + (td.r0 + tr) * d.side + td.c0;
-        if (d.kind == KIND_AUX) stencil_row8<true>(T, d, magic, xf, dis, n_first, td.ncols, n_frame, lane, s_a, tr * 8);
-        else stencil_row8<false>(T, d, magic, xf, dis, n_first, td.ncols, n_frame, lane, s_a, tr * 8);
+        if (d.kind == KIND_AUX) stencil_row8<true>(T, d, magic, xf, dis, n_first, td.ncols, n_frame, lane, s_a, s_x, tr * 8);
+        else stencil_row8<false>(T, d, magic, xf, dis, n_first, td.ncols, n_frame, lane, s_a, s_x, tr * 8);
     }
 }
 

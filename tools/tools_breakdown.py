@@ -1,7 +1,7 @@
 """Per-kernel timing of one eager step with HIP events (diagnostic)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 import torch, time
 from echoglad_amd import ops, nn as egnn
 from echoglad_amd.topology import TopologySpec, get_topology

@@ -1,7 +1,7 @@
 """Micro-timings on the GPU box: aggregation-only kernels vs a plain copy of the same bytes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 import torch
 from echoglad_amd import ops
 from echoglad_amd.topology import TopologySpec, get_topology

@@ -1,7 +1,7 @@
 """Diagnostic: per-phase cycle shares of the fused layer kernel (needs the -DEG_STAMP variant)."""
 import ctypes as ct, os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 import torch
 from echoglad_amd import ops, _lib
 from fixtures_util import synthetic_node_feats

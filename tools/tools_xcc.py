@@ -1,5 +1,5 @@
 import os, sys, ctypes as ct
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from echoglad_amd import _lib
 lib = _lib.load()
