@@ -93,19 +93,29 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
 
     float wreg[32];
     load_w_slice16(W, wave, lane_k, a.transpose_w, wreg);
-    // epilogue constants for this lane's 4 channels in the paired-row layout (row parity lane>>5, channels 4*(lane&31)..)
-    const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + 4 * (lane_k & 31)) : f32x4{1.f, 1.f, 1.f, 1.f};
-    const f32x4 sh = shift ? *reinterpret_cast<const f32x4*>(shift + 4 * (lane_k & 31)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // epilogue constants live in LDS (not in 8 VGPRs held across the whole tile loop): read per tile in phase 3
+    __shared__ __attribute__((aligned(16))) float s_scale[C];
+    __shared__ __attribute__((aligned(16))) float s_shift[C];
+    if (tid < C) {
+        s_scale[tid] = scale ? scale[tid] : 1.0f;
+        s_shift[tid] = shift ? shift[tid] : 0.0f;
+    }
 
     TileWalk walk(a.walk_mode, a.tiles_per_frame * a.batch, walk_counters, reinterpret_cast<int*>(&s_a[TILE * LDA]));
-    int tile;
 #ifdef EG_STAMP
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    while (walk.next(tile)) {
+    // the next tile is claimed by thread 0 at the top of an iteration and read back after barrier 1, so the
+    // queue's atomic round trip never sits on the critical path
+    walk.claim();
+    __syncthreads();
+    int tile = walk.fetch();
+    __syncthreads();                       // everyone has read the slot before thread 0 overwrites it
+    while (tile >= 0) {
         STAMP(0);
+        walk.claim_issue();
         // lane index made opaque per tile: keeps LLVM from hoisting dozens of lane-derived loop invariants
         // (slot masks = 2 SGPRs each, address pieces) out of the tile loop and pinning registers kernel-wide
         int lane = lane_k;
@@ -153,9 +163,11 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
                 }
             }
         }
+        walk.claim_commit();
         STAMP(1);
         __syncthreads();
         STAMP(2);
+        const int next_tile = walk.fetch();
 
         // ---- phase 2 (LDS rows without a node hold stale data; their accumulator columns are never read back)
         f32x4v acc[4];
@@ -204,6 +216,8 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
         // ---- phase 3
         if (seg_rows > 0) {                                                    // uniform; false only on ragged tiles
             float* op = out + seg_off;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(&s_scale[4 * pl.q]);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(&s_shift[4 * pl.q]);
             f32x4 v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -227,6 +241,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
             }
         }
         STAMP(7);
+        tile = next_tile;
     }
 #ifdef EG_STAMP
     if (lane_k == 0) {

@@ -611,6 +611,39 @@ struct TileWalk {
         }
     }
 
+    // Split form: claim_issue() starts thread 0's atomic on its home queue, claim_commit() (placed after this
+    // wave's phase-1 work, so the atomic's round trip is hidden) turns the ticket into a tile id — stealing from
+    // the other queues once the home chunk is drained — and publishes it in LDS; fetch() must be separated from
+    // the commit by a workgroup barrier.
+    int pend;
+    __device__ void claim_issue() {
+        pend = 0;
+        if (mode == WALK_QUEUE && threadIdx.x == 0) pend = atomicAdd(&counters[group * WALK_CTR_STRIDE], 1);
+    }
+    __device__ void claim_commit() {
+        if (mode != WALK_QUEUE) {
+            if (threadIdx.x == 0) *s_slot = (local < chunk && base + local < n_tiles) ? base + local : -1;
+            local += stride;
+            return;
+        }
+        if (threadIdx.x == 0) {
+            const int lo0 = group * chunk;
+            const int size0 = (n_tiles - lo0) < chunk ? (n_tiles - lo0) : chunk;
+            int t = pend < size0 ? lo0 + pend : -1;
+            for (int k = 1; k < WALK_GROUPS && t < 0; ++k) {
+                const int q = (group + k) % WALK_GROUPS;
+                const int lo = q * chunk;
+                const int size = (n_tiles - lo) < chunk ? (n_tiles - lo) : chunk;
+                if (size <= 0) continue;
+                const int got = atomicAdd(&counters[q * WALK_CTR_STRIDE], 1);
+                if (got < size) t = lo + got;
+            }
+            *s_slot = t;
+        }
+    }
+    __device__ void claim() { claim_issue(); claim_commit(); }
+    __device__ int fetch() const { return __builtin_amdgcn_readfirstlane(*s_slot); }
+
     // All threads of the workgroup must call this together (it contains a barrier in queue mode).
     __device__ bool next(int& tile) {
         if (mode != WALK_QUEUE) {
