@@ -4,9 +4,10 @@
 //
 // Same 8-wave tile machinery as the layer kernel (tile.h): the four first layers Linear(128,32) are
 // one [128 -> 4*32] product on the fp32 MFMA (wave w owns 16 of the 128 hidden channels), written
-// back to the LDS tile with BN+ReLU applied.  Then each wave finishes its own 8 rows: lane
-// (head = l>>4, o = l&15) keeps row o of that head's Linear(32,16) in 32 registers and reads the
-// row's 32 hidden values as LDS broadcasts; Linear(16,1) is a 16-lane reduction.  The valid rows
+// back to the LDS tile with BN+ReLU applied.  Linear(32,16) of head hd is a K = 32 product again on the
+// MFMA: wave w takes head w & 3 and the 32-row half w >> 2 (its 16 x 32 weight slice sits in 8 registers),
+// 8 MFMAs per 16 rows; BN + ReLU and Linear(16,1) follow on the accumulator (4 outputs per lane, two
+// cross-lane adds).  The valid rows
 // are a contiguous range per frame (the filter drops the leading connection rows / trailing
 // coordinate rows), so the filter is an address offset, not a gather.
 #include "tile.h"
@@ -38,18 +39,20 @@ __global__ __launch_bounds__(CLS_THREADS, 4) void k_classifier(const float* __re
     const int ch_d = 16 * wave + 4 * (lane_k >> 4);
     const f32x4 s1v = *reinterpret_cast<const f32x4*>(s1 + ch_d);
     const f32x4 t1v = *reinterpret_cast<const f32x4*>(t1 + ch_d);
-    // second / third layer: lane (head, o)
-    const int head = lane_k >> 4, o = lane_k & 15;
-    float w2r[32];
+    // second / third layer: wave -> (head, 32-row half); MFMA A operand lane (o = l&15, kq = l>>4): W2[head][o][8kq + s]
+    const int head = wave & 3, rhalf = wave >> 2;
+    float w2a[8];
     {
-        const f32x4* p = reinterpret_cast<const f32x4*>(w2 + (size_t)(head * 16 + o) * 32);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const f32x4 q = p[t];
-            w2r[4 * t + 0] = q.x; w2r[4 * t + 1] = q.y; w2r[4 * t + 2] = q.z; w2r[4 * t + 3] = q.w;
-        }
+        const f32x4* p = reinterpret_cast<const f32x4*>(w2 + (size_t)(head * 16 + (lane_k & 15)) * 32 + 8 * (lane_k >> 4));
+        const f32x4 q0 = p[0], q1 = p[1];
+        w2a[0] = q0.x; w2a[1] = q0.y; w2a[2] = q0.z; w2a[3] = q0.w; w2a[4] = q1.x; w2a[5] = q1.y; w2a[6] = q1.z; w2a[7] = q1.w;
     }
-    const float s2v = s2[head * 16 + o], t2v = t2[head * 16 + o], w3v = w3[head * 16 + o], b3v = b3[head];
+    // accumulator layout: lane (row j = l&15, q = l>>4) holds outputs 4q .. 4q+3 of the head
+    const int o4 = head * 16 + 4 * (lane_k >> 4);
+    const f32x4 s2v = *reinterpret_cast<const f32x4*>(s2 + o4);
+    const f32x4 t2v = *reinterpret_cast<const f32x4*>(t2 + o4);
+    const f32x4 w3v = *reinterpret_cast<const f32x4*>(w3 + o4);
+    const float b3v = b3[head];
 
     TileWalk walk(WALK_MOD8, a.tiles_per_frame * a.batch, nullptr, reinterpret_cast<int*>(&s_a[TILE * LDA]));
     int tile;
@@ -62,12 +65,16 @@ __global__ __launch_bounds__(CLS_THREADS, 4) void k_classifier(const float* __re
         const int rows_here = (a.n_valid - n0) < TILE ? (a.n_valid - n0) : TILE;
         const int rl0 = 8 * wave;
         const int last = a.n_valid - 1;
-        {
-            f32x2 v[8];
+        {   // paired-row loads: one wave access = 2 consecutive rows (16 B per lane)
+            const PairLane pl{lane >> 5, lane & 31};
+            f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = load_row2(hf, n0 + rl0 + u < last ? n0 + rl0 + u : last, lane);
+            for (int k = 0; k < 4; ++k) {
+                const int n = n0 + rl0 + 2 * k + pl.h;
+                v[k] = *reinterpret_cast<const f32x4*>(hf + ((unsigned)(n < last ? n : last) * (unsigned)C + 4u * pl.q));
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]) = v[u];
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(&s_a[(rl0 + 2 * k + pl.h) * LDA + 4 * pl.q]) = v[k];
         }
         __syncthreads();
         f32x4v acc[4];
@@ -89,31 +96,36 @@ __global__ __launch_bounds__(CLS_THREADS, 4) void k_classifier(const float* __re
             }
         }
         __syncthreads();
-        // this wave's 8 rows: Linear(32,16) + BN + ReLU per lane (head, o), Linear(16,1) as a 16-lane sum
-#pragma unroll 1
-        for (int u = 0; u < 8; ++u) {
-            const f32x4* hp = reinterpret_cast<const f32x4*>(&s_a[(rl0 + u) * LDA + 32 * head]);
-            float p = 0.f;
+        // Linear(32,16) + BN + ReLU + Linear(16,1) for (head, 32-row half): K = 32 on the MFMA
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const f32x4 q = hp[t];
-                p += w2r[4 * t + 0] * q.x + w2r[4 * t + 1] * q.y + w2r[4 * t + 2] * q.z + w2r[4 * t + 3] * q.w;
-            }
-            float y = w3v * fmaxf(p * s2v + t2v, 0.f);
-            y += __shfl_xor(y, 8, 16);
-            y += __shfl_xor(y, 4, 16);
-            y += __shfl_xor(y, 2, 16);
-            y += __shfl_xor(y, 1, 16);
+        for (int rb = 0; rb < 2; ++rb) {
+            const int row0 = 32 * rhalf + 16 * rb;
+            const int j = lane & 15, kq = lane >> 4;
+            const f32x4* hp = reinterpret_cast<const f32x4*>(&s_a[(row0 + j) * LDA + 32 * head + 8 * kq]);
+            const f32x4 b0 = hp[0], b1 = hp[1];
+            f32x4v z = {0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[0], b0.x, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[1], b0.y, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[2], b0.z, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[3], b0.w, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[4], b1.x, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[5], b1.y, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[6], b1.z, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[7], b1.w, z, 0, 0, 0);
+            float y = w3v.x * fmaxf(z.x * s2v.x + t2v.x, 0.f) + w3v.y * fmaxf(z.y * s2v.y + t2v.y, 0.f) +
+                      w3v.z * fmaxf(z.z * s2v.z + t2v.z, 0.f) + w3v.w * fmaxf(z.w * s2v.w + t2v.w, 0.f);
+            y += __shfl_xor(y, 16);
+            y += __shfl_xor(y, 32);
             y += b3v;
             if (a.sigmoid) y = 1.0f / (1.0f + __expf(-y));
-            if (o == 0) s_out[(rl0 + u) * 4 + head] = y;
+            if (kq == 0) s_out[(row0 + j) * 4 + head] = y;
         }
-        // the same wave stores its 8 rows of logits (its own LDS writes are visible to it in order)
-        if (lane < 8) {
-            const int n = n0 + rl0 + lane;
+        __syncthreads();
+        if (tid < TILE) {
+            const int n = n0 + tid;
             if (n < a.n_valid)
                 *reinterpret_cast<f32x4*>(logits + ((size_t)frame * a.n_valid + n) * 4) =
-                    *reinterpret_cast<const f32x4*>(&s_out[(rl0 + lane) * 4]);
+                    *reinterpret_cast<const f32x4*>(&s_out[tid * 4]);
         }
     }
 }
