@@ -27,6 +27,7 @@ struct LayerDims {
     int relu;
     int transpose_w;
     int walk_mode;
+    int stagger;           // experiment knob: the second half of the grid starts this many s_sleep(127) late
 };
 
 struct LayerArgs {         // host-side bundle only
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
+    if (a.stagger > 0 && blockIdx.x >= gridDim.x / 2)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     // the next tile is claimed by thread 0 at the top of an iteration and read back after barrier 1, so the
     // queue's atomic round trip never sits on the critical path
     walk.claim();
@@ -299,6 +302,7 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream) {
     if (n_tiles >= (1ll << 31)) return set_error(EG_ERR_ARG, "too many tiles");
     const dim3 grid(grid_for_tiles(n_tiles)), block(LAYER_THREADS);
     a.d.walk_mode = a.walk_counters ? env_int("EG_WALK_MODE", WALK_QUEUE) : WALK_MOD8;
+    a.d.stagger = env_int("EG_STAGGER", 0);
     if (a.d.walk_mode == WALK_QUEUE)
         EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * WALK_GROUPS * WALK_CTR_STRIDE, stream));
     const bool res_lds = (a.residual == nullptr) || (a.residual == a.x);     // epilogue residual from the LDS stash / none
