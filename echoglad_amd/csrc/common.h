@@ -42,6 +42,21 @@ struct TileDesc {
     int level, r0, c0, nrows, ncols, pad0, pad1, pad2;
 };
 
+enum { KIND_AUX = 0, KIND_MAIN = 1, KIND_COORD = 2 };      // LevelDesc::kind
+
+// Precomputed (host, at handle creation) description of one 8-node segment = patch row tr of a patch:
+// everything the aggregation needs that does not depend on the features.  One s_load_dwordx16 per segment.
+struct SegDesc {
+    int n_first, cnt, mode;      // first node id, nodes in the segment, 0 none / 1 fast (runs) / 2 per-node slow path
+    int pat;                     // index into the weight-pattern table (128 floats per pattern: 64 wa + 64 wb)
+    int up0, down0, par0;        // first row of the 8 rows above / below, of the 4 parent rows (clamped into the frame)
+    int left, right;             // the two edge rows (clamped)
+    int c0, c1, c2, c3;          // child runs: rows 2r cols 0-7 / 8-15 of the segment's children, rows 2r+1 likewise (aux)
+    int aux;                     // 1 on aux levels (children exist as slots)
+    int pad0;                    // patch row 2p only: rows 2p and 2p+1 can be aggregated as a pair (shared rows)
+    int pad1;
+};
+
 struct Topo {
     int n_desc;              // aux levels + main (+ coordinate pseudo-level)
     int pad_[3];
@@ -152,6 +167,9 @@ struct eg_graph {
     eg::Topo topo;            // kind == GRAPH_TOPO (host copy)
     eg::Topo* topo_dev;       // device copy read by the kernels through scalar loads
     eg::TileDesc* tiles_dev;  // device [n_tiles] 2-D patch table of one frame (kind == GRAPH_TOPO)
+    eg::SegDesc* segs_dev;    // device [n_tiles * 8] per-segment descriptors
+    float* pats_dev;          // device [n_pats * 128] weight patterns (most segments share a handful)
+    int n_pats;
     int n_tiles;
     float* dis;               // device [n_nodes]   (deg+1)^-1/2
     int* rowptr;              // device [n_nodes+1] kind == GRAPH_CSR
@@ -159,3 +177,8 @@ struct eg_graph {
     int64_t nnz;
     int* walk_counters;       // device [8 x 32] per-XCD tile queue heads, zeroed before every launch
 };
+
+// producer/consumer layer kernel (gcn_layer_ps.hip); EG_ERR_UNSUPPORTED -> caller uses the symmetric kernel
+int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
+                       const float* shift, const float* residual, int relu, int transpose_w, float* out,
+                       hipStream_t stream);

@@ -358,6 +358,9 @@ int eg_gcn_layer_fwd(const eg_graph* g, int batch, const float* x, const float* 
     int agg;
     int rc = fill_graph_args(g, batch, a, agg);
     if (rc != EG_OK) return rc;
+    // implicit topology with the residual in {none, x}: producer/consumer kernel
+    rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, transpose_w, out, (hipStream_t)stream);
+    if (rc != EG_ERR_UNSUPPORTED) return rc;
     a.x = x; a.W = W; a.scale = scale; a.shift = shift; a.residual = residual; a.out = out;
     a.d.relu = relu; a.d.transpose_w = transpose_w;
     return launch_layer(agg, a, (hipStream_t)stream);

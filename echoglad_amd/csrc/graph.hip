@@ -2,6 +2,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
+#include <map>
 #include <vector>
 
 #include "common.h"
@@ -205,9 +206,73 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
             tiles.push_back(TileDesc{T.n_levels, 0, 0, 1, d.end - d.base, 0, 0, 0});
         }
     }
+    // Per-segment descriptors (8 per patch) and the table of distinct weight patterns.  A pattern is the 64 + 64
+    // lane weights of a segment: lane (u, s) -> valid(slot s of node u) ? (deg + 1)^-1/2 of that neighbour : 0.
+    // Interior segments of a level all share one pattern, so the table stays at a few dozen entries.
+    std::vector<SegDesc> segs(tiles.size() * 8);
+    std::vector<float> pats;
+    {
+        std::map<std::vector<float>, int> pat_index;
+        auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        const int n_frame = T.n_nodes, hi8 = n_frame - 8, last = n_frame - 1;
+        std::vector<float> w(128);
+        for (size_t t = 0; t < tiles.size(); ++t) {
+            const TileDesc& td = tiles[t];
+            const LevelDesc& d = T.desc[td.level];
+            for (int tr = 0; tr < 8; ++tr) {
+                SegDesc sd{};
+                sd.n_first = d.base + (td.r0 + tr) * d.side + td.c0;
+                sd.cnt = tr < td.nrows ? td.ncols : 0;
+                const int idx = sd.n_first - d.base;
+                const int r = d.kind == KIND_COORD ? 0 : idx / d.side;
+                const int c0 = idx - r * d.side;
+                const int cb = d.cbase + 2 * (r - d.clo) * d.cside + 2 * (c0 - d.clo);
+                const bool kids = d.kind == KIND_AUX && r >= d.clo && r < d.chi;
+                // per-node scalar path: coordinate K4, and segments so close to the end of the frame that a run of
+                // 8 rows (self / below / children) would have to be clamped while some of its rows are real neighbours
+                const bool slow = d.kind == KIND_COORD || sd.n_first + d.side + 8 > n_frame || (kids && cb + d.cside + 16 > n_frame);
+                sd.mode = sd.cnt == 0 ? 0 : (slow ? 2 : 1);
+                sd.aux = d.kind == KIND_AUX;
+                if (sd.mode == 1) {
+                    sd.up0 = clampi(sd.n_first - d.side, 0, hi8);
+                    sd.down0 = clampi(sd.n_first + d.side, 0, hi8);
+                    sd.par0 = clampi(d.pbase + (d.poff + (r >> 1)) * d.pside + d.poff + (c0 >> 1), 0, hi8);
+                    sd.left = clampi(sd.n_first - 1, 0, last);
+                    sd.right = clampi(sd.n_first + 8, 0, last);
+                    sd.c0 = clampi(cb, 0, hi8);
+                    sd.c1 = clampi(cb + 8, 0, hi8);
+                    sd.c2 = clampi(cb + d.cside, 0, hi8);
+                    sd.c3 = clampi(cb + d.cside + 8, 0, hi8);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int u = lane >> 3, sl = lane & 7;
+                        const int n = sd.n_first + (u < sd.cnt ? u : sd.cnt - 1);
+                        neighbours(T, n, nb);
+                        w[lane] = nb.valid[sl] ? dis[nb.id[sl]] : 0.0f;
+                        const int sb = 8 + (sl & 1);
+                        w[64 + lane] = (sd.aux && nb.valid[sb]) ? dis[nb.id[sb]] : 0.0f;
+                    }
+                    auto it = pat_index.find(w);
+                    if (it == pat_index.end()) {
+                        it = pat_index.emplace(w, (int)pat_index.size()).first;
+                        pats.insert(pats.end(), w.begin(), w.end());
+                    }
+                    sd.pat = it->second;
+                }
+                segs[t * 8 + tr] = sd;
+            }
+            for (int tr = 0; tr < 8; tr += 2) {       // pad0 of an even patch row: it and the next row form a pair (seg_wide.h)
+                SegDesc& sa = segs[t * 8 + tr];
+                const SegDesc& sb = segs[t * 8 + tr + 1];
+                sa.pad0 = sa.mode == 1 && sb.mode == 1 && sa.aux == sb.aux && sa.par0 == sb.par0 && sa.down0 == sb.n_first &&
+                          sb.up0 == sa.n_first && sa.cnt == sb.cnt;
+            }
+        }
+        if (pats.empty()) pats.assign(128, 0.0f);
+    }
     eg_graph* g = new eg_graph{};
     g->kind = GRAPH_TOPO;
     g->n_nodes = T.n_nodes;
+    g->n_pats = (int)(pats.size() / 128);
     g->topo = T;
     g->n_tiles = (int)tiles.size();
     hipError_t e = hipMalloc((void**)&g->dis, sizeof(float) * T.n_nodes);
@@ -218,7 +283,13 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
     if (e == hipSuccess) e = hipMemcpy(g->topo_dev, &T, sizeof(Topo), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&g->tiles_dev, sizeof(TileDesc) * tiles.size());
     if (e == hipSuccess) e = hipMemcpy(g->tiles_dev, tiles.data(), sizeof(TileDesc) * tiles.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->segs_dev, sizeof(SegDesc) * segs.size());
+    if (e == hipSuccess) e = hipMemcpy(g->segs_dev, segs.data(), sizeof(SegDesc) * segs.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->pats_dev, sizeof(float) * pats.size());
+    if (e == hipSuccess) e = hipMemcpy(g->pats_dev, pats.data(), sizeof(float) * pats.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
+        if (g->segs_dev) (void)hipFree(g->segs_dev);
+        if (g->pats_dev) (void)hipFree(g->pats_dev);
         if (g->dis) (void)hipFree(g->dis);
         if (g->topo_dev) (void)hipFree(g->topo_dev);
         if (g->tiles_dev) (void)hipFree(g->tiles_dev);
@@ -315,6 +386,8 @@ int eg_graph_destroy(eg_graph* g) {
     if (!g) return EG_OK;
     if (g->dis) (void)hipFree(g->dis);
     if (g->topo_dev) (void)hipFree(g->topo_dev);
+    if (g->segs_dev) (void)hipFree(g->segs_dev);
+    if (g->pats_dev) (void)hipFree(g->pats_dev);
     if (g->tiles_dev) (void)hipFree(g->tiles_dev);
     if (g->walk_counters) (void)hipFree(g->walk_counters);
     if (g->rowptr) (void)hipFree(g->rowptr);

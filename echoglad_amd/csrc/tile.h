@@ -68,7 +68,6 @@ __device__ inline f32x2 agg_stencil(const Topo* __restrict__ Tp, const float* __
 // run or level change; after that the position advances incrementally on the scalar unit.
 // Loads of several nodes are issued together so one wave keeps ~20 row loads (512 B each)
 // in flight.
-enum { KIND_AUX = 0, KIND_MAIN = 1, KIND_COORD = 2 };
 #ifndef EG_MAIN_U
 #define EG_MAIN_U 4      // main-grid nodes per burst of row loads (24 loads in flight per wave)
 #endif
@@ -298,14 +297,17 @@ __device__ inline void stencil_row8(const Topo* __restrict__ T, const LevelDesc&
     asm volatile("" : "+v"(u_l), "+v"(s_l));
     const int n_l = n_first + (u_l < cnt ? u_l : cnt - 1);
     int id, valid;
+    // raw gathered weights; they are masked (valid ? w : 0) only after the row loads below have been issued,
+    // otherwise the wave would sit out the gather's round trip before issuing them
     lane_slot(d, magic, n_l, s_l, id, valid);
     const float dwa = dis[id];
-    const float wa = valid ? dwa : 0.0f;
-    float wb = 0.0f;
+    const int va = valid;
+    float dwb = 0.0f;
+    int vb = 0;
     if constexpr (AUX) {
         lane_slot(d, magic, n_l, 8 + (s_l & 1), id, valid);
-        const float dwb = dis[id];
-        wb = valid ? dwb : 0.0f;
+        dwb = dis[id];
+        vb = valid;
     }
     const PairLane pl{lane >> 5, lane & 31};
     const bool up_half = pl.h != 0;
@@ -325,6 +327,8 @@ __device__ inline void stencil_row8(const Topo* __restrict__ T, const LevelDesc&
     Le = *reinterpret_cast<const f32x4*>(xf + oL);
     Re = *reinterpret_cast<const f32x4*>(xf + oR);
     __builtin_amdgcn_sched_barrier(0);
+    const float wa = va ? dwa : 0.0f;
+    const float wb = vb ? dwb : 0.0f;
 
     f32x4 acc[4];
     {   // self + left + right.  M[j] = [node 2j-1 | node 2j] is the left neighbour vector of pair j and the right

@@ -16,9 +16,11 @@ for it in range(3):
     ops.gcn_layer_fwd(g, B, x, w, None, None, x, relu=True, out=out)
     lib.eg_debug_phase_cycles(g._h, buf, 1)
     v = list(buf)
-names = ["next_tile", "phase1", "barrier1", "mfma", "barrier2", "dwrite", "barrier3", "phase3"]
+names = ["c_mfma", "c_epilogue", "c_barrier", "c_loop", "p_issue", "p_main(wait+fma)", "p_kids+store", "p_claim+barrier"] if os.environ.get("EG_LAYER_IMPL", "0") != "0" else ["next_tile", "phase1", "barrier1", "mfma", "barrier2", "dwrite", "barrier3", "phase3"]
 tot = sum(v[:8]); waves = max(v[8], 1)
 tiles = 1128 * B
-print(f"waves={waves} tiles={tiles} cycles/wave={tot/waves:.0f} cycles/tile/wave={tot/waves/(tiles/ (waves/8)):.0f}")
+print(f"waves(counted)={waves} tiles={tiles}")
+wgs = 256 if os.environ.get("EG_LAYER_IMPL", "0") != "0" else waves / 8
+waves = wgs * 4 if os.environ.get("EG_LAYER_IMPL", "0") != "0" else waves
 for n, c in zip(names, v[:8]):
-    print(f"{n:10s} {100*c/tot:6.2f}%  {c/waves/(tiles/(waves/8)):9.0f} cyc/tile")
+    print(f"{n:10s} {100*c/tot:6.2f}%  {c/waves/(tiles/wgs):9.0f} cyc/tile")
