@@ -46,7 +46,10 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: s
     objdir.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.h")) + [PKG.parent / "include" / "echoglad_hip.h"]
     cc = hipcc()
-    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", *extra_flags]
+    # atomic optimizer off: it turns the single-lane queue claims into "atomic + wait + readfirstlane", which makes
+    # every claim a synchronous memory round trip in front of the tile's loads
+    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+             "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", *extra_flags]
     if verbose:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     objs = []

@@ -54,7 +54,7 @@ struct SegDesc {
     int c0, c1, c2, c3;          // child runs: rows 2r cols 0-7 / 8-15 of the segment's children, rows 2r+1 likewise (aux)
     int aux;                     // 1 on aux levels (children exist as slots)
     int pad0;                    // patch row 2p only: rows 2p and 2p+1 can be aggregated as a pair (shared rows)
-    int pad1;
+    int pad1;                    // patch row 2p only: number of parents whose 4 children are columns 2j, 2j+1 of rows 2p, 2p+1
 };
 
 struct Topo {
@@ -169,7 +169,9 @@ struct eg_graph {
     eg::TileDesc* tiles_dev;  // device [n_tiles] 2-D patch table of one frame (kind == GRAPH_TOPO)
     eg::SegDesc* segs_dev;    // device [n_tiles * 8] per-segment descriptors
     float* pats_dev;          // device [n_pats * 128] weight patterns (most segments share a handful)
+    float* patsq_dev;         // device [n_pats * 64] the same patterns in quad layout (graph.hip)
     int n_pats;
+    int kid_rows;             // rows per frame of the child-sum side buffer (= aux nodes), 0 when the topology does not qualify
     int n_tiles;
     float* dis;               // device [n_nodes]   (deg+1)^-1/2
     int* rowptr;              // device [n_nodes+1] kind == GRAPH_CSR
@@ -181,4 +183,4 @@ struct eg_graph {
 // producer/consumer layer kernel (gcn_layer_ps.hip); EG_ERR_UNSUPPORTED -> caller uses the symmetric kernel
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
-                       hipStream_t stream);
+                       const float* kin, float* kout, hipStream_t stream);

@@ -359,12 +359,28 @@ int eg_gcn_layer_fwd(const eg_graph* g, int batch, const float* x, const float* 
     int rc = fill_graph_args(g, batch, a, agg);
     if (rc != EG_OK) return rc;
     // implicit topology with the residual in {none, x}: producer/consumer kernel
-    rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, transpose_w, out, (hipStream_t)stream);
+    rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, transpose_w, out, nullptr, nullptr, (hipStream_t)stream);
     if (rc != EG_ERR_UNSUPPORTED) return rc;
     a.x = x; a.W = W; a.scale = scale; a.shift = shift; a.residual = residual; a.out = out;
     a.d.relu = relu; a.d.transpose_w = transpose_w;
     return launch_layer(agg, a, (hipStream_t)stream);
 }
+
+int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
+                           const float* shift, const float* residual, int relu, int transpose_w, float* out,
+                           const float* kidsum_in, float* kidsum_out, eg_stream_t stream) {
+    if (!x || !W || !out) return set_error(EG_ERR_ARG, "x, W and out must not be NULL");
+    if (out == x || out == residual) return set_error(EG_ERR_ARG, "out must not alias x or residual");
+    if (kidsum_in && kidsum_in == kidsum_out) return set_error(EG_ERR_ARG, "kidsum_out must not alias kidsum_in");
+    if (!kidsum_in && !kidsum_out) return eg_gcn_layer_fwd(g, batch, x, W, scale, shift, residual, relu, transpose_w, out, stream);
+    if (!g || batch <= 0) return set_error(EG_ERR_ARG, "bad graph handle or batch");
+    const int rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, transpose_w, out, kidsum_in, kidsum_out,
+                                      (hipStream_t)stream);
+    if (rc == EG_ERR_UNSUPPORTED)
+        return set_error(EG_ERR_UNSUPPORTED, "chained layers need a topology handle with eg_graph_kidsum_rows() > 0 and residual in {NULL, x}");
+    return rc;
+}
+
 
 int eg_gcn_aggregate(const eg_graph* g, int batch, const float* x, float* out, eg_stream_t stream) {
     if (!x || !out || x == out) return set_error(EG_ERR_ARG, "x/out NULL or aliased");

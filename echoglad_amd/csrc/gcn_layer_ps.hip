@@ -19,6 +19,8 @@ constexpr int PS_THREADS = 512;
 
 struct PsDims {
     int n_per_frame, batch, tiles_per_frame, relu, transpose_w, has_res;
+    int kid_rows;      // rows per frame of the child-sum side buffers (kin / kout)
+    int n_pats;
 };
 
 #ifdef EG_STAMP
@@ -66,11 +68,14 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                                                                 float* __restrict__ out, const float* __restrict__ dis,
                                                                 const Topo* __restrict__ T, const TileDesc* __restrict__ tiles,
                                                                 const SegDesc* __restrict__ segs, const float* __restrict__ pats,
+                                                                const float* __restrict__ patsq, const float* __restrict__ kin, float* __restrict__ kout,
                                                                 int* __restrict__ counters, const PsDims a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_a0 = smem;                               // [2][TILE * LDA]  aggregated tiles
     float* s_x0 = smem + 2 * TILE * LDA;              // [2][TILE * LDA]  raw self rows (residual); then the output tile
-    int* s_tile = reinterpret_cast<int*>(smem + 4 * TILE * LDA);                  // [4] ring of tile ids
+    int* s_tile = reinterpret_cast<int*>(smem + 4 * TILE * LDA);                  // [8] ring of tile ids
+    float* s_pat = smem + 4 * TILE * LDA + 8 + 2 * TILE;   // [n_pats][64] weight patterns, quad layout (seg_wide.h)
+    float* s_dis0 = smem + 4 * TILE * LDA + 8;        // [2][TILE] (deg+1)^-1/2 of the tile's rows (child sums of the output)
 
     const int tid = threadIdx.x;
     const int lane_k = tid & 63;
@@ -79,8 +84,13 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
     const int n_tiles = a.tiles_per_frame * a.batch;
     const int group = xcc_id();
 
-    // ---- prologue: tiles 0 and 1 claimed (before anyone reads the ring) ----------------------------------------
-    if (tid == 256) { ps_claim(counters, group, n_tiles, &s_tile[0]); ps_claim(counters, group, n_tiles, &s_tile[1]); }
+    // ---- prologue: tiles 0, 1 and 2 claimed (before anyone reads the ring) -------------------------------------
+    if (tid == 256) {
+        ps_claim(counters, group, n_tiles, &s_tile[0]);
+        ps_claim(counters, group, n_tiles, &s_tile[1]);
+        ps_claim(counters, group, n_tiles, &s_tile[2]);
+    }
+    for (int i = tid; i < a.n_pats * PATQ; i += PS_THREADS) s_pat[i] = patsq[i];
     __syncthreads();
 
     // The two roles run separate loops (so that neither carries the other's persistent registers); both execute
@@ -96,23 +106,53 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             sc[g] = scale ? *reinterpret_cast<const f32x4*>(scale + ch0) : f32x4{1.f, 1.f, 1.f, 1.f};
             sh[g] = shift ? *reinterpret_cast<const f32x4*>(shift + ch0) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // Descriptor words the epilogue needs (first node and count of the 8 segments, parent row and parent count of
+        // the 4 segment pairs) travel in one VGPR, fetched a tile ahead like the producers' (lane l: segment l >> 2,
+        // word {n_first, cnt, par0, pad1}[l & 3]).
+        auto load_cdesc = [&](int tile_i, int lane) -> int {
+            const int frame = tile_i / a.tiles_per_frame;
+            const int t_in = tile_i - frame * a.tiles_per_frame;
+            const int f = lane & 3;
+            const int word = f == 0 ? 0 : (f == 1 ? 1 : (f == 2 ? 6 : 15));
+            return reinterpret_cast<const int*>(segs)[(t_in * 8 + ((lane >> 2) & 7)) * 16 + word];
+        };
+        int cd_next = 0;
+        {
+            const int t0 = __builtin_amdgcn_readfirstlane(s_tile[0]);
+            if (t0 >= 0) cd_next = load_cdesc(t0, lane_k);
+        }
         __syncthreads();                                   // tile 0 is in buffer 0
         PSTAMP_INIT;
         for (int k = 0;; ++k) {
-            const int t_cur = __builtin_amdgcn_readfirstlane(s_tile[k & 3]);
+            const int t_cur = __builtin_amdgcn_readfirstlane(s_tile[k & 7]);
             if (t_cur < 0) break;
+            const int t_nx = __builtin_amdgcn_readfirstlane(s_tile[(k + 1) & 7]);
             int lane = lane_k;
             asm volatile("" : "+v"(lane));
+            const int cd = cd_next;
+            if (t_nx >= 0) cd_next = load_cdesc(t_nx, lane);
             PSTAMP(3);
             const float* s_a = s_a0 + (k & 1) * TILE * LDA;
             float* s_x = s_x0 + (k & 1) * TILE * LDA;
             const int frame = t_cur / a.tiles_per_frame;
-            const int t_in = t_cur - frame * a.tiles_per_frame;
             int seg_first[8], seg_cnt[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {                          // scalar loads, back long before the epilogue
-                seg_first[i] = segs[t_in * 8 + i].n_first;
-                seg_cnt[i] = segs[t_in * 8 + i].cnt;
+            for (int i = 0; i < 8; ++i) {
+                seg_first[i] = __builtin_amdgcn_readlane(cd, 4 * i);
+                seg_cnt[i] = __builtin_amdgcn_readlane(cd, 4 * i + 1);
+            }
+            // Child sums of the OUTPUT for the next layer (kout): lane -> (parent q = (lane >> 3) + 8 i, 16-B chunk lane & 7);
+            // the parent's four children are rows 2 pr, 2 pr + 1, columns 2 pc, 2 pc + 1 of this patch.
+            int kout_row[2];
+            if (kout) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool odd = (lane >> 5) != 0;                  // pr = 2 i + odd: segments 4 i (even pr) / 4 i + 2
+                    const int pc = (lane >> 3) & 3;
+                    const int npar = odd ? __builtin_amdgcn_readlane(cd, 4 * (4 * i + 2) + 3) : __builtin_amdgcn_readlane(cd, 4 * (4 * i) + 3);
+                    const int par0 = odd ? __builtin_amdgcn_readlane(cd, 4 * (4 * i + 2) + 2) : __builtin_amdgcn_readlane(cd, 4 * (4 * i) + 2);
+                    kout_row[i] = pc < npar ? par0 + pc : -1;
+                }
             }
             f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 acc1 = acc0;
@@ -151,6 +191,21 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     if (u < seg_cnt[i]) *reinterpret_cast<f32x4*>(ob + (size_t)(seg_first[i] + u) * C) = o[i];
+                if (kout) {
+                    float* kb = kout + (size_t)frame * a.kid_rows * C + 32 * wave + c4;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int q = (lane >> 3) + 8 * i;
+                        const int ra = 16 * (q >> 2) + 2 * (q & 3);            // LDS row of child (2 pr, 2 pc)
+                        const float* sp = s_x + ra * LDA + 32 * wave + c4;
+                        const float* dp = s_dis0 + (k & 1) * TILE + ra;
+                        f32x4 ks = dp[0] * *reinterpret_cast<const f32x4*>(sp);
+                        ks += dp[1] * *reinterpret_cast<const f32x4*>(sp + LDA);
+                        ks += dp[8] * *reinterpret_cast<const f32x4*>(sp + 8 * LDA);
+                        ks += dp[9] * *reinterpret_cast<const f32x4*>(sp + 9 * LDA);
+                        if (kout_row[i] >= 0) *reinterpret_cast<f32x4*>(kb + (size_t)kout_row[i] * C) = ks;
+                    }
+                }
             }
             PSTAMP(1);
             __syncthreads();                               // barrier k+1: buffer (k+1)&1 is full, buffer k&1 is free
@@ -164,76 +219,122 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         __builtin_amdgcn_s_setprio(3);
 #endif
         PSTAMP_INIT;
-        auto produce = [&](int tile_i, int buf, int lane) {
+        // The two segment descriptors of a tile (32 dwords) travel in ONE VGPR, lane l holding dword l & 31: they are
+        // fetched a whole tile ahead (a scalar load at the point of use costs a loaded-memory round trip, ~9k cycles
+        // measured, in front of the row loads) and turned into SGPRs with v_readlane when the tile is produced.
+        auto load_desc = [&](int tile_i, int lane) -> int {
             const int frame = tile_i / a.tiles_per_frame;
             const int t_in = tile_i - frame * a.tiles_per_frame;
+            return reinterpret_cast<const int*>(segs)[(t_in * 8 + 2 * p) * 16 + (lane & 31)];
+        };
+        auto desc_of = [](int dv, int o) -> SegDesc {
+            SegDesc d;
+            d.n_first = __builtin_amdgcn_readlane(dv, o + 0);  d.cnt = __builtin_amdgcn_readlane(dv, o + 1);
+            d.mode = __builtin_amdgcn_readlane(dv, o + 2);     d.pat = __builtin_amdgcn_readlane(dv, o + 3);
+            d.up0 = __builtin_amdgcn_readlane(dv, o + 4);      d.down0 = __builtin_amdgcn_readlane(dv, o + 5);
+            d.par0 = __builtin_amdgcn_readlane(dv, o + 6);     d.left = __builtin_amdgcn_readlane(dv, o + 7);
+            d.right = __builtin_amdgcn_readlane(dv, o + 8);    d.c0 = __builtin_amdgcn_readlane(dv, o + 9);
+            d.c1 = __builtin_amdgcn_readlane(dv, o + 10);      d.c2 = __builtin_amdgcn_readlane(dv, o + 11);
+            d.c3 = __builtin_amdgcn_readlane(dv, o + 12);      d.aux = __builtin_amdgcn_readlane(dv, o + 13);
+            d.pad0 = __builtin_amdgcn_readlane(dv, o + 14);    d.pad1 = __builtin_amdgcn_readlane(dv, o + 15);
+            return d;
+        };
+        auto produce = [&](int tile_i, int buf, int lane, int dv) {
+            const int frame = tile_i / a.tiles_per_frame;
             const float* __restrict__ xf = x + (size_t)frame * a.n_per_frame * C;
-            const SegDesc sd0 = segs[t_in * 8 + 2 * p];
-            const SegDesc sd1 = segs[t_in * 8 + 2 * p + 1];
+            const SegDesc sd0 = desc_of(dv, 0);
+            const SegDesc sd1 = desc_of(dv, 16);
             float* s_a = s_a0 + buf * TILE * LDA;
             float* s_x = a.has_res ? s_x0 + buf * TILE * LDA : nullptr;
             f32x4 acc0[4], acc1[4];
             if (sd0.pad0) {
+#ifdef EG_STAMP2              // finer producer stamps: 0 = descriptor wait, 1 = load issue, 2 = fma + kids + store, 3 = claim + barrier
+                PSTAMP(0);
+#define PS_ISSUE 1
+#define PS_MAIN 2
+#else
+#define PS_ISSUE 0
+#define PS_MAIN 1
+#endif
                 // ---- usual case: both segments on the fast path, vertically adjacent, same parents ----
                 SegPair A;
-                segp_issue(sd0, sd1, pats, xf, lane, A);
+                segp_issue(sd0, sd1, xf, lane, A);
 #ifdef EG_ABL_NO_LOADS        // timing-only ablation: producers do nothing (results wrong)
                 return;
 #endif
                 __builtin_amdgcn_sched_barrier(0);                  // every load of both segments is issued above this line
-                PSTAMP(0);
-                segw_rows(lane, A.wa_a, A.Sa, A.La, A.Ra, A.U, A.Sb, A.P, acc0, s_x, 16 * p);
-                segw_rows(lane, A.wa_b, A.Sb, A.Lb, A.Rb, A.Sa, A.D, A.P, acc1, s_x, 16 * p + 8);
+                PSTAMP(PS_ISSUE);
+                const float* wqa = s_pat + sd0.pat * PATQ + 32 * (lane >> 5);      // this lane's weights (LDS, quad layout)
+                const float* wqb = s_pat + sd1.pat * PATQ + 32 * (lane >> 5);
+                segw_rows(lane, wqa, A.Sa, A.LRa, A.LRa, A.U, A.Sb, A.P, acc0, s_x, 16 * p);
+                segw_rows(lane, wqb, A.Sb, A.LRb, A.LRb, A.Sa, A.D, A.P, acc1, s_x, 16 * p + 8);
                 pin_acc4(acc0);
-                pin_acc4(acc1);                                     // the 44 main-stage registers are dead from here on
+                pin_acc4(acc1);                                     // the 40 main-stage registers are dead from here on
                 __builtin_amdgcn_sched_barrier(0);
-                PSTAMP(1);
-                if (sd0.aux) {                                      // uniform: aux level, children exist as slots
-                    SegKids K0, K1;
-                    segw_kids_issue(sd0, xf, lane, K0);
-                    segw_kids_issue(sd1, xf, lane, K1);
-                    segw_kids_add(lane, A.wa_a, A.wb_a, K0, acc0);
-                    segw_kids_add(lane, A.wa_b, A.wb_b, K1, acc1);
+                PSTAMP(PS_MAIN);
+                if (sd0.aux && kin) {                               // children already summed by the previous layer's epilogue
+                    const float* kf = kin + (size_t)frame * a.kid_rows * C;
+                    segp_kidsum(sd0, sd1, kf, lane, wqa, wqb, acc0, acc1);
+                } else if (sd0.aux) {                               // uniform: aux level, children pulled as rows
+                    {
+                        SegKids K;
+                        segw_kids_issue(sd0, pats, xf, lane, K);
+                        segw_kids_add(lane, K, acc0);
+                    }
+                    pin_acc4(acc0);                                 // one segment's 16 child loads in flight at a time (registers)
+                    {
+                        SegKids K;
+                        segw_kids_issue(sd1, pats, xf, lane, K);
+                        segw_kids_add(lane, K, acc1);
+                    }
                 }
-                segw_store(lane, A.wa_a, acc0, s_a, 16 * p);
-                segw_store(lane, A.wa_b, acc1, s_a, 16 * p + 8);
+                segw_store(lane, wqa, acc0, s_a, 16 * p);
+                segw_store(lane, wqb, acc1, s_a, 16 * p + 8);
+                if (kout && (lane & 31) == 0) {                     // (deg+1)^-1/2 of the 16 nodes, for the consumers' child sums
+                    const f32x4 da = quad_w(wqa, SLOT_SELF), db = quad_w(wqb, SLOT_SELF);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        s_dis0[buf * TILE + 16 * p + 2 * k + (lane >> 5)] = da[k];
+                        s_dis0[buf * TILE + 16 * p + 8 + 2 * k + (lane >> 5)] = db[k];
+                    }
+                }
             } else {
-                // ---- ragged patches, coordinate nodes, frame end: one segment after the other ----
+                // ---- ragged patches, coordinate nodes, frame end (rare): node by node, scalar neighbour decode ----
 #pragma unroll 1
                 for (int e = 0; e < 2; ++e) {
-                    const SegDesc& sd = e ? sd1 : sd0;
+                    const int n0 = e ? sd1.n_first : sd0.n_first, cnt = e ? sd1.cnt : sd0.cnt;
                     const int rl = 16 * p + 8 * e;
-                    SegW A;
-                    segw_issue(sd, pats, xf, lane, A);
-                    segw_main(T, sd, xf, dis, lane, A, acc0, s_a, s_x, rl);
-                    if (A.mode == 1) {
-                        if (sd.aux) {
-                            SegKids K;
-                            segw_kids_issue(sd, xf, lane, K);
-                            segw_kids_add(lane, A.wa, A.wb, K, acc0);
-                        }
-                        segw_store(lane, A.wa, acc0, s_a, rl);
+#pragma unroll 1
+                    for (int u = 0; u < cnt; ++u) {
+                        *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = agg_stencil(T, xf, dis, n0 + u, lane);
+                        if (s_x) *reinterpret_cast<f32x2*>(&s_x[(rl + u) * LDA + 2 * lane]) = load_row2(xf, n0 + u, lane);
                     }
                 }
             }
             PSTAMP(2);
         };
+        int dv_next = 0;
         {
             const int t0 = __builtin_amdgcn_readfirstlane(s_tile[0]);
-            if (t0 >= 0) produce(t0, 0, lane_k);
+            const int t1 = __builtin_amdgcn_readfirstlane(s_tile[1]);
+            if (t0 >= 0) produce(t0, 0, lane_k, load_desc(t0, lane_k));
+            if (t1 >= 0) dv_next = load_desc(t1, lane_k);
         }
         __syncthreads();                                   // tile 0 is in buffer 0
         for (int k = 0;; ++k) {
-            const int t_cur = __builtin_amdgcn_readfirstlane(s_tile[k & 3]);
+            const int t_cur = __builtin_amdgcn_readfirstlane(s_tile[k & 7]);
             if (t_cur < 0) break;
-            const int t_next = __builtin_amdgcn_readfirstlane(s_tile[(k + 1) & 3]);
+            const int t_next = __builtin_amdgcn_readfirstlane(s_tile[(k + 1) & 7]);
+            const int t_nn = __builtin_amdgcn_readfirstlane(s_tile[(k + 2) & 7]);
             int lane = lane_k;
             asm volatile("" : "+v"(lane));
+            const int dv_cur = dv_next;
+            if (t_nn >= 0) dv_next = load_desc(t_nn, lane);                                 // used by the NEXT iteration
             int got = 0;
-            if (tid == 256) got = ps_claim_issue(counters, group);                          // two tiles ahead, asynchronous
+            if (tid == 256) got = ps_claim_issue(counters, group);                          // three tiles ahead, asynchronous
             PSTAMP(3);
-            if (t_next >= 0) produce(t_next, (k + 1) & 1, lane);
-            if (tid == 256) ps_claim_commit(counters, group, n_tiles, got, &s_tile[(k + 2) & 3]);
+            if (t_next >= 0) produce(t_next, (k + 1) & 1, lane, dv_cur);
+            if (tid == 256) ps_claim_commit(counters, group, n_tiles, got, &s_tile[(k + 3) & 7]);
             __syncthreads();                               // barrier k+1
             PSTAMP(3);
         }
@@ -254,24 +355,28 @@ using namespace eg;
 // Returns EG_ERR_UNSUPPORTED when the caller should fall back to the symmetric kernel.
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
-                       hipStream_t stream) {
+                       const float* kin, float* kout, hipStream_t stream) {
     if (!g || g->kind != GRAPH_TOPO || (residual != nullptr && residual != x)) return EG_ERR_UNSUPPORTED;
-    if (env_int_ps("EG_LAYER_IMPL", 0) == 0) return EG_ERR_UNSUPPORTED;
+    const bool chained = kin || kout;
+    if (chained && g->kid_rows == 0) return EG_ERR_UNSUPPORTED;
+    if (!chained && env_int_ps("EG_LAYER_IMPL", 0) == 0) return EG_ERR_UNSUPPORTED;
     PsDims a{};
     a.n_per_frame = (int)g->n_nodes; a.batch = batch; a.tiles_per_frame = g->n_tiles;
     a.relu = relu; a.transpose_w = transpose_w; a.has_res = residual != nullptr;
+    a.kid_rows = g->kid_rows; a.n_pats = g->n_pats;
     const long long n_tiles = (long long)a.tiles_per_frame * batch;
     if (n_tiles <= 0) return EG_OK;
-    const size_t lds = (size_t)(4 * TILE * LDA + 4) * sizeof(float);
+    const size_t lds = (size_t)(4 * TILE * LDA + 8 + 2 * TILE + g->n_pats * PATQ) * sizeof(float);
+    if (lds > 160 * 1024) return EG_ERR_UNSUPPORTED;             // more weight patterns than fit beside the tile buffers
     static bool attr_set = false;
     if (!attr_set) {
-        EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     EG_HIP_TRY(hipMemsetAsync(g->walk_counters, 0, sizeof(int) * WALK_GROUPS * WALK_CTR_STRIDE, stream));
     long long grid = n_tiles < 256 ? n_tiles : env_int_ps("EG_PS_GRID", 256);      // one persistent workgroup per CU
     hipLaunchKernelGGL(k_gcn_layer_ps, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out, g->dis,
-                       g->topo_dev, g->tiles_dev, g->segs_dev, g->pats_dev, g->walk_counters, a);
+                       g->topo_dev, g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, g->walk_counters, a);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

@@ -211,7 +211,11 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
     // Interior segments of a level all share one pattern, so the table stays at a few dozen entries.
     std::vector<SegDesc> segs(tiles.size() * 8);
     std::vector<float> pats;
+    int kid_rows = 0;
+    bool kidsum_ok = false;
     {
+        kid_rows = (T.n_aux > 0 && T.n_levels > 1) ? T.base[T.n_levels - 1] : 0;
+        kidsum_ok = kid_rows > 0;
         std::map<std::vector<float>, int> pat_index;
         auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
         const int n_frame = T.n_nodes, hi8 = n_frame - 8, last = n_frame - 1;
@@ -227,10 +231,13 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
                 const int r = d.kind == KIND_COORD ? 0 : idx / d.side;
                 const int c0 = idx - r * d.side;
                 const int cb = d.cbase + 2 * (r - d.clo) * d.cside + 2 * (c0 - d.clo);
-                const bool kids = d.kind == KIND_AUX && r >= d.clo && r < d.chi;
+                const bool kids = d.kind == KIND_AUX && r >= d.clo && r < d.chi && c0 < d.chi && c0 + 8 > d.clo;   // some node of the segment has children
                 // per-node scalar path: coordinate K4, and segments so close to the end of the frame that a run of
                 // 8 rows (self / below / children) would have to be clamped while some of its rows are real neighbours
-                const bool slow = d.kind == KIND_COORD || sd.n_first + d.side + 8 > n_frame || (kids && cb + d.cside + 16 > n_frame);
+                // (the rows below the LAST grid row are no neighbours: their clamped run carries weight 0)
+                const bool below = d.kind != KIND_COORD && r < d.side - 1;
+                const bool slow = d.kind == KIND_COORD || sd.n_first + 8 > n_frame || (below && sd.n_first + d.side + 8 > n_frame) ||
+                                  (kids && (cb < 0 || cb + d.cside + 16 > n_frame));
                 sd.mode = sd.cnt == 0 ? 0 : (slow ? 2 : 1);
                 sd.aux = d.kind == KIND_AUX;
                 if (sd.mode == 1) {
@@ -265,14 +272,44 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
                 const SegDesc& sb = segs[t * 8 + tr + 1];
                 sa.pad0 = sa.mode == 1 && sb.mode == 1 && sa.aux == sb.aux && sa.par0 == sb.par0 && sa.down0 == sb.n_first &&
                           sb.up0 == sa.n_first && sa.cnt == sb.cnt;
+                // pad1 = number of parents whose four children are exactly columns 2j, 2j+1 of this pair of rows
+                // (child-sum side buffer, gcn_layer_ps.hip).  Anything irregular switches the side buffer off.
+                if (sa.cnt > 0 && d.kind != KIND_COORD) {
+                    const int idx = sa.n_first - d.base, r = idx / d.side, c0 = idx - r * d.side;
+                    int npar = 0;
+                    if (r < d.plim) {
+                        const int cend = c0 + sa.cnt < d.plim ? c0 + sa.cnt : d.plim;
+                        npar = cend > c0 ? (cend - c0) / 2 : 0;
+                        if (cend > c0 && ((cend - c0) & 1)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: odd t=%zu tr=%d\n", t, tr); }
+                    }
+                    const int par_raw = d.pbase + (d.poff + (r >> 1)) * d.pside + d.poff + (c0 >> 1);
+                    if (npar > 0 && (!sa.pad0 || par_raw != sa.par0 || par_raw + npar > kid_rows)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: parent t=%zu tr=%d level=%d pad0=%d par_raw=%d par0=%d npar=%d kid_rows=%d modes %d %d\n", t, tr, td.level, sa.pad0, par_raw, sa.par0, npar, kid_rows, sa.mode, sb.mode); }
+                    sa.pad1 = npar;
+                    const bool kids = d.kind == KIND_AUX && ((r >= d.clo && r < d.chi) || (r + 1 >= d.clo && r + 1 < d.chi)) && c0 < d.chi && c0 + 8 > d.clo;
+                    if (kids && !sa.pad0) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: kids unpaired t=%zu tr=%d level=%d\n", t, tr, td.level); }      // a segment that would read the side buffer is not on the pair path
+                }
             }
         }
         if (pats.empty()) pats.assign(128, 0.0f);
+        if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "topo: %zu tiles, %zu patterns, kidsum %d\n", tiles.size(), pats.size() / 128, (int)kidsum_ok);
     }
     eg_graph* g = new eg_graph{};
     g->kind = GRAPH_TOPO;
     g->n_nodes = T.n_nodes;
     g->n_pats = (int)(pats.size() / 128);
+    // The same patterns in "quad" layout for the producer/consumer kernel, which keeps them in LDS: [pattern][row parity
+    // h][slot 0..7][k 0..3] = weight of (node 2k + h, slot); slot 6 = 1.0 when the node has children, slot 7 unused.
+    std::vector<float> patsq((size_t)g->n_pats * 64, 0.0f);
+    for (int pi = 0; pi < g->n_pats; ++pi)
+        for (int h = 0; h < 2; ++h)
+            for (int sl = 0; sl < 7; ++sl)
+                for (int k = 0; k < 4; ++k) {
+                    const float w = pats[(size_t)pi * 128 + (2 * k + h) * 8 + sl];
+                    patsq[(size_t)pi * 64 + h * 32 + sl * 4 + k] = sl < 6 ? w : (w != 0.0f ? 1.0f : 0.0f);
+                }
+    // chained layers run the producer/consumer kernel, which keeps the pattern table in LDS beside its tile buffers
+    const size_t ps_lds = (size_t)(4 * TILE * LDA + 8 + 2 * TILE + (pats.size() / 128) * 64) * sizeof(float);
+    g->kid_rows = (kidsum_ok && ps_lds <= 160 * 1024) ? kid_rows : 0;
     g->topo = T;
     g->n_tiles = (int)tiles.size();
     hipError_t e = hipMalloc((void**)&g->dis, sizeof(float) * T.n_nodes);
@@ -287,9 +324,12 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
     if (e == hipSuccess) e = hipMemcpy(g->segs_dev, segs.data(), sizeof(SegDesc) * segs.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&g->pats_dev, sizeof(float) * pats.size());
     if (e == hipSuccess) e = hipMemcpy(g->pats_dev, pats.data(), sizeof(float) * pats.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->patsq_dev, sizeof(float) * patsq.size());
+    if (e == hipSuccess) e = hipMemcpy(g->patsq_dev, patsq.data(), sizeof(float) * patsq.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (g->segs_dev) (void)hipFree(g->segs_dev);
         if (g->pats_dev) (void)hipFree(g->pats_dev);
+        if (g->patsq_dev) (void)hipFree(g->patsq_dev);
         if (g->dis) (void)hipFree(g->dis);
         if (g->topo_dev) (void)hipFree(g->topo_dev);
         if (g->tiles_dev) (void)hipFree(g->tiles_dev);
@@ -388,6 +428,7 @@ int eg_graph_destroy(eg_graph* g) {
     if (g->topo_dev) (void)hipFree(g->topo_dev);
     if (g->segs_dev) (void)hipFree(g->segs_dev);
     if (g->pats_dev) (void)hipFree(g->pats_dev);
+    if (g->patsq_dev) (void)hipFree(g->patsq_dev);
     if (g->tiles_dev) (void)hipFree(g->tiles_dev);
     if (g->walk_counters) (void)hipFree(g->walk_counters);
     if (g->rowptr) (void)hipFree(g->rowptr);
@@ -399,6 +440,8 @@ int eg_graph_destroy(eg_graph* g) {
 int64_t eg_graph_num_nodes(const eg_graph* g) { return g ? g->n_nodes : -1; }
 
 int eg_graph_is_structured(const eg_graph* g) { return g && g->kind == GRAPH_TOPO; }
+
+int64_t eg_graph_kidsum_rows(const eg_graph* g) { return (g && g->kind == GRAPH_TOPO) ? g->kid_rows : 0; }
 
 int64_t eg_graph_num_tiles(const eg_graph* g) { return g ? (g->kind == GRAPH_TOPO ? g->n_tiles : (g->n_nodes + TILE - 1) / TILE) : -1; }
 

@@ -18,6 +18,8 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -308,6 +310,10 @@ class HierarchicalPatchModel(nn.Module):
         self._fold_cache: Dict[str, tuple] = {}
         self._hip_graphs: Dict[tuple, tuple] = {}
         self.use_hip_graph = False
+        # eval path: layer i leaves the child sums of its output in a side buffer for layer i+1
+        # (eg_gcn_layer_fwd_chain); EG_CHAIN=0 runs every layer on its own
+        self.chain_layers = os.environ.get("EG_CHAIN", "1") != "0"
+        self._kidsum: Dict[tuple, tuple] = {}
 
     def enable_hip_graph(self, flag: bool = True) -> "HierarchicalPatchModel":
         """Inference only: capture the kernel sequence of ``forward_nodes`` (3 fused layers + classifier
@@ -410,14 +416,20 @@ class HierarchicalPatchModel(nn.Module):
         if fused and self.use_hip_graph and not self.use_coordinate_graph and not torch.cuda.is_current_stream_capturing():
             return self._forward_nodes_graphed(node_feats, edge_index, B), None
         hidden = [node_feats.contiguous()]
+        kid = (None, None)
         if fused:
             folded = self._folded_layers()
+            # chained layers: each layer leaves the child sums of its output behind for the next one
+            if self.chain_layers and not self.use_coordinate_graph and graph.kidsum_rows > 0 and self.num_gnn_layers > 1:
+                kid = self._kidsum_buffers(graph, gb)
         for i in range(self.num_gnn_layers):
             x_in = hidden[i]
             if fused:
                 w, scale, shift = folded[i]
+                last = i == self.num_gnn_layers - 1
                 h = ops.gcn_layer_fwd(graph, gb, x_in, w, scale, shift, x_in if self.residual else None,
-                                      relu=(i < self.num_gnn_layers - 1))
+                                      relu=not last, kidsum_in=kid[(i + 1) & 1] if i > 0 else None,
+                                      kidsum_out=None if last else kid[i & 1])
             elif self.training:
                 h = self._layer_train(i, x_in, graph, gb)
             else:
@@ -437,6 +449,16 @@ class HierarchicalPatchModel(nn.Module):
         if self.use_coordinate_graph:
             node_coords = node_coords.reshape(B * 4, -1)
         return out.squeeze(1), node_coords
+
+    def _kidsum_buffers(self, graph, gb):
+        key = (id(graph), gb)
+        hit = self._kidsum.get(key)
+        if hit is None:
+            if len(self._kidsum) > 4:
+                self._kidsum.clear()
+            hit = (ops.new_kidsum(graph, gb), ops.new_kidsum(graph, gb))
+            self._kidsum[key] = hit
+        return hit
 
     def _forward_nodes_graphed(self, node_feats, edge_index, B):
         key = (node_feats.data_ptr(), tuple(node_feats.shape), edge_index.data_ptr(), int(edge_index.shape[1]), B,

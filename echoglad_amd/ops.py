@@ -47,6 +47,8 @@ class Graph:
         self.structured = structured
         self.num_nodes = num_nodes
         self.device = device
+        # rows per frame of a child-sum side buffer (chained layers); 0 = not available for this handle
+        self.kidsum_rows = int(_lib.load().eg_graph_kidsum_rows(handle)) if structured else 0
 
     @classmethod
     def topo(cls, frame_size: int, num_aux_graphs: int, use_main_graph_only: bool = False,
@@ -101,8 +103,12 @@ def edge_hash(edge_index: torch.Tensor):
 def gcn_layer_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tensor,
                   scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
                   residual: Optional[torch.Tensor] = None, relu: bool = False, transpose_w: bool = False,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act((A_hat x) W^T * scale + shift) + residual in one kernel."""
+                  out: Optional[torch.Tensor] = None, kidsum_in: Optional[torch.Tensor] = None,
+                  kidsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act((A_hat x) W^T * scale + shift) + residual in one kernel.
+
+    kidsum_in / kidsum_out: child-sum side buffers of a chained stack of layers (see `new_kidsum`,
+    include/echoglad_hip.h eg_gcn_layer_fwd_chain)."""
     rows = graph.num_nodes * batch
     _check_rows(x, "x", rows)
     if weight.shape != (C, C) or not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous():
@@ -115,10 +121,31 @@ def gcn_layer_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tenso
         out = torch.empty_like(x)
     else:
         _check_rows(out, "out", rows)
+    if kidsum_in is not None or kidsum_out is not None:
+        krows = graph.kidsum_rows * batch
+        for name, t in (("kidsum_in", kidsum_in), ("kidsum_out", kidsum_out)):
+            if t is not None:
+                if krows == 0:
+                    raise RuntimeError("this graph handle has no child-sum side buffer (kidsum_rows == 0)")
+                _check_rows(t, name, krows)
+        _lib.check(_lib.load().eg_gcn_layer_fwd_chain(graph._h, batch, _ptr(x), _ptr(weight), _ptr(scale), _ptr(shift),
+                                                      _ptr(residual), int(relu), int(transpose_w), _ptr(out),
+                                                      _ptr(kidsum_in), _ptr(kidsum_out), _stream()),
+                   "eg_gcn_layer_fwd_chain")
+        return out
     _lib.check(_lib.load().eg_gcn_layer_fwd(graph._h, batch, _ptr(x), _ptr(weight), _ptr(scale), _ptr(shift),
                                             _ptr(residual), int(relu), int(transpose_w), _ptr(out), _stream()),
                "eg_gcn_layer_fwd")
     return out
+
+
+def new_kidsum(graph: Graph, batch: int) -> Optional[torch.Tensor]:
+    """Zero-filled child-sum side buffer [batch * kidsum_rows, 128] for chained layers, or None when the
+    topology does not qualify (generic CSR handles, irregular frames)."""
+    rows = graph.kidsum_rows
+    if rows == 0:
+        return None
+    return torch.zeros(rows * batch, C, device="cuda", dtype=torch.float32)
 
 
 def gcn_aggregate(graph: Graph, batch: int, x: torch.Tensor) -> torch.Tensor:

@@ -100,6 +100,20 @@ int eg_gcn_layer_fwd(const eg_graph* g, int batch, const float* x, const float* 
                      const float* shift, const float* residual, int relu, int transpose_w, float* out,
                      eg_stream_t stream);
 
+/* Chained form of eg_gcn_layer_fwd for a stack of layers on one topology handle (models.py:431-435 loops over
+ * gnn_layers).  A node's children contribute sum_c d_c^-1/2 x[c,:] to its aggregate; the layer that PRODUCES x can
+ * leave that sum behind for every node with children, so the layer that consumes x reads one row per aux node
+ * instead of four child rows:
+ *   kidsum_out [batch * eg_graph_kidsum_rows(g), 128] or NULL: child sums of `out`, for the next layer.
+ *              Zero-fill the buffer ONCE before its first use (rows of childless nodes are never written).
+ *   kidsum_in  same shape or NULL: child sums of `x`, written by the launch that produced x.
+ * Both NULL = eg_gcn_layer_fwd.  Needs eg_graph_kidsum_rows(g) > 0 and residual in {NULL, x}
+ * (EG_ERR_UNSUPPORTED otherwise). */
+int64_t eg_graph_kidsum_rows(const eg_graph* g);    /* rows per frame of a child-sum buffer; 0: not available */
+int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
+                           const float* shift, const float* residual, int relu, int transpose_w, float* out,
+                           const float* kidsum_in, float* kidsum_out, eg_stream_t stream);
+
 /* out = A_hat x  (aggregation only; training / backward building block) */
 int eg_gcn_aggregate(const eg_graph* g, int batch, const float* x, float* out, eg_stream_t stream);
 

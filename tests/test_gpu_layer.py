@@ -138,6 +138,50 @@ def test_fused_layer_vs_oracle(frame, naux, main_only, coord, relu):
         assert (got - want).abs().max() < 3e-5, (graph.structured, float((got - want).abs().max()))
 
 
+CHAIN_CASES = TOPO_CASES + [(224, 7, False, False), (128, 5, False, False)]
+
+
+@pytest.mark.parametrize("frame,naux,main_only,coord", CHAIN_CASES)
+def test_chained_layers_match_separate_layers(frame, naux, main_only, coord):
+    """eg_gcn_layer_fwd_chain (child sums handed from layer to layer) == the same layers run one by one."""
+    B = 2
+    g = ops.Graph.topo(frame, naux, main_only, coord)
+    if (frame, naux) in ((224, 7), (64, 6), (128, 5)):
+        assert g.kidsum_rows > 0                                   # the benchmark topology must take the chained path
+    rows = B * g.num_nodes
+    x = rand_rows(rows, seed=5).to(DEV)
+    ws = [rand_rows(128, seed=20 + i).to(DEV) * 0.08 for i in range(3)]
+    sc = rand_rows(1, seed=30).to(DEV).reshape(128) * 0.1 + 1.0
+    sh = rand_rows(1, seed=31).to(DEV).reshape(128) * 0.1
+    want = x
+    for i, w in enumerate(ws):
+        want = ops.gcn_layer_fwd(g, B, want, w, sc, sh, want, relu=i < 2)
+    if g.kidsum_rows == 0:
+        with pytest.raises(RuntimeError):
+            ops.gcn_layer_fwd(g, B, x, ws[0], sc, sh, x, relu=True, kidsum_out=torch.zeros(8, 128, device=DEV))
+        return
+    ka, kb = ops.new_kidsum(g, B), ops.new_kidsum(g, B)
+    for rep in range(2):                                           # second pass: buffers are reused as they are
+        h1 = ops.gcn_layer_fwd(g, B, x, ws[0], sc, sh, x, relu=True, kidsum_out=ka)
+        h2 = ops.gcn_layer_fwd(g, B, h1, ws[1], sc, sh, h1, relu=True, kidsum_in=ka, kidsum_out=kb)
+        h3 = ops.gcn_layer_fwd(g, B, h2, ws[2], sc, sh, h2, relu=False, kidsum_in=kb)
+        err = float((h3 - want).abs().max())
+        assert err < 2e-5 * max(1.0, float(want.abs().max())), err
+    # the side buffer itself: sum over the four children of dis[c] * h1[c]
+    topo = HierTopology(TopologySpec(frame, naux, main_only, coord))
+    dis = g.deg_inv_sqrt().double()
+    ei = torch.from_numpy(topo.edge_index()).to(DEV)
+    bases = torch.from_numpy(topo.level_table()[:, 0].astype(np.int64)).to(DEV)
+    lvl = torch.bucketize(torch.arange(g.num_nodes, device=DEV), bases, right=True)       # 1-based level of each grid node
+    src, dst = ei[0], ei[1]
+    child_edges = (lvl[src] == lvl[dst] + 1) & (src < topo.coord_base)                   # src one level below dst
+    want_k = torch.zeros(B, g.num_nodes, 128, dtype=torch.float64, device=DEV)
+    h1v = h1.view(B, g.num_nodes, 128).double()
+    want_k.index_add_(1, dst[child_edges], h1v[:, src[child_edges], :] * dis[src[child_edges]][None, :, None])
+    got_k = ka.view(B, g.kidsum_rows, 128).double()
+    assert float((got_k - want_k[:, :g.kidsum_rows]).abs().max()) < 1e-5
+
+
 def test_fused_layer_is_run_to_run_deterministic():
     topo, ei, _, _ = graph_tensors(64, 6, 2)
     x = rand_rows(2 * topo.num_nodes, seed=1).to(DEV)

@@ -12,15 +12,19 @@ w = (synthetic_node_feats(128, 128, 2) * 0.1).cuda()
 out = torch.empty_like(x)
 buf = (ct.c_uint64 * 9)()
 lib = _lib.load()
+form = os.environ.get("EG_STAMP_FORM", "")          # "", "kin", "kout", "kin+kout": chained forms run the producer/consumer kernel
+kw = {}
+if "kin" in form: kw["kidsum_in"] = ops.new_kidsum(g, B)
+if "kout" in form: kw["kidsum_out"] = ops.new_kidsum(g, B)
 for it in range(3):
-    ops.gcn_layer_fwd(g, B, x, w, None, None, x, relu=True, out=out)
+    ops.gcn_layer_fwd(g, B, x, w, None, None, x, relu=True, out=out, **kw)
     lib.eg_debug_phase_cycles(g._h, buf, 1)
     v = list(buf)
-names = ["c_mfma", "c_epilogue", "c_barrier", "c_loop", "p_issue", "p_main(wait+fma)", "p_kids+store", "p_claim+barrier"] if os.environ.get("EG_LAYER_IMPL", "0") != "0" else ["next_tile", "phase1", "barrier1", "mfma", "barrier2", "dwrite", "barrier3", "phase3"]
+names = ["c_mfma", "c_epilogue", "c_barrier", "c_loop", "p_issue", "p_main(wait+fma)", "p_kids+store", "p_claim+barrier"] if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else ["next_tile", "phase1", "barrier1", "mfma", "barrier2", "dwrite", "barrier3", "phase3"]
 tot = sum(v[:8]); waves = max(v[8], 1)
 tiles = 1128 * B
 print(f"waves(counted)={waves} tiles={tiles}")
-wgs = 256 if os.environ.get("EG_LAYER_IMPL", "0") != "0" else waves / 8
-waves = wgs * 4 if os.environ.get("EG_LAYER_IMPL", "0") != "0" else waves
+wgs = 256 if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else waves / 8
+waves = wgs * 4 if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else waves
 for n, c in zip(names, v[:8]):
     print(f"{n:10s} {100*c/tot:6.2f}%  {c/waves/(tiles/wgs):9.0f} cyc/tile")
