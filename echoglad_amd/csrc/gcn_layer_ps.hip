@@ -156,41 +156,60 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             }
             f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             f32x16 acc1 = acc0;
+            // Epilogue pieces, all branch-free so that they can sit in one scheduling region with MFMAs.
+            // Lane (row j of a 32-row block, half h) holds 16 channels of ONE row: stored from there a wave instruction
+            // would touch 32 rows x 32 B.  The finished values go back into this wave's own channel slice of the stash
+            // instead (where the residual was read from; no other wave touches that slice), are re-read 8 lanes per row,
+            // and leave as whole 128-B line segments: 8 stores per wave and tile.
+            const int j = lane & 31, h = lane >> 5;
+            const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+            const bool has_res = a.has_res != 0;
+            auto finish_group = [&](const f32x16& acc, int rb, int g) {          // 4 channels of row 32 rb + j -> LDS
+                float* xp = s_x + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g;   // LDS row = 8 * patch row + column
+                f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                v = v * sc[g] + sh[g];
+                v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+                const f32x4 r = *reinterpret_cast<const f32x4*>(xp);
+                v.x += has_res ? r.x : 0.f; v.y += has_res ? r.y : 0.f; v.z += has_res ? r.z : 0.f; v.w += has_res ? r.w : 0.f;
+                *reinterpret_cast<f32x4*>(xp) = v;
+            };
+            const int u8 = lane >> 3, c4 = 4 * (lane & 7);
+            float* ob = out + (size_t)frame * a.n_per_frame * C + 32 * wave + c4;
+            auto store_segments = [&](int i0) {                                  // patch rows i0 .. i0+3: 8 lanes per row
+                f32x4 o[4];
+                int node[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // an absent segment (ragged patch) repeats segment 0, a short one its last node: identical stores
+                    const int i = seg_cnt[i0 + e] > 0 ? i0 + e : 0;
+                    const int cnt = seg_cnt[i0 + e] > 0 ? seg_cnt[i0 + e] : seg_cnt[0];
+                    const int first = seg_cnt[i0 + e] > 0 ? seg_first[i0 + e] : seg_first[0];
+                    const int u = u8 < cnt ? u8 : cnt - 1;
+                    o[e] = *reinterpret_cast<const f32x4*>(s_x + (8 * i + u) * LDA + 32 * wave + c4);
+                    node[e] = first + u;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(ob + (size_t)node[e] * C) = o[e];
+            };
 #ifndef EG_ABL_NO_MFMA
             mfma_rowblock(s_a, 0, lane, wreg, acc0);
-            if (seg_cnt[4] > 0) mfma_rowblock(s_a, 32, lane, wreg, acc1);
+            // rows 32..63: the MFMA chain leaves ~60 issue cycles per instruction free; the epilogue of rows 0..31
+            // (VALU, LDS, and its global stores) is placed between the chunks of the chain
+            mfma_rowblock_with(s_a, 32, lane, wreg, acc1, [&](int c) {
+                if (c < 2) { finish_group(acc0, 0, 2 * c); finish_group(acc0, 0, 2 * c + 1); }
+                else if (c == 2) store_segments(0);
+            });
 #else
             acc0[0] = wreg[0] + s_a[lane]; acc1[0] = wreg[63];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
+            store_segments(0);
 #endif
             PSTAMP(0);
-            // Epilogue.  Lane (row j of the 32-row block, half h) holds 16 channels of ONE row: stored from there a
-            // wave instruction would touch 32 rows x 32 B.  The finished values go back into this wave's own channel
-            // slice of the stash instead (where the residual was read from; no other wave touches that slice), are
-            // re-read 8 lanes per row, and leave as whole 128-B line segments: 8 stores per wave and tile.
-            const int j = lane & 31, h = lane >> 5;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                float* xp = s_x + (32 * rb + j) * LDA + 32 * wave + 4 * h;     // LDS row = 8 * patch row + column
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-                    if (rb == 0) v = f32x4{acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
-                    else v = f32x4{acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
-                    v = v * sc[g] + sh[g];
-                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (a.has_res) v += *reinterpret_cast<const f32x4*>(xp + 8 * g);
-                    *reinterpret_cast<f32x4*>(xp + 8 * g) = v;
-                }
-            }
+            for (int g = 0; g < 4; ++g) finish_group(acc1, 1, g);
+            store_segments(4);
             {
-                const int u = lane >> 3, c4 = 4 * (lane & 7);
-                float* ob = out + (size_t)frame * a.n_per_frame * C + 32 * wave + c4;
-                f32x4 o[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = *reinterpret_cast<const f32x4*>(s_x + (8 * i + u) * LDA + 32 * wave + c4);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (u < seg_cnt[i]) *reinterpret_cast<f32x4*>(ob + (size_t)(seg_first[i] + u) * C) = o[i];
                 if (kout) {
                     float* kb = kout + (size_t)frame * a.kid_rows * C + 32 * wave + c4;
 #pragma unroll
@@ -258,6 +277,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
 #endif
                 // ---- usual case: both segments on the fast path, vertically adjacent, same parents ----
                 SegPair A;
+                const bool use_kin = sd0.aux && kin;                // uniform: children already summed by the previous layer
                 segp_issue(sd0, sd1, xf, lane, A);
 #ifdef EG_ABL_NO_LOADS        // timing-only ablation: producers do nothing (results wrong)
                 return;
@@ -272,9 +292,10 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 pin_acc4(acc1);                                     // the 40 main-stage registers are dead from here on
                 __builtin_amdgcn_sched_barrier(0);
                 PSTAMP(PS_MAIN);
-                if (sd0.aux && kin) {                               // children already summed by the previous layer's epilogue
-                    const float* kf = kin + (size_t)frame * a.kid_rows * C;
-                    segp_kidsum(sd0, sd1, kf, lane, wqa, wqb, acc0, acc1);
+                if (use_kin) {                                      // (issued here, not with the first batch: registers)
+                    SegKidsum KS;
+                    segp_kidsum_issue(sd0, sd1, kin + (size_t)frame * a.kid_rows * C, lane, KS);
+                    segp_kidsum_add(KS, wqa, wqb, acc0, acc1);
                 } else if (sd0.aux) {                               // uniform: aux level, children pulled as rows
                     {
                         SegKids K;

@@ -88,19 +88,23 @@ __device__ inline void segp_issue(const SegDesc& sa, const SegDesc& sb, const fl
 }
 
 // Aux levels, chained layers: the children's contribution of node n is ONE row of the side buffer (row n; the previous
-// layer's epilogue summed dis[c] * h[c] over the four children), so the children are one more run of 8 rows.
-__device__ inline void segp_kidsum(const SegDesc& sa, const SegDesc& sb, const float* __restrict__ kf, int lane,
-                                   const float* wqa, const float* wqb, f32x4 (&acc0)[4], f32x4 (&acc1)[4]) {
+// layer's epilogue summed dis[c] * h[c] over the four children), so the children are one more run of 8 rows per
+// segment, loaded once the main stage has freed its registers.
+struct SegKidsum { f32x4 Ka[4], Kb[4]; };
+
+__device__ inline void segp_kidsum_issue(const SegDesc& sa, const SegDesc& sb, const float* __restrict__ kf, int lane, SegKidsum& K) {
     const PairLane pl{lane >> 5, lane & 31};
     const unsigned oa = pair_off(sa.n_first, pl), ob = pair_off(sb.n_first, pl);
-    f32x4 Ka[4], Kb[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { Ka[k] = ld4(kf, oa, k); Kb[k] = ld4(kf, ob, k); }
+    for (int k = 0; k < 4; ++k) { K.Ka[k] = ld4(kf, oa, k); K.Kb[k] = ld4(kf, ob, k); }
+}
+
+__device__ inline void segp_kidsum_add(const SegKidsum& K, const float* wqa, const float* wqb, f32x4 (&acc0)[4], f32x4 (&acc1)[4]) {
     const f32x4 fa = quad_w(wqa, SLOT_HASKIDS), fb = quad_w(wqb, SLOT_HASKIDS);       // 1.0 / 0.0
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        acc0[k] += fa[k] * Ka[k];
-        acc1[k] += fb[k] * Kb[k];
+        acc0[k] += fa[k] * K.Ka[k];
+        acc1[k] += fb[k] * K.Kb[k];
     }
 }
 

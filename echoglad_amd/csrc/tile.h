@@ -509,6 +509,35 @@ __device__ inline void mfma_rowblock(const float* s_a, int row0, int lane, const
     mfma_chunk(a1, wreg, 12, acc);
 }
 
+// Same chain; between(c) is emitted in the scheduling region of chunk c (c = 0..3) so that independent VALU / LDS /
+// store work of the caller fills the issue slots the dependent 64-cycle MFMAs leave free.
+template <typename F>
+__device__ inline void mfma_rowblock_with(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc, F between) {
+    const int j = lane & 31, h = lane >> 5;
+    const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
+    f32x4 a0[4], a1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a0[t] = ap[t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a0, wreg, 0, acc);
+    between(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a1, wreg, 4, acc);
+    between(1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a0, wreg, 8, acc);
+    between(2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a1, wreg, 12, acc);
+    between(3);
+}
+
 // ---- 8-wave layout: wave w owns 16 output channels, v_mfma_f32_16x16x4_f32 ------------------------
 // A operand = W slice (32 VGPRs for the lifetime of the workgroup): lane (i = l&15, kq = l>>4) holds
 // W[16w+i][koff(kq) + s], s = 0..31.  B operand = LDS tile: lane (j = l&15, kq) reads a[row0+j][koff(kq)+s]
