@@ -241,6 +241,38 @@ def main():
             "stack_hbm_frac": round(frames_per_s / world * stack_bytes / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": roofline,
         }
+        # ---- the rows right after the path, timed beside it; NOT part of `value`
+        try:
+            from echoglad_amd import evaluators as EV, losses as LS
+            lg = out.detach().reshape(B * (out.shape[0] // B), 4).contiguous()
+            n_rows = lg.shape[0] // B
+            lv = LS.level_grids(args.frame, args.naux, args.main_only)
+            yl = torch.zeros_like(lg)
+            yl.view(B, n_rows, 4)[:, [st + (s // 2) * s + s // 2 for st, s in lv if st + s * s <= n_rows], :] = 1.0
+            vl = torch.ones_like(lg)
+            elm = LS.ExpectedLandmarkMSE(10, B, args.frame, args.naux, args.main_only)
+            bce = LS.WeightedBCEWithLogitsLoss("none", 9000, 1)
+
+            def timed(fn, iters=20):
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); e0.record()
+                for _ in range(iters):
+                    fn()
+                e1.record(); torch.cuda.synchronize()
+                return round(e0.elapsed_time(e1) / iters, 4)
+
+            def loss_step():
+                x = lg.detach().requires_grad_(True)
+                (elm.compute(x, yl, vl) + bce.compute(x, yl, vl)).backward()
+
+            result["after_path"] = {"landmark_decode_ms": timed(lambda: EV.decode_landmarks(lg, B, args.frame, yl, vl)),
+                                    "losses_fwd_bwd_ms": timed(loss_step),
+                                    "note": "softmax-expected + hard-argmax landmark decode of the step's logits, and "
+                                            "ExpectedLandmarkMSE + WeightedBCEWithLogits forward+backward, on the device"}
+        except Exception as ex:                                   # never lose the bench line over the side measurement
+            result["after_path"] = {"error": repr(ex)}
         if not args.no_cpu_baseline:
             cb, cpu_out, cpu_feats, cpu_ei = cpu_baseline(args, kw, model.state_dict())
             result["cpu_baseline"] = cb

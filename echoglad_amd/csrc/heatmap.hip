@@ -1,0 +1,328 @@
+// Losses on the logits and landmark decode for the hierarchical heat maps (gfx950).
+// Replaces, on the device and without host round trips:
+//   src/core/criterion.py:13-27     WeightedBCEWithLogitsLoss (numpy round trip for the weights, :18-21)
+//   src/core/criterion.py:93-151    ExpectedLandmarkMSE: per level softmax over the nodes -> expected (h, w), ground
+//                                   truth (h, w) from the label heat map, mean of `valid` per (frame, level, channel)
+//   src/core/evaluators.py:291-391  the same decode on the last F*F rows (+ hard argmax, models' landmark index)
+//
+// The logits of a frame are [n_rows, 4] with the levels stacked row-major (2x2, 4x4, ..., FxF).  All per-level
+// statistics of one (frame, level, channel) come out of ONE pass structure:
+//   k_hm_partial  one workgroup per 2048-row chunk of a level: chunk max, first arg max, sum exp(x - max),
+//                 sum exp * h, sum exp * w (fp64 accumulators, fixed tree order), label max / min h / min w of
+//                 the label maxima, sum of valid
+//   k_hm_final    merges the chunks of a level in order (softmax merge in fp64)
+// so the result is bitwise reproducible and independent of the grid.  Bandwidth is trivial (16 B per node).
+#include "common.h"
+
+namespace eg {
+
+constexpr int HM_MAX_LEVELS = 16;
+constexpr int HM_CHUNK = 2048;
+constexpr int HM_THREADS = 256;
+constexpr int HM_REC = 10;          // doubles per (frame, chunk, channel): m, s, sh, sw, best, bidx, g, gh, gw, vsum
+
+struct HmLevels {
+    int n_levels, n_rows, batch, total_chunks;
+    int start[HM_MAX_LEVELS], side[HM_MAX_LEVELS], chunk0[HM_MAX_LEVELS + 1];
+};
+
+__device__ inline double block_sum(double v, double* red, int tid) {
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = HM_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// max of v with the LOWEST index among equal maxima
+__device__ inline void block_argmax(float& v, int& idx, float* fv, int* fi, int tid) {
+    __syncthreads();
+    fv[tid] = v; fi[tid] = idx;
+    __syncthreads();
+#pragma unroll
+    for (int s = HM_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float o = fv[tid + s]; const int oi = fi[tid + s];
+            if (o > fv[tid] || (o == fv[tid] && oi < fi[tid])) { fv[tid] = o; fi[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    v = fv[0]; idx = fi[0];
+}
+
+// label maxima: value, min h and min w over all positions that hold the maximum
+__device__ inline void block_gtmax(float& g, int& gh, int& gw, float* fv, int* fi, int* fj, int tid) {
+    __syncthreads();
+    fv[tid] = g; fi[tid] = gh; fj[tid] = gw;
+    __syncthreads();
+#pragma unroll
+    for (int s = HM_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float o = fv[tid + s];
+            if (o > fv[tid]) { fv[tid] = o; fi[tid] = fi[tid + s]; fj[tid] = fj[tid + s]; }
+            else if (o == fv[tid]) { fi[tid] = min(fi[tid], fi[tid + s]); fj[tid] = min(fj[tid], fj[tid + s]); }
+        }
+        __syncthreads();
+    }
+    g = fv[0]; gh = fi[0]; gw = fj[0];
+}
+
+__global__ __launch_bounds__(HM_THREADS) void k_hm_partial(const float* __restrict__ logits, const float* __restrict__ y,
+                                                           const float* __restrict__ valid, double* __restrict__ part,
+                                                           const HmLevels L) {
+    __shared__ double red[HM_THREADS];
+    __shared__ float fv[HM_THREADS];
+    __shared__ int fi[HM_THREADS], fj[HM_THREADS];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / L.total_chunks, chunk = blockIdx.x - b * L.total_chunks;
+    int l = 0;
+    for (int k = 1; k < L.n_levels; ++k) l += chunk >= L.chunk0[k] ? 1 : 0;
+    const int side = L.side[l], n_lvl = side * side;
+    const int r0 = (chunk - L.chunk0[l]) * HM_CHUNK, r1 = min(r0 + HM_CHUNK, n_lvl);
+    const size_t base = ((size_t)b * L.n_rows + L.start[l]) * 4;
+    const float NEG = -__builtin_inff();
+
+    float m[4] = {NEG, NEG, NEG, NEG}, g[4] = {NEG, NEG, NEG, NEG};
+    int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    int gh[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff}, gw[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    double vs[4] = {0, 0, 0, 0};
+    for (int r = r0 + tid; r < r1; r += HM_THREADS) {
+        const float4 x = *reinterpret_cast<const float4*>(logits + base + (size_t)r * 4);
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (xv[c] > m[c]) { m[c] = xv[c]; bi[c] = r; }        // rows ascend: first max kept
+        if (y) {
+            const float4 t = *reinterpret_cast<const float4*>(y + base + (size_t)r * 4);
+            const float tv[4] = {t.x, t.y, t.z, t.w};
+            const int h = r / side, w = r - h * side;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (tv[c] > g[c]) { g[c] = tv[c]; gh[c] = h; gw[c] = w; }
+                else if (tv[c] == g[c]) { gh[c] = min(gh[c], h); gw[c] = min(gw[c], w); }
+            }
+        }
+        if (valid) {
+            const float4 t = *reinterpret_cast<const float4*>(valid + base + (size_t)r * 4);
+            vs[0] += t.x; vs[1] += t.y; vs[2] += t.z; vs[3] += t.w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        block_argmax(m[c], bi[c], fv, fi, tid);
+        if (y) block_gtmax(g[c], gh[c], gw[c], fv, fi, fj, tid);
+        if (valid) vs[c] = block_sum(vs[c], red, tid);
+    }
+    double s[4] = {0, 0, 0, 0}, sh[4] = {0, 0, 0, 0}, sw[4] = {0, 0, 0, 0};
+    for (int r = r0 + tid; r < r1; r += HM_THREADS) {
+        const float4 x = *reinterpret_cast<const float4*>(logits + base + (size_t)r * 4);
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+        const int h = r / side, w = r - h * side;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double e = (double)expf(xv[c] - m[c]);
+            s[c] += e; sh[c] += e * h; sw[c] += e * w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        s[c] = block_sum(s[c], red, tid);
+        sh[c] = block_sum(sh[c], red, tid);
+        sw[c] = block_sum(sw[c], red, tid);
+    }
+    if (tid == 0) {
+        double* p = part + ((size_t)blockIdx.x * 4) * HM_REC;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double* q = p + c * HM_REC;
+            q[0] = m[c]; q[1] = s[c]; q[2] = sh[c]; q[3] = sw[c]; q[4] = m[c]; q[5] = bi[c];
+            q[6] = g[c]; q[7] = gh[c]; q[8] = gw[c]; q[9] = vs[c];
+        }
+    }
+}
+
+// one thread per (frame, level, channel): merge the level's chunks in order
+__global__ void k_hm_final(const double* __restrict__ part, float* __restrict__ expect, float* __restrict__ stats,
+                           int64_t* __restrict__ argmax, float* __restrict__ gt, float* __restrict__ vmean, const HmLevels L) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L.batch * L.n_levels * 4) return;
+    const int c = t & 3, l = (t >> 2) % L.n_levels, b = (t >> 2) / L.n_levels;
+    const int k0 = L.chunk0[l], k1 = L.chunk0[l + 1];
+    double M = -__builtin_inf();
+    for (int k = k0; k < k1; ++k) M = fmax(M, part[(((size_t)b * L.total_chunks + k) * 4 + c) * HM_REC]);
+    double S = 0, SH = 0, SW = 0, VS = 0, best = -__builtin_inf(), bidx = 0, g = -__builtin_inf();
+    double gh = 2147483647.0, gw = 2147483647.0;
+    for (int k = k0; k < k1; ++k) {
+        const double* q = part + (((size_t)b * L.total_chunks + k) * 4 + c) * HM_REC;
+        const double f = q[0] == M ? 1.0 : exp(q[0] - M);
+        S += q[1] * f; SH += q[2] * f; SW += q[3] * f; VS += q[9];
+        if (q[4] > best) { best = q[4]; bidx = q[5]; }                 // chunks ascend: first maximum kept
+        if (q[6] > g) { g = q[6]; gh = q[7]; gw = q[8]; }
+        else if (q[6] == g) { gh = fmin(gh, q[7]); gw = fmin(gw, q[8]); }
+    }
+    const size_t o = ((size_t)b * L.n_levels + l) * 4 + c;
+    expect[o * 2] = (float)(SH / S);
+    expect[o * 2 + 1] = (float)(SW / S);
+    if (stats) { stats[o * 2] = (float)M; stats[o * 2 + 1] = (float)S; }
+    if (argmax) argmax[o] = (int64_t)bidx;
+    if (gt) { gt[o * 2] = (float)gh; gt[o * 2 + 1] = (float)gw; }
+    if (vmean) vmean[o] = (float)(VS / ((double)L.side[l] * L.side[l]));
+}
+
+// d logits[r, c] = p * ((h - E_h) * g_h + (w - E_w) * g_w),  p = exp(x - m) / s
+__global__ __launch_bounds__(HM_THREADS) void k_hm_bwd(const float* __restrict__ logits, const float* __restrict__ expect,
+                                                       const float* __restrict__ stats, const float* __restrict__ d_expect,
+                                                       float* __restrict__ d_logits, const HmLevels L) {
+    const long long t = (long long)blockIdx.x * HM_THREADS + threadIdx.x;
+    if (t >= (long long)L.batch * L.n_rows) return;
+    const int b = (int)(t / L.n_rows), r = (int)(t - (long long)b * L.n_rows);
+    int l = -1;
+    for (int k = 0; k < L.n_levels; ++k) if (r >= L.start[k] && r < L.start[k] + L.side[k] * L.side[k]) l = k;
+    float4 out = {0.f, 0.f, 0.f, 0.f};
+    if (l >= 0) {
+        const int rr = r - L.start[l], side = L.side[l];
+        const float h = (float)(rr / side), w = (float)(rr - (rr / side) * side);
+        const float4 x = *reinterpret_cast<const float4*>(logits + (size_t)t * 4);
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const size_t q = (((size_t)b * L.n_levels + l) * 4 + c) * 2;
+            const float p = expf(xv[c] - stats[q]) / stats[q + 1];
+            o[c] = p * ((h - expect[q]) * d_expect[q] + (w - expect[q + 1]) * d_expect[q + 1]);
+        }
+        out = float4{o[0], o[1], o[2], o[3]};
+    }
+    *reinterpret_cast<float4*>(d_logits + (size_t)t * 4) = out;
+}
+
+// ---- weighted BCE with logits ---------------------------------------------------------------------------------
+constexpr int BCE_BLOCKS = 512;
+
+__device__ inline float bce_logits(float x, float y) { return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))); }
+
+__global__ __launch_bounds__(HM_THREADS) void k_bce_partial(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ valid, long long n, float ones_weight,
+                                                            double* __restrict__ part) {
+    __shared__ double red[HM_THREADS];
+    const int tid = threadIdx.x;
+    double a = 0, v = 0;
+    for (long long i = (long long)blockIdx.x * HM_THREADS + tid; i < n; i += (long long)gridDim.x * HM_THREADS) {
+        const float yi = y[i], vi = valid ? valid[i] : 1.0f;
+        const float w = (ones_weight > 1.0f && yi == 1.0f) ? ones_weight : 1.0f;
+        a += (double)(w * bce_logits(x[i], yi)) * vi;
+        v += vi;
+    }
+    a = block_sum(a, red, tid);
+    v = block_sum(v, red, tid);
+    if (tid == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = v; }
+}
+
+__global__ void k_bce_final(const double* __restrict__ part, int blocks, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double a = 0, v = 0;
+    for (int k = 0; k < blocks; ++k) { a += part[2 * k]; v += part[2 * k + 1]; }
+    out[0] = (float)a; out[1] = (float)v; out[2] = (float)(a / v);
+}
+
+__global__ __launch_bounds__(HM_THREADS) void k_bce_bwd(const float* __restrict__ x, const float* __restrict__ y,
+                                                        const float* __restrict__ valid, long long n, float ones_weight,
+                                                        const float* __restrict__ scale, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * HM_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float yi = y[i], vi = valid ? valid[i] : 1.0f;
+    const float w = (ones_weight > 1.0f && yi == 1.0f) ? ones_weight : 1.0f;
+    const float sg = 1.0f / (1.0f + expf(-x[i]));
+    dx[i] = (sg - yi) * w * vi * scale[0];
+}
+
+static int fill_levels(int batch, int64_t n_rows, const int* level_start, const int* level_side, int n_levels, HmLevels& L) {
+    if (batch < 1 || n_rows < 1 || n_levels < 1 || n_levels > HM_MAX_LEVELS || !level_start || !level_side)
+        return set_error(EG_ERR_ARG, "bad level table");
+    if (n_rows * (int64_t)batch >= (1ll << 31)) return set_error(EG_ERR_ARG, "batch * rows exceeds int32");
+    L.n_levels = n_levels; L.n_rows = (int)n_rows; L.batch = batch;
+    int chunks = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const long long sz = (long long)level_side[l] * level_side[l];
+        if (level_side[l] < 1 || level_start[l] < 0 || level_start[l] + sz > n_rows) return set_error(EG_ERR_ARG, "level outside the frame's rows");
+        L.start[l] = level_start[l]; L.side[l] = level_side[l]; L.chunk0[l] = chunks;
+        chunks += (int)((sz + HM_CHUNK - 1) / HM_CHUNK);
+    }
+    L.chunk0[n_levels] = chunks;
+    L.total_chunks = chunks;
+    return EG_OK;
+}
+
+}  // namespace eg
+
+using namespace eg;
+
+extern "C" {
+
+size_t eg_heatmap_workspace_bytes(int batch, const int* level_side, int n_levels) {
+    if (batch < 1 || !level_side || n_levels < 1 || n_levels > HM_MAX_LEVELS) return 0;
+    size_t chunks = 0;
+    for (int l = 0; l < n_levels; ++l) chunks += ((size_t)level_side[l] * level_side[l] + HM_CHUNK - 1) / HM_CHUNK;
+    const size_t hm = (size_t)batch * chunks * 4 * HM_REC * sizeof(double);
+    const size_t bce = (size_t)BCE_BLOCKS * 2 * sizeof(double);
+    return hm > bce ? hm : bce;
+}
+
+int eg_heatmap_expect_fwd(const float* logits, const float* labels, const float* valid, int batch, int64_t n_rows,
+                          const int* level_start, const int* level_side, int n_levels, void* workspace, float* expect,
+                          float* stats, int64_t* argmax, float* gt, float* vmean, eg_stream_t stream) {
+    if (!logits || !workspace || !expect) return set_error(EG_ERR_ARG, "logits, workspace and expect must not be NULL");
+    if ((gt && !labels) || (vmean && !valid)) return set_error(EG_ERR_ARG, "gt needs labels, vmean needs valid");
+    HmLevels L{};
+    int rc = fill_levels(batch, n_rows, level_start, level_side, n_levels, L);
+    if (rc != EG_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_hm_partial, dim3((unsigned)(batch * L.total_chunks)), dim3(HM_THREADS), 0, s, logits,
+                       gt ? labels : nullptr, vmean ? valid : nullptr, (double*)workspace, L);
+    const int n_out = batch * n_levels * 4;
+    hipLaunchKernelGGL(k_hm_final, dim3((unsigned)((n_out + 63) / 64)), dim3(64), 0, s, (const double*)workspace, expect,
+                       stats, argmax, gt, vmean, L);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_heatmap_expect_bwd(const float* logits, const float* expect, const float* stats, const float* d_expect, int batch,
+                          int64_t n_rows, const int* level_start, const int* level_side, int n_levels, float* d_logits,
+                          eg_stream_t stream) {
+    if (!logits || !expect || !stats || !d_expect || !d_logits) return set_error(EG_ERR_ARG, "NULL argument");
+    HmLevels L{};
+    int rc = fill_levels(batch, n_rows, level_start, level_side, n_levels, L);
+    if (rc != EG_OK) return rc;
+    const long long n = (long long)batch * n_rows;
+    hipLaunchKernelGGL(k_hm_bwd, dim3((unsigned)((n + HM_THREADS - 1) / HM_THREADS)), dim3(HM_THREADS), 0, (hipStream_t)stream,
+                       logits, expect, stats, d_expect, d_logits, L);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_bce_logits_fwd(const float* logits, const float* labels, const float* valid, int64_t n, float ones_weight,
+                      void* workspace, float* out3, eg_stream_t stream) {
+    if (!logits || !labels || !workspace || !out3 || n < 1) return set_error(EG_ERR_ARG, "bad argument");
+    long long blocks = (n + HM_THREADS - 1) / HM_THREADS;
+    if (blocks > BCE_BLOCKS) blocks = BCE_BLOCKS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bce_partial, dim3((unsigned)blocks), dim3(HM_THREADS), 0, s, logits, labels, valid, (long long)n,
+                       ones_weight, (double*)workspace);
+    hipLaunchKernelGGL(k_bce_final, dim3(1), dim3(64), 0, s, (const double*)workspace, (int)blocks, out3);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_bce_logits_bwd(const float* logits, const float* labels, const float* valid, int64_t n, float ones_weight,
+                      const float* scale_dev, float* d_logits, eg_stream_t stream) {
+    if (!logits || !labels || !scale_dev || !d_logits || n < 1) return set_error(EG_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_bce_bwd, dim3((unsigned)((n + HM_THREADS - 1) / HM_THREADS)), dim3(HM_THREADS), 0, (hipStream_t)stream,
+                       logits, labels, valid, (long long)n, ones_weight, scale_dev, d_logits);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+"""Losses on the logits — host-side mirror of the reference's criterion classes over the HIP kernels in
+csrc/heatmap.hip.  Same class names, constructor arguments and ``compute`` signatures as
+``src/core/criterion.py`` so that a criterion builder can swap them in; everything stays on the device (the
+reference's WeightedBCE round-trips the labels through numpy to build its weight tensor, criterion.py:18-21).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+from . import ops
+
+
+def level_grids(frame_size: int, num_aux_graphs: int, use_main_graph_only: bool = False) -> List[Tuple[int, int]]:
+    """[(first row, side)] of every level inside a frame's rows (criterion.py:78-87)."""
+    sizes = [frame_size] if use_main_graph_only else [2 ** g for g in range(1, num_aux_graphs + 1)] + [frame_size]
+    out, start = [], 0
+    for s in sizes:
+        out.append((start, s))
+        start += s * s
+    return out
+
+
+def _rows4(t: torch.Tensor) -> torch.Tensor:
+    return t.reshape(-1, t.shape[-1]).to(torch.float32).contiguous()
+
+
+class WeightedBCEWithLogitsLoss:
+    """criterion.py:29-33 on top of WeightedBCE (:7-27): elementwise BCE-with-logits, ``ones_weight`` on the
+    positive labels, ``sum(loss * valid) / sum(valid)`` times ``loss_weight``."""
+
+    def __init__(self, reduction, ones_weight, loss_weight):
+        if reduction != "none":
+            raise NotImplementedError("the reference builds this loss with reduction='none' (configs/default.yml)")
+        self.ones_weight = ones_weight
+        self.loss_weight = loss_weight
+
+    def compute(self, pred_y, y, valid=None):
+        x = _rows4(pred_y)
+        return self.loss_weight * ops.bce_logits(x, _rows4(y), None if valid is None else _rows4(valid), self.ones_weight)
+
+
+class ExpectedLandmarkMSE:
+    """criterion.py:63-151: per level, softmax over the level's nodes -> expected (h, w), squared distance to the
+    label's (h, w) in units of the level's side, weighted by the per-(frame, channel) mean of ``valid``."""
+
+    def __init__(self, loss_weight=1, batch_size=2, frame_size=128, num_aux_graphs=6, use_main_graph_only=False,
+                 num_output_channels=4):
+        if num_output_channels != 4:
+            raise NotImplementedError("the HIP kernels are built for 4 landmark channels")
+        self.loss_weight = loss_weight
+        self.batch_size = batch_size
+        self.frame_size = frame_size
+        self.num_aux_graphs = num_aux_graphs
+        self.num_output_channels = num_output_channels
+        self.use_main_graph_only = use_main_graph_only
+        self.levels = level_grids(frame_size, num_aux_graphs, use_main_graph_only)
+        self.grid_sizes = [s for _, s in self.levels]
+        self.end_indices = [st + s * s for st, s in self.levels]
+
+    def compute(self, pred_y, y, valid):
+        expect, gt, vmean = ops.heatmap_expect(_rows4(pred_y), self.batch_size, self.levels, _rows4(y), _rows4(valid))
+        side = torch.tensor(self.grid_sizes, dtype=torch.float32, device=expect.device).view(1, -1, 1, 1)
+        nv = vmean.sum(dim=0, keepdim=True)                                    # [1,L,4]
+        nv = torch.where(nv == 0, torch.ones_like(nv), nv)
+        d = ((expect / side - gt / side) ** 2) * vmean.unsqueeze(-1)           # [B,L,4,2]
+        return (d.sum(dim=0) / nv[0].unsqueeze(-1)).sum() * self.loss_weight

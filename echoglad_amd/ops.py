@@ -320,3 +320,135 @@ def scatter_coord_rows(h, new_feats, batch, n_per_frame, coord_base) -> torch.Te
     tgt = h.clone() if need_grad else h
     tgt.view(batch, n_per_frame, C)[:, coord_base:coord_base + 4, :] = new_feats.view(batch, 4, C)
     return tgt
+
+
+# ---------------------------------------------------------------------------
+# losses on the logits / landmark decode (heatmap.hip)
+# ---------------------------------------------------------------------------
+def _check_logits(t: torch.Tensor, name: str, rows: Optional[int] = None) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA (ROCm) tensor: the HIP path has no CPU fallback")
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != 4 or not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous float32 [rows, 4], got {tuple(t.shape)} {t.dtype}")
+    if rows is not None and t.shape[0] != rows:
+        raise RuntimeError(f"{name} has {t.shape[0]} rows, expected {rows}")
+
+
+def _level_arrays(levels):
+    n = len(levels)
+    if not 1 <= n <= 16:
+        raise RuntimeError("1..16 levels supported")
+    start = (ct.c_int * n)(*[int(s) for s, _ in levels])
+    side = (ct.c_int * n)(*[int(p) for _, p in levels])
+    return start, side, n
+
+
+_hm_workspaces = {}
+
+
+def _hm_workspace(device, nbytes: int) -> torch.Tensor:
+    key = (torch.device(device), torch.cuda.current_stream().cuda_stream)
+    ws = _hm_workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+        _hm_workspaces[key] = ws
+    return ws
+
+
+def heatmap_expect_fwd(logits: torch.Tensor, batch: int, levels, labels: Optional[torch.Tensor] = None,
+                       valid: Optional[torch.Tensor] = None, want_argmax: bool = False):
+    """Per (frame, level, channel): softmax-expected (h, w), (max, sum-exp), first arg max, label (h, w), mean(valid).
+
+    levels: [(first row inside a frame's rows, side)]; logits [batch * n_rows, 4].
+    Returns dict(expect [B,L,4,2], stats [B,L,4,2], argmax [B,L,4] | None, gt [B,L,4,2] | None, vmean [B,L,4] | None)."""
+    if logits.shape[0] % batch:
+        raise RuntimeError("logit rows are not a multiple of the batch size")
+    n_rows = logits.shape[0] // batch
+    _check_logits(logits, "logits")
+    for name, t in (("labels", labels), ("valid", valid)):
+        if t is not None:
+            _check_logits(t, name, logits.shape[0])
+    start, side, n = _level_arrays(levels)
+    lib = _lib.load()
+    ws = _hm_workspace(logits.device, int(lib.eg_heatmap_workspace_bytes(batch, side, n)))
+    dev = logits.device
+    expect = torch.empty(batch, n, 4, 2, dtype=torch.float32, device=dev)
+    stats = torch.empty(batch, n, 4, 2, dtype=torch.float32, device=dev)
+    argmax = torch.empty(batch, n, 4, dtype=torch.int64, device=dev) if want_argmax else None
+    gt = torch.empty(batch, n, 4, 2, dtype=torch.float32, device=dev) if labels is not None else None
+    vmean = torch.empty(batch, n, 4, dtype=torch.float32, device=dev) if valid is not None else None
+    _lib.check(lib.eg_heatmap_expect_fwd(_ptr(logits), _ptr(labels), _ptr(valid), batch, n_rows, start, side, n, _ptr(ws),
+                                         _ptr(expect), _ptr(stats), _ptr(argmax), _ptr(gt), _ptr(vmean), _stream()),
+               "eg_heatmap_expect_fwd")
+    return {"expect": expect, "stats": stats, "argmax": argmax, "gt": gt, "vmean": vmean}
+
+
+def heatmap_expect_bwd(logits, expect, stats, d_expect, batch: int, levels) -> torch.Tensor:
+    n_rows = logits.shape[0] // batch
+    start, side, n = _level_arrays(levels)
+    d_logits = torch.empty_like(logits)
+    _lib.check(_lib.load().eg_heatmap_expect_bwd(_ptr(logits), _ptr(expect), _ptr(stats), _ptr(d_expect.contiguous()), batch,
+                                                 n_rows, start, side, n, _ptr(d_logits), _stream()), "eg_heatmap_expect_bwd")
+    return d_logits
+
+
+class _HeatmapExpectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, batch, levels, labels, valid):
+        r = heatmap_expect_fwd(logits, batch, levels, labels, valid)
+        ctx.save_for_backward(logits, r["expect"], r["stats"])
+        ctx.batch, ctx.levels = batch, levels
+        gt = r["gt"] if r["gt"] is not None else logits.new_zeros(0)
+        vm = r["vmean"] if r["vmean"] is not None else logits.new_zeros(0)
+        ctx.mark_non_differentiable(gt, vm)
+        return r["expect"], gt, vm
+
+    @staticmethod
+    def backward(ctx, d_expect, _dgt, _dvm):
+        logits, expect, stats = ctx.saved_tensors
+        return heatmap_expect_bwd(logits, expect, stats, d_expect, ctx.batch, ctx.levels), None, None, None, None
+
+
+def heatmap_expect(logits, batch: int, levels, labels=None, valid=None):
+    """(expect, gt, vmean) with autograd through `expect` (d/d logits)."""
+    return _HeatmapExpectFn.apply(logits, batch, tuple(levels), labels, valid)
+
+
+def bce_logits_fwd(logits, labels, valid, ones_weight: float) -> torch.Tensor:
+    """[sum(w * bce * valid), sum(valid), ratio] as a float32 device tensor (no host sync)."""
+    for name, t in (("logits", logits), ("labels", labels)):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError(f"{name} must be a contiguous CUDA float32 tensor")
+    if labels.numel() != logits.numel() or (valid is not None and valid.numel() != logits.numel()):
+        raise RuntimeError("logits, labels and valid must have the same number of elements")
+    lib = _lib.load()
+    one = (ct.c_int * 1)(1)
+    ws = _hm_workspace(logits.device, int(lib.eg_heatmap_workspace_bytes(1, one, 1)))
+    out = torch.empty(3, dtype=torch.float32, device=logits.device)
+    _lib.check(lib.eg_bce_logits_fwd(_ptr(logits), _ptr(labels), _ptr(valid), logits.numel(), ct.c_float(ones_weight),
+                                     _ptr(ws), _ptr(out), _stream()), "eg_bce_logits_fwd")
+    return out
+
+
+class _BCELogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, valid, ones_weight):
+        out = bce_logits_fwd(logits, labels, valid, ones_weight)
+        ctx.save_for_backward(logits, labels, valid if valid is not None else logits.new_zeros(0), out)
+        ctx.ones_weight, ctx.has_valid = ones_weight, valid is not None
+        return out[2]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, valid, out = ctx.saved_tensors
+        scale = (g / out[1]).reshape(1).to(torch.float32).contiguous()
+        dx = torch.empty_like(logits)
+        _lib.check(_lib.load().eg_bce_logits_bwd(_ptr(logits), _ptr(labels), _ptr(valid) if ctx.has_valid else None,
+                                                 logits.numel(), ct.c_float(ctx.ones_weight), _ptr(scale), _ptr(dx), _stream()),
+                   "eg_bce_logits_bwd")
+        return dx, None, None, None
+
+
+def bce_logits(logits, labels, valid=None, ones_weight: float = 1.0) -> torch.Tensor:
+    """sum(w * bce_with_logits(x, y) * valid) / sum(valid), w = ones_weight where y == 1 (autograd wrt logits)."""
+    return _BCELogitsFn.apply(logits, labels, valid, float(ones_weight))

@@ -171,6 +171,36 @@ int eg_bilinear4_fwd(const float* h, const float* coords, int batch, int points,
 int eg_bilinear4_bwd(const float* dout, const float* h, const float* coords, int batch, int points, int64_t n_per_frame,
                      int64_t main_base, int frame, float* dh, float* dcoords, eg_stream_t stream);
 
+/* ---- losses on the logits and landmark decode (the steps right after the hot path) ---------------------
+ * Reference: src/core/criterion.py:13-27 (WeightedBCEWithLogitsLoss), :93-151 (ExpectedLandmarkMSE),
+ * src/core/evaluators.py:291-391,485-495 (softmax heat map -> expected landmark position, hard argmax).
+ * The logits of a frame are [n_rows, 4]; level l occupies rows level_start[l] .. + level_side[l]^2, row-major
+ * (h, w).  level_start / level_side are HOST arrays of n_levels <= 16 ints.  workspace: device memory of
+ * eg_heatmap_workspace_bytes() bytes, owned by the caller.  Nothing here synchronises or reads back.
+ *
+ * eg_heatmap_expect_fwd: for every (frame b, level l, channel c)
+ *   expect [batch,n_levels,4,2] f32  softmax over the level's nodes, expectation of (h, w)
+ *   stats  [batch,n_levels,4,2] f32  (max logit, sum exp(x - max)) for the backward, or NULL
+ *   argmax [batch,n_levels,4]  i64   row index (within the level) of the first maximum logit, or NULL
+ *   gt     [batch,n_levels,4,2] f32  (h, w) of the label heat map: arg max over rows of the row maxima, over
+ *                                    columns of the column maxima (first index wins), needs labels; or NULL
+ *   vmean  [batch,n_levels,4]  f32   mean of `valid` over the level's nodes, needs valid; or NULL
+ * eg_heatmap_expect_bwd: d_logits[r,c] = p[r,c] * ((h - E_h) dE_h + (w - E_w) dE_w), rows outside every level 0.
+ * eg_bce_logits_fwd: out3 = { sum(w * bce(x, y) * valid), sum(valid), their ratio }, w = ones_weight where
+ *   y == 1 (when ones_weight > 1) else 1; valid may be NULL (= 1).  fp64 sums in a fixed order.
+ * eg_bce_logits_bwd: d_logits = (sigmoid(x) - y) * w * valid * scale_dev[0]. */
+size_t eg_heatmap_workspace_bytes(int batch, const int* level_side, int n_levels);
+int eg_heatmap_expect_fwd(const float* logits, const float* labels, const float* valid, int batch, int64_t n_rows,
+                          const int* level_start, const int* level_side, int n_levels, void* workspace, float* expect,
+                          float* stats, int64_t* argmax, float* gt, float* vmean, eg_stream_t stream);
+int eg_heatmap_expect_bwd(const float* logits, const float* expect, const float* stats, const float* d_expect, int batch,
+                          int64_t n_rows, const int* level_start, const int* level_side, int n_levels, float* d_logits,
+                          eg_stream_t stream);
+int eg_bce_logits_fwd(const float* logits, const float* labels, const float* valid, int64_t n, float ones_weight,
+                      void* workspace, float* out3, eg_stream_t stream);
+int eg_bce_logits_bwd(const float* logits, const float* labels, const float* valid, int64_t n, float ones_weight,
+                      const float* scale_dev, float* d_logits, eg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,9 @@ Outputs
   coord_f32_a4.npz     coordinate-graph path (B=2): coords per layer, logits, train-mode grad norms
   mainonly_f16.npz     use_main_graph_only ablation
   losses_f16_a3.npz    WeightedBCEWithLogits + ExpectedLandmarkMSE values on the KAT logits
+  decode_f16_a3.npz    seeded logits / labels / valid masks (B=3): both losses and their gradients w.r.t. the logits
+  decode_f30_a3.npz    (criterion.py, autograd of the reference's own classes) and every number that
+                       LandmarkExpectedCoordiantesEvaluator.update records (evaluators.py:291-391)
 """
 import hashlib
 import json
@@ -344,6 +347,61 @@ def make_losses(model, logits, B, frame, naux):
     print("losses", float(l_bce), float(l_elm))
 
 
+def make_decode(frame, naux, B, seed, tag):
+    """Losses + gradients (criterion.py:13-27,93-151) and landmark decode / width errors (evaluators.py:291-391,
+    485-495) from the reference's own classes on seeded logits with near-ties and partly invalid labels."""
+    from src.core import evaluators as RE
+    rs = np.random.RandomState(seed)
+    topo = HierTopology(TopologySpec(frame, naux))
+    n = topo.num_nodes
+    levels = [(lv.base, lv.side) for lv in topo.aux_levels] + [(topo.main.base, topo.main.side)]
+    logits = (rs.standard_normal((B, n, 4)) * 2.0).astype(np.float32)
+    y = np.zeros((B, n, 4), dtype=np.float32)
+    for b in range(B):
+        for ch in range(4):
+            hh, ww = rs.randint(0, frame, size=2)
+            ph, pw = rs.randint(0, frame, size=2)                       # where the prediction peaks
+            for base, side in levels:
+                y[b, base + (hh * side // frame) * side + (ww * side // frame), ch] = 1.0
+                logits[b, base + (ph * side // frame) * side + (pw * side // frame), ch] += 6.0
+    # a near-tie (two equal maxima) in frame 0, channel 1 of the main grid: first index must win
+    mb, ms = levels[-1]
+    logits[0, mb + 3 * ms + 5, 1] = logits[0, mb + 9 * ms + 2, 1] = 30.0
+    valid = np.ones((B, n, 4), dtype=np.float32)
+    valid[B - 1, :, 2] = 0.0                                             # one landmark unlabeled in the last frame
+    if B > 1:
+        valid[1, :, 0] = 0.0
+    lg = torch.from_numpy(logits).view(B * n, 4).requires_grad_(True)
+    y_t, v_t = torch.from_numpy(y).view(B * n, 4), torch.from_numpy(valid).view(B * n, 4)
+    bce = RC.WeightedBCEWithLogitsLoss(reduction="none", ones_weight=9000, loss_weight=1)
+    elm = RC.ExpectedLandmarkMSE(loss_weight=10, batch_size=B, frame_size=frame, num_aux_graphs=naux,
+                                 use_main_graph_only=False, num_output_channels=4)
+    l_bce = bce.compute(lg.view(B, n, 4), y_t.view(B, n, 4), v_t)
+    g_bce, = torch.autograd.grad(l_bce, lg)
+    l_elm = elm.compute(lg, y_t, v_t)
+    g_elm, = torch.autograd.grad(l_elm, lg)
+    ev = RE.LandmarkExpectedCoordiantesEvaluator(logger=None, batch_size=B, frame_size=frame, use_coord_graph=False)
+    pix_x = torch.from_numpy(rs.uniform(0.2, 0.6, B).astype(np.float32))
+    pix_y = torch.from_numpy(rs.uniform(0.2, 0.6, B).astype(np.float32))
+    ev.update(lg.detach(), y_t, pix_x, pix_y, v_t)
+    last = ev.get_last()
+    det = ev.get_predictions()
+    co = det["coordinates"]
+    names = ["lvid_top", "lvid_bot", "lvpw", "ivs"]
+    np.savez_compressed(
+        os.path.join(HERE, f"decode_{tag}.npz"), frame=frame, naux=naux, batch=B,
+        logits=logits.reshape(B * n, 4), labels=y.reshape(B * n, 4), valid=valid.reshape(B * n, 4),
+        pix2mm_x=pix_x.numpy(), pix2mm_y=pix_y.numpy(),
+        bce=np.float64(l_bce.item()), elm=np.float64(l_elm.item()), grad_bce=g_bce.numpy(), grad_elm=g_elm.numpy(),
+        pred_coords=np.stack([co["pred_" + k].numpy() for k in names], axis=1),          # [B,4,2] (h,w)
+        gt_coords=np.stack([co["gt_" + k].numpy() for k in names], axis=1).astype(np.int64),
+        last_keys=np.array(sorted(last.keys())), last_vals=np.array([float(last[k]) for k in sorted(last.keys())]),
+        width_keys=np.array(sorted(det["widths"].keys())),
+        width_vals=np.stack([det["widths"][k].numpy() for k in sorted(det["widths"].keys())], axis=0),
+        argmax_main=lg.detach().view(B, n, 4)[:, -frame * frame:, :].argmax(dim=1).numpy())
+    print("decode", tag, float(l_bce), float(l_elm), {k: round(float(v), 4) for k, v in last.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -356,4 +414,7 @@ if __name__ == "__main__":
         make_cfg1()
         make_coord()
         make_mainonly()
+    if "decode" in which or "models" in which:
+        make_decode(16, 3, 3, 11, "f16_a3")
+        make_decode(30, 3, 2, 12, "f30_a3")
     assert not os.path.exists(os.path.join(REF, "src", "__pycache__")), "bytecode leaked into the reference"

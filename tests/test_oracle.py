@@ -167,3 +167,47 @@ def test_argmax_fixture_with_near_ties():
     assert idx[0, 0].item() == F * F - 1 and idx[1, 3].item() == 7
     e = O.landmark_expected_coords(logits, B, F)
     assert e.shape == (B, 4, 2) and (e >= 0).all() and (e <= F - 1).all()
+
+
+# ---------------------------------------------------------------- losses / landmark decode
+from oracle import loss_oracle as LO   # noqa: E402
+
+DECODE_FIXTURES = ["decode_f16_a3.npz", "decode_f30_a3.npz"]
+
+
+@pytest.mark.parametrize("name", DECODE_FIXTURES)
+def test_loss_oracle_matches_reference_losses_and_gradients(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name))
+    B, F, naux = int(d["batch"]), int(d["frame"]), int(d["naux"])
+    lg = torch.from_numpy(d["logits"]).requires_grad_(True)
+    y, v = torch.from_numpy(d["labels"]), torch.from_numpy(d["valid"])
+    n = lg.shape[0] // B
+    bce = LO.weighted_bce_with_logits(lg.view(B, n, 4), y.view(B, n, 4), v, ones_weight=9000, loss_weight=1)
+    g, = torch.autograd.grad(bce, lg)
+    assert abs(float(bce.detach()) - float(d["bce"])) <= 1e-5 * abs(float(d["bce"]))
+    assert np.allclose(g.numpy(), d["grad_bce"], rtol=1e-5, atol=1e-9)
+    elm = LO.expected_landmark_mse(lg, y, v, B, F, naux, loss_weight=10)
+    g, = torch.autograd.grad(elm, lg)
+    assert abs(float(elm.detach()) - float(d["elm"])) <= 1e-5 * abs(float(d["elm"]))
+    assert np.allclose(g.numpy(), d["grad_elm"], rtol=1e-4, atol=1e-8)
+    # old value-only fixture of the KAT logits
+    assert LO.level_grids(16, 3) == [(0, 2), (4, 4), (20, 8), (84, 16)]
+
+
+@pytest.mark.parametrize("name", DECODE_FIXTURES)
+def test_loss_oracle_matches_reference_evaluator(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name))
+    B, F = int(d["batch"]), int(d["frame"])
+    got = LO.evaluate_landmarks(torch.from_numpy(d["logits"]), torch.from_numpy(d["labels"]),
+                                torch.from_numpy(d["pix2mm_x"]), torch.from_numpy(d["pix2mm_y"]),
+                                torch.from_numpy(d["valid"]), B, F)
+    for k, want in zip(d["last_keys"], d["last_vals"]):
+        assert abs(got[str(k)] - float(want)) <= 1e-5 * max(1.0, abs(float(want))), k
+    assert np.array_equal(got["gt_coords"].numpy(), d["gt_coords"])
+    assert np.allclose(got["pred_coords"].numpy(), d["pred_coords"], rtol=1e-6, atol=1e-5)
+    for k, want in zip(d["width_keys"], d["width_vals"]):
+        assert np.allclose(got["widths"][str(k)].numpy(), want, rtol=1e-5, atol=1e-5), k
+    # hard argmax over the main grid: the first of two equal maxima wins (frame 0, channel 1)
+    am = O.landmark_argmax(torch.from_numpy(d["logits"]), B, F).numpy()
+    assert np.array_equal(am, d["argmax_main"])
+    assert am[0, 1] == 3 * F + 5
