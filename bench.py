@@ -267,6 +267,13 @@ def main():
                 x = lg.detach().requires_grad_(True)
                 (elm.compute(x, yl, vl) + bce.compute(x, yl, vl)).backward()
 
+            if not args.main_only:
+                pm = [torch.randn(B, C, 2 ** g, 2 ** g, device=device) for g in range(1, args.naux + 1)]
+                pm.append(torch.randn(B, C, args.frame, args.frame, device=device))
+                pack_ms = timed(lambda: ops.pack_levels(pm, B, N, 0))
+                result["before_path"] = {"pack_levels_ms": pack_ms,
+                                         "pack_levels_GBs": round(2 * B * N * C * 4 / (pack_ms * 1e-3) / 1e9, 1),
+                                         "note": "SURVEY f-1: NCHW level maps -> node-major [B*N,128] in one launch (reads + writes B*N*512 B)"}
             result["after_path"] = {"landmark_decode_ms": timed(lambda: EV.decode_landmarks(lg, B, args.frame, yl, vl)),
                                     "losses_fwd_bwd_ms": timed(loss_step),
                                     "note": "softmax-expected + hard-argmax landmark decode of the step's logits, and "

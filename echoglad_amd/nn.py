@@ -487,24 +487,32 @@ class HierarchicalPatchModel(nn.Module):
 
     # ---- avg-pool node features (models.py:498-537): the step in front of the hot path ---------
     def create_node_pixels(self, echo_frames: torch.Tensor, num_samples_per_batch: int, node_coords=None):
+        """models.py:498-537: average-pooled pyramid of the frame embedding + the frame itself, node-major."""
         B = int(num_samples_per_batch)
-        n, _, _, main_base, _ = self._row_ranges()
-        fs = self.frame_size
-        parts = []
-        if self.use_connection_nodes:
-            conn = echo_frames.mean(dim=(2, 3)).unsqueeze(1).expand(B, self.num_aux_graphs + 1, C)
-            parts.append(conn)
+        maps = []
         if not self.use_main_graph_only:
-            for g in range(1, self.num_aux_graphs + 1):
-                pooled = F.adaptive_avg_pool2d(echo_frames, output_size=(2 ** g, 2 ** g))
-                parts.append(pooled.permute(0, 2, 3, 1).reshape(B, -1, C))
-        parts.append(echo_frames.permute(0, 2, 3, 1).reshape(B, -1, C))
-        if self.use_coordinate_graph and not self.use_main_graph_only:
-            parts.append(torch.zeros(B, 4, C, dtype=echo_frames.dtype, device=echo_frames.device))
-        feats = torch.cat(parts, dim=1).reshape(B * n, C).contiguous()
+            maps = [F.adaptive_avg_pool2d(echo_frames, output_size=(2 ** g, 2 ** g)) for g in range(1, self.num_aux_graphs + 1)]
+        maps.append(echo_frames)
+        conn = None
+        if self.use_connection_nodes and not self.use_main_graph_only:
+            conn = echo_frames.mean(dim=(2, 3)).unsqueeze(1).expand(B, self.num_aux_graphs + 1, C)
+        return self.pack_node_features(maps, B, node_coords, conn)
+
+    def pack_node_features(self, level_maps, num_samples_per_batch: int, node_coords=None, connection_embed=None):
+        """The tail every create_node_pixels variant of the reference shares (models.py:511-537, :603-636, :726-756):
+        NCHW level maps (coarse to fine, the last one is the frame-sized map) -> [B*N, 128] in the GNN's node order,
+        in one packing launch (eg_pack_levels) instead of a per-sample permute / cat loop.  The UNet / CNN variants
+        pass their own per-level feature maps and connection-node embeddings [B, naux+1, 128]."""
+        B = int(num_samples_per_batch)
+        n, n_conn, _, main_base, coord_base = self._row_ranges()
+        fs = self.frame_size
+        feats = ops.pack_levels([m.float() for m in level_maps], B, n, n_conn)
+        if n_conn:
+            feats = feats.clone() if feats.requires_grad else feats
+            feats.view(B, n, C)[:, :n_conn, :] = connection_embed
         if self.use_coordinate_graph and not self.use_main_graph_only:
             new = ops.bilinear4(feats, node_coords.reshape(B, 4, 2).contiguous(), B, n, main_base, fs)
-            feats = ops.scatter_coord_rows(feats, new, B, n, n - 4)
+            feats = ops.scatter_coord_rows(feats, new, B, n, coord_base)
         return feats
 
     def forward(self, data_batch=None, x=None, node_coords=None, edge_index=None, node_type=None, batch_idx=None):

@@ -452,3 +452,51 @@ class _BCELogitsFn(torch.autograd.Function):
 def bce_logits(logits, labels, valid=None, ones_weight: float = 1.0) -> torch.Tensor:
     """sum(w * bce_with_logits(x, y) * valid) / sum(valid), w = ones_weight where y == 1 (autograd wrt logits)."""
     return _BCELogitsFn.apply(logits, labels, valid, float(ones_weight))
+
+
+# ---------------------------------------------------------------------------
+# node-feature packing (pack.hip)
+# ---------------------------------------------------------------------------
+def _pack_call(fn_name, maps, nodes, batch, n_rows, row_offset):
+    n = len(maps)
+    if not 1 <= n <= 16:
+        raise RuntimeError("1..16 level maps supported")
+    sides = []
+    for m in maps:
+        if not m.is_cuda or m.dtype != torch.float32 or m.dim() != 4 or m.shape[0] != batch or m.shape[1] != C or \
+                m.shape[2] != m.shape[3] or not m.is_contiguous():
+            raise RuntimeError(f"level maps must be contiguous CUDA float32 [batch, {C}, side, side], got {tuple(m.shape)}")
+        sides.append(int(m.shape[2]))
+    ptrs = (ct.c_void_p * n)(*[m.data_ptr() for m in maps])
+    side = (ct.c_int * n)(*sides)
+    lib = _lib.load()
+    if fn_name == "eg_pack_levels":
+        rc = lib.eg_pack_levels(ptrs, side, n, batch, n_rows, row_offset, _ptr(nodes), _stream())
+    else:
+        rc = lib.eg_unpack_levels(_ptr(nodes), ptrs, side, n, batch, n_rows, row_offset, _stream())
+    _lib.check(rc, fn_name)
+
+
+class _PackLevelsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, batch, n_rows, row_offset, *maps):
+        maps = [m.contiguous() for m in maps]
+        used = sum(int(m.shape[2]) ** 2 for m in maps)
+        alloc = torch.empty if (row_offset == 0 and used == n_rows) else torch.zeros
+        nodes = alloc(batch * n_rows, C, dtype=torch.float32, device=maps[0].device)
+        _pack_call("eg_pack_levels", maps, nodes, batch, n_rows, row_offset)
+        ctx.meta = (batch, n_rows, row_offset, [tuple(m.shape) for m in maps])
+        return nodes
+
+    @staticmethod
+    def backward(ctx, d_nodes):
+        batch, n_rows, row_offset, shapes = ctx.meta
+        grads = [torch.empty(s, dtype=torch.float32, device=d_nodes.device) for s in shapes]
+        _pack_call("eg_unpack_levels", grads, d_nodes.contiguous(), batch, n_rows, row_offset)
+        return (None, None, None, *grads)
+
+
+def pack_levels(maps, batch: int, n_rows: int, row_offset: int = 0) -> torch.Tensor:
+    """NCHW level maps [batch,128,p,p] (coarse to fine) -> node-major [batch * n_rows, 128]; level l lands at rows
+    row_offset + sum_{k<l} p_k^2 of every frame.  Differentiable w.r.t. the maps."""
+    return _PackLevelsFn.apply(int(batch), int(n_rows), int(row_offset), *maps)

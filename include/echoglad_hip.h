@@ -201,6 +201,18 @@ int eg_bce_logits_fwd(const float* logits, const float* labels, const float* val
 int eg_bce_logits_bwd(const float* logits, const float* labels, const float* valid, int64_t n, float ones_weight,
                       const float* scale_dev, float* d_logits, eg_stream_t stream);
 
+/* ---- node-feature packing (the step right before the hot path) -------------------------------------------
+ * Reference: the per-sample loops at the tail of create_node_pixels (src/core/models.py:498-537, :590-636,
+ * :707-756): map[i].permute(1, 2, 0).reshape(-1, 128) of every level, concatenated per frame.
+ * level_maps: HOST array of n_levels (<= 16) DEVICE pointers to NCHW maps [batch, 128, side_l, side_l];
+ * nodes: [batch * n_rows, 128]; level l lands at rows row_offset + sum_{k<l} side_k^2 of every frame, row-major
+ * (h, w).  Rows outside the levels (connection / coordinate rows) are not touched.
+ * eg_unpack_levels is the reverse copy (the gradient of the packing w.r.t. the maps). */
+int eg_pack_levels(const float* const* level_maps, const int* level_side, int n_levels, int batch, int64_t n_rows,
+                   int64_t row_offset, float* nodes, eg_stream_t stream);
+int eg_unpack_levels(const float* nodes, float* const* level_maps, const int* level_side, int n_levels, int batch,
+                     int64_t n_rows, int64_t row_offset, eg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

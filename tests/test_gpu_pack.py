@@ -1,0 +1,58 @@
+"""-m gpu: node-feature packing (csrc/pack.hip) against the reference's op sequence."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, model_pair
+from fixtures_util import initial_coords, synthetic_frames
+from echoglad_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_pack(maps, batch, n_rows, row_offset):
+    """models.py:511-537 / :726-756: per frame, map[i].permute(1, 2, 0).reshape(-1, 128) of every level, concatenated."""
+    out = torch.zeros(batch, n_rows, 128, dtype=maps[0].dtype, device=maps[0].device)
+    for i in range(batch):
+        x = torch.cat([m[i].permute(1, 2, 0).reshape(-1, 128) for m in maps], dim=0)
+        out[i, row_offset:row_offset + x.shape[0]] = x
+    return out.reshape(batch * n_rows, 128)
+
+
+@pytest.mark.parametrize("sides,batch,extra_front,extra_back", [
+    ([2, 4, 8, 16], 3, 0, 0), ([2, 4, 30], 2, 4, 4), ([17], 2, 0, 0), ([2, 4, 8, 16, 32, 64, 128, 224], 2, 0, 0), ([1, 3, 65], 1, 2, 0)])
+def test_pack_levels_is_the_reference_permute_cat(sides, batch, extra_front, extra_back):
+    rs = np.random.RandomState(sum(sides))
+    maps = [torch.from_numpy(rs.standard_normal((batch, 128, s, s)).astype(np.float32)).to(DEV).requires_grad_(True) for s in sides]
+    n_rows = extra_front + sum(s * s for s in sides) + extra_back
+    got = ops.pack_levels(maps, batch, n_rows, extra_front)
+    want = _reference_pack(maps, batch, n_rows, extra_front)
+    assert torch.equal(got, want)                                   # a copy: bit-exact
+    g = torch.from_numpy(rs.standard_normal(tuple(got.shape)).astype(np.float32)).to(DEV)
+    got_g = torch.autograd.grad(got, maps, g)
+    want_g = torch.autograd.grad(want, maps, g)
+    for a, b in zip(got_g, want_g):
+        assert torch.equal(a, b)
+
+
+def test_pack_rejects_bad_maps():
+    with pytest.raises(RuntimeError):
+        ops.pack_levels([torch.zeros(1, 128, 4, 4)], 1, 16)                       # CPU tensor
+    with pytest.raises(RuntimeError):
+        ops.pack_levels([torch.zeros(1, 64, 4, 4, device=DEV)], 1, 16)            # wrong channel count
+    with pytest.raises(RuntimeError):
+        ops.pack_levels([torch.zeros(1, 128, 8, 8, device=DEV)], 1, 16)           # does not fit the frame's rows
+
+
+@pytest.mark.parametrize("frame,naux,coord,main_only", [(16, 3, False, False), (32, 4, True, False), (16, 2, False, True),
+                                                        (64, 2, False, False), (224, 7, False, False)])
+def test_create_node_pixels_matches_oracle(frame, naux, coord, main_only):
+    hip, ref = model_pair(frame, naux, 1, coord=coord, main_only=main_only)
+    B = 2
+    frames = synthetic_frames(B, 128, frame, seed=3)
+    coords = initial_coords(B, frame) if coord else None
+    with torch.no_grad():
+        want = ref.create_node_pixels(frames, B, None if coords is None else coords.view(B, 4, 2))
+        got = hip.create_node_pixels(frames.to(DEV), B, None if coords is None else coords.to(DEV)).cpu()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
