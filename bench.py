@@ -48,7 +48,92 @@ def parse():
     p.add_argument("--kernel-iters", type=int, default=30)
     p.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed steps before the warm-up steps")
     p.add_argument("--no-hip-graph", action="store_true", help="launch the 4 kernels of a step eagerly from Python")
+    p.add_argument("--mode", choices=["infer", "train"], default="infer",
+                   help="infer (default): BASELINE configs[1], the metric's configuration.  train: one full training "
+                        "step of the GNN stack on configs[3] (coordinate graph; SURVEY 8d), reported under its own metric name")
     return p.parse_args()
+
+
+def main_train(args, world, rank, device):
+    """forward + losses + backward + gradient all-reduce + Adam on the stack's parameters,
+    node features [B*N,128] resident in HBM, B frames per GPU (32 in BASELINE's cfg4), coordinate graph on."""
+    from echoglad_amd import engine, losses, nn as egnn
+    from echoglad_amd.parallel import GradientAllReducer, broadcast_parameters
+    from echoglad_amd.topology import TopologySpec, get_topology
+    from fixtures_util import fill_state_dict, initial_coords, synthetic_node_feats
+    B = args.batch
+    kw = dict(frame_size=args.frame, gnn_dropout_p=0.5, classifier_dropout_p=0.5, node_embedding_dim=C, node_hidden_dim=C,
+              num_output_channels=4, num_gnn_layers=args.layers, num_aux_graphs=args.naux, gnn_jk_mode="last",
+              classifier_hidden_dim=32, residual=True, use_coordinate_graph=True, output_activation="logit")
+    model = egnn.HierarchicalPatchModel(**kw)
+    fill_state_dict(model, seed=200)
+    model = model.to(device).train()
+    topo = get_topology(TopologySpec(args.frame, args.naux, False, True))
+    N, n_valid = topo.num_nodes, topo.num_valid_nodes
+    feats = synthetic_node_feats(B * N, C, seed=200 + rank).to(device)
+    edge_index = torch.from_numpy(topo.batched_edge_index(B)).to(device)
+    coords0 = initial_coords(B, args.frame).to(device)
+    rs = np.random.RandomState(300 + rank)
+    from echoglad_amd.data import node_labels
+    y = torch.from_numpy(np.stack([np.stack([node_labels(rs.randint(0, args.frame, 2), args.frame, args.naux) for _ in range(4)], 1)
+                                   for _ in range(B)])).reshape(B * n_valid, 4).to(device)
+    valid = torch.ones_like(y)
+    coord_y = torch.from_numpy(rs.uniform(0, args.frame - 1, (B * 4, 2)).astype(np.float32)).to(device)
+    crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1),
+            "elm": losses.ExpectedLandmarkMSE(10, B, args.frame, args.naux), "coordinate": engine.MSE(1)}
+    params = list(model.parameters())
+    opt = torch.optim.Adam(params, lr=1e-4)
+    reducer = None
+    if world > 1:
+        broadcast_parameters(model)
+        reducer = GradientAllReducer(params)
+
+    def step():
+        preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0.clone())
+        ls = engine.compute_loss(crit, preds, y, coord_preds, coord_y, valid, B)
+        loss = sum(ls.values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if reducer is not None:
+            reducer.allreduce()
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 2)):
+        loss = step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        fps = world * B * args.steps / elapsed
+        step_bytes = 3 * N * (args.layers * 1024 + 528)                 # SURVEY §8(d): train-step algorithmic floor per frame
+        print(json.dumps({
+            "metric": "echo frames/sec, one full training step of the GNN stack (fwd + losses + bwd + all-reduce + Adam)",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2),
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[3]: {args.frame}x{args.frame} frame, {args.naux} aux levels + 4 coordinate nodes, "
+                                   f"num_gnn_layers={args.layers}, batch={B} per GPU, train mode (batch-stat BN, dropout 0.5), "
+                                   "losses: weighted BCE + expected-landmark MSE + coordinate MSE, Adam",
+                       "nodes_per_frame": N, "global_batch": B * world,
+                       "parallelism": f"dp{world} (batch-sharded frames, one flat gradient all-reduce per step)"},
+            "stack_hbm_frac": round(fps / world * step_bytes / 1e9 / PEAK_HBM_GBS, 4), "final_loss": float(loss)}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def build_model(args, device):
@@ -122,6 +207,9 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+
+    if args.mode == "train":
+        return main_train(args, world, rank, device)
 
     from echoglad_amd import ops
     from echoglad_amd.topology import TopologySpec, get_topology

@@ -1,0 +1,136 @@
+"""Synthetic dataset, label construction and batch collation for the hierarchical graph —
+host-side counterpart of the reference's ``DummyDataset`` (src/core/datasets.py:1339-1612) and of the PyG
+``DataLoader`` collate it is used with (src/builders/dataloader_builder.py:5-33).
+
+The reference builds a networkx graph with O(n^2) list concatenation (7.5 s at the default config) and converts it
+with ``from_networkx`` for EVERY sample; here the topology is the closed form of ``echoglad_amd.topology`` (built
+once, shared by all samples and all batches) and a batch is a plain namespace with the attribute names the model's
+``forward(data_batch)`` reads (models.py:408-413): x, edge_index, batch, node_type, node_coords, plus y,
+valid_labels, node_coord_y, pix2mm_x, pix2mm_y for the losses / evaluators.
+"""
+from __future__ import annotations
+
+import types
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .topology import HierTopology, TopologySpec, get_topology
+
+AVERAGE_COORDS = [[99.99, 112.57], [142.71, 90.67], [151.18, 86.25], [91.81, 117.91]]     # datasets.py:1361
+
+
+def _wrap(i: int, n: int) -> int:
+    """numpy index semantics of ``y[i] = 1`` (datasets.py:1599,1607): negative indices count from the end, anything
+    outside [-n, n) is an IndexError there and here."""
+    if not -n <= i < n:
+        raise IndexError(f"label index {i} is out of bounds for a grid of side {n}")
+    return i % n
+
+
+def node_labels(coordinate: Sequence[int], frame_size: int, num_aux_graphs: int,
+                use_main_graph_only: bool = False) -> np.ndarray:
+    """One (h, w) landmark -> float32 one-hot over the grid nodes of a frame, one ``1`` per level
+    (datasets.py:1586-1612: ``np.digitize`` against ``linspace(0, F, p + 1)`` on the aux levels, the pixel itself
+    on the main grid)."""
+    h, w = int(coordinate[0]), int(coordinate[1])
+    parts: List[np.ndarray] = []
+    if not use_main_graph_only:
+        for g in range(1, num_aux_graphs + 1):
+            p = 2 ** g
+            bins = np.linspace(start=0, stop=frame_size, num=p + 1)
+            bh, bw = (int(v) for v in (np.digitize([h, w], bins=bins) - 1))
+            y = np.zeros(p * p, dtype=np.float32)
+            y[_wrap(bh, p) * p + _wrap(bw, p)] = 1.0
+            parts.append(y)
+    y = np.zeros(frame_size * frame_size, dtype=np.float32)
+    y[_wrap(h, frame_size) * frame_size + _wrap(w, frame_size)] = 1.0
+    parts.append(y)
+    return np.concatenate(parts)
+
+
+def draw_coords(frame_size: int, orig_frame_size: int = 224, rng=np.random) -> np.ndarray:
+    """datasets.py:1421-1438: three draws of 4 integers (LVIDd, IVS, LVPW) scaled by F/224, assembled in (h, w)
+    order as [lvid_top, lvid_bot, lvpw, ivs], each minus one (so -1 occurs and wraps in the labels)."""
+    def draw():
+        return np.round(rng.randint(low=0, high=frame_size, size=4) * frame_size / orig_frame_size).astype(int)
+    lvid, ivs, lvpw = draw(), draw(), draw()
+    return np.array([[lvid[1] - 1, lvid[0] - 1], [lvid[3] - 1, lvid[2] - 1], [lvpw[3] - 1, lvpw[2] - 1],
+                     [ivs[1] - 1, ivs[0] - 1]])
+
+
+class SyntheticEchoDataset(torch.utils.data.Dataset):
+    """Counterpart of ``DummyDataset``: 100 samples of N(0,1) frames with random landmark labels on the static
+    hierarchical graph.  ``transform`` maps the [1, 224, 224] frame to [1, F, F] (default: bilinear resize)."""
+
+    def __init__(self, num_aux_graphs: int, frame_size: int = 128, transform=None, average_coords=None,
+                 main_graph_type: str = "grid", aux_graph_type: str = "grid", use_coordinate_graph: bool = False,
+                 use_connection_nodes: bool = False, use_main_graph_only: bool = False, length: int = 100):
+        self.spec = TopologySpec(frame_size, num_aux_graphs, use_main_graph_only, use_coordinate_graph,
+                                 use_connection_nodes, main_graph_type, aux_graph_type)
+        self.topology: HierTopology = get_topology(self.spec)
+        self.frame_size = frame_size
+        self.num_aux_graphs = num_aux_graphs
+        self.use_coordinate_graph = use_coordinate_graph
+        self.use_main_graph_only = use_main_graph_only
+        self.average_coords = AVERAGE_COORDS if average_coords is None else average_coords
+        self.transform = transform or (lambda t: torch.nn.functional.interpolate(
+            t.unsqueeze(0), size=(frame_size, frame_size), mode="bilinear", align_corners=False).squeeze(0))
+        self.length = length
+        self.edge_index = torch.from_numpy(self.topology.edge_index())            # shared by every sample
+        self.node_type = torch.from_numpy(self.topology.node_type())              # float64 like the reference
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        frame = self.transform(torch.randn((1, 224, 224))).unsqueeze(0)           # [1,1,F,F]
+        coords = draw_coords(self.frame_size)
+        g = types.SimpleNamespace()
+        g.x = frame
+        g.y = torch.from_numpy(np.stack([node_labels(c, self.frame_size, self.num_aux_graphs, self.use_main_graph_only)
+                                         for c in coords], axis=1))             # [N_grid, 4]
+        g.valid_labels = torch.ones_like(g.y)
+        g.edge_index = self.edge_index
+        g.node_type = self.node_type
+        g.num_nodes = self.topology.num_nodes
+        if self.use_coordinate_graph and not self.use_main_graph_only:
+            g.node_coords = torch.tensor(self.average_coords, dtype=torch.float32)
+            g.node_coord_y = torch.tensor(coords, dtype=torch.float32)
+        g.pix2mm_x = torch.tensor(0.1 * 10, dtype=torch.float32)
+        g.pix2mm_y = torch.tensor(0.1 * 10, dtype=torch.float32)
+        return g
+
+
+def collate(samples: Sequence, topology: Optional[HierTopology] = None):
+    """PyG ``Batch.from_data_list`` semantics for these samples: node-level tensors concatenated on dim 0,
+    ``edge_index`` shifted by the per-sample node offset, 0-d tensors stacked, ``batch`` = sample id per node.
+    With ``topology`` given the batched ``edge_index`` comes from the closed form instead of B shifted copies."""
+    B = len(samples)
+    n = samples[0].num_nodes
+    out = types.SimpleNamespace()
+    out.num_graphs = B
+    out.x = torch.cat([s.x for s in samples], dim=0)
+    out.y = torch.cat([s.y for s in samples], dim=0)
+    out.valid_labels = torch.cat([s.valid_labels for s in samples], dim=0)
+    out.node_type = torch.cat([s.node_type for s in samples], dim=0)
+    if topology is not None:
+        out.edge_index = torch.from_numpy(topology.batched_edge_index(B))
+    else:
+        out.edge_index = torch.cat([s.edge_index + i * n for i, s in enumerate(samples)], dim=1)
+    out.batch = torch.arange(B).repeat_interleave(n)
+    if hasattr(samples[0], "node_coords"):
+        out.node_coords = torch.cat([s.node_coords for s in samples], dim=0)
+        out.node_coord_y = torch.cat([s.node_coord_y for s in samples], dim=0)
+    out.pix2mm_x = torch.stack([s.pix2mm_x for s in samples])
+    out.pix2mm_y = torch.stack([s.pix2mm_y for s in samples])
+    return out
+
+
+def to_device(batch, device):
+    """Moves every tensor attribute of a collated batch."""
+    for k, v in vars(batch).items():
+        if torch.is_tensor(v):
+            setattr(batch, k, v.to(device, non_blocking=True))
+    return batch

@@ -22,6 +22,7 @@ Outputs
   coord_f32_a4.npz     coordinate-graph path (B=2): coords per layer, logits, train-mode grad norms
   mainonly_f16.npz     use_main_graph_only ablation
   losses_f16_a3.npz    WeightedBCEWithLogits + ExpectedLandmarkMSE values on the KAT logits
+  labels.npz           DummyDataset.create_node_labels for hand-picked coordinates on 5 configs + one full sample
   decode_f16_a3.npz    seeded logits / labels / valid masks (B=3): both losses and their gradients w.r.t. the logits
   decode_f30_a3.npz    (criterion.py, autograd of the reference's own classes) and every number that
                        LandmarkExpectedCoordiantesEvaluator.update records (evaluators.py:291-391)
@@ -347,6 +348,47 @@ def make_losses(model, logits, B, frame, naux):
     print("losses", float(l_bce), float(l_elm))
 
 
+def make_labels():
+    """DummyDataset.create_node_labels (datasets.py:1586-1612) and one whole __getitem__ sample (:1381-1415) from the
+    reference's own class: positions of the ones per landmark for hand-picked coordinates (corners, -1 wrap, bin edges)."""
+    out = {}
+    for frame, naux, main_only in ((16, 3, False), (30, 3, False), (64, 2, False), (224, 7, False), (16, 2, True)):
+        ds = RD.DummyDataset(data_dir=None, data_info_file=None, mode="train", num_aux_graphs=naux, frame_size=frame,
+                             main_graph_type="grid", aux_graph_type="grid", use_coordinate_graph=False,
+                             use_connection_nodes=False, use_main_graph_only=main_only)
+        coords = np.array([[0, 0], [frame - 1, frame - 1], [-1, 3], [frame // 2, frame // 2 - 1], [5, frame - 2], [frame // 4, frame // 8],
+                           [7, -1], [frame - 1, 0]])
+        ones = []
+        for c in coords:
+            y = ds.create_node_labels(c).numpy()[:, 0]
+            assert set(np.unique(y)) <= {0.0, 1.0}
+            ones.append(np.nonzero(y)[0])
+        key = f"F{frame}_A{naux}_mo{int(main_only)}"
+        out[key + "_coords"] = coords
+        out[key + "_ones"] = np.stack(ones)              # one label per level: [n_coords, n_levels]
+        out[key + "_len"] = np.int64(len(y))
+    # one full sample under a fixed numpy seed (extract_coords draws from np.random, the frame from torch.randn)
+    np.random.seed(77)
+    torch.manual_seed(77)
+    ds = RD.DummyDataset(data_dir=None, data_info_file=None, mode="train", num_aux_graphs=3, frame_size=16,
+                         main_graph_type="grid", aux_graph_type="grid", use_coordinate_graph=True,
+                         use_connection_nodes=False, use_main_graph_only=False,
+                         transform=lambda t: torch.nn.functional.interpolate(t.unsqueeze(0), size=(16, 16)).squeeze(0))
+    np.random.seed(78)
+    g = ds[0]
+    out["sample_y"] = g.y.numpy()
+    out["sample_valid"] = g.valid_labels.numpy()
+    out["sample_node_type"] = g.node_type.numpy()
+    out["sample_node_coords"] = g.node_coords.numpy()
+    out["sample_node_coord_y"] = g.node_coord_y.numpy()
+    out["sample_pix2mm"] = np.array([float(g.pix2mm_x), float(g.pix2mm_y)])
+    out["sample_x_shape"] = np.array(g.x.shape)
+    np.random.seed(78)
+    out["sample_draws"] = np.random.randint(low=0, high=16, size=12)     # the 3 x 4 integers extract_coords consumes
+    np.savez_compressed(os.path.join(HERE, "labels.npz"), **out)
+    print("labels", {k: v.shape for k, v in out.items() if k.endswith("_ones")}, out["sample_node_coord_y"].tolist())
+
+
 def make_decode(frame, naux, B, seed, tag):
     """Losses + gradients (criterion.py:13-27,93-151) and landmark decode / width errors (evaluators.py:291-391,
     485-495) from the reference's own classes on seeded logits with near-ties and partly invalid labels."""
@@ -414,6 +456,8 @@ if __name__ == "__main__":
         make_cfg1()
         make_coord()
         make_mainonly()
+    if "labels" in which or "models" in which:
+        make_labels()
     if "decode" in which or "models" in which:
         make_decode(16, 3, 3, 11, "f16_a3")
         make_decode(30, 3, 2, 12, "f30_a3")

@@ -1,0 +1,64 @@
+"""CPU: dataset / label / collate host logic (echoglad_amd/data.py) against fixtures from the reference's DummyDataset."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from echoglad_amd import data
+from echoglad_amd.topology import HierTopology, TopologySpec
+
+
+@pytest.mark.parametrize("frame,naux,main_only", [(16, 3, False), (30, 3, False), (64, 2, False), (224, 7, False), (16, 2, True)])
+def test_node_labels_match_reference(golden_dir, frame, naux, main_only):
+    d = np.load(os.path.join(golden_dir, "labels.npz"))
+    key = f"F{frame}_A{naux}_mo{int(main_only)}"
+    for c, ones in zip(d[key + "_coords"], d[key + "_ones"]):
+        y = data.node_labels(c, frame, naux, main_only)
+        assert len(y) == int(d[key + "_len"]) and y.dtype == np.float32
+        assert np.array_equal(np.nonzero(y)[0], ones), (c, np.nonzero(y)[0], ones)
+        assert set(np.unique(y)) == {0.0, 1.0}
+
+
+def test_node_labels_out_of_range_raises_like_numpy():
+    with pytest.raises(IndexError):
+        data.node_labels([16, 0], 16, 3)           # digitize -> bin p: out of bounds in the reference too
+    with pytest.raises(IndexError):
+        data.node_labels([0, -17], 16, 2, True)
+
+
+def test_full_sample_matches_reference_under_the_same_seed(golden_dir):
+    d = np.load(os.path.join(golden_dir, "labels.npz"))
+    ds = data.SyntheticEchoDataset(num_aux_graphs=3, frame_size=16, use_coordinate_graph=True)
+    np.random.seed(78)
+    assert np.array_equal(np.random.randint(low=0, high=16, size=12), d["sample_draws"])
+    np.random.seed(78)
+    g = ds[0]
+    assert np.array_equal(g.y.numpy(), d["sample_y"])
+    assert np.array_equal(g.valid_labels.numpy(), d["sample_valid"])
+    assert np.array_equal(g.node_type.numpy(), d["sample_node_type"]) and g.node_type.dtype == torch.float64
+    assert np.allclose(g.node_coords.numpy(), d["sample_node_coords"])
+    assert np.array_equal(g.node_coord_y.numpy(), d["sample_node_coord_y"])
+    assert np.allclose([float(g.pix2mm_x), float(g.pix2mm_y)], d["sample_pix2mm"])
+    assert list(g.x.shape) == list(d["sample_x_shape"])
+    assert len(ds) == 100
+
+
+@pytest.mark.parametrize("coord", [False, True])
+def test_collate_is_a_disjoint_union(coord):
+    ds = data.SyntheticEchoDataset(num_aux_graphs=2, frame_size=8, use_coordinate_graph=coord)
+    samples = [ds[i] for i in range(3)]
+    b1, b2 = data.collate(samples), data.collate(samples, ds.topology)
+    n = ds.topology.num_nodes
+    assert b1.x.shape == (3, 1, 8, 8) and b1.y.shape == (3 * (4 + 16 + 64), 4) and b1.node_type.shape == (3 * n,)
+    assert torch.equal(b1.batch, torch.arange(3).repeat_interleave(n))
+    # same edge multiset either way, every edge inside its own frame
+    def canon(ei):
+        return ei[:, np.lexsort((ei[1].numpy(), ei[0].numpy()))]
+    assert torch.equal(canon(b1.edge_index), canon(b2.edge_index))
+    assert bool(((b1.edge_index[0] // n) == (b1.edge_index[1] // n)).all())
+    assert b1.pix2mm_x.shape == (3,)
+    if coord:
+        assert b1.node_coords.shape == (12, 2) and b1.node_coord_y.shape == (12, 2)
+    else:
+        assert not hasattr(b1, "node_coords")

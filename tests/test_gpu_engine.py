@@ -1,0 +1,93 @@
+"""-m gpu: one training / evaluation step through data.py -> engine.py -> the HIP model, losses and evaluator,
+against the same step computed by the CPU oracles on the same batch."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, model_pair
+from oracle import loss_oracle as LO
+from echoglad_amd import data, engine, evaluators, losses
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(frame, naux, coord, seed):
+    hip, ref = model_pair(frame, naux, 2, coord=coord, seed=seed)
+    torch.manual_seed(seed)
+    emb_ref = torch.nn.Conv2d(1, 128, kernel_size=1)
+    emb_hip = torch.nn.Conv2d(1, 128, kernel_size=1).to(DEV)
+    emb_hip.load_state_dict(emb_ref.state_dict())
+    np.random.seed(seed)
+    ds = data.SyntheticEchoDataset(num_aux_graphs=naux, frame_size=frame, use_coordinate_graph=coord)
+    return hip, ref, emb_hip, emb_ref, ds
+
+
+@pytest.mark.parametrize("frame,naux,coord", [(16, 3, False), (32, 4, True)])
+def test_train_step_losses_and_gradients_match_cpu_step(frame, naux, coord):
+    B = 2
+    hip, ref, emb_hip, emb_ref, ds = _setup(frame, naux, coord, 3)
+    batch = data.collate([ds[i] for i in range(B)], ds.topology)
+    # p = 0 dropout and train-mode BN: the only stochastic piece of the reference's train mode is switched off
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    hip.train(); ref.train()
+    crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1),
+            "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux)}
+    if coord:
+        crit["coordinate"] = engine.MSE(1)
+    params = list(hip.parameters()) + list(emb_hip.parameters())
+    opt = torch.optim.SGD(params, lr=0.0)                                      # lr 0: gradients stay inspectable
+    import copy
+    dev_batch = data.to_device(copy.copy(batch), DEV)
+    loss, parts, preds, _ = engine.train_step({"embedder": emb_hip, "landmark": hip}, dev_batch, crit, opt, B, coord)
+    # the same step on the CPU: oracle model + oracle losses
+    x = emb_ref(batch.x.cpu())
+    nc = batch.node_coords.cpu().clone() if coord else None
+    out = ref(x=x, node_coords=nc, edge_index=batch.edge_index.cpu(), batch_idx=batch.batch.cpu(), node_type=batch.node_type.cpu())
+    p_ref, c_ref = out
+    n = p_ref.shape[0] // B
+    want = LO.weighted_bce_with_logits(p_ref.view(B, n, 4), batch.y.cpu().view(B, n, 4), batch.valid_labels.cpu(), 9000, 1) + \
+        LO.expected_landmark_mse(p_ref, batch.y.cpu(), batch.valid_labels.cpu(), B, frame, naux, loss_weight=10)
+    if coord:
+        want = want + torch.nn.functional.mse_loss(c_ref, batch.node_coord_y.cpu())
+    want.backward()
+    assert abs(float(loss) - float(want.detach())) <= 2e-4 * abs(float(want.detach()))
+    assert float((preds.cpu() - p_ref.detach()).abs().max()) < 2e-4
+    ref_grads = dict(ref.named_parameters())
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    for name, p in hip.named_parameters():
+        g_ref = ref_grads[name].grad
+        if g_ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        # GCN biases in front of a train-mode BatchNorm have a mathematically zero gradient: absolute floor
+        err = float((p.grad.cpu() - g_ref).abs().max())
+        assert err <= 2e-2 * float(g_ref.abs().max()) + 1e-4 * gmax, (name, err, float(g_ref.abs().max()), gmax)
+    ge = emb_hip.weight.grad.cpu()
+    assert float((ge - emb_ref.weight.grad).abs().max()) <= 2e-2 * float(emb_ref.weight.grad.abs().max()) + 1e-6
+
+
+def test_training_reduces_the_loss_and_eval_step_feeds_the_evaluator():
+    B, frame, naux = 2, 16, 3
+    hip, _, emb_hip, _, ds = _setup(frame, naux, False, 5)
+    batch = data.to_device(data.collate([ds[i] for i in range(B)], ds.topology), DEV)
+    crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1), "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux)}
+    model = {"embedder": emb_hip, "landmark": hip}
+    opt = torch.optim.Adam(list(hip.parameters()) + list(emb_hip.parameters()), lr=1e-3)
+    hip.train()
+    first = last = None
+    for it in range(12):
+        loss, _, _, _ = engine.train_step(model, batch, crit, opt, B)
+        first = float(loss) if first is None else first
+        last = float(loss)
+    assert last < 0.95 * first, (first, last)
+    hip.eval()
+    ev = {"landmark": evaluators.LandmarkExpectedCoordiantesEvaluator(None, B, frame, False)}
+    preds, _, ls = engine.eval_step(model, batch, crit, B, evaluators=ev)
+    rec = ev["landmark"].get_last()
+    want = LO.evaluate_landmarks(preds.cpu(), batch.y.cpu(), batch.pix2mm_x.cpu(), batch.pix2mm_y.cpu(), batch.valid_labels.cpu(), B, frame)
+    for k, v in rec.items():
+        # degenerate synthetic labels (two landmarks on one pixel) give inf / nan percentages in the reference too
+        assert np.isclose(float(v), float(want[k]), rtol=1e-4, atol=1e-4, equal_nan=True), (k, float(v), float(want[k]))
+    assert set(ls) == {"bce", "elm"}
