@@ -270,8 +270,11 @@ def main():
             # (first: writes child sums; middle: reads + writes; last: reads) and report their mean, which is what
             # a kernel trace shows as the average duration of k_gcn_layer_ps
             ka, kb = model._kidsum_buffers(graph, gb)
-            forms = [dict(kidsum_out=ka)] + [dict(kidsum_in=ka, kidsum_out=kb)] * max(args.layers - 2, 0) + [dict(kidsum_in=ka)]
-            kname = "k_gcn_layer_ps"
+            forms = [dict(kidsum_out=ka)] + [dict(kidsum_in=ka, kidsum_out=kb)] * max(args.layers - 2, 0)
+            fused_cls = bool(model.fuse_classifier) and topo.n_conn == 0 and topo.num_valid_nodes == N
+            if not fused_cls:
+                forms.append(dict(kidsum_in=ka))          # (with the classifier fused, the last layer is k_gcn_layer_ps<true>)
+            kname = "k_gcn_layer_ps<false>" if fused_cls else "k_gcn_layer_ps"
         else:
             forms = [dict()]
             kname = "k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>"
@@ -325,7 +328,10 @@ def main():
                                    "node features [B*N,128] in HBM -> logits [B*N_valid,4] in HBM",
                        "nodes_per_frame": N, "directed_edges_per_frame": e_dir, "global_batch": B * world,
                        "parallelism": f"dp{world} (batch-sharded frames, no data-path collective)",
-                       "launch": "eager" if args.no_hip_graph else "hipGraph replay of the step's kernels"},
+                       "launch": "eager" if args.no_hip_graph else "hipGraph replay of the step's kernels",
+                       "kernels_per_step": ("2 x k_gcn_layer_ps<false> (chained layers) + k_gcn_layer_ps<true> (last layer + "
+                                            "classifier heads)") if (graph.kidsum_rows > 0 and model.chain_layers and
+                                                                      model.fuse_classifier) else "3 layer launches + k_classifier"},
             "stack_hbm_frac": round(frames_per_s / world * stack_bytes / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": roofline,
         }

@@ -181,6 +181,16 @@ struct eg_graph {
 };
 
 // producer/consumer layer kernel (gcn_layer_ps.hip); EG_ERR_UNSUPPORTED -> caller uses the symmetric kernel
+namespace eg {
+// Classifier heads fused behind the LAST layer of a stack: node-type filter + 4 x [Linear(128,32)-BN-ReLU-Linear(32,16)-
+// BN-ReLU-Linear(16,1)] of src/core/models.py:363-377, :485-490, eval-mode BN folded by the caller (same packing as
+// eg_classifier_fwd).  The layer's output tile never leaves LDS.
+struct ClsArgs {
+    const float *w1, *s1, *t1, *w2, *s2, *t2, *w3, *b3;
+    float* logits;
+    int sigmoid;
+};
+}  // namespace eg
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
-                       const float* kin, float* kout, hipStream_t stream);
+                       const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream);

@@ -359,7 +359,7 @@ int eg_gcn_layer_fwd(const eg_graph* g, int batch, const float* x, const float* 
     int rc = fill_graph_args(g, batch, a, agg);
     if (rc != EG_OK) return rc;
     // implicit topology with the residual in {none, x}: producer/consumer kernel
-    rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, transpose_w, out, nullptr, nullptr, (hipStream_t)stream);
+    rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, transpose_w, out, nullptr, nullptr, nullptr, (hipStream_t)stream);
     if (rc != EG_ERR_UNSUPPORTED) return rc;
     a.x = x; a.W = W; a.scale = scale; a.shift = shift; a.residual = residual; a.out = out;
     a.d.relu = relu; a.d.transpose_w = transpose_w;
@@ -375,9 +375,25 @@ int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const f
     if (!kidsum_in && !kidsum_out) return eg_gcn_layer_fwd(g, batch, x, W, scale, shift, residual, relu, transpose_w, out, stream);
     if (!g || batch <= 0) return set_error(EG_ERR_ARG, "bad graph handle or batch");
     const int rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, transpose_w, out, kidsum_in, kidsum_out,
-                                      (hipStream_t)stream);
+                                      nullptr, (hipStream_t)stream);
     if (rc == EG_ERR_UNSUPPORTED)
         return set_error(EG_ERR_UNSUPPORTED, "chained layers need a topology handle with eg_graph_kidsum_rows() > 0 and residual in {NULL, x}");
+    return rc;
+}
+
+int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
+                         const float* shift, const float* residual, int relu, const float* kidsum_in, const float* w1,
+                         const float* s1, const float* t1, const float* w2, const float* s2, const float* t2,
+                         const float* w3, const float* b3, int sigmoid, float* logits, eg_stream_t stream) {
+    if (!x || !W || !logits || !w1 || !s1 || !t1 || !w2 || !s2 || !t2 || !w3 || !b3) return set_error(EG_ERR_ARG, "NULL argument");
+    if (!g || batch <= 0) return set_error(EG_ERR_ARG, "bad graph handle or batch");
+    if (g->kind != GRAPH_TOPO || g->topo.coord_base < g->n_nodes)
+        return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs a topology handle whose rows are all valid nodes (no coordinate nodes)");
+    eg::ClsArgs c{w1, s1, t1, w2, s2, t2, w3, b3, logits, sigmoid};
+    const int rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, 0, nullptr, kidsum_in, nullptr, &c,
+                                      (hipStream_t)stream);
+    if (rc == EG_ERR_UNSUPPORTED)
+        return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs eg_graph_kidsum_rows() > 0 and residual in {NULL, x}");
     return rc;
 }
 

@@ -16,6 +16,8 @@
 namespace eg {
 
 constexpr int PS_THREADS = 512;
+constexpr int PS_LDS_DIS = 4 * TILE * LDA + 16;       // float offsets inside the dynamic LDS block
+constexpr int PS_LDS_PAT = PS_LDS_DIS + 2 * TILE;
 
 struct PsDims {
     int n_per_frame, batch, tiles_per_frame, relu, transpose_w, has_res;
@@ -63,19 +65,26 @@ __device__ inline void ps_claim(int* __restrict__ counters, int group, int n_til
     *slot = t;
 }
 
+// Classifier heads fused behind the LAST layer of a stack (CLS = true): node-type filter + 4 x [Linear(128,32)-BN-ReLU-
+// Linear(32,16)-BN-ReLU-Linear(16,1)] of src/core/models.py:363-377, :485-490, eval-mode BN folded by the caller
+// (same packing as eg_classifier_fwd).  The layer's output tile never leaves LDS.
+
+template <bool CLS>
 __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ out, const float* __restrict__ dis,
                                                                 const Topo* __restrict__ T, const TileDesc* __restrict__ tiles,
                                                                 const SegDesc* __restrict__ segs, const float* __restrict__ pats,
                                                                 const float* __restrict__ patsq, const float* __restrict__ kin, float* __restrict__ kout,
-                                                                int* __restrict__ counters, const PsDims a) {
+                                                                int* __restrict__ counters, const PsDims a, const ClsArgs ca) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_a0 = smem;                               // [2][TILE * LDA]  aggregated tiles
     float* s_x0 = smem + 2 * TILE * LDA;              // [2][TILE * LDA]  raw self rows (residual); then the output tile
     int* s_tile = reinterpret_cast<int*>(smem + 4 * TILE * LDA);                  // [8] ring of tile ids
-    float* s_pat = smem + 4 * TILE * LDA + 8 + 2 * TILE;   // [n_pats][64] weight patterns, quad layout (seg_wide.h)
-    float* s_dis0 = smem + 4 * TILE * LDA + 8;        // [2][TILE] (deg+1)^-1/2 of the tile's rows (child sums of the output)
+    int* s_sync = s_tile + 8;                         // consumer-only tile counter (CLS)
+    float* s_dis0 = smem + PS_LDS_DIS;                // [2][TILE] (deg+1)^-1/2 of the tile's rows (child sums of the output)
+    float* s_pat = smem + PS_LDS_PAT;                 // [n_pats][64] weight patterns, quad layout (seg_wide.h)
+    float* s_bn = s_pat + a.n_pats * PATQ;            // CLS only: [4][128] layer scale, shift, classifier s1, t1
 
     const int tid = threadIdx.x;
     const int lane_k = tid & 63;
@@ -91,6 +100,15 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         ps_claim(counters, group, n_tiles, &s_tile[2]);
     }
     for (int i = tid; i < a.n_pats * PATQ; i += PS_THREADS) s_pat[i] = patsq[i];
+    if (CLS) {
+        if (tid < C) {
+            s_bn[tid] = scale ? scale[tid] : 1.0f;
+            s_bn[C + tid] = shift ? shift[tid] : 0.0f;
+            s_bn[2 * C + tid] = ca.s1[tid];
+            s_bn[3 * C + tid] = ca.t1[tid];
+        }
+        if (tid == 0) *s_sync = 0;
+    }
     __syncthreads();
 
     // The two roles run separate loops (so that neither carries the other's persistent registers); both execute
@@ -100,11 +118,31 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         float wreg[64];
         load_w_slice(W, wave, lane_k, a.transpose_w, wreg);
         f32x4 sc[4], sh[4];
+        if (!CLS) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch0 = 32 * wave + 8 * g + 4 * (lane_k >> 5);
-            sc[g] = scale ? *reinterpret_cast<const f32x4*>(scale + ch0) : f32x4{1.f, 1.f, 1.f, 1.f};
-            sh[g] = shift ? *reinterpret_cast<const f32x4*>(shift + ch0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 4; ++g) {
+                const int ch0 = 32 * wave + 8 * g + 4 * (lane_k >> 5);
+                sc[g] = scale ? *reinterpret_cast<const f32x4*>(scale + ch0) : f32x4{1.f, 1.f, 1.f, 1.f};
+                sh[g] = shift ? *reinterpret_cast<const f32x4*>(shift + ch0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // CLS: wave = classifier head.  First-layer slice of the stacked [128,128] weight in 64 more VGPRs (the per-channel
+        // scale / shift vectors of both stages then live in LDS, not in registers); second layer as in classifier.hip:
+        // MFMA 16x16x4 A operand lane (o = l & 15, kq = l >> 4) holds W2[head][o][8 kq + s].
+        float wreg2[64];
+        float w2a[8];
+        f32x4 s2v, t2v, w3v;
+        float b3v = 0.f;
+        if (CLS) {
+            load_w_slice(ca.w1, wave, lane_k, 0, wreg2);
+            const f32x4* pw = reinterpret_cast<const f32x4*>(ca.w2 + (size_t)(wave * 16 + (lane_k & 15)) * 32 + 8 * (lane_k >> 4));
+            const f32x4 q0 = pw[0], q1 = pw[1];
+            w2a[0] = q0.x; w2a[1] = q0.y; w2a[2] = q0.z; w2a[3] = q0.w; w2a[4] = q1.x; w2a[5] = q1.y; w2a[6] = q1.z; w2a[7] = q1.w;
+            const int o4 = wave * 16 + 4 * (lane_k >> 4);
+            s2v = *reinterpret_cast<const f32x4*>(ca.s2 + o4);
+            t2v = *reinterpret_cast<const f32x4*>(ca.t2 + o4);
+            w3v = *reinterpret_cast<const f32x4*>(ca.w3 + o4);
+            b3v = ca.b3[wave];
         }
         // Descriptor words the epilogue needs (first node and count of the 8 segments, parent row and parent count of
         // the 4 segment pairs) travel in one VGPR, fetched a tile ahead like the producers' (lane l: segment l >> 2,
@@ -132,7 +170,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             const int cd = cd_next;
             if (t_nx >= 0) cd_next = load_cdesc(t_nx, lane);
             PSTAMP(3);
-            const float* s_a = s_a0 + (k & 1) * TILE * LDA;
+            float* s_a = s_a0 + (k & 1) * TILE * LDA;
             float* s_x = s_x0 + (k & 1) * TILE * LDA;
             const int frame = t_cur / a.tiles_per_frame;
             int seg_first[8], seg_cnt[8];
@@ -164,20 +202,35 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             const int j = lane & 31, h = lane >> 5;
             const float relu_floor = a.relu ? 0.f : -__builtin_inff();
             const bool has_res = a.has_res != 0;
+            // residual rows of both 32-row blocks, read BEFORE the MFMA chains: an LDS wait inside a chain stalls the
+            // wave's next MFMA as well (in-order issue)
+            f32x4 res[2][4];
+            if (!CLS) {                                                       // (the fused-classifier variant has no registers to spare)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        res[rb][g] = *reinterpret_cast<const f32x4*>(s_x + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g);
+            }
             auto finish_group = [&](const f32x16& acc, int rb, int g) {          // 4 channels of row 32 rb + j -> LDS
                 float* xp = s_x + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g;   // LDS row = 8 * patch row + column
                 f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                v = v * sc[g] + sh[g];
+                if (CLS) {
+                    const float* bp = s_bn + 32 * wave + 4 * h + 8 * g;
+                    v = v * *reinterpret_cast<const f32x4*>(bp) + *reinterpret_cast<const f32x4*>(bp + C);
+                } else {
+                    v = v * sc[g] + sh[g];
+                }
                 v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-                const f32x4 r = *reinterpret_cast<const f32x4*>(xp);
+                const f32x4 r = CLS ? *reinterpret_cast<const f32x4*>(xp) : res[rb][g];
                 v.x += has_res ? r.x : 0.f; v.y += has_res ? r.y : 0.f; v.z += has_res ? r.z : 0.f; v.w += has_res ? r.w : 0.f;
                 *reinterpret_cast<f32x4*>(xp) = v;
             };
             const int u8 = lane >> 3, c4 = 4 * (lane & 7);
             float* ob = out + (size_t)frame * a.n_per_frame * C + 32 * wave + c4;
-            auto store_segments = [&](int i0) {                                  // patch rows i0 .. i0+3: 8 lanes per row
-                f32x4 o[4];
-                int node[4];
+            f32x4 o[4];
+            int node[4];
+            auto read_segments = [&](int i0) {                                   // patch rows i0 .. i0+3: 8 lanes per row
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // an absent segment (ragged patch) repeats segment 0, a short one its last node: identical stores
@@ -188,28 +241,33 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     o[e] = *reinterpret_cast<const f32x4*>(s_x + (8 * i + u) * LDA + 32 * wave + c4);
                     node[e] = first + u;
                 }
+            };
+            auto store_segments = [&]() {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(ob + (size_t)node[e] * C) = o[e];
             };
 #ifndef EG_ABL_NO_MFMA
             mfma_rowblock(s_a, 0, lane, wreg, acc0);
             // rows 32..63: the MFMA chain leaves ~60 issue cycles per instruction free; the epilogue of rows 0..31
-            // (VALU, LDS, and its global stores) is placed between the chunks of the chain
+            // (VALU, LDS, and its global stores) is placed between the chunks of the chain, every LDS read one chunk
+            // ahead of its use
             mfma_rowblock_with(s_a, 32, lane, wreg, acc1, [&](int c) {
                 if (c < 2) { finish_group(acc0, 0, 2 * c); finish_group(acc0, 0, 2 * c + 1); }
-                else if (c == 2) store_segments(0);
+                else if (!CLS && c == 2) read_segments(0);
+                else if (!CLS) store_segments();
             });
 #else
             acc0[0] = wreg[0] + s_a[lane]; acc1[0] = wreg[63];
 #pragma unroll
             for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
-            store_segments(0);
+            if (!CLS) { read_segments(0); store_segments(); }
 #endif
             PSTAMP(0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) finish_group(acc1, 1, g);
-            store_segments(4);
-            {
+            if (!CLS) {
+                read_segments(4);
+                store_segments();
                 if (kout) {
                     float* kb = kout + (size_t)frame * a.kid_rows * C + 32 * wave + c4;
 #pragma unroll
@@ -224,6 +282,62 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                         ks += dp[9] * *reinterpret_cast<const f32x4*>(sp + 9 * LDA);
                         if (kout_row[i] >= 0) *reinterpret_cast<f32x4*>(kb + (size_t)kout_row[i] * C) = ks;
                     }
+                }
+            } else {
+                // ---- classifier heads on the finished tile (all 128 channels of it are needed: the four consumer waves
+                // meet on an LDS counter; the producers are not involved and keep filling the other buffer) -------------
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(s_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int target = 4 * (k + 1);
+                while (__hip_atomic_load(s_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // first layers: hidden[row][32 wave + c] = relu(bn(h3[row][:] . W1[32 wave + c][:])), into this wave's column
+                // slice of the A tile (dead now: every wave is past its MFMAs on it)
+                f32x16& hc0 = acc0;
+                f32x16& hc1 = acc1;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { hc0[i] = 0.f; hc1[i] = 0.f; }
+                auto hidden_group = [&](const f32x16& hc, int rb, int g) {
+                    const float* bp = s_bn + 2 * C + 32 * wave + 4 * h + 8 * g;
+                    f32x4 v = f32x4{hc[4 * g], hc[4 * g + 1], hc[4 * g + 2], hc[4 * g + 3]};
+                    v = v * *reinterpret_cast<const f32x4*>(bp) + *reinterpret_cast<const f32x4*>(bp + C);
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    *reinterpret_cast<f32x4*>(s_a + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g) = v;
+                };
+                mfma_rowblock(s_x, 0, lane, wreg2, hc0);
+                mfma_rowblock_with(s_x, 32, lane, wreg2, hc1, [&](int c) { hidden_group(hc0, 0, c); });
+#pragma unroll
+                for (int g = 0; g < 4; ++g) hidden_group(hc1, 1, g);
+                // second / third layers per 16-row block: K = 32 on the MFMA (8 x 16x16x4), BN + ReLU + the 16-wide dot
+                // on the accumulator (4 outputs per lane, two cross-lane adds), as in classifier.hip
+                const int j16 = lane & 15, kq = lane >> 4;
+                float* lg = ca.logits + ((size_t)frame * a.n_per_frame) * 4 + wave;
+                f32x4 hb[4][2];
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    const f32x4* hp = reinterpret_cast<const f32x4*>(s_a + (16 * b4 + j16) * LDA + 32 * wave + 8 * kq);
+                    hb[b4][0] = hp[0]; hb[b4][1] = hp[1];
+                }
+                f32x4v z[4];
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) z[b4] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 8; ++t)                       // the four 16-row blocks interleaved: independent chains
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4)
+                        z[b4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[t], hb[b4][t >> 2][t & 3], z[b4], 0, 0, 0);
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    float y = w3v.x * fmaxf(z[b4].x * s2v.x + t2v.x, 0.f) + w3v.y * fmaxf(z[b4].y * s2v.y + t2v.y, 0.f) +
+                              w3v.z * fmaxf(z[b4].z * s2v.z + t2v.z, 0.f) + w3v.w * fmaxf(z[b4].w * s2v.w + t2v.w, 0.f);
+                    y += __shfl_xor(y, 16);
+                    y += __shfl_xor(y, 32);
+                    y += b3v;
+                    if (ca.sigmoid) y = 1.0f / (1.0f + __expf(-y));
+                    const bool hi = (j16 >> 3) != 0;                     // patch row 2 b4 + hi, column j16 & 7
+                    const int first = hi ? seg_first[2 * b4 + 1] : seg_first[2 * b4];
+                    const int cnt = hi ? seg_cnt[2 * b4 + 1] : seg_cnt[2 * b4];
+                    if (kq == 0 && (j16 & 7) < cnt) lg[(size_t)(first + (j16 & 7)) * 4] = y;
                 }
             }
             PSTAMP(1);
@@ -376,9 +490,9 @@ using namespace eg;
 // Returns EG_ERR_UNSUPPORTED when the caller should fall back to the symmetric kernel.
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
-                       const float* kin, float* kout, hipStream_t stream) {
+                       const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream) {
     if (!g || g->kind != GRAPH_TOPO || (residual != nullptr && residual != x)) return EG_ERR_UNSUPPORTED;
-    const bool chained = kin || kout;
+    const bool chained = kin || kout || cls;
     if (chained && g->kid_rows == 0) return EG_ERR_UNSUPPORTED;
     if (!chained && env_int_ps("EG_LAYER_IMPL", 0) == 0) return EG_ERR_UNSUPPORTED;
     PsDims a{};
@@ -387,17 +501,24 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     a.kid_rows = g->kid_rows; a.n_pats = g->n_pats;
     const long long n_tiles = (long long)a.tiles_per_frame * batch;
     if (n_tiles <= 0) return EG_OK;
-    const size_t lds = (size_t)(4 * TILE * LDA + 8 + 2 * TILE + g->n_pats * PATQ) * sizeof(float);
+    const size_t lds = (size_t)(PS_LDS_PAT + g->n_pats * PATQ + (cls ? 4 * C : 0)) * sizeof(float);
     if (lds > 160 * 1024) return EG_ERR_UNSUPPORTED;             // more weight patterns than fit beside the tile buffers
     static bool attr_set = false;
     if (!attr_set) {
-        EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     EG_HIP_TRY(hipMemsetAsync(g->walk_counters, 0, sizeof(int) * WALK_GROUPS * WALK_CTR_STRIDE, stream));
     long long grid = n_tiles < 256 ? n_tiles : env_int_ps("EG_PS_GRID", 256);      // one persistent workgroup per CU
-    hipLaunchKernelGGL(k_gcn_layer_ps, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out, g->dis,
-                       g->topo_dev, g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, g->walk_counters, a);
+    if (cls)
+        hipLaunchKernelGGL(k_gcn_layer_ps<true>, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out,
+                           g->dis, g->topo_dev, g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout,
+                           g->walk_counters, a, *cls);
+    else
+        hipLaunchKernelGGL(k_gcn_layer_ps<false>, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out,
+                           g->dis, g->topo_dev, g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout,
+                           g->walk_counters, a, ClsArgs{});
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

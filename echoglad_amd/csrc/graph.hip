@@ -308,7 +308,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
                     patsq[(size_t)pi * 64 + h * 32 + sl * 4 + k] = sl < 6 ? w : (w != 0.0f ? 1.0f : 0.0f);
                 }
     // chained layers run the producer/consumer kernel, which keeps the pattern table in LDS beside its tile buffers
-    const size_t ps_lds = (size_t)(4 * TILE * LDA + 8 + 2 * TILE + (pats.size() / 128) * 64) * sizeof(float);
+    const size_t ps_lds = (size_t)(4 * TILE * LDA + 16 + 2 * TILE + (pats.size() / 128) * 64 + 4 * C) * sizeof(float);   // incl. the fused-classifier tables
     g->kid_rows = (kidsum_ok && ps_lds <= 160 * 1024) ? kid_rows : 0;
     g->topo = T;
     g->n_tiles = (int)tiles.size();

@@ -332,6 +332,8 @@ class HierarchicalPatchModel(nn.Module):
         # eval path: layer i leaves the child sums of its output in a side buffer for layer i+1
         # (eg_gcn_layer_fwd_chain); EG_CHAIN=0 runs every layer on its own
         self.chain_layers = os.environ.get("EG_CHAIN", "1") != "0"
+        # ... and the last layer runs the classifier heads on its output tile inside the kernel (EG_FUSE_CLS=0: separate)
+        self.fuse_classifier = os.environ.get("EG_FUSE_CLS", "1") != "0"
         self._kidsum: Dict[tuple, tuple] = {}
 
     def enable_hip_graph(self, flag: bool = True) -> "HierarchicalPatchModel":
@@ -441,11 +443,19 @@ class HierarchicalPatchModel(nn.Module):
             # chained layers: each layer leaves the child sums of its output behind for the next one
             if self.chain_layers and not self.use_coordinate_graph and graph.kidsum_rows > 0 and self.num_gnn_layers > 1:
                 kid = self._kidsum_buffers(graph, gb)
+        fuse_cls = (fused and kid[0] is not None and self.fuse_classifier and n_conn == 0 and n_valid == n
+                    and self.num_output_channels == 4 and self.classifier_hidden_dim == 32)
         for i in range(self.num_gnn_layers):
             x_in = hidden[i]
             if fused:
                 w, scale, shift = folded[i]
                 last = i == self.num_gnn_layers - 1
+                if last and fuse_cls:
+                    # the last layer hands its output tile to the classifier heads inside the kernel
+                    out = ops.gcn_layer_cls_fwd(graph, gb, x_in, w, scale, shift, x_in if self.residual else None, False,
+                                                self._packed_classifier(), sigmoid=(self.output_activation == "sigmoid"),
+                                                kidsum_in=kid[(i + 1) & 1] if i > 0 else None)
+                    return out.squeeze(1), None
                 h = ops.gcn_layer_fwd(graph, gb, x_in, w, scale, shift, x_in if self.residual else None,
                                       relu=not last, kidsum_in=kid[(i + 1) & 1] if i > 0 else None,
                                       kidsum_out=None if last else kid[i & 1])

@@ -139,6 +139,28 @@ def gcn_layer_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tenso
     return out
 
 
+def gcn_layer_cls_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tensor, scale, shift, residual, relu: bool,
+                      packed: dict, sigmoid: bool = False, kidsum_in: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Last layer + node-type filter + 4 classifier heads in one kernel -> logits [batch * num_nodes, 4]."""
+    rows = graph.num_nodes * batch
+    _check_rows(x, "x", rows)
+    if weight.shape != (C, C) or not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous():
+        raise RuntimeError("weight must be a contiguous CUDA float32 [128, 128] tensor")
+    _check_vec(scale, "scale", C)
+    _check_vec(shift, "shift", C)
+    if residual is not None:
+        _check_rows(residual, "residual", rows)
+    if kidsum_in is not None:
+        _check_rows(kidsum_in, "kidsum_in", graph.kidsum_rows * batch)
+    out = torch.empty(rows, 4, dtype=torch.float32, device=x.device)
+    p = packed
+    _lib.check(_lib.load().eg_gcn_layer_cls_fwd(graph._h, batch, _ptr(x), _ptr(weight), _ptr(scale), _ptr(shift), _ptr(residual),
+                                                int(relu), _ptr(kidsum_in), _ptr(p["w1"]), _ptr(p["s1"]), _ptr(p["t1"]),
+                                                _ptr(p["w2"]), _ptr(p["s2"]), _ptr(p["t2"]), _ptr(p["w3"]), _ptr(p["b3"]),
+                                                int(sigmoid), _ptr(out), _stream()), "eg_gcn_layer_cls_fwd")
+    return out
+
+
 def new_kidsum(graph: Graph, batch: int) -> Optional[torch.Tensor]:
     """Zero-filled child-sum side buffer [batch * kidsum_rows, 128] for chained layers, or None when the
     topology does not qualify (generic CSR handles, irregular frames)."""

@@ -182,6 +182,39 @@ def test_chained_layers_match_separate_layers(frame, naux, main_only, coord):
     assert float((got_k - want_k[:, :g.kidsum_rows]).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("frame,naux,main_only,coord", CHAIN_CASES)
+@pytest.mark.parametrize("sigmoid", [False, True])
+def test_last_layer_with_fused_classifier_matches_separate_kernels(frame, naux, main_only, coord, sigmoid):
+    """eg_gcn_layer_cls_fwd == eg_gcn_layer_fwd followed by eg_classifier_fwd (both oracle-checked elsewhere)."""
+    B = 2
+    g = ops.Graph.topo(frame, naux, main_only, coord)
+    rs = np.random.RandomState(frame + naux)
+    rows = B * g.num_nodes
+    x = rand_rows(rows, seed=9).to(DEV)
+    w = rand_rows(128, seed=21).to(DEV) * 0.08
+    sc = rand_rows(1, seed=30).to(DEV).reshape(128) * 0.1 + 1.0
+    sh = rand_rows(1, seed=31).to(DEV).reshape(128) * 0.1
+    f = lambda *shape: torch.from_numpy(rs.uniform(-0.3, 0.3, shape).astype(np.float32)).to(DEV)
+    packed = {"w1": f(128, 128), "s1": f(128) + 1.0, "t1": f(128), "w2": f(4, 16, 32), "s2": f(64) + 1.0, "t2": f(64),
+              "w3": f(4, 16), "b3": f(4)}
+    if g.kidsum_rows == 0 or coord:
+        with pytest.raises(RuntimeError):
+            ops.gcn_layer_cls_fwd(g, B, x, w, sc, sh, x, False, packed, sigmoid)
+        return
+    h = ops.gcn_layer_fwd(g, B, x, w, sc, sh, x, relu=False)
+    want = ops.classifier_fwd(h, B, g.num_nodes, 0, g.num_nodes, packed, sigmoid=sigmoid)
+    got = ops.gcn_layer_cls_fwd(g, B, x, w, sc, sh, x, False, packed, sigmoid)
+    assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    # chained form: child sums of x from a previous layer
+    ka = ops.new_kidsum(g, B)
+    h0 = ops.gcn_layer_fwd(g, B, x, w, sc, sh, x, relu=True, kidsum_out=ka)
+    want2 = ops.classifier_fwd(ops.gcn_layer_fwd(g, B, h0, w, sc, sh, h0, relu=False), B, g.num_nodes, 0, g.num_nodes, packed,
+                               sigmoid=sigmoid)
+    got2 = ops.gcn_layer_cls_fwd(g, B, h0, w, sc, sh, h0, False, packed, sigmoid, kidsum_in=ka)
+    assert float((got2 - want2).abs().max()) < 2e-5 * max(1.0, float(want2.abs().max()))
+    assert torch.equal(got2, ops.gcn_layer_cls_fwd(g, B, h0, w, sc, sh, h0, False, packed, sigmoid, kidsum_in=ka))   # deterministic
+
+
 def test_fused_layer_is_run_to_run_deterministic():
     topo, ei, _, _ = graph_tensors(64, 6, 2)
     x = rand_rows(2 * topo.num_nodes, seed=1).to(DEV)
