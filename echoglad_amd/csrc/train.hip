@@ -50,12 +50,22 @@ __device__ inline void column_partials(long long rows, double* __restrict__ part
 
 // stage 2: fixed-order sum over the workgroup partials -> totals[NQ][C] (double, first NQ*C of the workspace tail)
 template <int NQ>
-__global__ void k_reduce_partials(const double* __restrict__ partial, int nblocks, double* __restrict__ totals) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NQ * C) return;
+__global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, int nblocks, double* __restrict__ totals) {
+    // one workgroup per 8 columns: thread (col = t & 7, slice = t >> 3) sums every 32nd partial in ascending order, the 32
+    // slice sums are then added in a fixed tree -> the same bits on every run, and no single thread walks all partials
+    __shared__ double red[256];
+    const int t = threadIdx.x, col = blockIdx.x * 8 + (t & 7), sl = t >> 3;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * NQ * C + i];
-    totals[i] = s;
+    if (col < NQ * C)
+        for (int b = sl; b < nblocks; b += 32) s += partial[(size_t)b * NQ * C + col];
+    red[t] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = 16; st > 0; st >>= 1) {
+        if (sl < st) red[t] += red[t + 8 * st];
+        __syncthreads();
+    }
+    if (sl == 0 && col < NQ * C) totals[col] = red[t];
 }
 
 __global__ __launch_bounds__(RED_THREADS) void k_colsum_partial(const float* __restrict__ x, long long rows, double* __restrict__ partial) {
@@ -264,7 +274,7 @@ int eg_colsum128(const float* x, int64_t rows, void* workspace, float* out, eg_s
     const int nb = red_blocks(rows);
     double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
     hipLaunchKernelGGL(k_colsum_partial, dim3(nb), dim3(RED_THREADS), 0, stream, x, (long long)rows, partial);
-    hipLaunchKernelGGL(k_reduce_partials<1>, dim3(1), dim3(128), 0, stream, partial, nb, totals);
+    hipLaunchKernelGGL(k_reduce_partials<1>, dim3(C / 8), dim3(256), 0, stream, partial, nb, totals);
     hipLaunchKernelGGL(k_colsum_final, dim3(1), dim3(128), 0, stream, totals, out);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
@@ -277,7 +287,7 @@ int eg_bn_stats(const float* x, int64_t rows, void* workspace, float* mean, floa
     const int nb = red_blocks(rows);
     double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
     hipLaunchKernelGGL(k_stats_partial, dim3(nb), dim3(RED_THREADS), 0, stream, x, (long long)rows, partial);
-    hipLaunchKernelGGL(k_reduce_partials<2>, dim3(1), dim3(256), 0, stream, partial, nb, totals);
+    hipLaunchKernelGGL(k_reduce_partials<2>, dim3(2 * C / 8), dim3(256), 0, stream, partial, nb, totals);
     hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(128), 0, stream, totals, (long long)rows, mean, var);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
@@ -313,7 +323,7 @@ int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* me
     const int nb = red_blocks(rows);
     double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
     hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nb), dim3(RED_THREADS), 0, stream, dy, z, mean, invstd, gamma, beta, partial, a);
-    hipLaunchKernelGGL(k_reduce_partials<2>, dim3(1), dim3(256), 0, stream, partial, nb, totals);
+    hipLaunchKernelGGL(k_reduce_partials<2>, dim3(2 * C / 8), dim3(256), 0, stream, partial, nb, totals);
     hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(128), 0, stream, totals, dgamma, dbeta);
     long long blocks = (rows + 3) / 4;
     if (blocks > 4096) blocks = 4096;

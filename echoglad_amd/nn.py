@@ -161,6 +161,51 @@ class _BNActFn(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None, (dy if has_res else None), None, None, None, None, None
 
 
+class _LayerTrainFn(torch.autograd.Function):
+    """One whole train-mode layer as a single autograd node (models.py:328-335, :431-435):
+    z = A_hat x W^T + b;  y = relu|id(dropout(BN_batch(z))) + x.
+    Backward shares one aggregation g = A_hat dz between dX = g W and dW = g^T x, and hands the residual's gradient to
+    the dX kernel as its `residual` input, so autograd never adds two [B*N,128] tensors for this layer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, graph, batch, relu, p, momentum, eps, seed,
+                residual):
+        x = x.contiguous()
+        z = ops.gcn_layer_fwd(graph, batch, x, weight.contiguous(), None, bias.contiguous(), None, False)
+        mean, var = ops.bn_stats(z)
+        n = z.shape[0]
+        with torch.no_grad():
+            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        invstd = torch.rsqrt(var + eps)
+        scale = (gamma * invstd).contiguous()
+        shift = (beta - mean * scale).contiguous()
+        out = ops.bn_act_fwd(z, scale, shift, x if residual else None, relu, p, seed)
+        ctx.save_for_backward(x, z, weight.detach().contiguous(), mean, invstd, gamma.detach().contiguous(),
+                              beta.detach().contiguous())
+        ctx.cfg = (graph, batch, relu, p, seed, residual)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, weight, mean, invstd, gamma, beta = ctx.saved_tensors
+        graph, batch, relu, p, seed, residual = ctx.cfg
+        dy = dy.contiguous()
+        dz, dgamma, dbeta = ops.bn_act_bwd(dy, z, mean, invstd, gamma, beta, relu, p, seed)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx = dw = db = None
+        if need_w:
+            g = ops.gcn_aggregate(graph, batch, dz)
+            dw = ops.dweight128(g, x)
+            if need_x:
+                dx = ops.linear128_fwd(g, weight, None, None, dy if residual else None, False, transpose_w=True)
+        elif need_x:
+            dx = ops.gcn_layer_fwd(graph, batch, dz, weight, None, None, dy if residual else None, False, transpose_w=True)
+        if need_b:
+            db = ops.colsum128(dz)
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+
+
 # ---------------------------------------------------------------------------
 # torch_geometric-compatible modules
 # ---------------------------------------------------------------------------
@@ -391,13 +436,12 @@ class HierarchicalPatchModel(nn.Module):
     def _layer_train(self, i: int, x_in: torch.Tensor, graph: ops.Graph, gb: int) -> torch.Tensor:
         layer = self.gnn_layers[i]
         conv, bn, drop = layer.module_0, layer.module_1, layer.module_2
-        z = conv.forward_graph(x_in, graph, gb)
         p = float(drop.p)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0      # host RNG: reproducible under torch.manual_seed
         relu = i < self.num_gnn_layers - 1
-        res = x_in if (self.residual and z.shape[1] == x_in.shape[1]) else None
         momentum = 0.1 if bn.momentum is None else bn.momentum
-        h = _BNActFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu, p, momentum, bn.eps, seed)
+        h = _LayerTrainFn.apply(x_in, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual))
         with torch.no_grad():
             bn.num_batches_tracked += 1
         return h
