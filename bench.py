@@ -333,6 +333,9 @@ def main():
                                             "classifier heads)") if (graph.kidsum_rows > 0 and model.chain_layers and
                                                                       model.fuse_classifier) else "3 layer launches + k_classifier"},
             "stack_hbm_frac": round(frames_per_s / world * stack_bytes / 1e9 / PEAK_HBM_GBS, 4),
+            # whole-stack FLOPs per frame: N*(L*2*C^2 + 36,992) + L*(E_dir + N)*2*C, against the fp32-MFMA peak
+            "stack_mfma_frac": round(frames_per_s / world * (N * (args.layers * 2 * C * C + 36992) + args.layers * (e_dir + N) * 2 * C)
+                                     / 1e12 / PEAK_F32_MFMA_TF, 4),
             "roofline": roofline,
         }
         # ---- the rows right after the path, timed beside it; NOT part of `value`

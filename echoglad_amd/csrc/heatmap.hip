@@ -221,11 +221,14 @@ __global__ __launch_bounds__(HM_THREADS) void k_bce_partial(const float* __restr
     if (tid == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = v; }
 }
 
-__global__ void k_bce_final(const double* __restrict__ part, int blocks, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void k_bce_final(const double* __restrict__ part, int blocks, float* __restrict__ out) {
+    // one wave: lane l sums partials l, l+64, ... in ascending order, then a fixed xor tree (same bits every run)
+    const int l = threadIdx.x;
     double a = 0, v = 0;
-    for (int k = 0; k < blocks; ++k) { a += part[2 * k]; v += part[2 * k + 1]; }
-    out[0] = (float)a; out[1] = (float)v; out[2] = (float)(a / v);
+    for (int k = l; k < blocks; k += 64) { a += part[2 * k]; v += part[2 * k + 1]; }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) { a += __shfl_xor(a, s); v += __shfl_xor(v, s); }
+    if (l == 0) { out[0] = (float)a; out[1] = (float)v; out[2] = (float)(a / v); }
 }
 
 __global__ __launch_bounds__(HM_THREADS) void k_bce_bwd(const float* __restrict__ x, const float* __restrict__ y,
