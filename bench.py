@@ -277,7 +277,8 @@ def main():
             kname = "k_gcn_layer_ps<false>" if fused_cls else "k_gcn_layer_ps"
         else:
             forms = [dict()]
-            kname = "k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>"
+            flat = graph.structured and graph.kidsum_rows == 0 and graph.fused_classifier_ok       # single-level topology
+            kname = "k_gcn_layer_ps<false>" if flat else ("k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>")
 
         def layer_launches():
             for f in forms:

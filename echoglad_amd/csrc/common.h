@@ -172,6 +172,8 @@ struct eg_graph {
     float* patsq_dev;         // device [n_pats * 64] the same patterns in quad layout (graph.hip)
     int n_pats;
     int kid_rows;             // rows per frame of the child-sum side buffer (= aux nodes), 0 when the topology does not qualify
+    int flat;                 // 1: a single grid level (use_main_graph_only): no parents, no children; the producer/consumer
+                              //    kernel needs no child sums there and is the default layer kernel when its tables fit LDS
     int n_tiles;
     float* dis;               // device [n_nodes]   (deg+1)^-1/2
     int* rowptr;              // device [n_nodes+1] kind == GRAPH_CSR

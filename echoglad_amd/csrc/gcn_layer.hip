@@ -381,6 +381,10 @@ int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const f
     return rc;
 }
 
+int eg_graph_fused_classifier_ok(const eg_graph* g) {
+    return g && g->kind == GRAPH_TOPO && (g->kid_rows > 0 || g->flat) && g->topo.coord_base >= g->n_nodes;
+}
+
 int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                          const float* shift, const float* residual, int relu, const float* kidsum_in, const float* w1,
                          const float* s1, const float* t1, const float* w2, const float* s2, const float* t2,
@@ -393,7 +397,7 @@ int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const flo
     const int rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, 0, nullptr, kidsum_in, nullptr, &c,
                                       (hipStream_t)stream);
     if (rc == EG_ERR_UNSUPPORTED)
-        return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs eg_graph_kidsum_rows() > 0 and residual in {NULL, x}");
+        return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs eg_graph_fused_classifier_ok() and residual in {NULL, x}");
     return rc;
 }
 

@@ -492,9 +492,12 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
                        const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream) {
     if (!g || g->kind != GRAPH_TOPO || (residual != nullptr && residual != x)) return EG_ERR_UNSUPPORTED;
-    const bool chained = kin || kout || cls;
+    const bool chained = kin || kout;
     if (chained && g->kid_rows == 0) return EG_ERR_UNSUPPORTED;
-    if (!chained && env_int_ps("EG_LAYER_IMPL", 0) == 0) return EG_ERR_UNSUPPORTED;
+    if (cls && g->kid_rows == 0 && !g->flat) return EG_ERR_UNSUPPORTED;
+    // plain calls: this kernel by default on single-level topologies (no tiles that pull child rows), the symmetric
+    // kernel otherwise; EG_LAYER_IMPL = 0 / 1 forces one of them
+    if (!chained && !cls && env_int_ps("EG_LAYER_IMPL", g->flat ? 1 : 0) == 0) return EG_ERR_UNSUPPORTED;
     PsDims a{};
     a.n_per_frame = (int)g->n_nodes; a.batch = batch; a.tiles_per_frame = g->n_tiles;
     a.relu = relu; a.transpose_w = transpose_w; a.has_res = residual != nullptr;

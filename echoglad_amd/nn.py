@@ -487,7 +487,8 @@ class HierarchicalPatchModel(nn.Module):
             # chained layers: each layer leaves the child sums of its output behind for the next one
             if self.chain_layers and not self.use_coordinate_graph and graph.kidsum_rows > 0 and self.num_gnn_layers > 1:
                 kid = self._kidsum_buffers(graph, gb)
-        fuse_cls = (fused and kid[0] is not None and self.fuse_classifier and n_conn == 0 and n_valid == n
+        fuse_cls = (fused and self.fuse_classifier and graph.fused_classifier_ok and not self.use_coordinate_graph
+                    and (kid[0] is not None or graph.kidsum_rows == 0) and n_conn == 0 and n_valid == n
                     and self.num_output_channels == 4 and self.classifier_hidden_dim == 32)
         for i in range(self.num_gnn_layers):
             x_in = hidden[i]

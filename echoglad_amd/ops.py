@@ -49,6 +49,8 @@ class Graph:
         self.device = device
         # rows per frame of a child-sum side buffer (chained layers); 0 = not available for this handle
         self.kidsum_rows = int(_lib.load().eg_graph_kidsum_rows(handle)) if structured else 0
+        # eg_gcn_layer_cls_fwd (last layer + classifier heads in one kernel) is available for this handle
+        self.fused_classifier_ok = bool(_lib.load().eg_graph_fused_classifier_ok(handle)) if structured else False
 
     @classmethod
     def topo(cls, frame_size: int, num_aux_graphs: int, use_main_graph_only: bool = False,
