@@ -286,11 +286,13 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             } else {
                 // ---- classifier heads on the finished tile (all 128 channels of it are needed: the four consumer waves
                 // meet on an LDS counter; the producers are not involved and keep filling the other buffer) -------------
+                PSTAMP(1);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_fetch_add(s_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int target = 4 * (k + 1);
                 while (__hip_atomic_load(s_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                PSTAMP(2);                                 // (stamp builds: the consumers' wait for each other counts as barrier time)
                 // first layers: hidden[row][32 wave + c] = relu(bn(h3[row][:] . W1[32 wave + c][:])), into this wave's column
                 // slice of the A tile (dead now: every wave is past its MFMAs on it)
                 f32x16& hc0 = acc0;
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 };
                 mfma_rowblock(s_x, 0, lane, wreg2, hc0);
                 mfma_rowblock_with(s_x, 32, lane, wreg2, hc1, [&](int c) { hidden_group(hc0, 0, c); });
+                PSTAMP(3);                                 // (stamp builds: the second GEMM counts as "loop")
 #pragma unroll
                 for (int g = 0; g < 4; ++g) hidden_group(hc1, 1, g);
                 // second / third layers per 16-row block: K = 32 on the MFMA (8 x 16x16x4), BN + ReLU + the 16-wide dot

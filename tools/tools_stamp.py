@@ -12,12 +12,19 @@ w = (synthetic_node_feats(128, 128, 2) * 0.1).cuda()
 out = torch.empty_like(x)
 buf = (ct.c_uint64 * 9)()
 lib = _lib.load()
-form = os.environ.get("EG_STAMP_FORM", "")          # "", "kin", "kout", "kin+kout": chained forms run the producer/consumer kernel
+form = os.environ.get("EG_STAMP_FORM", "")          # "", "kin", "kout", "kin+kout", "kin+cls": chained forms run the producer/consumer kernel
 kw = {}
 if "kin" in form: kw["kidsum_in"] = ops.new_kidsum(g, B)
 if "kout" in form: kw["kidsum_out"] = ops.new_kidsum(g, B)
+packed = None
+if "cls" in form:                                    # last layer + fused classifier heads (k_gcn_layer_ps<true>)
+    f = lambda *shape: (synthetic_node_feats(int(torch.tensor(shape).prod()), 1, 7).reshape(shape) * 0.1).cuda().contiguous()
+    packed = {"w1": f(128, 128), "s1": f(128) + 1, "t1": f(128), "w2": f(4, 16, 32), "s2": f(64) + 1, "t2": f(64), "w3": f(4, 16), "b3": f(4)}
 for it in range(3):
-    ops.gcn_layer_fwd(g, B, x, w, None, None, x, relu=True, out=out, **kw)
+    if packed is not None:
+        ops.gcn_layer_cls_fwd(g, B, x, w, None, None, x, False, packed, kidsum_in=kw.get("kidsum_in"))
+    else:
+        ops.gcn_layer_fwd(g, B, x, w, None, None, x, relu=True, out=out, **kw)
     lib.eg_debug_phase_cycles(g._h, buf, 1)
     v = list(buf)
 names = ["c_mfma", "c_epilogue", "c_barrier", "c_loop", "p_issue", "p_main(wait+fma)", "p_kids+store", "p_claim+barrier"] if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else ["next_tile", "phase1", "barrier1", "mfma", "barrier2", "dwrite", "barrier3", "phase3"]
