@@ -10,23 +10,28 @@ resident in HBM -> logits resident in HBM.  Workload = BASELINE.json configs[1]
 (default.yml: 224x224 frame, 7 aux levels, 3 GNN layers, batch 8 per GPU).  Frames are
 independent units, so ranks shard the batch with no data-path collective (weak scaling).
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child processes, created before
+this process touches the GPU; a failed rank makes the parent exit non-zero).  Under torch.distributed.run the
+environment's RANK / LOCAL_RANK / WORLD_SIZE are used as they are.
+
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel, measured live with HIP events on
-the launch stream) and `cpu_baseline` (the CPU oracle = port of the reference PyG op sequence,
-timed on this box's host cores on a bounded sample)."""
+the launch stream), `cpu_baseline` (the CPU oracle = port of the reference PyG op sequence,
+timed on this box's host cores on a bounded sample), `repeats` (the timed loop repeated) and — at N = 1 —
+`other_configs`: BASELINE configs[2] (main grid only, batch 32), configs[4] (448x448, 8 aux levels, batch 8) and one
+configs[3] training step (coordinate graph, batch 32), each timed the same way; they never enter `value`."""
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-
-import numpy as np
-import torch
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_MFMA_TF = 157.3       # MI355X_MICROARCH.md: dense fp32 MFMA peak
@@ -44,8 +49,10 @@ def parse():
     p.add_argument("--layers", type=int, default=3)
     p.add_argument("--main-only", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] / [3] / [4] side measurements")
     p.add_argument("--cpu-frames", type=int, default=2, help="frames in the CPU-baseline sample")
     p.add_argument("--kernel-iters", type=int, default=30)
+    p.add_argument("--repeats", type=int, default=5, help="extra repeats of the K-step timed loop (reported under `repeats`)")
     p.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed steps before the warm-up steps")
     p.add_argument("--no-hip-graph", action="store_true", help="launch the 4 kernels of a step eagerly from Python")
     p.add_argument("--mode", choices=["infer", "train"], default="infer",
@@ -54,39 +61,116 @@ def parse():
     return p.parse_args()
 
 
-def main_train(args, world, rank, device):
+# ---------------------------------------------------------------------------------------------------------------------
+# N ranks on one node without torchrun
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n: int) -> int:
+    """Start n copies of this command, one per GPU, BEFORE this process makes any GPU call (a process that initialised
+    the GPU must never exec / be replaced; children are plain subprocesses).  Returns the worst exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            rc = p.poll()
+            if rc is None:
+                continue
+            procs.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                deadline = deadline or time.time() + 30.0        # a dead rank would leave the others in a collective forever
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()
+            worst = worst or 1
+            break
+        time.sleep(0.05)
+    return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# models / workloads
+# ---------------------------------------------------------------------------------------------------------------------
+def model_kwargs(frame, naux, layers, main_only=False, coord=False):
+    return dict(frame_size=frame, gnn_dropout_p=0.5, classifier_dropout_p=0.5, node_embedding_dim=C,
+                node_hidden_dim=C, num_output_channels=4, num_gnn_layers=layers, num_aux_graphs=naux,
+                gnn_jk_mode="last", classifier_hidden_dim=32, residual=True, use_coordinate_graph=coord,
+                output_activation="logit", use_main_graph_only=main_only)
+
+
+def build_model(kw, device, train=False):
+    from echoglad_amd import nn as egnn
+    from fixtures_util import fill_state_dict
+    model = egnn.HierarchicalPatchModel(**kw)
+    fill_state_dict(model, seed=200)          # glorot-like weights, trained-like BN stats (seed: default.yml:24)
+    model = model.to(device)
+    return model.train() if train else model.eval()
+
+
+def stack_work(topo, layers):
+    """algorithmic bytes and FLOPs of the whole stack per frame."""
+    n, e_dir = topo.num_nodes, 2 * topo.num_undirected_edges
+    return n * (layers * 1024 + 528), n * (layers * 2 * C * C + 36992) + layers * (e_dir + n) * 2 * C
+
+
+def infer_workload(frame, naux, layers, main_only, B, device, rank, hip_graph=True):
+    import torch
+    from echoglad_amd.topology import TopologySpec, get_topology
+    from fixtures_util import synthetic_node_feats
+    kw = model_kwargs(frame, naux, layers, main_only)
+    model = build_model(kw, device)
+    model.enable_hip_graph(hip_graph)
+    topo = get_topology(TopologySpec(frame, naux, main_only))
+    # this rank's shard of the global batch: frames [rank*B, (rank+1)*B) — synthetic N(0,1) node features
+    feats = synthetic_node_feats(B * topo.num_nodes, C, seed=200 + rank).to(device)
+    edge_index = torch.from_numpy(topo.batched_edge_index(B)).to(device)
+
+    def step():
+        with torch.no_grad():
+            return model.forward_nodes(feats, edge_index, B)[0]
+
+    return model, kw, topo, feats, edge_index, step
+
+
+def train_workload(frame, naux, layers, B, device, world, rank):
     """forward + losses + backward + gradient all-reduce + Adam on the stack's parameters,
     node features [B*N,128] resident in HBM, B frames per GPU (32 in BASELINE's cfg4), coordinate graph on."""
-    from echoglad_amd import engine, losses, nn as egnn
+    import numpy as np
+    import torch
+    from echoglad_amd import engine, losses
+    from echoglad_amd.data import node_labels
     from echoglad_amd.parallel import GradientAllReducer, broadcast_parameters
     from echoglad_amd.topology import TopologySpec, get_topology
-    from fixtures_util import fill_state_dict, initial_coords, synthetic_node_feats
-    B = args.batch
-    kw = dict(frame_size=args.frame, gnn_dropout_p=0.5, classifier_dropout_p=0.5, node_embedding_dim=C, node_hidden_dim=C,
-              num_output_channels=4, num_gnn_layers=args.layers, num_aux_graphs=args.naux, gnn_jk_mode="last",
-              classifier_hidden_dim=32, residual=True, use_coordinate_graph=True, output_activation="logit")
-    model = egnn.HierarchicalPatchModel(**kw)
-    fill_state_dict(model, seed=200)
-    model = model.to(device).train()
-    topo = get_topology(TopologySpec(args.frame, args.naux, False, True))
+    from fixtures_util import initial_coords, synthetic_node_feats
+    model = build_model(model_kwargs(frame, naux, layers, coord=True), device, train=True)
+    topo = get_topology(TopologySpec(frame, naux, False, True))
     N, n_valid = topo.num_nodes, topo.num_valid_nodes
     feats = synthetic_node_feats(B * N, C, seed=200 + rank).to(device)
     edge_index = torch.from_numpy(topo.batched_edge_index(B)).to(device)
-    coords0 = initial_coords(B, args.frame).to(device)
+    coords0 = initial_coords(B, frame).to(device)
     rs = np.random.RandomState(300 + rank)
-    from echoglad_amd.data import node_labels
-    y = torch.from_numpy(np.stack([np.stack([node_labels(rs.randint(0, args.frame, 2), args.frame, args.naux) for _ in range(4)], 1)
+    y = torch.from_numpy(np.stack([np.stack([node_labels(rs.randint(0, frame, 2), frame, naux) for _ in range(4)], 1)
                                    for _ in range(B)])).reshape(B * n_valid, 4).to(device)
     valid = torch.ones_like(y)
-    coord_y = torch.from_numpy(rs.uniform(0, args.frame - 1, (B * 4, 2)).astype(np.float32)).to(device)
+    coord_y = torch.from_numpy(rs.uniform(0, frame - 1, (B * 4, 2)).astype(np.float32)).to(device)
     crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1),
-            "elm": losses.ExpectedLandmarkMSE(10, B, args.frame, args.naux), "coordinate": engine.MSE(1)}
+            "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux), "coordinate": engine.MSE(1)}
     params = list(model.parameters())
     opt = torch.optim.Adam(params, lr=1e-4)
     reducer = None
     if world > 1:
         broadcast_parameters(model)
         reducer = GradientAllReducer(params)
+        reducer.attach_hooks()
 
     def step():
         preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0.clone())
@@ -95,12 +179,16 @@ def main_train(args, world, rank, device):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         if reducer is not None:
-            reducer.allreduce()
+            reducer.finish()
         opt.step()
         return loss
 
-    for _ in range(max(args.warmup, 2)):
-        loss = step()
+    return step, topo
+
+
+def timed_loop(step, steps, world, device):
+    """K steps bracketed by barrier + synchronize on both sides; max over ranks."""
+    import torch
 
     def barrier():
         if world > 1:
@@ -109,17 +197,26 @@ def main_train(args, world, rank, device):
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for _ in range(steps):
+        out = step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    return elapsed, out
+
+
+def main_train(args, world, rank, device):
+    B = args.batch
+    step, topo = train_workload(args.frame, args.naux, args.layers, B, device, world, rank)
+    for _ in range(max(args.warmup, 2)):
+        loss = step()
+    elapsed, loss = timed_loop(step, args.steps, world, device)
     if rank == 0:
         fps = world * B * args.steps / elapsed
-        step_bytes = 3 * N * (args.layers * 1024 + 528)                 # train-step algorithmic floor per frame
+        sb, sf = stack_work(topo, args.layers)
         print(json.dumps({
             "metric": "echo frames/sec, one full training step of the GNN stack (fwd + losses + bwd + all-reduce + Adam)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2),
@@ -128,30 +225,19 @@ def main_train(args, world, rank, device):
             "config": {"workload": f"configs[3]: {args.frame}x{args.frame} frame, {args.naux} aux levels + 4 coordinate nodes, "
                                    f"num_gnn_layers={args.layers}, batch={B} per GPU, train mode (batch-stat BN, dropout 0.5), "
                                    "losses: weighted BCE + expected-landmark MSE + coordinate MSE, Adam",
-                       "nodes_per_frame": N, "global_batch": B * world,
-                       "parallelism": f"dp{world} (batch-sharded frames, one flat gradient all-reduce per step)"},
-            "stack_hbm_frac": round(fps / world * step_bytes / 1e9 / PEAK_HBM_GBS, 4), "final_loss": float(loss)}), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
-
-
-def build_model(args, device):
-    from echoglad_amd import nn as egnn
-    from fixtures_util import fill_state_dict
-    kw = dict(frame_size=args.frame, gnn_dropout_p=0.5, classifier_dropout_p=0.5, node_embedding_dim=C,
-              node_hidden_dim=C, num_output_channels=4, num_gnn_layers=args.layers, num_aux_graphs=args.naux,
-              gnn_jk_mode="last", classifier_hidden_dim=32, residual=True, use_coordinate_graph=False,
-              output_activation="logit", use_main_graph_only=args.main_only)
-    model = egnn.HierarchicalPatchModel(**kw)
-    fill_state_dict(model, seed=200)          # glorot-like weights, trained-like BN stats (seed: default.yml:24)
-    return model.to(device).eval(), kw
+                       "nodes_per_frame": topo.num_nodes, "global_batch": B * world,
+                       "parallelism": f"dp{world} (batch-sharded frames, gradient all-reduce overlapped with backward)"},
+            # train-step floor = 3 x the forward's algorithmic bytes / FLOPs
+            "stack_hbm_frac": round(fps / world * 3 * sb / 1e9 / PEAK_HBM_GBS, 4),
+            "stack_mfma_frac": round(fps / world * 3 * sf / 1e12 / PEAK_F32_MFMA_TF, 4), "final_loss": float(loss)}), flush=True)
 
 
 def cpu_baseline(args, kw, state_dict):
     """The oracle (a port of the reference's PyG op sequence: gcn_norm recomputed per layer,
     x W^T, index_select gather, scale, index_add_ scatter, BN, ReLU, residual, 4 classifier MLPs)
     on the host cores, on a bounded sample of the same workload."""
+    import numpy as np
+    import torch
     from oracle import gnn_oracle as O
     from echoglad_amd.topology import TopologySpec, get_topology
     from fixtures_util import synthetic_node_feats
@@ -192,8 +278,108 @@ def cpu_baseline(args, kw, state_dict):
                       f"(fastest of the probed thread counts {sorted(probe)} on {avail} host cores)"}, out, feats, ei
 
 
+def kernel_source_digest() -> str:
+    """sha256 over the kernel sources: ties a committed PMC summary to the code it was measured on (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "echoglad_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch of the dominant kernel from the newest profiles/*_pmc.json (tools/profile_round.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  A summary measured
+    on other kernel sources is NOT used: `traffic` stays null and the source says why."""
+    pdir = os.path.join(ROOT, "profiles")
+    cands = sorted([f for f in os.listdir(pdir) if f.endswith("_pmc.json")], reverse=True) if os.path.isdir(pdir) else []
+    if not cands:
+        return None, "no profiles/*_pmc.json"
+    try:
+        pm = json.load(open(os.path.join(pdir, cands[0])))
+        if pm.get("kernel_source_digest") != kernel_source_digest():
+            return None, (f"profiles/{cands[0]} is stale (measured on kernel sources {pm.get('kernel_source_digest')}, "
+                          f"current {kernel_source_digest()}): re-run tools/profile_round.sh")
+        return int(pm[kernel_key]["hbm_bytes_per_launch"]), "profiles/" + cands[0]
+    except Exception as ex:
+        return None, f"profiles/{cands[0]}: {ex!r}"
+
+
+def time_steps(step, iters=20, warm=5):
+    """ms per call of `step` with HIP events on the current stream."""
+    import torch
+    for _ in range(warm):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def other_configs(args, device):
+    """The BASELINE configs the metric is not quoted on, timed like the headline (HIP-graph replay, inputs in HBM);
+    reported beside it, never inside `value`."""
+    import gc
+    import torch
+    out = {}
+    for key, frame, naux, main_only, B, what in (
+            ("cfg3", 224, 7, True, 32, "configs[2]: use_main_graph_only, 224x224, batch 32, eval"),
+            ("cfg5", 448, 8, False, 8, "configs[4]: 448x448, 8 aux levels (N = 288,084 per frame), batch 8 per GPU, eval")):
+        try:
+            model, kw, topo, feats, ei, step = infer_workload(frame, naux, args.layers, main_only, B, device, 0)
+            ms = time_steps(step, iters=20, warm=5)
+            sb, sf = stack_work(topo, args.layers)
+            fps = B / (ms * 1e-3)
+            out[key] = {"workload": what, "ms_per_step": round(ms, 4), "frames_s": round(fps, 1),
+                        "mfma_frac": round(fps * sf / 1e12 / PEAK_F32_MFMA_TF, 4),
+                        "hbm_frac": round(fps * sb / 1e9 / PEAK_HBM_GBS, 4), "nodes_per_frame": topo.num_nodes}
+            del model, feats, ei, step
+        except Exception as ex:
+            out[key] = {"workload": what, "error": repr(ex)}
+        gc.collect()
+        torch.cuda.empty_cache()
+    what = ("configs[3]: 224x224, 7 aux levels + coordinate graph, batch 32 per GPU, one training step "
+            "(fwd + 3 losses + bwd + Adam; dropout 0.5, batch-stat BN)")
+    try:
+        B = 32
+        step, topo = train_workload(224, 7, args.layers, B, device, 1, 0)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 8
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        sb, sf = stack_work(topo, args.layers)
+        fps = B / (ms * 1e-3)
+        out["cfg4_train"] = {"workload": what, "ms_per_step": round(ms, 3), "frames_s": round(fps, 1),
+                             "mfma_frac": round(fps * 3 * sf / 1e12 / PEAK_F32_MFMA_TF, 4),
+                             "hbm_frac": round(fps * 3 * sb / 1e9 / PEAK_HBM_GBS, 4), "nodes_per_frame": topo.num_nodes,
+                             "floor": "3 x the forward's algorithmic bytes / FLOPs (SURVEY 8d)"}
+        del step
+    except Exception as ex:
+        out["cfg4_train"] = {"workload": what, "error": repr(ex)}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no GPU call has happened in this process; the ranks are children, this process only waits for them
+        sys.exit(spawn_ranks(args.gpus))
+
+    import numpy as np  # noqa: F401
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -201,32 +387,37 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dist_info = {"world_size": 1, "backend": None, "allreduce_check": None}
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-    if args.gpus != world and rank == 0 and world > 1:
+        dist.init_process_group("nccl", device_id=device)          # "nccl" IS RCCL on ROCm
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                     "allreduce_check": float(one.item()) == float(world)}
+        if not dist_info["allreduce_check"]:
+            raise SystemExit(f"rank {rank}: all-reduce of ones over {world} ranks gave {float(one.item())}")
+    if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+    try:
+        if args.mode == "train":
+            main_train(args, world, rank, device)
+        else:
+            main_infer(args, world, rank, device, dist_info)
+    finally:
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
 
-    if args.mode == "train":
-        return main_train(args, world, rank, device)
 
+def main_infer(args, world, rank, device, dist_info):
+    import torch
     from echoglad_amd import ops
-    from echoglad_amd.topology import TopologySpec, get_topology
-    from fixtures_util import synthetic_node_feats
-
-    model, kw = build_model(args, device)
-    model.enable_hip_graph(not args.no_hip_graph)
-    topo = get_topology(TopologySpec(args.frame, args.naux, args.main_only))
-    B, N = args.batch, topo.num_nodes
-    # this rank's shard of the global batch: frames [rank*B, (rank+1)*B) — synthetic N(0,1) node features
-    feats = synthetic_node_feats(B * N, C, seed=200 + rank).to(device)
-    edge_index = torch.from_numpy(topo.batched_edge_index(B)).to(device)
-
-    def step():
-        with torch.no_grad():
-            return model.forward_nodes(feats, edge_index, B)[0]
-
+    B = args.batch
+    model, kw, topo, feats, edge_index, step = infer_workload(args.frame, args.naux, args.layers, args.main_only, B, device,
+                                                              rank, hip_graph=not args.no_hip_graph)
+    N = topo.num_nodes
     # clock / allocator spin-up before the W warm-up steps (untimed): freshly started boxes showed one-off
     # stalls of tens of ms (first graph replays, allocator growth, DVFS ramp) that would land in a short timed loop
     t_spin = time.perf_counter()
@@ -240,159 +431,120 @@ def main():
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = step()
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, out = timed_loop(step, args.steps, world, device)          # THE timed region: exactly K steps
     frames_per_s = world * B * args.steps / elapsed
+    rep = [1e3 * timed_loop(step, args.steps, world, device)[0] / args.steps for _ in range(max(args.repeats, 0))]
 
-    result = None
-    if rank == 0:
-        # ---- dominant kernel: the fused GCN layer, timed with HIP events on the launch stream
-        graph, gb = model._resolver.resolve(edge_index, feats.shape[0])
-        w, scale, shift = model._folded_layers()[0]
-        buf = torch.empty_like(feats)
-        chained = bool(model.chain_layers and graph.kidsum_rows > 0 and args.layers > 1)
-        if chained:
-            # the step's layers run chained (eg_gcn_layer_fwd_chain): time the three forms the step launches
-            # (first: writes child sums; middle: reads + writes; last: reads) and report their mean, which is what
-            # a kernel trace shows as the average duration of k_gcn_layer_ps
-            ka, kb = model._kidsum_buffers(graph, gb)
-            forms = [dict(kidsum_out=ka)] + [dict(kidsum_in=ka, kidsum_out=kb)] * max(args.layers - 2, 0)
-            fused_cls = bool(model.fuse_classifier) and topo.n_conn == 0 and topo.num_valid_nodes == N
-            if not fused_cls:
-                forms.append(dict(kidsum_in=ka))          # (with the classifier fused, the last layer is k_gcn_layer_ps<true>)
-            kname = "k_gcn_layer_ps<false>" if fused_cls else "k_gcn_layer_ps"
-        else:
-            forms = [dict()]
-            flat = graph.structured and graph.kidsum_rows == 0 and graph.fused_classifier_ok       # single-level topology
-            kname = "k_gcn_layer_ps<false>" if flat else ("k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>")
+    if rank != 0:
+        return
+    # ---- dominant kernel: the fused GCN layer, timed with HIP events on the launch stream
+    graph, gb = model._resolver.resolve(edge_index, feats.shape[0])
+    w, scale, shift = model._folded_layers()[0]
+    buf = torch.empty_like(feats)
+    chained = bool(model.chain_layers and graph.kidsum_rows > 0 and args.layers > 1)
+    if chained:
+        # the step's layers run chained (eg_gcn_layer_fwd_chain): time the three forms the step launches
+        # (first: writes child sums; middle: reads + writes; last: reads) and report their mean, which is what
+        # a kernel trace shows as the average duration of k_gcn_layer_ps
+        ka, kb = model._kidsum_buffers(graph, gb)
+        forms = [dict(kidsum_out=ka)] + [dict(kidsum_in=ka, kidsum_out=kb)] * max(args.layers - 2, 0)
+        fused_cls = bool(model.fuse_classifier) and topo.n_conn == 0 and topo.num_valid_nodes == N
+        if not fused_cls:
+            forms.append(dict(kidsum_in=ka))          # (with the classifier fused, the last layer is k_gcn_layer_ps<true>)
+        kname = "k_gcn_layer_ps<false>" if fused_cls else "k_gcn_layer_ps"
+    else:
+        forms = [dict()]
+        flat = graph.structured and graph.kidsum_rows == 0 and graph.fused_classifier_ok       # single-level topology
+        kname = "k_gcn_layer_ps<false>" if flat else ("k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>")
 
-        def layer_launches():
-            for f in forms:
-                ops.gcn_layer_fwd(graph, gb, feats, w, scale, shift, feats, relu=True, out=buf, **f)
+    def layer_launches():
+        for f in forms:
+            ops.gcn_layer_fwd(graph, gb, feats, w, scale, shift, feats, relu=True, out=buf, **f)
 
-        for _ in range(3):
-            layer_launches()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(args.kernel_iters):
-            layer_launches()
-        ev1.record()
-        torch.cuda.synchronize()
-        layer_ms = ev0.elapsed_time(ev1) / (args.kernel_iters * len(forms))
-        e_dir = 2 * topo.num_undirected_edges
-        flops = B * (N * 2 * C * C + (e_dir + N) * 2 * C)             # SURVEY §8(d) per-layer FLOPs
-        bytes_alg = B * N * 2 * C * 4                                  # read x once + write out once
-        tf = flops / (layer_ms * 1e-3) / 1e12
-        gbs = bytes_alg / (layer_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes of the same command (tools/profile_round.sh), committed under profiles/
-        traffic, traffic_src = None, None
-        for cand in sorted([f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")], reverse=True) \
-                if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                if args.frame == 224 and args.naux == 7 and B == 8 and not args.main_only:
-                    traffic, traffic_src = int(pm["k_gcn_layer"]["hbm_bytes_per_launch"]), "profiles/" + cand
-                break
-            except Exception:
-                continue
-        roofline = {"bound": "mfma", "kernel": kname,
-                    "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "avg_launch_ms": round(layer_ms, 4),
-                    "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": bytes_alg}}
-        # whole-stack algorithmic bytes: N * (L*1024 + 528) per frame
-        stack_bytes = N * (args.layers * 1024 + 528)
-        result = {
-            "metric": "echo frames/sec through full GNN stack (224x224 default hier-graph); MAE parity",
-            "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1] default.yml: {args.frame}x{args.frame} frame, "
-                                   f"{'main grid only' if args.main_only else str(args.naux) + ' aux levels'}, "
-                                   f"num_gnn_layers={args.layers}, batch={B} per GPU, eval mode, "
-                                   "node features [B*N,128] in HBM -> logits [B*N_valid,4] in HBM",
-                       "nodes_per_frame": N, "directed_edges_per_frame": e_dir, "global_batch": B * world,
-                       "parallelism": f"dp{world} (batch-sharded frames, no data-path collective)",
-                       "launch": "eager" if args.no_hip_graph else "hipGraph replay of the step's kernels",
-                       "kernels_per_step": ("2 x k_gcn_layer_ps<false> (chained layers) + k_gcn_layer_ps<true> (last layer + "
-                                            "classifier heads)") if (graph.kidsum_rows > 0 and model.chain_layers and
-                                                                      model.fuse_classifier) else "3 layer launches + k_classifier"},
-            "stack_hbm_frac": round(frames_per_s / world * stack_bytes / 1e9 / PEAK_HBM_GBS, 4),
-            # whole-stack FLOPs per frame: N*(L*2*C^2 + 36,992) + L*(E_dir + N)*2*C, against the fp32-MFMA peak
-            "stack_mfma_frac": round(frames_per_s / world * (N * (args.layers * 2 * C * C + 36992) + args.layers * (e_dir + N) * 2 * C)
-                                     / 1e12 / PEAK_F32_MFMA_TF, 4),
-            "roofline": roofline,
-        }
-        # ---- the rows right after the path, timed beside it; NOT part of `value`
-        try:
-            from echoglad_amd import evaluators as EV, losses as LS
-            lg = out.detach().reshape(B * (out.shape[0] // B), 4).contiguous()
-            n_rows = lg.shape[0] // B
-            lv = LS.level_grids(args.frame, args.naux, args.main_only)
-            yl = torch.zeros_like(lg)
-            yl.view(B, n_rows, 4)[:, [st + (s // 2) * s + s // 2 for st, s in lv if st + s * s <= n_rows], :] = 1.0
-            vl = torch.ones_like(lg)
-            elm = LS.ExpectedLandmarkMSE(10, B, args.frame, args.naux, args.main_only)
-            bce = LS.WeightedBCEWithLogitsLoss("none", 9000, 1)
+    layer_ms = time_steps(layer_launches, iters=args.kernel_iters, warm=3) / len(forms)
+    e_dir = 2 * topo.num_undirected_edges
+    flops = B * (N * 2 * C * C + (e_dir + N) * 2 * C)             # SURVEY §8(d) per-layer FLOPs
+    bytes_alg = B * N * 2 * C * 4                                  # read x once + write out once
+    tf = flops / (layer_ms * 1e-3) / 1e12
+    gbs = bytes_alg / (layer_ms * 1e-3) / 1e9
+    traffic, traffic_src = (None, "measured only for the default workload")
+    if args.frame == 224 and args.naux == 7 and B == 8 and not args.main_only:
+        traffic, traffic_src = pmc_traffic("k_gcn_layer")
+    roofline = {"bound": "mfma", "kernel": kname,
+                "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": round(layer_ms, 4),
+                "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": bytes_alg}}
+    stack_bytes, stack_flops = stack_work(topo, args.layers)
+    result = {
+        "metric": "echo frames/sec through full GNN stack (224x224 default hier-graph); MAE parity",
+        "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1] default.yml: {args.frame}x{args.frame} frame, "
+                               f"{'main grid only' if args.main_only else str(args.naux) + ' aux levels'}, "
+                               f"num_gnn_layers={args.layers}, batch={B} per GPU, eval mode, "
+                               "node features [B*N,128] in HBM -> logits [B*N_valid,4] in HBM",
+                   "nodes_per_frame": N, "directed_edges_per_frame": e_dir, "global_batch": B * world,
+                   "parallelism": f"dp{world} (batch-sharded frames, no data-path collective)",
+                   "launch": "eager" if args.no_hip_graph else "hipGraph replay of the step's kernels",
+                   "kernels_per_step": ("2 x k_gcn_layer_ps<false> (chained layers) + k_gcn_layer_ps<true> (last layer + "
+                                        "classifier heads)") if (graph.kidsum_rows > 0 and model.chain_layers and
+                                                                  model.fuse_classifier) else "3 layer launches + k_classifier"},
+        "distributed": dist_info,
+        "repeats": ({"ms_per_step": {"min": round(min(rep), 4), "median": round(sorted(rep)[len(rep) // 2], 4),
+                                     "max": round(max(rep), 4)}, "n": len(rep),
+                     "note": "the K-step timed loop run again n times after the reported one"} if rep else None),
+        "stack_hbm_frac": round(frames_per_s / world * stack_bytes / 1e9 / PEAK_HBM_GBS, 4),
+        "stack_mfma_frac": round(frames_per_s / world * stack_flops / 1e12 / PEAK_F32_MFMA_TF, 4),
+        "roofline": roofline,
+    }
+    # ---- the rows right after the path, timed beside it; NOT part of `value`
+    try:
+        from echoglad_amd import evaluators as EV, losses as LS
+        lg = out.detach().reshape(B * (out.shape[0] // B), 4).contiguous()
+        n_rows = lg.shape[0] // B
+        lv = LS.level_grids(args.frame, args.naux, args.main_only)
+        yl = torch.zeros_like(lg)
+        yl.view(B, n_rows, 4)[:, [st + (s // 2) * s + s // 2 for st, s in lv if st + s * s <= n_rows], :] = 1.0
+        vl = torch.ones_like(lg)
+        elm = LS.ExpectedLandmarkMSE(10, B, args.frame, args.naux, args.main_only)
+        bce = LS.WeightedBCEWithLogitsLoss("none", 9000, 1)
 
-            def timed(fn, iters=20):
-                for _ in range(3):
-                    fn()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize(); e0.record()
-                for _ in range(iters):
-                    fn()
-                e1.record(); torch.cuda.synchronize()
-                return round(e0.elapsed_time(e1) / iters, 4)
+        def loss_step():
+            x = lg.detach().requires_grad_(True)
+            (elm.compute(x, yl, vl) + bce.compute(x, yl, vl)).backward()
 
-            def loss_step():
-                x = lg.detach().requires_grad_(True)
-                (elm.compute(x, yl, vl) + bce.compute(x, yl, vl)).backward()
-
-            if not args.main_only:
-                pm = [torch.randn(B, C, 2 ** g, 2 ** g, device=device) for g in range(1, args.naux + 1)]
-                pm.append(torch.randn(B, C, args.frame, args.frame, device=device))
-                pack_ms = timed(lambda: ops.pack_levels(pm, B, N, 0))
-                result["before_path"] = {"pack_levels_ms": pack_ms,
-                                         "pack_levels_GBs": round(2 * B * N * C * 4 / (pack_ms * 1e-3) / 1e9, 1),
-                                         "note": "SURVEY f-1: NCHW level maps -> node-major [B*N,128] in one launch (reads + writes B*N*512 B)"}
-            result["after_path"] = {"landmark_decode_ms": timed(lambda: EV.decode_landmarks(lg, B, args.frame, yl, vl)),
-                                    "losses_fwd_bwd_ms": timed(loss_step),
-                                    "note": "softmax-expected + hard-argmax landmark decode of the step's logits, and "
-                                            "ExpectedLandmarkMSE + WeightedBCEWithLogits forward+backward, on the device"}
-        except Exception as ex:                                   # never lose the bench line over the side measurement
-            result["after_path"] = {"error": repr(ex)}
-        if not args.no_cpu_baseline:
-            cb, cpu_out, cpu_feats, cpu_ei = cpu_baseline(args, kw, model.state_dict())
-            result["cpu_baseline"] = cb
-            # parity of the measured path on the CPU sample (same inputs): logits + landmark indices
-            from oracle import gnn_oracle as O
-            with torch.no_grad():
-                got = model.forward_nodes(cpu_feats.to(device), cpu_ei.to(device), args.cpu_frames)[0].cpu()
-            result["parity"] = {"max_abs_err_vs_oracle": float((got - cpu_out).abs().max()),
-                                "landmark_argmax_equal": bool(torch.equal(
-                                    O.landmark_argmax(got, args.cpu_frames, args.frame),
-                                    O.landmark_argmax(cpu_out, args.cpu_frames, args.frame)))}
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        if not args.main_only:
+            pm = [torch.randn(B, C, 2 ** g, 2 ** g, device=device) for g in range(1, args.naux + 1)]
+            pm.append(torch.randn(B, C, args.frame, args.frame, device=device))
+            pack_ms = round(time_steps(lambda: ops.pack_levels(pm, B, N, 0), 20, 3), 4)
+            result["before_path"] = {"pack_levels_ms": pack_ms,
+                                     "pack_levels_GBs": round(2 * B * N * C * 4 / (pack_ms * 1e-3) / 1e9, 1),
+                                     "note": "SURVEY f-1: NCHW level maps -> node-major [B*N,128] in one launch (reads + writes B*N*512 B)"}
+            del pm
+        result["after_path"] = {"landmark_decode_ms": round(time_steps(lambda: EV.decode_landmarks(lg, B, args.frame, yl, vl), 20, 3), 4),
+                                "losses_fwd_bwd_ms": round(time_steps(loss_step, 20, 3), 4),
+                                "note": "softmax-expected + hard-argmax landmark decode of the step's logits, and "
+                                        "ExpectedLandmarkMSE + WeightedBCEWithLogits forward+backward, on the device"}
+    except Exception as ex:                                   # never lose the bench line over the side measurement
+        result["after_path"] = {"error": repr(ex)}
+    if not args.no_cpu_baseline:
+        cb, cpu_out, cpu_feats, cpu_ei = cpu_baseline(args, kw, model.state_dict())
+        result["cpu_baseline"] = cb
+        # parity of the measured path on the CPU sample (same inputs): logits + landmark indices
+        from oracle import gnn_oracle as O
+        with torch.no_grad():
+            got = model.forward_nodes(cpu_feats.to(device), cpu_ei.to(device), args.cpu_frames)[0].cpu()
+        result["parity"] = {"max_abs_err_vs_oracle": float((got - cpu_out).abs().max()),
+                            "landmark_argmax_equal": bool(torch.equal(
+                                O.landmark_argmax(got, args.cpu_frames, args.frame),
+                                O.landmark_argmax(cpu_out, args.cpu_frames, args.frame)))}
+    if world == 1 and not args.no_other_configs:
+        del buf
+        result["other_configs"] = other_configs(args, device)
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

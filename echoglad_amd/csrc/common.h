@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/echoglad_hip.h"
@@ -158,6 +159,29 @@ __host__ __device__ inline void neighbours(const Topo& T, int n, Nbrs& nb) {
 
 enum GraphKind { GRAPH_TOPO = 1, GRAPH_CSR = 2 };
 
+// Experiment knobs, read from the environment ONCE (per handle at creation; process-wide for handle-less entry points),
+// never on a launch path.
+struct Knobs {
+    int walk_mode;      // EG_WALK_MODE   tile walk of the symmetric kernel (tile.h WALK_*), default queue
+    int stagger;        // EG_STAGGER     experiment: second half of the grid starts late
+    int grid_cap;       // EG_GRID        persistent grid of the symmetric kernel (default 512 = 2 workgroups per CU)
+    int layer_impl;     // EG_LAYER_IMPL  -1 auto, 0 symmetric kernel, 1 producer/consumer kernel for plain calls
+    int ps_grid;        // EG_PS_GRID     persistent grid of the producer/consumer kernel (default 256 = 1 per CU)
+};
+Knobs read_knobs();
+const Knobs& process_knobs();
+
+// Tile-queue heads: 8 per-XCD counters, one 128-B line each = 256 ints per launch.  A handle owns a RING of such slices;
+// every launch takes the next slice (host atomic), zeroes it on its stream and hands it to its kernel, so launches on
+// different streams that share a handle never touch the same counters.
+constexpr int QUEUE_SLICE_INTS = 8 * 32;
+#ifdef EG_STAMP
+constexpr int QUEUE_SLOTS = 1;          // stamp builds keep their cycle sums right behind the (single) slice
+#else
+constexpr int QUEUE_SLOTS = 64;
+#endif
+constexpr int QUEUE_TAIL_INTS = 64;     // stamp statistics (diagnostic builds)
+
 }  // namespace eg
 
 // The opaque handle of the public ABI.
@@ -179,7 +203,15 @@ struct eg_graph {
     int* rowptr;              // device [n_nodes+1] kind == GRAPH_CSR
     int* colidx;              // device [nnz]
     int64_t nnz;
-    int* walk_counters;       // device [8 x 32] per-XCD tile queue heads, zeroed before every launch
+    int* walk_counters;       // device [QUEUE_SLOTS][8 x 32] ring of per-launch tile-queue heads (+ QUEUE_TAIL_INTS)
+    mutable std::atomic<unsigned> launch_seq;   // next slice of the ring (the only host state a launch touches)
+    eg::Knobs knobs;          // environment knobs, read once at creation
+
+    // the slice of the queue ring for one launch
+    int* next_queue_slice() const {
+        const unsigned s = launch_seq.fetch_add(1u, std::memory_order_relaxed) % (unsigned)eg::QUEUE_SLOTS;
+        return walk_counters + (size_t)s * eg::QUEUE_SLICE_INTS;
+    }
 };
 
 // producer/consumer layer kernel (gcn_layer_ps.hip); EG_ERR_UNSUPPORTED -> caller uses the symmetric kernel

@@ -39,7 +39,8 @@ struct LayerArgs {         // host-side bundle only
     float* out;
     GraphPtrs gp;
     LayerDims d;
-    int* walk_counters;
+    int* walk_counters;    // this launch's slice of the handle's queue ring (NULL: static walk)
+    Knobs knobs;
 };
 
 // Diagnostic build only (-DEG_STAMP): per-wave cycle sums per phase, added to a stats area behind the
@@ -280,15 +281,10 @@ __global__ void k_debug_xcc(int* __restrict__ out) {
     }
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 // Persistent grid: what is resident at once (256 CUs x 2 workgroups of 8 waves at this kernel's register
 // budget).  A larger grid would run a second, under-occupied round.
-static int grid_for_tiles(long long n_tiles) {
-    const long long cap = env_int("EG_GRID", 512);
+static int grid_for_tiles(long long n_tiles, const Knobs& kn) {
+    const long long cap = kn.grid_cap;
     long long g = n_tiles < cap ? n_tiles : cap;
     g = (g + 7) / 8 * 8;                                     // static walk modes use groups of 8
     return (int)g;
@@ -300,11 +296,11 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream) {
     const long long n_tiles = (long long)a.d.tiles_per_frame * a.d.batch;
     if (n_tiles <= 0) return EG_OK;
     if (n_tiles >= (1ll << 31)) return set_error(EG_ERR_ARG, "too many tiles");
-    const dim3 grid(grid_for_tiles(n_tiles)), block(LAYER_THREADS);
-    a.d.walk_mode = a.walk_counters ? env_int("EG_WALK_MODE", WALK_QUEUE) : WALK_MOD8;
-    a.d.stagger = env_int("EG_STAGGER", 0);
+    const dim3 grid(grid_for_tiles(n_tiles, a.knobs)), block(LAYER_THREADS);
+    a.d.walk_mode = a.walk_counters ? a.knobs.walk_mode : WALK_MOD8;
+    a.d.stagger = a.knobs.stagger;
     if (a.d.walk_mode == WALK_QUEUE)
-        EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * WALK_GROUPS * WALK_CTR_STRIDE, stream));
+        EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
     const bool res_lds = (a.residual == nullptr) || (a.residual == a.x);     // epilogue residual from the LDS stash / none
     switch (agg) {
         case AGG_NONE: hipLaunchKernelGGL((k_gcn_layer<AGG_NONE, true>), grid, block, 0, stream, LAYER_KARGS); break;
@@ -326,7 +322,8 @@ static int fill_graph_args(const eg_graph* g, int batch, LayerArgs& a, int& agg)
     a.gp.rowptr = g->rowptr;
     a.gp.colidx = g->colidx;
     a.gp.topo = g->topo_dev;
-    a.walk_counters = g->walk_counters;
+    a.walk_counters = g->next_queue_slice();
+    a.knobs = g->knobs;
     a.d.n_per_frame = (int)g->n_nodes;
     a.d.batch = batch;
     a.gp.tiles = g->tiles_dev;
@@ -432,6 +429,7 @@ int eg_linear128_fwd(const float* x, int64_t rows, const float* W, const float* 
     a.d.n_per_frame = (int)rows;
     a.d.batch = 1;
     a.d.tiles_per_frame = (int)((rows + TILE - 1) / TILE);
+    a.knobs = process_knobs();
     return launch_layer(AGG_NONE, a, (hipStream_t)stream);
 }
 

@@ -480,11 +480,6 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
     }
 }
 
-static int env_int_ps(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 }  // namespace eg
 
 using namespace eg;
@@ -500,7 +495,7 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     if (cls && g->kid_rows == 0 && !g->flat) return EG_ERR_UNSUPPORTED;
     // plain calls: this kernel by default on single-level topologies (no tiles that pull child rows), the symmetric
     // kernel otherwise; EG_LAYER_IMPL = 0 / 1 forces one of them
-    if (!chained && !cls && env_int_ps("EG_LAYER_IMPL", g->flat ? 1 : 0) == 0) return EG_ERR_UNSUPPORTED;
+    if (!chained && !cls && (g->knobs.layer_impl < 0 ? g->flat : g->knobs.layer_impl) == 0) return EG_ERR_UNSUPPORTED;
     PsDims a{};
     a.n_per_frame = (int)g->n_nodes; a.batch = batch; a.tiles_per_frame = g->n_tiles;
     a.relu = relu; a.transpose_w = transpose_w; a.has_res = residual != nullptr;
@@ -509,22 +504,27 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     if (n_tiles <= 0) return EG_OK;
     const size_t lds = (size_t)(PS_LDS_PAT + g->n_pats * PATQ + (cls ? 4 * C : 0)) * sizeof(float);
     if (lds > 160 * 1024) return EG_ERR_UNSUPPORTED;             // more weight patterns than fit beside the tile buffers
-    static bool attr_set = false;
-    if (!attr_set) {
-        EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    {   // 160 KB of dynamic LDS needs the attribute once per device (idempotent, so a benign race sets it twice at worst)
+        static std::atomic<bool> attr_set[64];
+        int dev = 0;
+        EG_HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
+        }
     }
-    EG_HIP_TRY(hipMemsetAsync(g->walk_counters, 0, sizeof(int) * WALK_GROUPS * WALK_CTR_STRIDE, stream));
-    long long grid = n_tiles < 256 ? n_tiles : env_int_ps("EG_PS_GRID", 256);      // one persistent workgroup per CU
+    int* const queue = g->next_queue_slice();
+    EG_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
+    long long grid = n_tiles < 256 ? n_tiles : g->knobs.ps_grid;      // one persistent workgroup per CU
     if (cls)
         hipLaunchKernelGGL(k_gcn_layer_ps<true>, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out,
                            g->dis, g->topo_dev, g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout,
-                           g->walk_counters, a, *cls);
+                           queue, a, *cls);
     else
         hipLaunchKernelGGL(k_gcn_layer_ps<false>, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out,
                            g->dis, g->topo_dev, g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout,
-                           g->walk_counters, a, ClsArgs{});
+                           queue, a, ClsArgs{});
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

@@ -16,6 +16,28 @@ int set_error(int code, const std::string& msg) {
     return code;
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+Knobs read_knobs() {
+    Knobs k;
+    k.walk_mode = env_int("EG_WALK_MODE", 0);
+    k.stagger = env_int("EG_STAGGER", 0);
+    k.grid_cap = env_int("EG_GRID", 512);
+    k.layer_impl = env_int("EG_LAYER_IMPL", -1);
+    k.ps_grid = env_int("EG_PS_GRID", 256);
+    return k;
+}
+
+const Knobs& process_knobs() {
+    static const Knobs k = read_knobs();      // thread-safe one-time initialisation
+    return k;
+}
+
+constexpr size_t QUEUE_RING_BYTES = sizeof(int) * ((size_t)QUEUE_SLOTS * QUEUE_SLICE_INTS + QUEUE_TAIL_INTS);
+
 // Python floor division
 static inline int floordiv(int a, int b) {
     int q = a / b;
@@ -295,6 +317,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
     }
     eg_graph* g = new eg_graph{};
     g->kind = GRAPH_TOPO;
+    g->knobs = read_knobs();
     g->n_nodes = T.n_nodes;
     g->n_pats = (int)(pats.size() / 128);
     // The same patterns in "quad" layout for the producer/consumer kernel, which keeps them in LDS: [pattern][row parity
@@ -315,8 +338,8 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
     g->n_tiles = (int)tiles.size();
     hipError_t e = hipMalloc((void**)&g->dis, sizeof(float) * T.n_nodes);
     if (e == hipSuccess) e = hipMemcpy(g->dis, dis.data(), sizeof(float) * T.n_nodes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->walk_counters, sizeof(int) * (8 * 32 + 64));
-    if (e == hipSuccess) e = hipMemset(g->walk_counters, 0, sizeof(int) * (8 * 32 + 64));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->walk_counters, QUEUE_RING_BYTES);
+    if (e == hipSuccess) e = hipMemset(g->walk_counters, 0, QUEUE_RING_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&g->topo_dev, sizeof(Topo));
     if (e == hipSuccess) e = hipMemcpy(g->topo_dev, &T, sizeof(Topo), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&g->tiles_dev, sizeof(TileDesc) * tiles.size());
@@ -353,6 +376,7 @@ int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream
     const int m = (int)n_edges;
     eg_graph* g = new eg_graph{};
     g->kind = GRAPH_CSR;
+    g->knobs = read_knobs();
     g->n_nodes = n_nodes;
     int *keys = nullptr, *vals = nullptr, *keys_out = nullptr, *counts = nullptr;
     void* tmp = nullptr;
@@ -387,8 +411,8 @@ int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream
     CSR_TRY(hipMalloc((void**)&g->colidx, sizeof(int) * mm));
     CSR_TRY(hipMalloc((void**)&g->rowptr, sizeof(int) * ((size_t)n + 1)));
     CSR_TRY(hipMalloc((void**)&g->dis, sizeof(float) * (size_t)n));
-    CSR_TRY(hipMalloc((void**)&g->walk_counters, sizeof(int) * (8 * 32 + 64)));
-    CSR_TRY(hipMemsetAsync(g->walk_counters, 0, sizeof(int) * (8 * 32 + 64), stream));
+    CSR_TRY(hipMalloc((void**)&g->walk_counters, QUEUE_RING_BYTES));
+    CSR_TRY(hipMemsetAsync(g->walk_counters, 0, QUEUE_RING_BYTES, stream));
     CSR_TRY(hipMemsetAsync(counts, 0, sizeof(int) * ((size_t)n + 1), stream));
     if (m > 0) {
         hipLaunchKernelGGL(k_edge_keys, dim3((m + 255) / 256), dim3(256), 0, stream, ei, n_edges, n, keys, vals, counts);
@@ -455,8 +479,9 @@ int eg_graph_deg_inv_sqrt(const eg_graph* g, float* out_dev, eg_stream_t stream)
 int eg_debug_phase_cycles(eg_graph* g, uint64_t* out_host, int reset) {
     if (!g || !out_host) return set_error(EG_ERR_ARG, "NULL argument");
     EG_HIP_TRY(hipDeviceSynchronize());
-    EG_HIP_TRY(hipMemcpy(out_host, g->walk_counters + 8 * 32, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) EG_HIP_TRY(hipMemset(g->walk_counters + 8 * 32, 0, 16 * sizeof(uint64_t)));
+    int* const tail = g->walk_counters + (size_t)QUEUE_SLOTS * QUEUE_SLICE_INTS;
+    EG_HIP_TRY(hipMemcpy(out_host, tail, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) EG_HIP_TRY(hipMemset(tail, 0, 16 * sizeof(uint64_t)));
     return EG_OK;
 }
 

@@ -65,9 +65,9 @@ def train_step(model: Dict[str, torch.nn.Module], batch, criterion: Dict[str, ob
     losses = compute_loss(criterion, preds, batch.y, coord_preds, coord_y, batch.valid_labels, batch_size)
     loss = sum(losses.values())
     optimizer.zero_grad()
-    loss.backward()
+    loss.backward()                 # with reducer.attach_hooks(): the buckets' all-reduces are issued from inside backward
     if reducer is not None:
-        reducer.allreduce()
+        reducer.finish()
     optimizer.step()
     if evaluators:
         with torch.no_grad():

@@ -15,17 +15,19 @@ used for parameter storage, autograd bookkeeping, streams and the tiny
 per-landmark coordinate MLP (4 rows per frame).  There is no CPU fallback."""
 from __future__ import annotations
 
+import os
+import weakref
+from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
-import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .topology import TopologySpec, commutative_edge_hash, get_topology
+from .topology import TopologySpec, candidate_specs, commutative_edge_hash, get_topology
 
 C = ops.C
 
@@ -33,53 +35,92 @@ C = ops.C
 # ---------------------------------------------------------------------------
 # graph resolution: incoming PyG edge_index -> implicit topology or CSR handle
 # ---------------------------------------------------------------------------
-class GraphResolver:
-    """Maps an incoming ``edge_index`` to a kernel graph handle, once per tensor.
+_TOPO_GRAPHS: Dict[tuple, ops.Graph] = {}          # (structured spec fields, device) -> handle, shared by every resolver
+_EXPECTED_HASH: Dict[tuple, Tuple[int, int]] = {}  # (spec, batch) -> (E_dir, digest) of the closed form
 
-    If the model's static topology (frame_size, num_aux_graphs, flags) is
-    structured and the edge_index digest equals the closed form's for the
-    implied batch size, the implicit-stencil handle is used (no edge list is
-    ever read again); otherwise a CSR handle is built from the edge_index."""
+
+def _topo_graph(spec: TopologySpec, device) -> ops.Graph:
+    device = torch.device(device)
+    key = (spec.frame_size, 0 if spec.use_main_graph_only else spec.num_aux_graphs, spec.use_main_graph_only,
+           spec.use_coordinate_graph and not spec.use_main_graph_only, device)
+    g = _TOPO_GRAPHS.get(key)
+    if g is None:
+        g = ops.Graph.topo(spec.frame_size, spec.num_aux_graphs, spec.use_main_graph_only, spec.use_coordinate_graph,
+                           device=device)
+        _TOPO_GRAPHS[key] = g
+    return g
+
+
+def _expected_hash(spec: TopologySpec, batch: int) -> Tuple[int, int]:
+    key = (spec, batch)
+    if key not in _EXPECTED_HASH:
+        if len(_EXPECTED_HASH) > 64:
+            _EXPECTED_HASH.clear()
+        _EXPECTED_HASH[key] = commutative_edge_hash(get_topology(spec).batched_edge_index(batch))
+    return _EXPECTED_HASH[key]
+
+
+class GraphResolver:
+    """Maps an incoming ``edge_index`` to a kernel graph handle.
+
+    Two cache levels.  (1) identity: the same live tensor object at the same ``_version`` resolves without touching
+    the device (a weak reference is kept, so a freed-and-reallocated tensor at the same address can never hit).
+    (2) content: anything else is digested on the device (``eg_edge_hash``: edge count + order-independent 64-bit sum,
+    one 16-byte read-back) and looked up by ``(device, rows, E, digest)``; only an unseen digest builds a handle.
+
+    A handle is the implicit-stencil topology when the digest equals the closed form's — of the model's own static
+    topology (``spec``), or, for a stand-alone ``GCNConv`` (``spec=None``: it is constructed without any graph
+    information, models.py:330-331), of whichever structured closed form has these node and edge counts
+    (``topology.candidate_specs``) — and a CSR built from the edge_index otherwise."""
+
+    MAX_HANDLES = 16
 
     def __init__(self, spec: Optional[TopologySpec] = None):
         self.spec = spec
-        self._topo_graph: Dict[torch.device, ops.Graph] = {}
-        self._expected: Dict[int, Tuple[int, int]] = {}
-        self._cache: Dict[tuple, Tuple[ops.Graph, int]] = {}
-
-    def _expected_hash(self, batch: int) -> Tuple[int, int]:
-        if batch not in self._expected:
-            topo = get_topology(self.spec)
-            self._expected[batch] = commutative_edge_hash(topo.batched_edge_index(batch))
-        return self._expected[batch]
+        self._ident: Dict[int, tuple] = {}
+        self._by_digest: "OrderedDict[tuple, Tuple[ops.Graph, int]]" = OrderedDict()
 
     def topo_graph(self, device) -> ops.Graph:
-        device = torch.device(device)
-        if device not in self._topo_graph:
-            s = self.spec
-            self._topo_graph[device] = ops.Graph.topo(s.frame_size, s.num_aux_graphs, s.use_main_graph_only,
-                                                      s.use_coordinate_graph, device=device)
-        return self._topo_graph[device]
+        return _topo_graph(self.spec, device)
 
-    def resolve(self, edge_index: torch.Tensor, num_rows: int) -> Tuple[ops.Graph, int]:
-        key = (edge_index.data_ptr(), int(edge_index.shape[1]), edge_index._version, num_rows, edge_index.device)
-        hit = self._cache.get(key)
-        if hit is not None:
-            return hit
-        result = None
+    def _candidates(self, num_rows: int, n_edges: int):
         if self.spec is not None:
             topo = get_topology(self.spec)
             if topo.is_structured() and num_rows % topo.num_nodes == 0:
                 batch = num_rows // topo.num_nodes
-                if edge_index.shape[1] == batch * 2 * topo.num_undirected_edges:
-                    if ops.edge_hash(edge_index) == self._expected_hash(batch):
-                        result = (self.topo_graph(edge_index.device), batch)
+                if n_edges == batch * 2 * topo.num_undirected_edges:
+                    return [(self.spec, batch)]
+            return []
+        return candidate_specs(num_rows, n_edges)
+
+    def resolve(self, edge_index: torch.Tensor, num_rows: int) -> Tuple[ops.Graph, int]:
+        ent = self._ident.get(id(edge_index))
+        if ent is not None and ent[0]() is edge_index and ent[1] == edge_index._version and ent[2] == num_rows:
+            return ent[3]
+        n_edges, digest = ops.edge_hash(edge_index)
+        key = (edge_index.device, num_rows, n_edges, digest)
+        result = self._by_digest.get(key)
         if result is None:
-            result = (ops.Graph.csr(edge_index, num_rows), 1)
-        if len(self._cache) > 16:
-            self._cache.clear()
-        self._cache[key] = result
+            for spec, batch in self._candidates(num_rows, n_edges):
+                if _expected_hash(spec, batch) == (n_edges, digest):
+                    result = (_topo_graph(spec, edge_index.device), batch)
+                    break
+            if result is None:
+                result = (ops.Graph.csr(edge_index, num_rows), 1)
+            while len(self._by_digest) >= self.MAX_HANDLES:
+                self._by_digest.popitem(last=False)       # (a handle still referenced elsewhere, e.g. by a captured HIP graph, lives on)
+            self._by_digest[key] = result
+        else:
+            self._by_digest.move_to_end(key)
+        if len(self._ident) > 64:
+            self._ident = {k: v for k, v in self._ident.items() if v[0]() is not None}
+            if len(self._ident) > 64:
+                self._ident.clear()
+        self._ident[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, num_rows, result)
         return result
+
+
+_SHARED_RESOLVER = GraphResolver(None)      # every stand-alone GCNConv: the layers of a stack see the same edge_index
 
 
 # ---------------------------------------------------------------------------
@@ -131,6 +172,27 @@ class _Linear128Fn(torch.autograd.Function):
         return dx, dw, db
 
 
+def _update_running(running_mean, running_var, mean, var, n: int, momentum) -> None:
+    """nn.BatchNorm1d's running-statistics update (unbiased variance); momentum None = nothing to update."""
+    if momentum is None or running_mean is None:
+        return
+    with torch.no_grad():
+        running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+        running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+
+
+def _bn_step(bn: nn.BatchNorm1d):
+    """What nn.BatchNorm1d.forward decides before calling F.batch_norm: (use batch statistics?, update factor | None).
+    Counts the batch in ``num_batches_tracked``; ``momentum=None`` is the cumulative moving average."""
+    use_batch = bn.training or bn.running_mean is None
+    factor = None
+    if bn.training and bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        factor = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else float(bn.momentum)
+    return use_batch, factor
+
+
 class _BNActFn(torch.autograd.Function):
     """Train-mode tail of one GNN layer in two HIP passes: BatchNorm1d with batch statistics over all rows
     of the batch, Dropout, ReLU|Identity and the residual add (src/core/models.py:333-335, :434-435).
@@ -140,10 +202,7 @@ class _BNActFn(torch.autograd.Function):
     def forward(ctx, z, gamma, beta, running_mean, running_var, residual, relu, p, momentum, eps, seed):
         z = z.contiguous()
         mean, var = ops.bn_stats(z)
-        n = z.shape[0]
-        with torch.no_grad():
-            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-            running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        _update_running(running_mean, running_var, mean, var, z.shape[0], momentum)
         invstd = torch.rsqrt(var + eps)
         scale = (gamma * invstd).contiguous()
         shift = (beta - mean * scale).contiguous()
@@ -173,10 +232,7 @@ class _LayerTrainFn(torch.autograd.Function):
         x = x.contiguous()
         z = ops.gcn_layer_fwd(graph, batch, x, weight.contiguous(), None, bias.contiguous(), None, False)
         mean, var = ops.bn_stats(z)
-        n = z.shape[0]
-        with torch.no_grad():
-            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-            running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        _update_running(running_mean, running_var, mean, var, z.shape[0], momentum)
         invstd = torch.rsqrt(var + eps)
         scale = (gamma * invstd).contiguous()
         shift = (beta - mean * scale).contiguous()
@@ -234,10 +290,9 @@ class GCNConv(nn.Module):
         self.in_channels, self.out_channels = in_channels, out_channels
         self.lin = _GlorotLinear(in_channels, out_channels)
         self.bias = nn.Parameter(torch.zeros(out_channels))
-        self._resolver = GraphResolver(None)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
-        graph, batch = self._resolver.resolve(edge_index, x.shape[0])
+        graph, batch = _SHARED_RESOLVER.resolve(edge_index, x.shape[0])
         return self.forward_graph(x, graph, batch)
 
     def forward_graph(self, x, graph: ops.Graph, batch: int) -> torch.Tensor:
@@ -439,12 +494,13 @@ class HierarchicalPatchModel(nn.Module):
         p = float(drop.p)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0      # host RNG: reproducible under torch.manual_seed
         relu = i < self.num_gnn_layers - 1
-        momentum = 0.1 if bn.momentum is None else bn.momentum
-        h = _LayerTrainFn.apply(x_in, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual))
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
-        return h
+        if not (bn.training and bn.affine and drop.training):
+            # a frozen (eval-mode) BatchNorm / Dropout inside a training model: GCNConv kernel + the torch modules
+            h = layer.forward_graph(x_in, graph, gb)
+            return h + x_in if self.residual else h
+        _, momentum = _bn_step(bn)
+        return _LayerTrainFn.apply(x_in, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual))
 
     # ---- coordinate-graph update (models.py:438-473) ---------------------------------------
     def _coordinate_update(self, i: int, h: torch.Tensor, node_coords: torch.Tensor, batch: int):
@@ -529,8 +585,11 @@ class HierarchicalPatchModel(nn.Module):
 
     # ---- the 4 classifier heads in train mode as ONE stacked network ----------------------------------------
     def _stacked_heads_ok(self) -> bool:
+        plain_bn = all(m.training and m.affine and m.track_running_stats and m.momentum is not None
+                       for hd in self.node_classifiers for m in (hd[1], hd[5]))
+        drops_on = all(m.training for hd in self.node_classifiers for m in (hd[3], hd[7]))
         return (self.num_output_channels == 4 and self.classifier_hidden_dim == 32 and self.node_embedding_dim == C
-                and os.environ.get("EG_STACKED_HEADS", "1") != "0")
+                and plain_bn and drops_on and os.environ.get("EG_STACKED_HEADS", "1") != "0")
 
     def _classifier_train(self, hv: torch.Tensor) -> torch.Tensor:
         """models.py:363-377, :488-490 in train mode.  The four heads Linear(128,32)-BN-ReLU-Drop-Linear(32,16)-BN-ReLU-
@@ -581,17 +640,19 @@ class HierarchicalPatchModel(nn.Module):
     def _kidsum_buffers(self, graph, gb):
         key = (id(graph), gb)
         hit = self._kidsum.get(key)
-        if hit is None:
+        if hit is None or hit[0] is not graph:
             if len(self._kidsum) > 4:
-                self._kidsum.clear()
-            hit = (ops.new_kidsum(graph, gb), ops.new_kidsum(graph, gb))
+                self._kidsum.clear()                  # (captured HIP graphs keep their own references, see below)
+            hit = (graph, ops.new_kidsum(graph, gb), ops.new_kidsum(graph, gb))
             self._kidsum[key] = hit
-        return hit
+        return hit[1], hit[2]
 
     def _forward_nodes_graphed(self, node_feats, edge_index, B):
-        key = (node_feats.data_ptr(), tuple(node_feats.shape), edge_index.data_ptr(), int(edge_index.shape[1]), B,
+        key = (id(node_feats), node_feats.data_ptr(), tuple(node_feats.shape), id(edge_index), edge_index._version, B,
                tuple(_versions(l) for l in self.gnn_layers), tuple(_versions(c) for c in self.node_classifiers))
         hit = self._hip_graphs.get(key)
+        if hit is not None and (hit[2] is not node_feats or hit[3] is not edge_index):
+            hit = None
         if hit is None:
             was = self.use_hip_graph
             self.use_hip_graph = False
@@ -608,7 +669,11 @@ class HierarchicalPatchModel(nn.Module):
                 self.use_hip_graph = was
             if len(self._hip_graphs) > 8:
                 self._hip_graphs.clear()
-            hit = (g, out)
+            # everything the captured kernels point at stays alive with the entry: the input tensors, the graph handle,
+            # the child-sum side buffers and the folded / packed parameters (their caches may evict independently)
+            graph, gb = self._resolver.resolve(edge_index, node_feats.shape[0])
+            keep = (graph, self._kidsum.get((id(graph), gb)), self._fold_cache.get("layers"), self._fold_cache.get("cls"))
+            hit = (g, out, node_feats, edge_index, keep)
             self._hip_graphs[key] = hit
         hit[0].replay()
         return hit[1]

@@ -19,7 +19,13 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ct.c_void_p(t.data_ptr())
 
 
-def _stream():
+def _stream(t: Optional[torch.Tensor] = None):
+    """The caller's current stream on the device of ``t`` (default: the current device).  The kernels launch on the
+    device that is current for the calling thread, so a tensor on another device is an error, not a silent cross-device
+    launch."""
+    if t is not None and t.is_cuda and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                           "wrap the call in torch.cuda.device(tensor.device)")
     return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -28,6 +34,9 @@ def _check_rows(t: torch.Tensor, name: str, rows: Optional[int] = None) -> None:
         raise RuntimeError(f"{name} must be a CUDA (ROCm) tensor: the HIP path has no CPU fallback")
     if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != C or not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous float32 [rows, {C}], got {tuple(t.shape)} {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"{name} is on {t.device} but the current device is cuda:{torch.cuda.current_device()} "
+                           "(kernels launch on the current device: use torch.cuda.device(tensor.device))")
     if rows is not None and t.shape[0] != rows:
         raise RuntimeError(f"{name} has {t.shape[0]} rows, expected {rows}")
 
@@ -169,7 +178,7 @@ def new_kidsum(graph: Graph, batch: int) -> Optional[torch.Tensor]:
     rows = graph.kidsum_rows
     if rows == 0:
         return None
-    return torch.zeros(rows * batch, C, device="cuda", dtype=torch.float32)
+    return torch.zeros(rows * batch, C, device=graph.device, dtype=torch.float32)
 
 
 def gcn_aggregate(graph: Graph, batch: int, x: torch.Tensor) -> torch.Tensor:

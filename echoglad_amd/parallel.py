@@ -5,8 +5,8 @@ The reference's only multi-GPU mechanism is single-process ``torch_geometric.nn.
 parameter broadcast from GPU 0, scatter of the sample list, output gather and gradient reduce to GPU 0,
 BatchNorm statistics per replica.  Here every rank owns a contiguous shard of frames (frames are
 independent graph components, so the forward needs no exchange at all) and training adds exactly one
-collective per step: a sum all-reduce of one flat fp32 gradient buffer over RCCL/xGMI (backend "nccl" on
-ROCm; "gloo" in the CPU tests), divided by the world size.  BatchNorm statistics stay per rank, matching
+kind of collective per step: sum all-reduces over the buckets of one flat fp32 gradient buffer over RCCL/xGMI (backend
+"nccl" on ROCm; "gloo" in the CPU tests), issued from inside backward on a side stream and divided by the world size.  BatchNorm statistics stay per rank, matching
 the reference's DataParallel semantics."""
 from __future__ import annotations
 
@@ -50,69 +50,159 @@ def shard_frames(rank: int, world: int, nodes_per_frame: int, *, frames: Optiona
     return out
 
 
-class GradientAllReducer:
-    """One flat fp32 buffer for all gradients -> ONE all-reduce per step (277 KB for the GNN + classifier
-    parameters, 32 MB with the UNet front-end: far below where a ring's per-link bandwidth matters, so a
-    single collective keeps the launch/latency cost to one)."""
+class _Bucket:
+    __slots__ = ("params", "lo", "hi", "ready", "launched")
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, average: bool = True):
+    def __init__(self, params, lo, hi):
+        self.params, self.lo, self.hi = params, lo, hi
+        self.ready, self.launched = 0, False
+
+
+class GradientAllReducer:
+    """Bucketed gradient all-reduce, overlapped with backward.
+
+    The parameters are laid out in ONE flat fp32 buffer in REVERSE registration order (the order backward finishes
+    them: classifier heads first, the first GNN layer last) and cut into a few contiguous buckets.  With
+    ``attach_hooks()`` every parameter's post-accumulate-grad hook counts its bucket down; the moment a bucket is
+    complete it is packed (one ``torch.cat`` into its slice) on the producing stream and its sum all-reduce is issued on
+    a SIDE stream behind an event, so RCCL moves the finished layers' gradients over xGMI while the kernels of the
+    remaining backward keep running.  ``finish()`` (after ``loss.backward()``) issues whatever never fired (parameters
+    without a gradient contribute zeros), waits for the collectives, divides by the world size and hands the reduced
+    values back as ``p.grad``.  Replaces torch_geometric's DataParallel reduce-to-GPU-0 (src/engine.py:105-110).
+
+    Sizing for xGMI (point-to-point links, ~20 us per collective): the 277 KB of GNN + classifier gradients go out as
+    at most ~5 collectives; with a 32 MB front-end the buckets grow to total / 8 (4 MB), capped at 8 MB."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, average: bool = True,
+                 bucket_bytes: Optional[int] = None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.average = average
+        order = list(reversed(self.params))
+        total = sum(p.numel() for p in order)
+        if bucket_bytes is None:
+            bucket_bytes = min(max(4 * total // 8, 64 << 10), 8 << 20)
+        self.bucket_bytes = int(bucket_bytes)
         self._flat: Optional[torch.Tensor] = None
+        self._total = total
+        self._buckets: List[_Bucket] = []
+        self._where = {}
+        lo = off = 0
+        cur: List[torch.nn.Parameter] = []
+        for p in order:
+            cur.append(p)
+            off += p.numel()
+            if 4 * (off - lo) >= self.bucket_bytes:
+                self._buckets.append(_Bucket(cur, lo, off))
+                cur, lo = [], off
+        if cur:
+            self._buckets.append(_Bucket(cur, lo, off))
+        for bi, b in enumerate(self._buckets):
+            for p in b.params:
+                self._where[id(p)] = bi
+        self._hooks = []
+        self._works = []
+        self._side = None
 
+    # ---- plumbing -----------------------------------------------------------------------------------------------
     def _buffer(self) -> torch.Tensor:
-        n = sum(p.numel() for p in self.params)
         p0 = self.params[0]
-        if self._flat is None or self._flat.numel() != n or self._flat.device != p0.device:
-            self._flat = torch.zeros(n, dtype=torch.float32, device=p0.device)
+        if self._flat is None or self._flat.device != p0.device:
+            self._flat = torch.zeros(self._total, dtype=torch.float32, device=p0.device)
         return self._flat
 
-    def allreduce(self, async_op: bool = False):
-        """Pack -> all_reduce(SUM) -> (divide) -> unpack into ``p.grad``.  Parameters without a gradient on this
-        rank contribute zeros (every rank must call this with the same parameter list)."""
-        if not self.params:
-            return None
-        flat = self._buffer()
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                flat[off:off + n].zero_()
-            else:
-                flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        work = None
-        if world > 1:
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-        if async_op and work is not None:
-            return _Pending(self, work, world)
-        self._finish(world)
-        return None
+    def _world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
-    def _finish(self, world: int) -> None:
-        flat = self._flat
+    def attach_hooks(self) -> "GradientAllReducer":
+        """Fire each bucket's all-reduce from inside backward, as soon as its last gradient has been accumulated."""
+        if not self._hooks:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        return self
+
+    def detach_hooks(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        b = self._buckets[self._where[id(p)]]
+        b.ready += 1
+        if b.ready == len(b.params) and not b.launched:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket) -> None:
+        flat = self._buffer()
+        piece = flat[b.lo:b.hi]
+        parts = [(p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), dtype=flat.dtype, device=flat.device))
+                 for p in b.params]
+        torch.cat(parts, out=piece)                          # pack: one kernel per bucket, on the producing stream
+        b.launched = True
+        if self._world() > 1:
+            if flat.is_cuda:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=flat.device)
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ev)
+                    self._works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                self._works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        """After backward: flush, wait, average, unpack into ``p.grad``.  Every rank must call it every step."""
+        if not self.params:
+            return
+        for b in self._buckets:
+            if not b.launched:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        flat = self._buffer()
+        if flat.is_cuda and self._side is not None:
+            torch.cuda.current_stream(flat.device).wait_stream(self._side)
+        world = self._world()
         if self.average and world > 1:
             flat.div_(world)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            g = flat[off:off + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
+        have, views = [], []
+        for b in self._buckets:
+            off = b.lo
+            for p in b.params:
+                v = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                if p.grad is None:
+                    p.grad = v.clone()
+                else:
+                    have.append(p.grad)
+                    views.append(v)
+            b.ready, b.launched = 0, False
+        if have:
+            torch._foreach_copy_(have, views)
+        self._works = []
+
+    # ---- hook-less form (kept for callers that reduce after backward has returned) ---------------------------------
+    def allreduce(self, async_op: bool = False):
+        """Pack -> all_reduce(SUM) -> (divide) -> unpack into ``p.grad`` for every bucket now.  Parameters without a
+        gradient on this rank contribute zeros (every rank must call this with the same parameter list)."""
+        if not self.params:
+            return None
+        for b in self._buckets:
+            if not b.launched:
+                self._launch(b)
+        if async_op:
+            return _Pending(self)
+        self.finish()
+        return None
 
 
 class _Pending:
-    def __init__(self, owner: GradientAllReducer, work, world: int):
-        self.owner, self.work, self.world = owner, work, world
+    def __init__(self, owner: GradientAllReducer):
+        self.owner = owner
 
     def wait(self) -> None:
-        self.work.wait()
-        self.owner._finish(self.world)
+        self.owner.finish()
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:

@@ -191,9 +191,29 @@ class HierTopology:
         return (d ** np.float32(-0.5)).astype(np.float32)
 
     # -------------------------------------------------------------- summaries
+    def count_undirected_edges(self) -> int:
+        """Closed-form edge count (no arrays): what `undirected_edges()` would return, in O(levels)."""
+        s = self.spec
+
+        def grid(p, diagonal):
+            return 2 * p * (p - 1) + (2 * (p - 1) * (p - 1) if diagonal else 0)
+
+        e = grid(self.main.side, s.main_graph_type == "grid-diagonal")
+        for lv in self.aux_levels:
+            e += grid(lv.side, s.aux_graph_type == "grid-diagonal")
+        for lv in self.aux_levels[:-1]:
+            e += 4 * lv.size                                  # parent <-> its 4 children
+        e += 4 * len(self.crop_rows) ** 2                     # last aux level <-> main grid through the crop
+        if self.n_conn:
+            e += self.n_conn * (self.n_conn - 1) // 2
+            e += sum(self.aux_levels[g - 1].size for g in range(1, s.num_aux_graphs))
+        if self.n_coord:
+            e += 6
+        return e
+
     @property
     def num_undirected_edges(self) -> int:
-        return int(self.undirected_edges().shape[1])
+        return self.count_undirected_edges()
 
     @property
     def num_valid_nodes(self) -> int:
@@ -240,6 +260,28 @@ class HierTopology:
 @lru_cache(maxsize=32)
 def get_topology(spec: TopologySpec) -> HierTopology:
     return HierTopology(spec)
+
+
+def candidate_specs(num_rows: int, num_directed_edges: int, max_frame: int = 4096, max_aux: int = 12):
+    """Every structured closed-form topology (plain grids, no connection nodes) and batch size whose node and edge
+    counts equal the given totals: [(TopologySpec, batch)].  Lets a stand-alone ``GCNConv`` — which is constructed
+    without any graph information (models.py:330-331) — recognise the reference's graphs from an incoming
+    ``edge_index``; a candidate still has to pass the edge-digest check before it is used."""
+    out = []
+    if num_rows <= 0 or num_directed_edges <= 0 or num_directed_edges % 2:
+        return out
+    F = np.arange(2, max_frame + 1, dtype=np.int64)
+    variants = [(True, 1, 0)] + [(False, a, c) for a in range(1, max_aux + 1) for c in (0, 4)]
+    for main_only, naux, n_coord in variants:
+        aux_nodes = 0 if main_only else sum(4 ** k for k in range(1, naux + 1))
+        n = aux_nodes + F * F + n_coord
+        for f in F[(n <= num_rows) & (num_rows % n == 0)]:
+            spec = TopologySpec(int(f), naux, main_only, n_coord > 0)
+            topo = HierTopology(spec)
+            batch = num_rows // topo.num_nodes
+            if 2 * batch * topo.count_undirected_edges() == num_directed_edges:
+                out.append((spec, batch))
+    return out
 
 
 def commutative_edge_hash(edge_index: np.ndarray) -> Tuple[int, int]:

@@ -22,8 +22,16 @@
  *   - return 0 on success, <0 on failure: EG_ERR_ARG bad argument,
  *     EG_ERR_UNSUPPORTED shape/topology outside what the kernels cover,
  *     EG_ERR_HIP a HIP runtime error; text via eg_last_error() (thread local).
- *   - functions are re-entrant; no global mutable state besides the
- *     thread-local error string.
+ *   - functions are re-entrant and may be called from several host threads
+ *     and on several streams at once, also with a SHARED graph handle: the
+ *     only host state a launch touches is one atomic counter in the handle
+ *     that picks the launch's own slice of the handle's tile-queue ring
+ *     (64 slices; a slice is zeroed on the launch's stream right before its
+ *     kernel, so more than 64 launches of one handle must not be IN FLIGHT on
+ *     different streams at the same time).  Process-wide state: the
+ *     thread-local error string, and an idempotent per-device "kernel
+ *     attribute set" flag.  Environment knobs (EG_*) are read once, when a
+ *     handle is created, never on a launch path.
  */
 #ifndef ECHOGLAD_HIP_H
 #define ECHOGLAD_HIP_H
@@ -62,7 +70,10 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
 /* Generic CSR (by target node) from a device edge_index [2, n_edges] int64 in
  * PyG layout (row 0 = source, row 1 = target).  Deterministic: neighbours keep
  * their edge_index order.  Self loops in the input are dropped and one self
- * loop per node is implied (gcn_norm / add_remaining_self_loops).
+ * loop per node is implied (gcn_norm / add_remaining_self_loops).  DUPLICATE
+ * edges are kept and count every time, in the degree and in the sum, exactly
+ * as gcn_norm's scatter_add over edge_index does (a multigraph is not
+ * coalesced).  Edges with an endpoint outside [0, n_nodes) are dropped.
  * Set-up call: allocates and synchronises the stream. */
 int eg_csr_create(const int64_t* edge_index_dev, int64_t n_nodes, int64_t n_edges, eg_stream_t stream,
                   eg_graph** out);
@@ -110,6 +121,9 @@ int eg_gcn_layer_fwd(const eg_graph* g, int batch, const float* x, const float* 
  * Both NULL = eg_gcn_layer_fwd.  Needs eg_graph_kidsum_rows(g) > 0 and residual in {NULL, x}
  * (EG_ERR_UNSUPPORTED otherwise). */
 int64_t eg_graph_kidsum_rows(const eg_graph* g);    /* rows per frame of a child-sum buffer; 0: not available */
+/* 1 when eg_gcn_layer_cls_fwd (below) covers this handle: a topology handle without coordinate / connection rows
+ * whose layer kernel is the producer/consumer form (child sums available, or a single-level grid); else 0. */
+int eg_graph_fused_classifier_ok(const eg_graph* g);
 int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                            const float* shift, const float* residual, int relu, int transpose_w, float* out,
                            const float* kidsum_in, float* kidsum_out, eg_stream_t stream);

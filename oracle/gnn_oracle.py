@@ -31,8 +31,12 @@ PyG itself cannot be installed here.  Everything except ``GCNConv`` is pinned
 by running the reference's own ``models.py`` / ``datasets.py`` in this
 container (third-party imports stubbed, ``GCNConv`` stub = ``OracleGCNConv``)
 and committing its outputs under tests/golden/ (generator:
-tests/golden/make_golden.py).  ``GCNConv`` is pinned only by the agreement of
-the two independent restatements above.
+tests/golden/make_golden.py).  ``GCNConv`` is pinned by the agreement of the
+two independent restatements above (also on multigraphs: duplicate edges count
+every time in both) and by a literal hand-computed known-answer case
+(tests/golden/fixtures_util.py ``gcn_known_answer``: existing self loop,
+isolated node, one-directional edge, duplicate edge) that both restatements and
+the HIP CSR kernel must reproduce.
 """
 from __future__ import annotations
 
@@ -84,7 +88,8 @@ def gcn_conv_dense64(x, edge_index, weight, bias):
     a = torch.zeros(n, n, dtype=torch.float64)
     row, col = edge_index[0], edge_index[1]
     keep = row != col
-    a[col[keep], row[keep]] = 1.0           # a[dst, src]
+    # a[dst, src] += 1 per edge: duplicate edges count every time, as in gcn_norm's scatter_add (a multigraph is not coalesced)
+    a.index_put_((col[keep], row[keep]), torch.ones(int(keep.sum()), dtype=torch.float64), accumulate=True)
     a = a + torch.eye(n, dtype=torch.float64)
     deg = a.sum(dim=1)
     dis = deg.pow(-0.5)

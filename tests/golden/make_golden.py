@@ -20,6 +20,8 @@ Outputs
   kat_f16_a3.npz       layer KAT: inputs, weights seed, per-layer outputs, logits (eval)
   cfg1_f64_a2.npz      BASELINE config 1 (64x64, 2 aux, L=2, B=1): sampled rows, digests, argmax
   coord_f32_a4.npz     coordinate-graph path (B=2): coords per layer, logits, train-mode grad norms
+  cfg4_f224_a7_coord.npz  BASELINE configs[3] shape (224x224, 7 aux, coordinate graph): eval at B=2 (sampled rows, digests,
+                       coordinates per layer, argmax) and a train-mode (p=0) step at B=1 (loss, gradient norms); `cfg4` target
   mainonly_f16.npz     use_main_graph_only ablation
   losses_f16_a3.npz    WeightedBCEWithLogits + ExpectedLandmarkMSE values on the KAT logits
   labels.npz           DummyDataset.create_node_labels for hand-picked coordinates on 5 configs + one full sample
@@ -126,6 +128,8 @@ TOPO_CONFIGS = [
     (224, 7, False, False, False, "grid", "grid"),         # BASELINE cfg 2 (default.yml)
     (224, 7, True, False, False, "grid", "grid"),          # BASELINE cfg 3
     (224, 7, False, True, False, "grid", "grid"),          # BASELINE cfg 4
+    (448, 8, False, False, False, "grid", "grid"),         # BASELINE cfg 5 (c0 = 16, 9-level pyramid; ~3 min in the reference's O(n^2) builder)
+    (448, 7, False, False, False, "grid", "grid"),         # the degenerate naux for 448: only a 48^2 corner of level 7 links to the frame
 ]
 
 
@@ -157,7 +161,9 @@ def make_topology():
     out = {}
     for cfg in TOPO_CONFIGS:
         frame, naux, main_only, coord, conn, mt, at = cfg
-        if frame == 224 and os.environ.get("GOLDEN_SKIP_224"):
+        if frame >= 224 and os.environ.get("GOLDEN_SKIP_224"):
+            continue
+        if frame >= 448 and os.environ.get("GOLDEN_SKIP_448"):
             continue
         ei, nt, n = reference_graph(*cfg)
         entry, und = topo_entry(ei, nt, n)
@@ -303,6 +309,59 @@ def make_coord():
                         train_loss=np.float64(loss.item()),
                         grad_keys=np.array(keys), grad_norms=np.array([gn[k] for k in keys], dtype=np.float64))
     print("coord", logits.shape, out_coords.tolist())
+
+
+def make_cfg4():
+    """BASELINE configs[3] shape: 224x224, 7 aux levels, coordinate graph on, L=3.  Eval forward at B=2 and one train-mode
+    (dropout p=0) forward+backward at B=1 through the reference's own forward (dense bilinear_interpolation included)."""
+    frame, naux, L, B = 224, 7, 3, 2
+    ei, nt, n = reference_graph(frame, naux, False, True, False, "grid", "grid")
+    edge_index, node_type, batch_idx = collate(ei, nt, n, B)
+    model = build_ref_model(frame, naux, L, coord=True)
+    fill_state_dict(model, seed=2024)
+    frames = synthetic_frames(B, 128, frame, seed=203)
+    coords0 = initial_coords(B, frame)
+    model.eval()
+    deltas = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: deltas.append(o.detach().clone())) for m in model.node_coordinate_mlp]
+    with torch.no_grad():
+        logits, out_coords, node_feats, layer_out = run_ref(model, frames, edge_index, node_type, batch_idx, coords0)
+    for h in hooks:
+        h.remove()
+    nv = logits.shape[0] // B
+    rows = np.unique(np.concatenate([np.linspace(0, B * nv - 1, 384).astype(np.int64),
+                                     np.arange(nv - 8, nv + 8), np.arange(0, 24)]))
+    hrows = np.unique(np.concatenate([np.linspace(0, B * n - 1, 256).astype(np.int64), np.arange(n - 6, n + 6)]))
+    arg = O.landmark_argmax(logits, B, frame)
+    out = dict(frame=frame, naux=naux, layers=L, batch=B, weight_seed=2024, frame_seed=203, num_nodes=n,
+               coords0=coords0.numpy(), deltas=np.stack([d.numpy() for d in deltas]), out_coords=out_coords.numpy(),
+               sample_rows=rows, logits_rows=logits.numpy()[rows], hidden_rows=hrows,
+               node_feats_rows=node_feats.numpy()[hrows], layer2_rows=layer_out[2].numpy()[hrows],
+               logits_sum=np.float64(logits.double().sum().item()),
+               logits_abs_sum=np.float64(logits.double().abs().sum().item()), argmax=arg.numpy())
+    print("cfg4 eval", logits.shape, out_coords.tolist(), flush=True)
+    # train mode, p = 0, B = 1
+    Bt = 1
+    edge_index, node_type, batch_idx = collate(ei, nt, n, Bt)
+    model_t = build_ref_model(frame, naux, L, coord=True)
+    for mod in model_t.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    fill_state_dict(model_t, seed=2024)
+    model_t.train()
+    frames_t = synthetic_frames(Bt, 128, frame, seed=204)
+    logits_t, coords_t, _, _ = run_ref(model_t, frames_t, edge_index, node_type, batch_idx, initial_coords(Bt, frame))
+    loss = (logits_t ** 2).mean() + (coords_t ** 2).mean() * 1e-3
+    loss.backward()
+    gn = {k: float(p.grad.double().norm()) for k, p in model_t.named_parameters() if p.grad is not None}
+    keys = sorted(gn)
+    trows = np.linspace(0, logits_t.shape[0] - 1, 256).astype(np.int64)
+    out.update(train_frame_seed=204, train_rows=trows, train_logits_rows=logits_t.detach().numpy()[trows],
+               train_coords=coords_t.detach().numpy(), train_loss=np.float64(loss.item()), grad_keys=np.array(keys),
+               grad_norms=np.array([gn[k] for k in keys], dtype=np.float64),
+               grad_w0=model_t.gnn_layers[0].module_0.lin.weight.grad.numpy()[::8, ::8].copy())
+    np.savez_compressed(os.path.join(HERE, "cfg4_f224_a7_coord.npz"), **out)
+    print("cfg4 train", float(loss), flush=True)
 
 
 def make_mainonly():
@@ -458,6 +517,8 @@ if __name__ == "__main__":
         make_mainonly()
     if "labels" in which or "models" in which:
         make_labels()
+    if "cfg4" in which:
+        make_cfg4()
     if "decode" in which or "models" in which:
         make_decode(16, 3, 3, 11, "f16_a3")
         make_decode(30, 3, 2, 12, "f30_a3")

@@ -10,12 +10,13 @@ from echoglad_amd.topology import HierTopology, TopologySpec
 DEV = "cuda:0"
 
 
-def model_pair(frame, naux, layers, coord=False, main_only=False, seed=0, output_activation="logit"):
+def model_pair(frame, naux, layers, coord=False, main_only=False, seed=0, output_activation="logit", **extra):
     """(HIP model on the GPU, oracle model on the CPU) with identical trained-like weights."""
     kw = dict(frame_size=frame, gnn_dropout_p=0.5, classifier_dropout_p=0.5, node_embedding_dim=128,
               node_hidden_dim=128, num_output_channels=4, num_gnn_layers=layers, num_aux_graphs=naux,
               classifier_hidden_dim=32, use_coordinate_graph=coord, output_activation=output_activation,
               use_main_graph_only=main_only)
+    kw.update(extra)
     ref = O.OracleHierarchicalPatchModel(**kw)
     fill_state_dict(ref, seed)
     hip = egnn.HierarchicalPatchModel(**kw)

@@ -22,6 +22,17 @@ def test_every_header_symbol_is_exported(built_lib):
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
 
 
+def test_header_signatures_and_exports_agree_in_both_directions(built_lib):
+    """Every ctypes signature names a declared symbol, and the library exports no eg_* entry point the header hides."""
+    declared = set(_lib.header_symbols())
+    assert set(_lib.SIGNATURES) == declared, (sorted(set(_lib.SIGNATURES) - declared), sorted(declared - set(_lib.SIGNATURES)))
+    out = subprocess.run(["nm", "-D", "--defined-only", str(built_lib)], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("eg_")
+                and ln.split()[-2] in ("T", "t", "W")}
+    # C++-mangled internals do not start with eg_; what remains must be exactly the public ABI
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+
+
 def test_code_object_targets_gfx950(built_lib):
     out = subprocess.run(["strings", "-a", str(built_lib)], capture_output=True, text=True).stdout
     assert "gfx950" in out

@@ -86,6 +86,29 @@ def test_aggregate_csr_generic_graphs():
     assert torch.allclose(got[3:], x[3:])
 
 
+def test_gcn_conv_literal_known_answer_on_the_csr_kernel():
+    """The hand-computed 6-node case (fixtures_util.gcn_known_answer: existing self loop, isolated node, one-directional
+    edge, duplicate edge) through eg_csr_create + the fused layer kernel, the aggregation kernel and nn.GCNConv."""
+    from fixtures_util import gcn_known_answer
+    from echoglad_amd import nn as egnn
+    ei, x, w, b, want, dis = gcn_known_answer()
+    g = ops.Graph.csr(ei.to(DEV), 6)
+    assert (g.deg_inv_sqrt().cpu().double() - dis).abs().max() < 1e-7
+    got = ops.gcn_layer_fwd(g, 1, x.to(DEV), w.to(DEV), None, b.to(DEV), None, False)
+    assert (got.cpu().double() - want).abs().max() < 1e-6
+    agg = ops.gcn_aggregate(g, 1, x.to(DEV)).cpu().double()          # A_hat x: channel 0 of x is n + 1
+    a_hat_x0 = torch.tensor([0.5 * 1 + 0.35355339 * 2, 0.70710678 * 1 + 0.25 * 2 + 0.35355339 * 3, 0.35355339 * 2 + 0.5 * 3,
+                             4.0, 0.70710678 * 4 + 0.5 * 5, 6.0], dtype=torch.float64)
+    assert (agg[:, 0] - a_hat_x0).abs().max() < 1e-6
+    conv = egnn.GCNConv(128, 128)
+    with torch.no_grad():
+        conv.lin.weight.copy_(w); conv.bias.copy_(b)
+    conv = conv.to(DEV)
+    with torch.no_grad():
+        got2 = conv(x.to(DEV), ei.to(DEV))
+    assert (got2.cpu().double() - want).abs().max() < 1e-6
+
+
 @pytest.mark.parametrize("rows", [1, 31, 32, 33, 64, 65, 200, 4116])
 @pytest.mark.parametrize("transpose", [False, True])
 def test_linear128(rows, transpose):

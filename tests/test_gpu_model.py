@@ -62,6 +62,8 @@ def test_main_only_fixture(golden_dir):
 @pytest.mark.parametrize("frame,naux,layers,batch,main_only", [
     (224, 7, 3, 2, False),      # BASELINE cfg 2 shape (default.yml), reduced batch so the oracle takes seconds
     (224, 7, 3, 2, True),       # BASELINE cfg 3 shape
+    (448, 8, 3, 1, False),      # BASELINE cfg 5 shape (448x448, 8 aux levels, N = 288,084): crop offset 16, 9-level pyramid
+    (448, 7, 2, 1, False),      # the degenerate 448 / naux = 7 wiring (a 48^2 corner of level 7 links to the frame)
     (64, 6, 3, 3, False), (30, 3, 2, 2, False), (17, 3, 1, 2, False),
 ])
 def test_stack_vs_oracle_from_node_features(frame, naux, layers, batch, main_only):
@@ -129,3 +131,51 @@ def test_round_trip_properties_at_full_size():
     assert torch.equal(a, b)
     nv = topo.num_valid_nodes
     assert torch.equal(a[3 * nv:4 * nv], c)
+
+
+def _full_size_properties(frame, naux, B, main_only=False, layers=3, seed=5):
+    """Size-independent checks at a BASELINE config's full per-GPU batch: linearity and symmetry of the aggregation,
+    frame independence, determinism of the whole stack, and one frame of the batch against the CPU oracle."""
+    from echoglad_amd import ops
+    g = ops.Graph.topo(frame, naux, main_only)
+    n = g.num_nodes
+    x = synthetic_node_feats(B * n, 128, seed=3).to(DEV)
+    y = synthetic_node_feats(B * n, 128, seed=4).to(DEV)
+    ax, ay = ops.gcn_aggregate(g, B, x), ops.gcn_aggregate(g, B, y)
+    axy = ops.gcn_aggregate(g, B, 2.0 * x - 0.5 * y)
+    assert (axy - (2.0 * ax - 0.5 * ay)).abs().max() < 1e-4
+    lhs, rhs = (ax.double() * y.double()).sum(), (x.double() * ay.double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6
+    f = B - 2
+    one = ops.gcn_aggregate(g, 1, x[f * n:(f + 1) * n].contiguous())
+    assert torch.equal(one, ax[f * n:(f + 1) * n])
+    del ax, ay, axy, y
+    hip, ref = model_pair(frame, naux, layers, main_only=main_only, seed=seed)
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, main_only=main_only)
+    ei1 = torch.from_numpy(topo.edge_index())
+    with torch.no_grad():
+        a, _ = hip.forward_nodes(x, ei.to(DEV), B)
+        b, _ = hip.forward_nodes(x, ei.to(DEV), B)
+        c, _ = hip.forward_nodes(x[f * n:(f + 1) * n].contiguous(), ei1.to(DEV), 1)
+        want, _ = ref.forward_nodes(x[f * n:(f + 1) * n].cpu(), ei1, nt[:n], 1)
+    assert torch.equal(a, b)
+    nv = topo.num_valid_nodes
+    assert torch.equal(a[f * nv:(f + 1) * nv], c)
+    assert (c.cpu() - want).abs().max() < TOL
+    assert torch.equal(O.landmark_argmax(c.cpu(), 1, frame), O.landmark_argmax(want, 1, frame))
+    # the HIP-graph replay path (what bench.py times) gives the same bits
+    hip.enable_hip_graph(True)
+    with torch.no_grad():
+        d = hip.forward_nodes(x, ei.to(DEV), B)[0].clone()
+        e = hip.forward_nodes(x, ei.to(DEV), B)[0].clone()
+    assert torch.equal(d, a) and torch.equal(e, a)
+
+
+def test_cfg3_main_only_full_batch_32():
+    """BASELINE configs[2]: use_main_graph_only, 224x224, batch 32 per GPU."""
+    _full_size_properties(224, 7, 32, main_only=True)
+
+
+def test_cfg5_448_full_batch_8():
+    """BASELINE configs[4]: 448x448, 8 aux levels, 8 frames per GPU (N = 288,084 per frame, 1.18 GB of node features)."""
+    _full_size_properties(448, 8, 8)

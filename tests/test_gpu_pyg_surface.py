@@ -1,0 +1,235 @@
+"""-m gpu: the torch_geometric-shaped operator surface — the call shapes the reference's unmodified model code uses
+(src/core/models.py:5, :329-335 construction, :431 ``layer(x, edge_index)``, :434-435 residual, :479-482 JumpingKnowledge)
+— forward AND backward through the HIP kernels against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from fixtures_util import fill_state_dict, synthetic_frames, synthetic_node_feats
+from gpu_util import DEV, graph_tensors, model_pair
+from oracle import gnn_oracle as O
+from echoglad_amd import nn as egnn
+from echoglad_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack(conv_cls, seq_cls, jk_cls, layers, jk):
+    """The reference's constructor loop (models.py:328-335, :380-382) with the given torch_geometric.nn classes."""
+    m = nn.Module()
+    m.gnn_layers = nn.ModuleList()
+    for i in range(layers):
+        m.gnn_layers.append(seq_cls("x, edge_index", [
+            (conv_cls(in_channels=128, out_channels=128), "x, edge_index -> x"),
+            nn.BatchNorm1d(128), nn.Dropout(p=0.0), nn.Identity() if i == layers - 1 else nn.ReLU(inplace=True)]))
+    m.jk = jk_cls(jk) if jk != "last" else None
+    return m
+
+
+def _loop(m, x, edge_index):
+    """models.py:426-435, :476-482."""
+    hidden = [x]
+    for i in range(len(m.gnn_layers)):
+        h = m.gnn_layers[i](hidden[i], edge_index)
+        h = h + hidden[i]
+        hidden.append(h)
+    return m.jk(hidden) if m.jk is not None else hidden[-1]
+
+
+def _random_multigraph(n, e, seed):
+    rs = np.random.RandomState(seed)
+    src, dst = rs.randint(0, n, e), rs.randint(0, n, e)
+    ei = np.stack([np.concatenate([src, dst, src[:50]]), np.concatenate([dst, src, dst[:50]])])    # + 50 duplicate edges
+    ei[:, 3] = [7, 7]                                                                              # + an explicit self loop
+    return torch.from_numpy(ei.astype(np.int64))
+
+
+@pytest.mark.parametrize("graph_kind", ["closed_form", "diagonal", "multigraph"])
+@pytest.mark.parametrize("jk", ["last", "max"])
+@pytest.mark.parametrize("train", [False, True])
+def test_reference_shaped_loop_forward_backward(graph_kind, jk, train):
+    L = 3
+    hip = _stack(egnn.GCNConv, egnn.Sequential, egnn.JumpingKnowledge, L, jk)
+    ref = _stack(O.OracleGCNConv, O.OracleSequential, O.OracleJumpingKnowledge, L, jk)
+    fill_state_dict(ref, seed=17)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    # state_dict keys are the reference's: gnn_layers.{i}.module_0.lin.weight / .bias, module_1.*
+    assert "gnn_layers.0.module_0.lin.weight" in hip.state_dict() and "gnn_layers.2.module_1.running_var" in hip.state_dict()
+    hip = hip.to(DEV)
+    hip.train(train); ref.train(train)
+    if graph_kind == "multigraph":
+        n = 777
+        ei = _random_multigraph(n, 3000, 5)
+    else:
+        diag = "grid-diagonal" if graph_kind == "diagonal" else "grid"
+        topo, ei, nt, bi = graph_tensors(16, 3, 2, main_type=diag, aux_type=diag)
+        n = 2 * topo.num_nodes
+    x = synthetic_node_feats(n, 128, seed=3)
+    xr = x.clone().requires_grad_(True)
+    xh = x.clone().to(DEV).requires_grad_(True)
+    eih = ei.to(DEV)
+    want = _loop(ref, xr, ei)
+    got = _loop(hip, xh, eih)
+    structured = egnn._SHARED_RESOLVER.resolve(eih, n)[0].structured
+    assert structured == (graph_kind == "closed_form")      # a stand-alone GCNConv recognises the reference's topology
+    assert (got.detach().cpu() - want.detach()).abs().max() < 2e-4
+    (want ** 2).mean().backward()
+    (got ** 2).mean().backward()
+    gx = xr.grad
+    assert (xh.grad.cpu() - gx).abs().max() < 5e-3 * gx.abs().max() + 1e-7
+    ref_grads = dict(ref.named_parameters())
+    for name, p in hip.named_parameters():
+        rg = ref_grads[name].grad
+        assert p.grad is not None, name
+        err = (p.grad.cpu() - rg).abs().max().item()
+        assert err < 5e-3 * rg.abs().max().item() + 1e-6, (name, err, rg.abs().max().item())
+
+
+def test_gcnconv_alone_matches_dense_fp64():
+    topo, ei, nt, bi = graph_tensors(30, 3, 1)
+    conv = egnn.GCNConv(128, 128)
+    fill_state_dict(conv, seed=2)
+    x = synthetic_node_feats(topo.num_nodes, 128, seed=8)
+    want = O.gcn_conv_dense64(x, ei, conv.lin.weight.detach(), conv.bias.detach())
+    conv = conv.to(DEV)
+    with torch.no_grad():
+        got = conv(x.to(DEV), ei.to(DEV))
+    assert (got.cpu().double() - want).abs().max() < 2e-5
+    with pytest.raises(NotImplementedError):
+        egnn.GCNConv(128, 64)
+    with pytest.raises(NotImplementedError):
+        egnn.GCNConv(128, 128, improved=True)
+
+
+@pytest.mark.parametrize("frame,naux,batch", [(16, 3, 2), (64, 6, 2)])
+def test_model_jumping_knowledge_max(frame, naux, batch):
+    """gnn_jk_mode='max' (models.py:380-382, :479-482) through the whole model."""
+    hip, ref = model_pair(frame, naux, 3, seed=21, gnn_jk_mode="max")
+    topo, ei, nt, bi = graph_tensors(frame, naux, batch)
+    frames = synthetic_frames(batch, 128, frame, 9)
+    with torch.no_grad():
+        want, _ = ref(x=frames, edge_index=ei, node_type=nt, batch_idx=bi)
+        got, _ = hip(x=frames.to(DEV), edge_index=ei.to(DEV), node_type=nt.to(DEV), batch_idx=bi.to(DEV))
+    assert (got.cpu() - want).abs().max() < 1e-4
+    assert torch.equal(O.landmark_argmax(got.cpu(), batch, frame), O.landmark_argmax(want, batch, frame))
+    with pytest.raises(NotImplementedError):
+        model_pair(frame, naux, 3, gnn_jk_mode="cat")
+
+
+@pytest.mark.parametrize("coord", [False, True])
+def test_model_with_connection_nodes(coord):
+    """use_connection_nodes=True (datasets.py:1450-1456, :1512-1515; models.py:520-524 connection-node features,
+    :485 node-type filter dropping the LEADING naux+1 rows of every frame): eval logits, then a train step (p = 0)."""
+    frame, naux, B, L = 16, 3, 2, 3
+    hip, ref = model_pair(frame, naux, L, coord=coord, seed=13, use_connection_nodes=True)
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=coord, conn=True)
+    assert topo.n_conn == naux + 1
+    frames = synthetic_frames(B, 128, frame, 4)
+    from fixtures_util import initial_coords
+    c0 = initial_coords(B, frame) if coord else None
+
+    def run(m, dev):
+        return m(x=frames.to(dev), node_coords=None if c0 is None else c0.clone().to(dev), edge_index=ei.to(dev),
+                 node_type=nt.to(dev), batch_idx=bi.to(dev))
+
+    with torch.no_grad():
+        want, wc = run(ref, "cpu")
+        got, gc = run(hip, DEV)
+    assert got.shape == want.shape == (B * topo.num_valid_nodes, 4)
+    assert (got.cpu() - want).abs().max() < 1e-4
+    if coord:
+        assert (gc.cpu() - wc).abs().max() < 1e-4
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    hip.train(); ref.train()
+    want, wc = run(ref, "cpu")
+    got, gc = run(hip, DEV)
+    assert (got.detach().cpu() - want.detach()).abs().max() < 2e-4
+    (want ** 2).mean().backward(); (got ** 2).mean().backward()
+    ref_grads = dict(ref.named_parameters())
+    for name, p in hip.named_parameters():
+        rg = ref_grads[name].grad
+        if rg is None:
+            continue
+        err = (p.grad.cpu() - rg).abs().max().item()
+        assert err < 5e-3 * rg.abs().max().item() + 1e-6, (name, err, rg.abs().max().item())
+
+
+@pytest.mark.parametrize("coord", [False, True])
+def test_eval_mode_with_gradients(coord):
+    """model.eval() with autograd on (e.g. saliency / fine-tuning with frozen statistics): the un-fused branch gives the
+    fused branch's logits and the oracle's gradients."""
+    frame, naux, B = 32, 4, 2
+    hip, ref = model_pair(frame, naux, 3, coord=coord, seed=3)
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=coord)
+    feats = synthetic_node_feats(B * topo.num_nodes, 128, seed=6)
+    from fixtures_util import initial_coords
+    c0 = initial_coords(B, frame) if coord else None
+    with torch.no_grad():
+        fused, _ = hip.forward_nodes(feats.to(DEV), ei.to(DEV), B, None if c0 is None else c0.clone().to(DEV))
+    xh = feats.clone().to(DEV).requires_grad_(True)
+    xr = feats.clone().requires_grad_(True)
+    got, _ = hip.forward_nodes(xh, ei.to(DEV), B, None if c0 is None else c0.clone().to(DEV))
+    want, _ = ref.forward_nodes(xr, ei, nt, B, None if c0 is None else c0.clone())
+    assert (got.detach() - fused).abs().max() < 2e-5
+    assert (got.detach().cpu() - want.detach()).abs().max() < 1e-4
+    (got ** 2).mean().backward(); (want ** 2).mean().backward()
+    assert (xh.grad.cpu() - xr.grad).abs().max() < 5e-3 * xr.grad.abs().max()
+    ref_grads = dict(ref.named_parameters())
+    for name, p in hip.named_parameters():
+        rg = ref_grads[name].grad
+        err = (p.grad.cpu() - rg).abs().max().item()
+        assert err < 5e-3 * rg.abs().max().item() + 1e-6, (name, err)
+
+
+def test_resolver_never_serves_a_stale_graph():
+    """A loader that frees and re-allocates edge_index every batch gets the same address back from the caching
+    allocator; a different graph of the same shape must not hit the old handle (nn.py:65)."""
+    conv = egnn.GCNConv(128, 128)
+    fill_state_dict(conv, seed=1)
+    w, b = conv.lin.weight.detach().clone(), conv.bias.detach().clone()
+    conv = conv.to(DEV)
+    n = 500
+    x = synthetic_node_feats(n, 128, seed=2)
+    ptrs = []
+    for seed in (1, 2, 3, 1):
+        ei = _random_multigraph(n, 2000, seed)
+        eid = ei.to(DEV)
+        ptrs.append(eid.data_ptr())
+        with torch.no_grad():
+            got = conv(x.to(DEV), eid).cpu()
+        want = O.gcn_conv_sparse(x, ei, w, b)
+        assert (got - want).abs().max() < 1e-4, seed
+        del eid
+    assert len(set(ptrs)) < len(ptrs), "the test did not exercise address reuse"
+    # in-place modification of a live tensor is seen too (_version)
+    ei = _random_multigraph(n, 2000, 9).to(DEV)
+    with torch.no_grad():
+        a = conv(x.to(DEV), ei)
+        ei[:, :100] = 0
+        bb = conv(x.to(DEV), ei)
+    want = O.gcn_conv_sparse(x, ei.cpu(), w, b)
+    assert (bb.cpu() - want).abs().max() < 1e-4 and not torch.equal(a, bb)
+
+
+def test_shared_handle_on_two_streams():
+    """One graph handle, launches on two streams at once (include/echoglad_hip.h: re-entrant): every launch has its own
+    slice of the handle's tile-queue ring, so the results are the serial results, bit for bit."""
+    B = 4
+    g = ops.Graph.topo(64, 6)
+    n = g.num_nodes
+    rs = np.random.RandomState(0)
+    w = torch.from_numpy(rs.uniform(-0.1, 0.1, (128, 128)).astype(np.float32)).to(DEV)
+    xs = [synthetic_node_feats(B * n, 128, seed=s).to(DEV) for s in (1, 2)]
+    serial = [ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True) for x in xs]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(20):
+        outs = []
+        for st, x in ((s1, xs[0]), (s2, xs[1])):
+            with torch.cuda.stream(st):
+                outs.append(ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], serial[0]) and torch.equal(outs[1], serial[1])

@@ -169,3 +169,63 @@ def test_train_with_dropout_runs_and_is_seeded():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in hip.parameters())
     # GNN-layer dropout is keyed on the host RNG (classifier dropout uses torch's device RNG)
     assert a.shape == b.shape == c.shape
+
+
+def test_cfg4_eval_vs_reference_fixture(golden_dir):
+    """BASELINE configs[3] shape: 224x224, 7 aux levels, coordinate graph on.  Eval forward at B = 2 against the output of
+    the reference's own forward (tests/golden/make_golden.py cfg4: dense bilinear_interpolation, models.py:438-473)."""
+    g = np.load(os.path.join(golden_dir, "cfg4_f224_a7_coord.npz"))
+    frame, naux, L, B = int(g["frame"]), int(g["naux"]), int(g["layers"]), int(g["batch"])
+    hip, ref = model_pair(frame, naux, L, coord=True, seed=int(g["weight_seed"]))
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+    frames = synthetic_frames(B, 128, frame, int(g["frame_seed"]))
+    coords0 = torch.from_numpy(g["coords0"])
+    with torch.no_grad():
+        got, gc = hip(x=frames.to(DEV), node_coords=coords0.clone().to(DEV), edge_index=ei.to(DEV),
+                      node_type=nt.to(DEV), batch_idx=bi.to(DEV))
+        feats = hip.create_node_pixels(frames.to(DEV), B, coords0.view(B, 4, 2).to(DEV))
+    got = got.cpu()
+    assert np.abs(feats.cpu().numpy()[g["hidden_rows"]] - g["node_feats_rows"]).max() < 1e-5
+    assert np.abs(gc.cpu().numpy() - g["out_coords"]).max() < 2e-4
+    assert np.abs(got.numpy()[g["sample_rows"]] - g["logits_rows"]).max() < 1e-4
+    assert abs(float(got.double().sum()) - float(g["logits_sum"])) < 1e-6 * float(g["logits_abs_sum"])
+    assert np.array_equal(O.landmark_argmax(got, B, frame).numpy(), g["argmax"])
+
+
+def test_cfg4_train_step_vs_reference_fixture(golden_dir):
+    """Same shape, train mode with dropout p = 0 at B = 1: loss, logits, coordinates and the norm of every parameter
+    gradient against the reference's own forward + autograd backward; every gradient element against the oracle."""
+    g = np.load(os.path.join(golden_dir, "cfg4_f224_a7_coord.npz"))
+    frame, naux, L, B = int(g["frame"]), int(g["naux"]), int(g["layers"]), 1
+    hip, ref = model_pair(frame, naux, L, coord=True, seed=int(g["weight_seed"]))
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    hip.train(); ref.train()
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+    frames = synthetic_frames(B, 128, frame, int(g["train_frame_seed"]))
+    coords0 = initial_coords(B, frame)
+    got, gc = hip(x=frames.to(DEV), node_coords=coords0.clone().to(DEV), edge_index=ei.to(DEV), node_type=nt.to(DEV),
+                  batch_idx=bi.to(DEV))
+    loss = (got ** 2).mean() + (gc ** 2).mean() * 1e-3
+    loss.backward()
+    assert np.abs(got.detach().cpu().numpy()[g["train_rows"]] - g["train_logits_rows"]).max() < 3e-4
+    assert np.abs(gc.detach().cpu().numpy() - g["train_coords"]).max() < 5e-4
+    assert abs(float(loss) - float(g["train_loss"])) < 1e-4 * float(g["train_loss"])
+    want_norm = dict(zip([str(k) for k in g["grad_keys"]], g["grad_norms"]))
+    for name, p in hip.named_parameters():
+        assert p.grad is not None, name
+        wn = want_norm[name]
+        gn = float(p.grad.double().norm())
+        # (a bias in front of a train-mode BatchNorm has an exactly-zero gradient: both sides are rounding noise)
+        assert abs(gn - wn) < 5e-3 * wn + 1e-5, (name, gn, wn)
+    w0 = hip.gnn_layers[0].module_0.lin.weight.grad.cpu().numpy()[::8, ::8]
+    assert np.abs(w0 - g["grad_w0"]).max() < 5e-3 * np.abs(g["grad_w0"]).max()
+    # element-wise against the oracle's autograd
+    want, wc = ref(x=frames, node_coords=coords0.clone(), edge_index=ei, node_type=nt, batch_idx=bi)
+    ((want ** 2).mean() + (wc ** 2).mean() * 1e-3).backward()
+    ref_grads = dict(ref.named_parameters())
+    for name, p in hip.named_parameters():
+        rg = ref_grads[name].grad
+        err = (p.grad.cpu() - rg).abs().max().item()
+        assert err < 5e-3 * rg.abs().max().item() + 1e-6, (name, err, rg.abs().max().item())

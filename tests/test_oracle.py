@@ -76,6 +76,34 @@ def test_gcn_norm_known_answer():
     assert ei3.shape[1] == 4 and torch.allclose(w3, torch.full((4,), 0.5))
 
 
+def test_gcn_conv_literal_known_answer():
+    """Both restatements against hand-computed numbers: an existing self loop, an isolated node, a one-directional edge
+    and a duplicate edge (which PyG's scatter_add counts twice)."""
+    from fixtures_util import gcn_known_answer
+    ei, x, w, b, want, dis = gcn_known_answer()
+    s = O.gcn_conv_sparse(x, ei, w, b)
+    d = O.gcn_conv_dense64(x, ei, w, b)
+    assert (s.double() - want).abs().max() < 1e-6
+    assert (d - want).abs().max() < 1e-7
+    ei2, wts = O.gcn_norm(ei, 6)
+    assert ei2.shape[1] == 6 + 6                       # 7 edges - 1 self loop + 6 self loops
+    deg = torch.zeros(6, dtype=torch.float64).index_add_(0, ei2[1], torch.ones(12, dtype=torch.float64))
+    assert deg.tolist() == [2, 4, 2, 1, 2, 1]
+    assert (deg.pow(-0.5) - dis).abs().max() < 1e-7
+
+
+def test_dense_and_sparse_agree_on_multigraphs():
+    rs = np.random.RandomState(0)
+    n, e = 40, 300                                     # dense enough that many (src, dst) pairs repeat
+    ei = torch.from_numpy(np.stack([rs.randint(0, n, e), rs.randint(0, n, e)]).astype(np.int64))
+    assert len({(int(a), int(b)) for a, b in ei.t()}) < e
+    x = torch.from_numpy(rs.standard_normal((n, 128)).astype(np.float32))
+    w = torch.from_numpy(rs.uniform(-0.1, 0.1, (128, 128)).astype(np.float32))
+    s = O.gcn_conv_sparse(x, ei, w, None)
+    d = O.gcn_conv_dense64(x, ei, w, None)
+    assert (s.double() - d).abs().max() < 1e-5
+
+
 def test_cfg1_plumbing(golden_dir):
     """BASELINE config 1: single 64x64 frame, 2 aux levels, 2 GNN layers, batch 1."""
     g = np.load(os.path.join(golden_dir, "cfg1_f64_a2.npz"))
@@ -211,3 +239,23 @@ def test_loss_oracle_matches_reference_evaluator(golden_dir, name):
     am = O.landmark_argmax(torch.from_numpy(d["logits"]), B, F).numpy()
     assert np.array_equal(am, d["argmax_main"])
     assert am[0, 1] == 3 * F + 5
+
+
+def test_cfg4_fixture_eval(golden_dir):
+    """BASELINE configs[3] shape (224x224, 7 aux levels, coordinate graph on) at B = 2: the oracle against what the
+    reference's own forward produced (sampled rows, coordinates after every layer, arg-max indices)."""
+    g = np.load(os.path.join(golden_dir, "cfg4_f224_a7_coord.npz"))
+    frame, naux, L, B = int(g["frame"]), int(g["naux"]), int(g["layers"]), int(g["batch"])
+    m = _oracle_model(frame, naux, L, coord=True, seed=int(g["weight_seed"]))
+    topo, ei, nt, bi = _graph(frame, naux, B, coord=True)
+    assert topo.num_nodes == int(g["num_nodes"])
+    frames = synthetic_frames(B, 128, frame, int(g["frame_seed"]))
+    coords0 = torch.from_numpy(g["coords0"])
+    with torch.no_grad():
+        feats = m.create_node_pixels(frames, B, coords0.view(B, 4, 2))
+        assert np.abs(feats.numpy()[g["hidden_rows"]] - g["node_feats_rows"]).max() < 1e-5
+        logits, coords, hidden = m.forward_nodes(feats, ei, nt, B, coords0.clone(), return_hidden=True)
+    assert np.abs(coords.numpy() - g["out_coords"]).max() < 1e-4
+    assert np.abs(logits.numpy()[g["sample_rows"]] - g["logits_rows"]).max() < 5e-5
+    assert abs(float(logits.double().sum()) - float(g["logits_sum"])) < 1e-6 * float(g["logits_abs_sum"])
+    assert np.array_equal(O.landmark_argmax(logits, B, frame).numpy(), g["argmax"])

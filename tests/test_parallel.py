@@ -43,7 +43,7 @@ def _model(frame, naux):
     return m.eval()          # eval-mode BN so that shard-wise and full-batch losses are identical functions
 
 
-def _worker(rank, world, port, frame, naux, B, out_dir):
+def _worker(rank, world, port, frame, naux, B, out_dir, mode="after"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,22 +63,47 @@ def _worker(rank, world, port, frame, naux, B, out_dir):
     nt = torch.from_numpy(np.tile(topo.node_type(), b))
     logits, _ = model.forward_nodes(shard["node_feats"], ei, nt, b)
     loss = (logits ** 2).sum() / (B * n)            # global mean written as a sum of shard sums
-    loss.backward()
-    red = parallel.GradientAllReducer(model.parameters(), average=False)
-    pending = red.allreduce(async_op=True)
-    pending.wait()
+    if mode == "after":                             # reduce once backward has returned
+        loss.backward()
+        red = parallel.GradientAllReducer(model.parameters(), average=False)
+        pending = red.allreduce(async_op=True)
+        pending.wait()
+    else:                                           # overlapped: buckets fire from post-accumulate-grad hooks inside backward
+        red = parallel.GradientAllReducer(model.parameters(), average=False, bucket_bytes=16 << 10).attach_hooks()
+        assert len(red._buckets) >= 4
+        fired = []
+        orig = red._launch
+        red._launch = lambda b: (fired.append(b), orig(b))[1]
+        if rank == 1:                               # a parameter that gets no gradient on one rank contributes zeros
+            model.node_classifiers[3][8].bias.requires_grad_(False)
+        loss.backward()
+        n_in_backward = len(fired)
+        model.node_classifiers[3][8].bias.requires_grad_(True)
+        red.finish()
+        assert n_in_backward >= len(red._buckets) - 1 and len(fired) == len(red._buckets)
+        # the classifier heads' bucket goes out first, the first GNN layer's last
+        names = {id(p): k for k, p in model.named_parameters()}
+        assert names[id(fired[0].params[0])].startswith("node_classifiers")
+        assert any(names[id(p)].startswith("gnn_layers.0.") for p in fired[-1].params)
+        # second step with the same reducer: counters were reset
+        for p in model.parameters():
+            p.grad = None
+        logits, _ = model.forward_nodes(shard["node_feats"], ei, nt, b)
+        ((logits ** 2).sum() / (B * n)).backward()
+        red.finish()
     if rank == 0:
         torch.save({k: p.grad.clone() for k, p in model.named_parameters()}, os.path.join(out_dir, "grads.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gradients_match_single_process(tmp_path):
+@pytest.mark.parametrize("mode", ["after", "overlapped"])
+def test_two_rank_gradients_match_single_process(tmp_path, mode):
     frame, naux, B, world = 8, 2, 4, 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(world, port, frame, naux, B, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, frame, naux, B, str(tmp_path), mode), nprocs=world, join=True)
     got = torch.load(os.path.join(tmp_path, "grads.pt"))
     topo = HierTopology(TopologySpec(frame, naux))
     n = topo.num_nodes
@@ -90,3 +115,18 @@ def test_two_rank_gradients_match_single_process(tmp_path):
     ((logits ** 2).sum() / (B * n)).backward()
     for k, p in model.named_parameters():
         assert torch.allclose(got[k], p.grad, rtol=1e-4, atol=1e-6), k
+
+
+def test_bench_starts_its_own_ranks_and_propagates_failure():
+    """`python bench.py --gpus 2` without WORLD_SIZE starts 2 rank processes itself (before any GPU call in the parent).
+    In this container there is no GPU, so both ranks refuse to run and the parent must exit non-zero."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.is_available():
+        pytest.skip("exercised for real by the GPU runs")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("needs a GPU") == 2, r.stderr

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/profiles
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="bench.py --steps 30 --warmup 5 --no-cpu-baseline"
+CMD="bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --repeats 0"
 cd $PWD
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/trace -- python3 $CMD > $OUT/${TAG}_trace_run.log 2>&1
 cp $(find /tmp/prof_$TAG/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv 2>/dev/null
@@ -37,6 +37,9 @@ for name,cs in agg.items():
         r["hbm_bytes_per_launch"]=r["hbm_read_bytes_per_launch"]+r["hbm_write_bytes_per_launch"]
     out[name]=r
 out["command"]="rocprofv3 --pmc <counter set> -- python3 $CMD   (one pass per counter set)"
+import sys; sys.path.insert(0, ".")
+import bench
+out["kernel_source_digest"]=bench.kernel_source_digest()   # bench.py only trusts a summary measured on the current kernel sources
 json.dump(out, open("$OUT/${TAG}_pmc.json","w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
 PY

@@ -1,10 +1,15 @@
 #!/bin/bash
+# run from the repo root on the GPU box
+shopt -s globstar
 export TMPDIR=/tmp
 run() { # tag, env...
   tag=$1; shift
   for pmc in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
     n=$(echo $pmc | tr ' ' '_')
-    env "$@" rocprofv3 --pmc $pmc --output-format csv -d /tmp/p2_${tag}_$n -- python3 tools_micro.py > /tmp/p2_${tag}_$n.log 2>&1
+    env "$@" rocprofv3 --pmc $pmc --output-format csv -d /tmp/p2_${tag}_$n -- python3 tools/tools_micro.py > /tmp/p2_${tag}_$n.log 2>&1
+    if ! ls /tmp/p2_${tag}_$n/**/*counter_collection.csv /tmp/p2_${tag}_$n/*/*counter_collection.csv >/dev/null 2>&1; then
+      echo "tools_pmc2: no counter_collection.csv for $tag / $pmc (run from the repo root); log:" >&2; tail -5 /tmp/p2_${tag}_$n.log >&2; exit 1
+    fi
   done
   python3 - <<PY
 import csv, glob, collections
