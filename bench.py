@@ -229,7 +229,7 @@ def main_train(args, world, rank, device):
                        "parallelism": f"dp{world} (batch-sharded frames, gradient all-reduce overlapped with backward)"},
             # train-step floor = 3 x the forward's algorithmic bytes / FLOPs
             "stack_hbm_frac": round(fps / world * 3 * sb / 1e9 / PEAK_HBM_GBS, 4),
-            "stack_mfma_frac": round(fps / world * 3 * sf / 1e12 / PEAK_F32_MFMA_TF, 4), "final_loss": float(loss)}), flush=True)
+            "stack_mfma_frac": round(fps / world * 3 * sf / 1e12 / PEAK_F32_MFMA_TF, 4), "final_loss": float(loss.detach())}), flush=True)
 
 
 def cpu_baseline(args, kw, state_dict):

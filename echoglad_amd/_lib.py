@@ -22,12 +22,26 @@ _p = ct.c_void_p
 _i = ct.c_int
 _i64 = ct.c_int64
 
+class ClsTrainParams(ct.Structure):
+    """eg_cls_train_params of include/echoglad_hip.h (stacked parameters of the 4 classifier heads, train mode)."""
+    _fields_ = [(n, _p) for n in ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3", "b3",
+                                  "running_mean1", "running_var1", "running_mean2", "running_var2")] + \
+               [(n, ct.c_float) for n in ("eps1", "eps2", "momentum1", "momentum2", "p1", "p2")] + \
+               [("seed1", ct.c_uint64), ("seed2", ct.c_uint64)]
+
+
+_f = ct.c_float
+_u64 = ct.c_uint64
+_pp = ct.POINTER(ClsTrainParams)
+
 # name -> (restype, argtypes); must list every symbol the header declares
 SIGNATURES: Dict[str, tuple] = {
     "eg_version": (_i, []),
     "eg_last_error": (ct.c_char_p, []),
     "eg_topo_create": (_i, [_i, _i, _i, _i, ct.POINTER(_p)]),
     "eg_csr_create": (_i, [_p, _i64, _i64, _p, ct.POINTER(_p)]),
+    "eg_graph_is_symmetric": (_i, [_p]),
+    "eg_csr_create_transposed": (_i, [_p, _p, _i64, _p, ct.POINTER(_p)]),
     "eg_graph_destroy": (_i, [_p]),
     "eg_graph_num_nodes": (_i64, [_p]),
     "eg_graph_is_structured": (_i, [_p]),
@@ -50,6 +64,11 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_bn_stats": (_i, [_p, _i64, _p, _p, _p, _p]),
     "eg_bn_act_fwd": (_i, [_p, _i64, _p, _p, _p, _i, ct.c_float, ct.c_uint64, _p, _p]),
     "eg_bn_act_bwd": (_i, [_p, _p, _i64, _p, _p, _p, _p, _i, ct.c_float, ct.c_uint64, _p, _p, _p, _p, _p]),
+    "eg_gcn_layer_train_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _f, _u64, _i, _p, _p, _p, _p, _p, _p]),
+    "eg_gcn_layer_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _f, _u64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "eg_classifier_train_workspace_bytes": (ct.c_size_t, []),
+    "eg_classifier_train_fwd": (_i, [_p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _i, _p, _p]),
+    "eg_classifier_bwd": (_i, [_p, _p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "eg_bilinear4_fwd": (_i, [_p, _p, _i, _i, _i64, _i64, _i, _p, _p]),
     "eg_bilinear4_bwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i, _p, _p, _p]),
     "eg_pack_levels": (_i, [ct.POINTER(_p), ct.POINTER(_i), _i, _i, _i64, _i64, _p, _p]),

@@ -1,0 +1,552 @@
+// Train-mode classifier heads for gfx950: forward and backward of
+//     h[node_type == 0]  ->  4 x [Linear(128,32)-BN-ReLU-Drop-Linear(32,16)-BN-ReLU-Drop-Linear(16,1)]  ->  cat
+// (reference src/core/models.py:363-377 heads, :485 node-type filter, :488-490 cat) with BATCH statistics in both
+// BatchNorm layers, as ONE stacked network: the four first layers are one [128 -> 128] product (4 x BatchNorm1d(32) on the
+// stacked output IS BatchNorm1d(128) with stacked parameters), the four second layers one block-diagonal [128 -> 64]
+// product, the third a 16-wide dot per head.
+//
+// What is kept for the backward: z1 [R,128] and z2 [R,64] (pre-BatchNorm activations of the two hidden layers, R = valid
+// rows) and the BatchNorm statistics; the hidden activations h1 / h2 themselves are never written: every kernel that needs
+// them recomputes BN + ReLU + Dropout (a counter-based mask, a pure function of (seed, element)) from z on load.
+//
+//   forward   k_lin128_map<stats>   z1 = h[valid rows] W1^T + b1, column sums of z1, z1^2          (fp32 MFMA 16x16x4)
+//             k_cls_mid_fwd         h1 = drop(relu(bn1(z1)));  z2 = h1 W2^T + b2 per head, column sums of z2, z2^2
+//             k_cls_out_fwd         h2 = drop(relu(bn2(z2)));  logit = h2 . w3 + b3
+//   backward  k_cls_out_bwd_sums    g2 = dlogit w3 mask2:  sum g2, sum g2 xhat2 (-> dgamma2, dbeta2), dw3, db3
+//             k_cls_mid_bwd         dz2 = bn2'(g2);  dW2 += dz2^T h1;  dh1 = dz2 W2   (pre-mask gradient of h1)
+//             eg_bn_act_bwd         dz1 = bn1'(dh1 mask1), dgamma1, dbeta1                                  (train.hip)
+//             k_lin128_map          dh[valid rows] = dz1 W1                                          (transposed W)
+//             k_dweight_partial     dW1 = dz1^T h[valid rows]                                               (train.hip)
+// Biases in front of a train-mode BatchNorm (b1, b2) have an identically zero gradient (the batch mean absorbs them).
+// Every reduction is two-stage with a fixed order: bitwise reproducible, no float atomics.
+#include "train_common.h"
+
+namespace eg {
+
+constexpr int H1 = 128;             // 4 heads x 32
+constexpr int H2 = 64;              // 4 heads x 16
+constexpr int LDZ = H2 + 4;         // LDS row stride of a [64][64] tile
+constexpr int CT_THREADS = 256;
+constexpr int CT_MAX_BLOCKS = 1024; // partial slabs per kernel
+
+struct ClsBn {                      // per-channel vectors of one BatchNorm layer (device pointers)
+    const float *mean, *invstd, *scale, *shift, *gamma;
+};
+struct ClsDrop {
+    float p, inv_keep;
+    unsigned long long seed;
+};
+
+// ---- z1 = x[in rows] W^T (+ bias) -> out[out rows]  (+ column sums of the result) ---------------------------------
+// 8 waves, 64-row tiles that never straddle a frame; wave w owns output channels 16w..16w+15 (W slice in 32 VGPRs).
+struct LinMapDims {
+    int n_valid, tiles_per_frame, batch, transpose_w;
+    int in_stride, in_lo, out_stride, out_lo;
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(512, 4) void k_lin128_map(const float* __restrict__ x, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       float* __restrict__ partial, const LinMapDims a) {
+    __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA + 4];
+    const int tid = threadIdx.x, lane_k = tid & 63, wave = wave_id();
+    float wreg[32];
+    load_w_slice16(W, wave, lane_k, a.transpose_w, wreg);
+    const int ch_d = 16 * wave + 4 * (lane_k >> 4);
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + ch_d) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs = 0.f, cq = 0.f;                              // STATS: thread -> channel tid & 127, rows 16 (tid >> 7) ..
+    const int n_tiles = a.tiles_per_frame * a.batch;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
+        const int frame = tile / a.tiles_per_frame;
+        const int n0 = (tile - frame * a.tiles_per_frame) * TILE;
+        const int rows_here = (a.n_valid - n0) < TILE ? (a.n_valid - n0) : TILE;
+        const float* __restrict__ xf = x + ((size_t)frame * a.in_stride + a.in_lo + n0) * C;
+        float* __restrict__ of = out + ((size_t)frame * a.out_stride + a.out_lo + n0) * C;
+        const int rl0 = 8 * wave;
+        const PairLane pl{lane >> 5, lane & 31};
+        {
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rl0 + 2 * k + pl.h;
+                v[k] = *reinterpret_cast<const f32x4*>(xf + ((unsigned)(r < rows_here ? r : rows_here - 1) * (unsigned)C + 4u * pl.q));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(&s_a[(rl0 + 2 * k + pl.h) * LDA + 4 * pl.q]) = v[k];
+        }
+        __syncthreads();
+        f32x4v acc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        mfma16_pair<false>(s_a, 0, lane, wreg, acc[0], acc[1]);
+        if (rows_here > 32) mfma16_pair<false>(s_a, 32, lane, wreg, acc[2], acc[3]);
+        __syncthreads();
+        {
+            const int j = lane & 15, q4 = lane >> 4;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                f32x4v o;
+                o.x = acc[b].x + bv.x; o.y = acc[b].y + bv.y; o.z = acc[b].z + bv.z; o.w = acc[b].w + bv.w;
+                *reinterpret_cast<f32x4v*>(&s_a[(16 * b + j) * LDA + 16 * wave + 4 * q4]) = o;
+            }
+        }
+        __syncthreads();
+        if (rl0 < rows_here) {                              // (uniform per wave) whole 512-B rows, a duplicate store for a missing row
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rl0 + 2 * k + pl.h;
+                const int rr = r < rows_here ? r : rows_here - 1;
+                *reinterpret_cast<f32x4*>(of + (size_t)rr * C + 4 * pl.q) = *reinterpret_cast<const f32x4*>(&s_a[rr * LDA + 4 * pl.q]);
+            }
+        }
+        if (STATS) {
+            const int c = tid & 127, r0 = 16 * (tid >> 7);
+#pragma unroll 4
+            for (int r = r0; r < r0 + 16; ++r) {
+                const float v = r < rows_here ? s_a[r * LDA + c] : 0.f;
+                cs += v; cq += v * v;
+            }
+        }
+        __syncthreads();
+    }
+    if (STATS) {
+        float* red = s_a;                                   // [4 row groups][2][128]
+        red[(tid >> 7) * 256 + (tid & 127)] = cs;
+        red[(tid >> 7) * 256 + 128 + (tid & 127)] = cq;
+        __syncthreads();
+        if (tid < 256) partial[(size_t)blockIdx.x * 256 + tid] = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+    }
+}
+
+// ---- hidden activation of a BN-ReLU-Dropout block, recomputed from z ------------------------------------------------
+__device__ inline float hidden_act(float z, float scale, float shift, const ClsDrop& d, unsigned long long idx) {
+    float v = fmaxf(z * scale + shift, 0.f);
+    if (d.p > 0.f) v *= keep_scale(d.seed, idx, d.p, d.inv_keep);
+    return v;
+}
+
+// 64 rows of z1 -> h1 tile in LDS (row stride LDA); rows >= rows_here are zero
+__device__ inline void load_h1_tile(const float* __restrict__ z1, long long row0, int rows_here, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const ClsDrop& d, float* s_h, int tid) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = tid + CT_THREADS * it;                // float4 index inside the tile: row e / 32, channels 4 (e % 32)
+        const int r = e >> 5, c4 = (e & 31) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows_here) {
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(z1 + (size_t)(row0 + r) * H1 + c4);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4);
+            const unsigned long long idx = (unsigned long long)(row0 + r) * H1 + c4;
+            v.x = hidden_act(zz.x, sc.x, sh.x, d, idx + 0);
+            v.y = hidden_act(zz.y, sc.y, sh.y, d, idx + 1);
+            v.z = hidden_act(zz.z, sc.z, sh.z, d, idx + 2);
+            v.w = hidden_act(zz.w, sc.w, sh.w, d, idx + 3);
+        }
+        *reinterpret_cast<f32x4*>(&s_h[r * LDA + c4]) = v;
+    }
+}
+
+// ---- forward, second layers: z2 = h1 W2^T + b2 (block diagonal: head = wave), column sums of z2 -----------------------
+__global__ __launch_bounds__(CT_THREADS) void k_cls_mid_fwd(const float* __restrict__ z1, long long rows, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, const ClsBn bn1, const ClsDrop d1,
+                                                            float* __restrict__ z2, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float s_h[TILE * LDA];
+    __shared__ __attribute__((aligned(16))) float s_z[TILE * LDZ];
+    const int tid = threadIdx.x, lane = tid & 63, head = wave_id();
+    // MFMA 16x16x4 A operand: lane (o = l & 15, kq = l >> 4) holds W2[head][o][8 kq + t], t = 0..7
+    float w2a[8];
+    {
+        const f32x4* p = reinterpret_cast<const f32x4*>(w2 + (size_t)(head * 16 + (lane & 15)) * 32 + 8 * (lane >> 4));
+        const f32x4 q0 = p[0], q1 = p[1];
+        w2a[0] = q0.x; w2a[1] = q0.y; w2a[2] = q0.z; w2a[3] = q0.w; w2a[4] = q1.x; w2a[5] = q1.y; w2a[6] = q1.z; w2a[7] = q1.w;
+    }
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(b2 + head * 16 + 4 * (lane >> 4));
+    float cs = 0.f, cq = 0.f;                               // thread -> channel tid & 63, rows 16 (tid >> 6) ..
+    const long long n_tiles = (rows + TILE - 1) / TILE;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row0 = tile * TILE;
+        const int rows_here = (int)((rows - row0) < TILE ? (rows - row0) : TILE);
+        load_h1_tile(z1, row0, rows_here, bn1.scale, bn1.shift, d1, s_h, tid);
+        __syncthreads();
+        const int j = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) {
+            const f32x4* hp = reinterpret_cast<const f32x4*>(&s_h[(16 * b4 + j) * LDA + 32 * head + 8 * kq]);
+            const f32x4 h0 = hp[0], h1v = hp[1];
+            f32x4v z = {0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[0], h0.x, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[1], h0.y, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[2], h0.z, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[3], h0.w, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[4], h1v.x, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[5], h1v.y, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[6], h1v.z, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[7], h1v.w, z, 0, 0, 0);
+            // D: lane (row j, q = kq), reg e -> z2[16 b4 + j][16 head + 4 q + e]
+            f32x4v o;
+            o.x = z.x + b2v.x; o.y = z.y + b2v.y; o.z = z.z + b2v.z; o.w = z.w + b2v.w;
+            *reinterpret_cast<f32x4v*>(&s_z[(16 * b4 + j) * LDZ + 16 * head + 4 * kq]) = o;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = tid + CT_THREADS * it, r = e >> 4, c4 = (e & 15) * 4;
+            if (r < rows_here)
+                *reinterpret_cast<f32x4*>(z2 + (size_t)(row0 + r) * H2 + c4) = *reinterpret_cast<const f32x4*>(&s_z[r * LDZ + c4]);
+        }
+        {
+            const int c = tid & 63, r0 = 16 * (tid >> 6);
+#pragma unroll 4
+            for (int r = r0; r < r0 + 16; ++r) {
+                const float v = r < rows_here ? s_z[r * LDZ + c] : 0.f;
+                cs += v; cq += v * v;
+            }
+        }
+        __syncthreads();
+    }
+    float* red = s_z;                                       // [4 row groups][2][64]
+    red[(tid >> 6) * 128 + (tid & 63)] = cs;
+    red[(tid >> 6) * 128 + 64 + (tid & 63)] = cq;
+    __syncthreads();
+    if (tid < 128) partial[(size_t)blockIdx.x * 128 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+}
+
+// ---- forward, third layers: one thread per (row, head) -----------------------------------------------------------------
+__global__ __launch_bounds__(CT_THREADS) void k_cls_out_fwd(const float* __restrict__ z2, long long rows, const ClsBn bn2, const ClsDrop d2,
+                                                            const float* __restrict__ w3, const float* __restrict__ b3, int sigmoid,
+                                                            float* __restrict__ logits) {
+    const long long n = rows * 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int head = (int)(i & 3);
+        const long long row = i >> 2;
+        const float* zp = z2 + (size_t)row * H2 + 16 * head;
+        float y = b3[head];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(zp + 4 * q);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(bn2.scale + 16 * head + 4 * q);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(bn2.shift + 16 * head + 4 * q);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(w3 + 16 * head + 4 * q);
+            const unsigned long long idx = (unsigned long long)row * H2 + 16 * head + 4 * q;
+            y += ww.x * hidden_act(zz.x, sc.x, sh.x, d2, idx + 0) + ww.y * hidden_act(zz.y, sc.y, sh.y, d2, idx + 1) +
+                 ww.z * hidden_act(zz.z, sc.z, sh.z, d2, idx + 2) + ww.w * hidden_act(zz.w, sc.w, sh.w, d2, idx + 3);
+        }
+        if (sigmoid) y = 1.0f / (1.0f + __expf(-y));
+        logits[i] = y;
+    }
+}
+
+// ---- backward of the third layers: column sums ----------------------------------------------------------------------------
+// thread = (row, head): g2[c] = dlogit * w3[c] * mask2[c];  sums over rows of g2, g2 * xhat2, dlogit * h2 (= dw3) and dlogit (= db3).
+// partial layout per block: [3][64] + [4]
+constexpr int OUT_SUMS = 3 * H2 + 4;
+__global__ __launch_bounds__(CT_THREADS) void k_cls_out_bwd_sums(const float* __restrict__ dlogits, const float* __restrict__ z2, long long rows,
+                                                                 const ClsBn bn2, const ClsDrop d2, const float* __restrict__ w3,
+                                                                 float* __restrict__ partial) {
+    __shared__ float red[4][CT_THREADS / 4][17];            // [head][thread of the head][channel]
+    const int tid = threadIdx.x, head = tid & 3;
+    float mean[16], istd[16], scl[16], sft[16], w3v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int ch = 16 * head + c;
+        mean[c] = bn2.mean[ch]; istd[c] = bn2.invstd[ch]; scl[c] = bn2.scale[ch]; sft[c] = bn2.shift[ch]; w3v[c] = w3[ch];
+    }
+    float sg[16], sgx[16], sw[16], sb = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sg[c] = sgx[c] = sw[c] = 0.f;
+    const long long n = rows * 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + tid; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i >> 2;                       // (i & 3) == head: blockDim and gridDim * blockDim are multiples of 4
+        const float dl = dlogits[i];
+        const float* zp = z2 + (size_t)row * H2 + 16 * head;
+        sb += dl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 zq = *reinterpret_cast<const f32x4*>(zp + 4 * q);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = 4 * q + u;
+                const float zz = zq[u];
+                const float xh = (zz - mean[c]) * istd[c];
+                const float v = zz * scl[c] + sft[c];
+                const float k = d2.p > 0.f ? keep_scale(d2.seed, (unsigned long long)row * H2 + 16 * head + c, d2.p, d2.inv_keep) : 1.0f;
+                const float m = v > 0.f ? k : 0.f;
+                const float g = dl * w3v[c] * m;
+                sg[c] += g; sgx[c] += g * xh; sw[c] += dl * v * m;
+            }
+        }
+    }
+    // block reduction over the 64 threads of each head, in a fixed order
+    float* out = partial + (size_t)blockIdx.x * OUT_SUMS;
+#pragma unroll 1
+    for (int q = 0; q < 3; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) red[head][tid >> 2][c] = q == 0 ? sg[c] : (q == 1 ? sgx[c] : sw[c]);
+        __syncthreads();
+        if (tid < H2) {
+            const int hd = tid >> 4, c = tid & 15;
+            float s = 0.f;
+            for (int t = 0; t < CT_THREADS / 4; ++t) s += red[hd][t][c];
+            out[q * H2 + tid] = s;
+        }
+    }
+    __syncthreads();
+    red[head][tid >> 2][16] = sb;
+    __syncthreads();
+    if (tid < 4) {
+        float s = 0.f;
+        for (int t = 0; t < CT_THREADS / 4; ++t) s += red[tid][t][16];
+        out[3 * H2 + tid] = s;
+    }
+}
+
+// ---- backward of the second layers ------------------------------------------------------------------------------------------
+// per 64-row tile: dz2 = gamma2 invstd2 (g2 - mean(g2) - xhat2 mean(g2 xhat2));  dW2[head] += dz2^T h1 (K = rows, MFMA);
+// dh1 = dz2 W2 (MFMA), written as whole rows.  tot = the reduced sums of k_cls_out_bwd_sums (double).
+__global__ __launch_bounds__(CT_THREADS) void k_cls_mid_bwd(const float* __restrict__ dlogits, const float* __restrict__ z2,
+                                                            const float* __restrict__ z1, long long rows, const ClsBn bn1, const ClsDrop d1,
+                                                            const ClsBn bn2, const ClsDrop d2, const float* __restrict__ w2,
+                                                            const float* __restrict__ w3, const double* __restrict__ tot,
+                                                            float* __restrict__ dh1, float* __restrict__ partial_dw2) {
+    __shared__ __attribute__((aligned(16))) float s_h[TILE * LDA];      // h1 tile, then the dh1 tile
+    __shared__ __attribute__((aligned(16))) float s_dz[TILE * LDZ];
+    __shared__ float s_c[3][H2];                                          // a2 = gamma2 invstd2, mean g2, mean g2 xhat2
+    const int tid = threadIdx.x, lane = tid & 63, head = wave_id();
+    if (tid < H2) {
+        const double inv_n = 1.0 / (double)rows;
+        s_c[0][tid] = bn2.gamma[tid] * bn2.invstd[tid];
+        s_c[1][tid] = (float)(tot[tid] * inv_n);
+        s_c[2][tid] = (float)(tot[H2 + tid] * inv_n);
+    }
+    // dh1 = dz2 W2: MFMA A operand lane (m = l & 15, kq = l >> 4) holds W2[head][4 t + kq][16 ib + m], t = 0..3, ib = 0, 1
+    float wt[2][4];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wt[ib][t] = w2[(size_t)(head * 16 + 4 * t + (lane >> 4)) * 32 + 16 * ib + (lane & 15)];
+    f32x4v dw[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};      // dW2[head][4 q + e][16 ib + i]
+    __syncthreads();
+    const long long n_tiles = (rows + TILE - 1) / TILE;
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row0 = tile * TILE;
+        const int rows_here = (int)((rows - row0) < TILE ? (rows - row0) : TILE);
+        load_h1_tile(z1, row0, rows_here, bn1.scale, bn1.shift, d1, s_h, tid);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                                 // dz2 tile: rows >= rows_here are zero
+            const int e = tid + CT_THREADS * it, r = e >> 4, c4 = (e & 15) * 4;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (r < rows_here) {
+                const long long row = row0 + r;
+                const float dl = dlogits[row * 4 + (c4 >> 4)];
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(z2 + (size_t)row * H2 + c4);
+                const f32x4 mn = *reinterpret_cast<const f32x4*>(bn2.mean + c4), is = *reinterpret_cast<const f32x4*>(bn2.invstd + c4);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(bn2.scale + c4), sh = *reinterpret_cast<const f32x4*>(bn2.shift + c4);
+                const f32x4 ww = *reinterpret_cast<const f32x4*>(w3 + c4);
+                float ov[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ch = c4 + u;
+                    const float xh = (zz[u] - mn[u]) * is[u];
+                    const float v = zz[u] * sc[u] + sh[u];
+                    const float k = d2.p > 0.f ? keep_scale(d2.seed, (unsigned long long)row * H2 + ch, d2.p, d2.inv_keep) : 1.0f;
+                    const float g = v > 0.f ? dl * ww[u] * k : 0.f;
+                    ov[u] = s_c[0][ch] * (g - s_c[1][ch] - xh * s_c[2][ch]);
+                }
+                o = f32x4{ov[0], ov[1], ov[2], ov[3]};
+            }
+            *reinterpret_cast<f32x4*>(&s_dz[r * LDZ + c4]) = o;
+        }
+        __syncthreads();
+        const int i16 = lane & 15, kq = lane >> 4;
+        // dW2[head] += dz2[:, head]^T h1[:, head]:  A[o][k] = dz2[4 s + k][16 head + o],  B[k][i] = h1[4 s + k][32 head + 16 ib + i]
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const float av = s_dz[(4 * s + kq) * LDZ + 16 * head + i16];
+            const float b0 = s_h[(4 * s + kq) * LDA + 32 * head + i16];
+            const float b1 = s_h[(4 * s + kq) * LDA + 32 * head + 16 + i16];
+            dw[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, dw[0], 0, 0, 0);
+            dw[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, dw[1], 0, 0, 0);
+        }
+        __syncthreads();                                                  // every wave is done with h1: the tile becomes dh1
+        // dh1[r][32 head + 16 ib + m] = sum_o dz2[r][16 head + o] W2[head][o][16 ib + m]:  B[k][n] = dz2[16 b4 + n][16 head + 4 t + k]
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) {
+            f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float bv = s_dz[(16 * b4 + i16) * LDZ + 16 * head + 4 * t + kq];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[0][t], bv, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[1][t], bv, acc1, 0, 0, 0);
+            }
+            // D: lane (row n = i16, q = kq), reg e -> dh1[16 b4 + n][32 head + 16 ib + 4 q + e]
+            *reinterpret_cast<f32x4v*>(&s_h[(16 * b4 + i16) * LDA + 32 * head + 4 * kq]) = acc0;
+            *reinterpret_cast<f32x4v*>(&s_h[(16 * b4 + i16) * LDA + 32 * head + 16 + 4 * kq]) = acc1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = tid + CT_THREADS * it, r = e >> 5, c4 = (e & 31) * 4;
+            if (r < rows_here)
+                *reinterpret_cast<f32x4*>(dh1 + (size_t)(row0 + r) * H1 + c4) = *reinterpret_cast<const f32x4*>(&s_h[r * LDA + c4]);
+        }
+        __syncthreads();
+    }
+    // per-block dW2 partial [4][16][32]: lane (i = l & 15, q), reg e -> [head][4 q + e][16 ib + i]
+    float* p = partial_dw2 + (size_t)blockIdx.x * (4 * 16 * 32) + head * 512;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[(4 * (lane >> 4) + e) * 32 + 16 * ib + (lane & 15)] = dw[ib][e];
+}
+
+__global__ void k_zero_rows(float* __restrict__ x, int batch, int stride, int lo, int n_valid) {
+    // rows [0, lo) and [lo + n_valid, stride) of every frame (the rows the node-type filter drops: their gradient is zero)
+    const int per = stride - n_valid;
+    const long long n4 = (long long)batch * per * (C / 4);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long rr = i / (C / 4);
+        const int f = (int)(rr / per), k = (int)(rr - (long long)f * per);
+        const int row = k < lo ? k : n_valid + k;
+        *reinterpret_cast<f32x4*>(x + ((size_t)f * stride + row) * C + (i % (C / 4)) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+__global__ void k_cls_grads_final(const double* __restrict__ tot_out, const double* __restrict__ tot_dw2, float* __restrict__ grads) {
+    // grads layout: eg_classifier_bwd in the header
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    float* dw2 = grads + 128 * 128 + 3 * 128;
+    float* tail = dw2 + 4 * 16 * 32;                        // db2[64], dgamma2[64], dbeta2[64], dw3[64], db3[4]
+    if (t < 4 * 16 * 32) dw2[t] = (float)tot_dw2[t];
+    if (t < H2) {
+        tail[t] = 0.f;                                      // db2: a bias in front of a train-mode BatchNorm
+        tail[H2 + t] = (float)tot_out[H2 + t];              // dgamma2 = sum g2 xhat2
+        tail[2 * H2 + t] = (float)tot_out[t];               // dbeta2 = sum g2
+        tail[3 * H2 + t] = (float)tot_out[2 * H2 + t];      // dw3
+    }
+    if (t < 4) tail[4 * H2 + t] = (float)tot_out[3 * H2 + t];
+    if (t < 128) grads[128 * 128 + t] = 0.f;                // db1
+}
+
+static int grid_for(long long work_items, int per_block, int cap) {
+    long long b = (work_items + per_block - 1) / per_block;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace eg
+
+using namespace eg;
+
+// internal launchers of train.hip
+int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, int relu, float dropout_p, unsigned long long seed, void* workspace, float* dz,
+                     float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream);
+
+extern "C" {
+
+// workspace layout (bytes): [0, 8 MB) float partial slabs; then 4096 doubles of totals; eg_bn_act_bwd / dweight use the
+// region from offset CLS_WS_SHARED on (eg_workspace_bytes() bytes)
+static const size_t CLS_WS_PARTIAL = (size_t)CT_MAX_BLOCKS * 2048 * sizeof(float);
+static const size_t CLS_WS_TOTALS = 4096 * sizeof(double);
+static const size_t CLS_WS_SHARED = CLS_WS_PARTIAL + CLS_WS_TOTALS;
+
+size_t eg_classifier_train_workspace_bytes(void) { return CLS_WS_SHARED + eg_workspace_bytes(); }
+
+int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                            const eg_cls_train_params* P, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
+                            float* logits, eg_stream_t stream_) {
+    if (!h || !P || !workspace || !z1 || !z2 || !bn || !logits) return set_error(EG_ERR_ARG, "NULL argument");
+    if (batch < 1 || n_per_frame < 1 || row_lo < 0 || n_valid < 1 || row_lo + n_valid > n_per_frame)
+        return set_error(EG_ERR_ARG, "bad row range");
+    if (n_per_frame * (int64_t)batch >= (1ll << 31)) return set_error(EG_ERR_ARG, "batch * nodes exceeds int32");
+    if (!(P->p1 >= 0.f && P->p1 < 1.f && P->p2 >= 0.f && P->p2 < 1.f)) return set_error(EG_ERR_ARG, "dropout p must be in [0, 1)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long rows = (long long)batch * n_valid;
+    float* partial = (float*)workspace;
+    double* totals = (double*)((char*)workspace + CLS_WS_PARTIAL);
+    // ---- first layers + BatchNorm1d(128) statistics
+    LinMapDims d{};
+    d.n_valid = (int)n_valid; d.tiles_per_frame = (int)((n_valid + TILE - 1) / TILE); d.batch = batch; d.transpose_w = 0;
+    d.in_stride = (int)n_per_frame; d.in_lo = (int)row_lo; d.out_stride = (int)n_valid; d.out_lo = 0;
+    const long long n_tiles = (long long)d.tiles_per_frame * batch;
+    const int g1 = (int)(n_tiles < 512 ? n_tiles : 512);
+    hipLaunchKernelGGL(k_lin128_map<true>, dim3(g1), dim3(512), 0, stream, h, P->w1, P->b1, z1, partial, d);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(8), dim3(256), 0, stream, partial, g1, 256, totals);
+    BnFinalize f1{totals, rows, H1, P->gamma1, P->beta1, P->eps1, P->momentum1, P->running_mean1, P->running_var1,
+                  bn + 0 * H1, bn + 1 * H1, bn + 2 * H1, bn + 3 * H1};
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(128), 0, stream, f1);
+    // ---- second layers + BatchNorm1d(64) statistics
+    float* bn2p = bn + 4 * H1;
+    const ClsBn bn1{bn + 0 * H1, bn + 1 * H1, bn + 2 * H1, bn + 3 * H1, P->gamma1};
+    const ClsDrop d1{P->p1, P->p1 > 0.f ? 1.0f / (1.0f - P->p1) : 1.0f, P->seed1};
+    const int g2 = grid_for(rows, TILE, 768);
+    hipLaunchKernelGGL(k_cls_mid_fwd, dim3(g2), dim3(CT_THREADS), 0, stream, z1, rows, P->w2, P->b2, bn1, d1, z2, partial);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4), dim3(256), 0, stream, partial, g2, 128, totals + 256);
+    BnFinalize f2{totals + 256, rows, H2, P->gamma2, P->beta2, P->eps2, P->momentum2, P->running_mean2, P->running_var2,
+                  bn2p + 0 * H2, bn2p + 1 * H2, bn2p + 2 * H2, bn2p + 3 * H2};
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, stream, f2);
+    // ---- third layers
+    const ClsBn bn2{bn2p + 0 * H2, bn2p + 1 * H2, bn2p + 2 * H2, bn2p + 3 * H2, P->gamma2};
+    const ClsDrop d2{P->p2, P->p2 > 0.f ? 1.0f / (1.0f - P->p2) : 1.0f, P->seed2};
+    hipLaunchKernelGGL(k_cls_out_fwd, dim3(grid_for(rows * 4, CT_THREADS, 4096)), dim3(CT_THREADS), 0, stream, z2, rows, bn2, d2,
+                       P->w3, P->b3, sigmoid, logits);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                      const eg_cls_train_params* P, const float* z1, const float* z2, const float* bn, void* workspace,
+                      float* dh1_scratch, float* dz1_scratch, float* dh, float* grads, eg_stream_t stream_) {
+    if (!dlogits || !h || !P || !z1 || !z2 || !bn || !workspace || !dh1_scratch || !dz1_scratch || !grads)
+        return set_error(EG_ERR_ARG, "NULL argument");
+    if (batch < 1 || n_per_frame < 1 || row_lo < 0 || n_valid < 1 || row_lo + n_valid > n_per_frame)
+        return set_error(EG_ERR_ARG, "bad row range");
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long rows = (long long)batch * n_valid;
+    float* partial = (float*)workspace;
+    double* totals = (double*)((char*)workspace + CLS_WS_PARTIAL);
+    void* shared = (char*)workspace + CLS_WS_SHARED;
+    const float* bn2p = bn + 4 * H1;
+    const ClsBn bn1{bn + 0 * H1, bn + 1 * H1, bn + 2 * H1, bn + 3 * H1, P->gamma1};
+    const ClsBn bn2{bn2p + 0 * H2, bn2p + 1 * H2, bn2p + 2 * H2, bn2p + 3 * H2, P->gamma2};
+    const ClsDrop d1{P->p1, P->p1 > 0.f ? 1.0f / (1.0f - P->p1) : 1.0f, P->seed1};
+    const ClsDrop d2{P->p2, P->p2 > 0.f ? 1.0f / (1.0f - P->p2) : 1.0f, P->seed2};
+    // ---- third layers: sums
+    const int ga = grid_for(rows * 4, CT_THREADS * 8, CT_MAX_BLOCKS);
+    hipLaunchKernelGGL(k_cls_out_bwd_sums, dim3(ga), dim3(CT_THREADS), 0, stream, dlogits, z2, rows, bn2, d2, P->w3, partial);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3((OUT_SUMS + 31) / 32), dim3(256), 0, stream, partial, ga, OUT_SUMS, totals);
+    // ---- second layers: dz2, dW2, dh1
+    const int gb = grid_for(rows, TILE, 768);
+    float* partial2 = partial + (size_t)CT_MAX_BLOCKS * OUT_SUMS;
+    hipLaunchKernelGGL(k_cls_mid_bwd, dim3(gb), dim3(CT_THREADS), 0, stream, dlogits, z2, z1, rows, bn1, d1, bn2, d2, P->w2, P->w3,
+                       totals, dh1_scratch, partial2);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4 * 16 * 32 / 32), dim3(256), 0, stream, partial2, gb, 4 * 16 * 32, totals + 256);
+    hipLaunchKernelGGL(k_cls_grads_final, dim3(8), dim3(256), 0, stream, totals, totals + 256, grads);
+    EG_HIP_TRY(hipGetLastError());
+    // ---- first layers: dz1 (+ dgamma1, dbeta1), dh, dW1
+    float* dgamma1 = grads + 128 * 128 + 128;
+    float* dbeta1 = dgamma1 + 128;
+    // dz1 (+ dgamma1, dbeta1) fused with dW1 = dz1^T h[valid rows]
+    const RowMap xm{(int)n_valid, (int)n_per_frame, (int)row_lo};
+    int rc = eg_launch_bn_bwd(dh1_scratch, z1, rows, bn + 0 * H1, bn + 1 * H1, P->gamma1, P->beta1, 1, P->p1, P->seed1, shared,
+                              dz1_scratch, dgamma1, dbeta1, h, &xm, grads, stream);
+    if (rc != EG_OK) return rc;
+    if (dh) {
+        if (n_valid < n_per_frame)
+            hipLaunchKernelGGL(k_zero_rows, dim3(64), dim3(256), 0, stream, dh, batch, (int)n_per_frame, (int)row_lo, (int)n_valid);
+        LinMapDims d{};
+        d.n_valid = (int)n_valid; d.tiles_per_frame = (int)((n_valid + TILE - 1) / TILE); d.batch = batch; d.transpose_w = 1;
+        d.in_stride = (int)n_valid; d.in_lo = 0; d.out_stride = (int)n_per_frame; d.out_lo = (int)row_lo;
+        const long long n_tiles = (long long)d.tiles_per_frame * batch;
+        hipLaunchKernelGGL(k_lin128_map<false>, dim3((unsigned)(n_tiles < 512 ? n_tiles : 512)), dim3(512), 0, stream, dz1_scratch,
+                           P->w1, (const float*)nullptr, dh, (float*)nullptr, d);
+        EG_HIP_TRY(hipGetLastError());
+    }
+    return EG_OK;
+}
+
+}  // extern "C"

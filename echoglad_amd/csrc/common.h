@@ -203,6 +203,7 @@ struct eg_graph {
     int* rowptr;              // device [n_nodes+1] kind == GRAPH_CSR
     int* colidx;              // device [nnz]
     int64_t nnz;
+    int symmetric;            // kind == GRAPH_CSR: the kept edge multiset equals its transpose (A_hat^T == A_hat)
     int* walk_counters;       // device [QUEUE_SLOTS][8 x 32] ring of per-launch tile-queue heads (+ QUEUE_TAIL_INTS)
     mutable std::atomic<unsigned> launch_seq;   // next slice of the ring (the only host state a launch touches)
     eg::Knobs knobs;          // environment knobs, read once at creation
@@ -225,6 +226,11 @@ struct ClsArgs {
     int sigmoid;
 };
 }  // namespace eg
+// symmetric 8-wave layer kernel (gcn_layer.hip) for any handle; agg_out (nullable) receives the aggregated rows A_hat x,
+// stats_partial (nullable) per-workgroup column sums of out and out^2 as float [*grid_out][2][128]
+int eg_launch_layer_sym(const eg_graph* g, int batch, const float* x, const float* W, const float* scale, const float* shift,
+                        const float* residual, int relu, int transpose_w, float* out, float* agg_out, float* stats_partial,
+                        int* grid_out, hipStream_t stream);
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
                        const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream);

@@ -37,6 +37,8 @@ struct LayerArgs {         // host-side bundle only
     const float* shift;
     const float* residual;
     float* out;
+    float* agg_out;        // nullable: the aggregated rows A_hat x (what the weight gradient of a train-mode layer needs)
+    float* stats_partial;  // nullable (train forward): per-workgroup column sums of out and out^2, [grid][2][128]
     GraphPtrs gp;
     LayerDims d;
     int* walk_counters;    // this launch's slice of the handle's queue ring (NULL: static walk)
@@ -76,10 +78,15 @@ constexpr int LAYER_THREADS = 512;
 // RES_GLOBAL: the residual rows are fetched from global memory in the epilogue (any pointer).  The hot
 // instantiation <AGG_STENCIL, false> instead reuses the self rows that phase 1 stashed in LDS (residual == x)
 // or has no residual at all, and carries no registers for the residual.
-template <int AGG, bool RES_GLOBAL>
+// WAGG = train-mode forward (its own instantiation so that the inference instantiations keep their register allocation):
+// the aggregated rows are also written to agg_out (when given) and the column sums of the output and its square —
+// the BatchNorm batch statistics — are accumulated in the epilogue (stats_partial, when given), which saves the separate
+// statistics pass over z.
+template <int AGG, bool RES_GLOBAL, bool WAGG = false>
 __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __restrict__ x, const float* __restrict__ W,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    const float* __restrict__ residual, float* __restrict__ out,
+                                                   float* __restrict__ agg_out, float* __restrict__ stats_partial,
                                                    const float* __restrict__ dis, const int* __restrict__ rowptr,
                                                    const int* __restrict__ colidx, const Topo* __restrict__ T,
                                                    const TileDesc* __restrict__ tiles,
@@ -103,6 +110,12 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
         s_shift[tid] = shift ? shift[tid] : 0.0f;
     }
 
+    // train forward: per-thread column sums live in LDS (lane (h, q): channels 4q..4q+3 -> [sum x4 | sum of squares x4])
+    __shared__ __attribute__((aligned(16))) float s_stat[WAGG ? LAYER_THREADS * 8 : 4];
+    if constexpr (WAGG) {
+        *reinterpret_cast<f32x4*>(&s_stat[tid * 8]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&s_stat[tid * 8 + 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     TileWalk walk(a.walk_mode, a.tiles_per_frame * a.batch, walk_counters, reinterpret_cast<int*>(&s_a[TILE * LDA]));
 #ifdef EG_STAMP
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -165,6 +178,17 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
                     *reinterpret_cast<f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]) =
                         produce_row<AGG>(dis, rowptr, colidx, T, xf, n, lane);
                 }
+            }
+        }
+        if (WAGG && agg_out && seg_rows > 0) {
+            // the wave's own 8 aggregated rows (it wrote them itself), whole 512-B rows; a missing row repeats a real one
+            const PairLane pa{lane >> 5, lane & 31};
+            const int fix = pa.h < seg_rows ? pa.h : 0;
+            float* ap = agg_out + (frame_row0 + seg_first) * C + 4 * pa.q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = (2 * k + pa.h) < seg_rows ? 2 * k + pa.h : fix;
+                *reinterpret_cast<f32x4*>(ap + (size_t)row * C) = *reinterpret_cast<const f32x4*>(&s_a[(rl0 + row) * LDA + 4 * pa.q]);
             }
         }
         walk.claim_commit();
@@ -234,6 +258,20 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
                 else { if (s_x) t += *reinterpret_cast<const f32x4*>(&s_x[(rl0 + row) * C + 4 * pl.q]); }
                 v[k] = t;
             }
+            if constexpr (WAGG) {
+                if (stats_partial) {                                             // (uniform) rows that hold no node do not count
+                    f32x4 cs = *reinterpret_cast<const f32x4*>(&s_stat[tid * 8]);
+                    f32x4 cq = *reinterpret_cast<const f32x4*>(&s_stat[tid * 8 + 4]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float m = (2 * k + pl.h) < seg_rows ? 1.0f : 0.0f;
+                        const f32x4 t = v[k] * m;
+                        cs += t; cq += t * v[k];
+                    }
+                    *reinterpret_cast<f32x4*>(&s_stat[tid * 8]) = cs;
+                    *reinterpret_cast<f32x4*>(&s_stat[tid * 8 + 4]) = cq;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int row = (2 * k + pl.h) < seg_rows ? 2 * k + pl.h : fix_row;
@@ -246,6 +284,20 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
         }
         STAMP(7);
         tile = next_tile;
+    }
+    if constexpr (WAGG) {
+        if (stats_partial) {
+            __syncthreads();
+            if (tid < 2 * C) {                                                   // fixed order over the 8 waves x 2 row parities
+                const int quantity = tid >> 7, c = tid & 127, q = c >> 2, e = c & 3;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) s += s_stat[(w * 64 + h * 32 + q) * 8 + quantity * 4 + e];
+                stats_partial[(size_t)blockIdx.x * 2 * C + tid] = s;
+            }
+        }
     }
 #ifdef EG_STAMP
     if (lane_k == 0) {
@@ -290,13 +342,16 @@ static int grid_for_tiles(long long n_tiles, const Knobs& kn) {
     return (int)g;
 }
 
-#define LAYER_KARGS a.x, a.W, a.scale, a.shift, a.residual, a.out, a.gp.dis, a.gp.rowptr, a.gp.colidx, a.gp.topo, a.gp.tiles, a.walk_counters, a.d
+#define LAYER_KARGS a.x, a.W, a.scale, a.shift, a.residual, a.out, a.agg_out, a.stats_partial, a.gp.dis, a.gp.rowptr, a.gp.colidx, a.gp.topo, a.gp.tiles, a.walk_counters, a.d
 
-static int launch_layer(int agg, LayerArgs& a, hipStream_t stream) {
+static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out = nullptr) {
     const long long n_tiles = (long long)a.d.tiles_per_frame * a.d.batch;
+    if (grid_out) *grid_out = 0;
     if (n_tiles <= 0) return EG_OK;
     if (n_tiles >= (1ll << 31)) return set_error(EG_ERR_ARG, "too many tiles");
     const dim3 grid(grid_for_tiles(n_tiles, a.knobs)), block(LAYER_THREADS);
+    if (grid_out) *grid_out = (int)grid.x;
+    const bool train = a.agg_out || a.stats_partial;
     a.d.walk_mode = a.walk_counters ? a.knobs.walk_mode : WALK_MOD8;
     a.d.stagger = a.knobs.stagger;
     if (a.d.walk_mode == WALK_QUEUE)
@@ -304,9 +359,13 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream) {
     const bool res_lds = (a.residual == nullptr) || (a.residual == a.x);     // epilogue residual from the LDS stash / none
     switch (agg) {
         case AGG_NONE: hipLaunchKernelGGL((k_gcn_layer<AGG_NONE, true>), grid, block, 0, stream, LAYER_KARGS); break;
-        case AGG_CSR: hipLaunchKernelGGL((k_gcn_layer<AGG_CSR, true>), grid, block, 0, stream, LAYER_KARGS); break;
+        case AGG_CSR:
+            if (train) hipLaunchKernelGGL((k_gcn_layer<AGG_CSR, true, true>), grid, block, 0, stream, LAYER_KARGS);
+            else hipLaunchKernelGGL((k_gcn_layer<AGG_CSR, true>), grid, block, 0, stream, LAYER_KARGS);
+            break;
         default:
-            if (res_lds) hipLaunchKernelGGL((k_gcn_layer<AGG_STENCIL, false>), grid, block, 0, stream, LAYER_KARGS);
+            if (train) hipLaunchKernelGGL((k_gcn_layer<AGG_STENCIL, true, true>), grid, block, 0, stream, LAYER_KARGS);
+            else if (res_lds) hipLaunchKernelGGL((k_gcn_layer<AGG_STENCIL, false>), grid, block, 0, stream, LAYER_KARGS);
             else hipLaunchKernelGGL((k_gcn_layer<AGG_STENCIL, true>), grid, block, 0, stream, LAYER_KARGS);
             break;
     }
@@ -336,6 +395,22 @@ static int fill_graph_args(const eg_graph* g, int batch, LayerArgs& a, int& agg)
 }  // namespace eg
 
 using namespace eg;
+
+int eg_launch_layer_sym(const eg_graph* g, int batch, const float* x, const float* W, const float* scale, const float* shift,
+                        const float* residual, int relu, int transpose_w, float* out, float* agg_out, float* stats_partial,
+                        int* grid_out, hipStream_t stream) {
+    if (!x || !W || !out) return set_error(EG_ERR_ARG, "x, W and out must not be NULL");
+    if (out == x || out == residual || (agg_out && (agg_out == x || agg_out == out)))
+        return set_error(EG_ERR_ARG, "out / agg_out must not alias the inputs or each other");
+    LayerArgs a{};
+    int agg;
+    const int rc = fill_graph_args(g, batch, a, agg);
+    if (rc != EG_OK) return rc;
+    a.x = x; a.W = W; a.scale = scale; a.shift = shift; a.residual = residual; a.out = out; a.agg_out = agg_out;
+    a.stats_partial = stats_partial;
+    a.d.relu = relu; a.d.transpose_w = transpose_w;
+    return launch_layer(agg, a, stream, grid_out);
+}
 
 extern "C" {
 

@@ -111,15 +111,17 @@ static int build_topo(int frame, int naux, int main_only, int coord_nodes, Topo&
 }
 
 // ---------------------------------------------------------------- CSR build
-__global__ void k_edge_keys(const int64_t* __restrict__ ei, int64_t n_edges, int n_nodes, int* __restrict__ keys,
+// transposed = 0: rows are targets (A_hat);  1: rows are sources (A_hat^T, the backward's adjacency of a directed graph)
+__global__ void k_edge_keys(const int64_t* __restrict__ ei, int64_t n_edges, int n_nodes, int transposed, int* __restrict__ keys,
                             int* __restrict__ vals, int* __restrict__ counts) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
     const int64_t src = ei[e], dst = ei[n_edges + e];
     const bool drop = (src == dst) || src < 0 || dst < 0 || src >= n_nodes || dst >= n_nodes;
-    keys[e] = drop ? n_nodes : (int)dst;          // dropped edges sort behind every real row
-    vals[e] = (int)src;
-    if (!drop) atomicAdd(&counts[dst], 1);        // integer: order-independent
+    const int64_t row = transposed ? src : dst, col = transposed ? dst : src;
+    keys[e] = drop ? n_nodes : (int)row;          // dropped edges sort behind every real row
+    vals[e] = (int)col;
+    if (!drop) atomicAdd(&counts[row], 1);        // integer: order-independent
 }
 
 __global__ void k_dis_from_counts(const int* __restrict__ counts, int n, float* __restrict__ dis) {
@@ -145,13 +147,29 @@ __global__ void k_edge_hash(const int64_t* __restrict__ ei, int64_t n_edges, uns
     if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (unsigned long long)n_edges;
 }
 
+// out[0] = sum mix64(src, dst), out[1] = sum mix64(dst, src) over the edges a CSR keeps: equal <=> (up to a 2^-64 collision)
+// the edge multiset equals its own transpose <=> A_hat is symmetric
+__global__ void k_edge_sym(const int64_t* __restrict__ ei, int64_t n_edges, int64_t n_nodes, unsigned long long* __restrict__ out) {
+    unsigned long long a = 0, b = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = ei[e], dst = ei[n_edges + e];
+        if (src == dst || src < 0 || dst < 0 || src >= n_nodes || dst >= n_nodes) continue;
+        a += mix64((unsigned long long)src, (unsigned long long)dst);
+        b += mix64((unsigned long long)dst, (unsigned long long)src);
+    }
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], a); atomicAdd(&out[1], b); }
+}
+
+static int csr_build(const int64_t* ei, int64_t n_nodes, int64_t n_edges, hipStream_t stream, const eg_graph* base, eg_graph** out);
+
 }  // namespace eg
 
 using namespace eg;
 
 extern "C" {
 
-int eg_version(void) { return 100; }
+int eg_version(void) { return 110; }
 
 const char* eg_last_error(void) { return g_last_error.c_str(); }
 
@@ -365,13 +383,27 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
     return EG_OK;
 }
 
-int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream_t stream_, eg_graph** out) {
+int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream_t stream, eg_graph** out) {
+    return csr_build(ei, n_nodes, n_edges, (hipStream_t)stream, nullptr, out);
+}
+
+int eg_csr_create_transposed(const eg_graph* base, const int64_t* ei, int64_t n_edges, eg_stream_t stream, eg_graph** out) {
+    if (!base || base->kind != GRAPH_CSR) return set_error(EG_ERR_ARG, "base must be a CSR handle");
+    return csr_build(ei, base->n_nodes, n_edges, (hipStream_t)stream, base, out);
+}
+
+int eg_graph_is_symmetric(const eg_graph* g) { return g && (g->kind == GRAPH_TOPO || g->symmetric); }
+
+}  // extern "C"
+
+// base == NULL: rows = targets, (deg+1)^-1/2 from the in-degrees.  base != NULL: rows = sources (the transposed adjacency
+// of the same edge_index), normalisation copied from base.
+static int eg::csr_build(const int64_t* ei, int64_t n_nodes, int64_t n_edges, hipStream_t stream, const eg_graph* base, eg_graph** out) {
     if (!out) return set_error(EG_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (n_nodes <= 0 || n_nodes >= (1ll << 31) - 1 || n_edges < 0 || n_edges >= (1ll << 31) - 1)
         return set_error(EG_ERR_ARG, "n_nodes / n_edges out of int32 range");
     if (n_edges > 0 && !ei) return set_error(EG_ERR_ARG, "edge_index is NULL");
-    hipStream_t stream = (hipStream_t)stream_;
     const int n = (int)n_nodes;
     const int m = (int)n_edges;
     eg_graph* g = new eg_graph{};
@@ -379,6 +411,7 @@ int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream
     g->knobs = read_knobs();
     g->n_nodes = n_nodes;
     int *keys = nullptr, *vals = nullptr, *keys_out = nullptr, *counts = nullptr;
+    unsigned long long* sym = nullptr;
     void* tmp = nullptr;
     size_t tmp_bytes = 0, tmp2 = 0;
     auto cleanup = [&](bool all) {
@@ -386,6 +419,7 @@ int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream
         if (vals) (void)hipFree(vals);
         if (keys_out) (void)hipFree(keys_out);
         if (counts) (void)hipFree(counts);
+        if (sym) (void)hipFree(sym);
         if (tmp) (void)hipFree(tmp);
         if (all) {
             if (g->dis) (void)hipFree(g->dis);
@@ -415,7 +449,7 @@ int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream
     CSR_TRY(hipMemsetAsync(g->walk_counters, 0, QUEUE_RING_BYTES, stream));
     CSR_TRY(hipMemsetAsync(counts, 0, sizeof(int) * ((size_t)n + 1), stream));
     if (m > 0) {
-        hipLaunchKernelGGL(k_edge_keys, dim3((m + 255) / 256), dim3(256), 0, stream, ei, n_edges, n, keys, vals, counts);
+        hipLaunchKernelGGL(k_edge_keys, dim3((m + 255) / 256), dim3(256), 0, stream, ei, n_edges, n, base ? 1 : 0, keys, vals, counts);
         CSR_TRY(hipGetLastError());
         // stable LSD radix sort by target: neighbours keep their edge_index order
         int end_bit = 1;
@@ -435,17 +469,33 @@ int eg_csr_create(const int64_t* ei, int64_t n_nodes, int64_t n_edges, eg_stream
         size_t tb = tmp_bytes;
         CSR_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, counts, g->rowptr, n + 1, stream));
     }
-    hipLaunchKernelGGL(k_dis_from_counts, dim3((n + 255) / 256), dim3(256), 0, stream, counts, n, g->dis);
-    CSR_TRY(hipGetLastError());
+    unsigned long long sym_host[2] = {0, 0};
+    if (base) {
+        CSR_TRY(hipMemcpyAsync(g->dis, base->dis, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    } else {
+        hipLaunchKernelGGL(k_dis_from_counts, dim3((n + 255) / 256), dim3(256), 0, stream, counts, n, g->dis);
+        CSR_TRY(hipGetLastError());
+        CSR_TRY(hipMalloc((void**)&sym, 2 * sizeof(unsigned long long)));
+        CSR_TRY(hipMemsetAsync(sym, 0, 2 * sizeof(unsigned long long), stream));
+        if (m > 0) {
+            int blocks = (m + 255) / 256;
+            hipLaunchKernelGGL(k_edge_sym, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, stream, ei, n_edges, n_nodes, sym);
+            CSR_TRY(hipGetLastError());
+        }
+        CSR_TRY(hipMemcpyAsync(sym_host, sym, sizeof(sym_host), hipMemcpyDeviceToHost, stream));
+    }
     int nnz = 0;
     CSR_TRY(hipMemcpyAsync(&nnz, g->rowptr + n, sizeof(int), hipMemcpyDeviceToHost, stream));
     CSR_TRY(hipStreamSynchronize(stream));
     g->nnz = nnz;
+    g->symmetric = base ? base->symmetric : (sym_host[0] == sym_host[1]);
     cleanup(false);
 #undef CSR_TRY
     *out = g;
     return EG_OK;
 }
+
+extern "C" {
 
 int eg_graph_destroy(eg_graph* g) {
     if (!g) return EG_OK;

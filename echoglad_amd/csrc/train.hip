@@ -7,22 +7,12 @@
 //   eg_bn_act_bwd     dz, dgamma, dbeta from dy (two passes: reduce, apply); dropout mask regenerated from the seed
 // All reductions are two-stage (per-workgroup partials in a caller-provided workspace, then one fixed-order
 // pass), so results are bitwise reproducible run to run: no float atomics anywhere.
-#include "tile.h"
+#include "train_common.h"
 
 namespace eg {
 
 constexpr int RED_BLOCKS = 1024;           // stage-1 workgroups of the column reductions
 constexpr int RED_THREADS = 256;
-
-// ---- counter-based dropout mask: keep iff hash(seed, element) >= p ---------------------------------
-__device__ inline float keep_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
-    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    const float u = (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);     // 24 random bits -> [0,1)
-    return u >= p ? inv_keep : 0.0f;
-}
 
 // ---- stage 1: per-workgroup column partials of up to NQ quantities ---------------------------------
 // lane = channel pair; a wave walks rows; 4 waves of a block are combined through LDS.
@@ -45,6 +35,43 @@ __device__ inline void column_partials(long long rows, double* __restrict__ part
     for (int i = threadIdx.x; i < NQ * C; i += RED_THREADS) {
         const int q = i / C, c = i % C;
         partial[((size_t)blockIdx.x * NQ + q) * C + c] = s_red[0][q][c] + s_red[1][q][c] + s_red[2][q][c] + s_red[3][q][c];
+    }
+}
+
+// one workgroup (256 threads) per 32 columns: thread (col = t & 31, slice = t >> 5) sums every 8th partial in ascending
+// order, the 8 slice sums are added in a fixed tree: the same bits on every run.  Launch with ceil(n / 32) workgroups.
+__global__ __launch_bounds__(256) void k_reduce_f32_partials(const float* __restrict__ partial, int nblocks, int n, double* __restrict__ totals) {
+    __shared__ double red[256];
+    const int t = threadIdx.x, col = blockIdx.x * 32 + (t & 31), sl = t >> 5;
+    double s = 0.0;
+    if (col < n)
+        for (int b = sl; b < nblocks; b += 8) s += (double)partial[(size_t)b * n + col];
+    red[t] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = 4; st > 0; st >>= 1) {
+        if (sl < st) red[t] += red[t + 32 * st];
+        __syncthreads();
+    }
+    if (sl == 0 && col < n) totals[col] = red[t];
+}
+
+__global__ void k_bn_finalize(const BnFinalize a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.cc) return;
+    const double m = a.totals[c] / (double)a.rows;
+    double v = a.totals[a.cc + c] / (double)a.rows - m * m;
+    v = v > 0.0 ? v : 0.0;
+    const float is = (float)(1.0 / sqrt(v + (double)a.eps));
+    const float sc = a.gamma[c] * is;
+    a.mean[c] = (float)m;
+    a.invstd[c] = is;
+    a.scale[c] = sc;
+    a.shift[c] = a.beta[c] - (float)m * sc;
+    if (a.momentum >= 0.f && a.running_mean && a.running_var) {
+        const double unb = a.rows > 1 ? v * (double)a.rows / (double)(a.rows - 1) : v;
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
     }
 }
 
@@ -189,9 +216,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 // LDS; v_mfma_f32_32x32x2_f32: A[i][k] = g[row k][32w + i] (lane i = l&31, k = l>>5), B[k][j] = x[row k][32jb + j].
 constexpr int DW_ROWS = 32;
 constexpr int DW_BLOCKS = 512;
+// workspace layout: [0, WS_RED_BYTES) column-reduction partials (doubles) + totals; then DW_BLOCKS slabs of [128,128] floats
+constexpr size_t WS_RED_BYTES = (((size_t)RED_BLOCKS * 2 * C + 2 * C) * sizeof(double) + 4095) / 4096 * 4096;
 
+// xm.n_valid > 0: row r of g pairs with row map_row(xm, r) of x (x is the unfiltered array of a node-type filter)
 __global__ __launch_bounds__(256) void k_dweight_partial(const float* __restrict__ g, const float* __restrict__ x, long long rows,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, const RowMap xm) {
     __shared__ __attribute__((aligned(16))) float s_g[DW_ROWS * C];
     __shared__ __attribute__((aligned(16))) float s_x[DW_ROWS * C];
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
@@ -211,8 +241,9 @@ __global__ __launch_bounds__(256) void k_dweight_partial(const float* __restrict
             const long long r = r0 + e / 32;
             f32x4 vg = {0.f, 0.f, 0.f, 0.f}, vx = vg;
             if (r < rows) {
+                const long long rx = xm.n_valid > 0 ? map_row(xm, r) : r;
                 vg = *reinterpret_cast<const f32x4*>(g + (size_t)r * C + (e % 32) * 4);
-                vx = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + (e % 32) * 4);
+                vx = *reinterpret_cast<const f32x4*>(x + (size_t)rx * C + (e % 32) * 4);
             }
             *reinterpret_cast<f32x4*>(&s_g[e * 4]) = vg;
             *reinterpret_cast<f32x4*>(&s_x[e * 4]) = vx;
@@ -239,12 +270,93 @@ __global__ __launch_bounds__(256) void k_dweight_partial(const float* __restrict
         }
 }
 
-__global__ void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= C * C) return;
+// fixed-order sum of the per-workgroup slabs: workgroup = 32 elements x 8 slices of the slab list (launch with C*C/32 workgroups)
+__global__ __launch_bounds__(256) void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw) {
+    __shared__ double red[256];
+    const int t = threadIdx.x, idx = blockIdx.x * 32 + (t & 31), sl = t >> 5;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C * C + idx];
-    dw[idx] = (float)s;
+    for (int b = sl; b < nblocks; b += 8) s += (double)partial[(size_t)b * C * C + idx];
+    red[t] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = 4; st > 0; st >>= 1) {
+        if (sl < st) red[t] += red[t + 32 * st];
+        __syncthreads();
+    }
+    if (sl == 0) dw[idx] = (float)red[t];
+}
+
+// ---- BN backward apply fused with the weight gradient: dz = BN'(dy * mask) is written AND fed (through LDS) to
+// dW += dz^T x, so dz is not read back for the weight gradient.  Same tiling as k_dweight_partial.
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_dw(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const double* __restrict__ totals, float* __restrict__ dz,
+                                                         float* __restrict__ partial, const ActArgs a, const RowMap xm) {
+    __shared__ __attribute__((aligned(16))) float s_g[DW_ROWS * C];
+    __shared__ __attribute__((aligned(16))) float s_x[DW_ROWS * C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int i = lane & 31, kh = lane >> 5;
+    // every float4 this thread touches has the same 4 channels: c4 = 4 (tid % 32)
+    const int c4 = (tid & 31) * 4;
+    const double inv_n = 1.0 / (double)a.rows;
+    const f32x4 mn = *reinterpret_cast<const f32x4*>(mean + c4), is = *reinterpret_cast<const f32x4*>(invstd + c4);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c4), be = *reinterpret_cast<const f32x4*>(beta + c4);
+    f32x4 mg, mgx;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { mg[u] = (float)(totals[c4 + u] * inv_n); mgx[u] = (float)(totals[C + c4 + u] * inv_n); }
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+    const long long n_tiles = (a.rows + DW_ROWS - 1) / DW_ROWS;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long long r0 = t * DW_ROWS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            const long long r = r0 + e / 32;
+            f32x4 vg = {0.f, 0.f, 0.f, 0.f}, vx = vg;
+            if (r < a.rows) {
+                const size_t off = (size_t)r * C + c4;
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + off);
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + off);
+                const long long rx = xm.n_valid > 0 ? map_row(xm, r) : r;
+                vx = *reinterpret_cast<const f32x4*>(x + (size_t)rx * C + c4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float xh = (zz[u] - mn[u]) * is[u];
+                    const float v = xh * ga[u] + be[u];
+                    float g = d[u];
+                    if (a.p > 0.f) g *= keep_scale(a.seed, (unsigned long long)off + u, a.p, a.inv_keep);
+                    if (a.relu) g = v > 0.f ? g : 0.f;
+                    vg[u] = ga[u] * is[u] * (g - mg[u] - xh * mgx[u]);
+                }
+                *reinterpret_cast<f32x4*>(dz + off) = vg;
+            }
+            *reinterpret_cast<f32x4*>(&s_g[e * 4]) = vg;
+            *reinterpret_cast<f32x4*>(&s_x[e * 4]) = vx;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < DW_ROWS / 2; ++s) {
+            const int r = 2 * s + kh;
+            const float av = s_g[r * C + 32 * wave + i];
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+                acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_x[r * C + 32 * jb + i], acc[jb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* p = partial + (size_t)blockIdx.x * C * C;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
+            p[(size_t)(32 * wave + m) * C + 32 * jb + i] = acc[jb][e];
+        }
 }
 
 static int red_blocks(long long rows) {
@@ -257,15 +369,60 @@ static int red_blocks(long long rows) {
 
 using namespace eg;
 
+int eg_launch_dweight(const float* g, const float* x, long long rows, const eg::RowMap* xmap, void* workspace, float* dw, hipStream_t stream) {
+    if (!g || !x || !workspace || !dw || rows < 1) return set_error(EG_ERR_ARG, "bad argument");
+    long long nt = (rows + DW_ROWS - 1) / DW_ROWS;
+    const int nb = (int)(nt < DW_BLOCKS ? nt : DW_BLOCKS);
+    const RowMap xm = xmap ? *xmap : RowMap{0, 0, 0};
+    float* slabs = (float*)((char*)workspace + WS_RED_BYTES);
+    hipLaunchKernelGGL(k_dweight_partial, dim3(nb), dim3(256), 0, stream, g, x, rows, slabs, xm);
+    hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(256), 0, stream, (const float*)slabs, nb, dw);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+static ActArgs make_act(int64_t rows, int relu, float p, uint64_t seed) {
+    ActArgs a{};
+    a.rows = rows; a.relu = relu; a.p = p; a.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    return a;
+}
+
+// BatchNorm backward of  y = relu?(dropout(BN_train(z)))  given dy, optionally fused with the weight gradient dW = dz^T x:
+// sums pass -> (dgamma, dbeta) -> apply pass writing dz (and accumulating dW when x / dw are given).
+int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, int relu, float dropout_p, unsigned long long seed, void* workspace, float* dz,
+                     float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream) {
+    if (!dy || !z || !mean || !invstd || !gamma || !beta || !workspace || !dz || !dgamma || !dbeta || rows < 1)
+        return set_error(EG_ERR_ARG, "bad argument");
+    if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    const ActArgs a = make_act(rows, relu, dropout_p, seed);
+    double* partial = (double*)workspace;
+    const int nb = red_blocks(rows);
+    double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
+    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nb), dim3(RED_THREADS), 0, stream, dy, z, mean, invstd, gamma, beta, partial, a);
+    hipLaunchKernelGGL(k_reduce_partials<2>, dim3(2 * C / 8), dim3(256), 0, stream, partial, nb, totals);
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(128), 0, stream, totals, dgamma, dbeta);
+    if (dw && x) {
+        long long nt = (rows + DW_ROWS - 1) / DW_ROWS;
+        const int nd = (int)(nt < DW_BLOCKS ? nt : DW_BLOCKS);
+        const RowMap xm = xmap ? *xmap : RowMap{0, 0, 0};
+        float* slabs = (float*)((char*)workspace + WS_RED_BYTES);
+        hipLaunchKernelGGL(k_bn_bwd_apply_dw, dim3(nd), dim3(256), 0, stream, dy, z, x, mean, invstd, gamma, beta, totals, dz, slabs, a, xm);
+        hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(256), 0, stream, (const float*)slabs, nd, dw);
+    } else {
+        long long blocks = (rows + 3) / 4;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, stream, dy, z, mean, invstd, gamma, beta, totals, dz, a);
+    }
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
 extern "C" {
 
 // doubles needed by the two-stage reductions: RED_BLOCKS * 2 * 128 partials + 2 * 128 totals; dW needs
 // DW_BLOCKS * 128 * 128 floats.  One buffer of eg_workspace_bytes() serves every call below.
-size_t eg_workspace_bytes(void) {
-    const size_t red = ((size_t)RED_BLOCKS * 2 * C + 2 * C) * sizeof(double);
-    const size_t dw = (size_t)DW_BLOCKS * C * C * sizeof(float);
-    return red > dw ? red : dw;
-}
+size_t eg_workspace_bytes(void) { return WS_RED_BYTES + (size_t)DW_BLOCKS * C * C * sizeof(float); }
 
 int eg_colsum128(const float* x, int64_t rows, void* workspace, float* out, eg_stream_t stream_) {
     if (!x || !workspace || !out || rows < 1) return set_error(EG_ERR_ARG, "bad argument");
@@ -293,12 +450,6 @@ int eg_bn_stats(const float* x, int64_t rows, void* workspace, float* mean, floa
     return EG_OK;
 }
 
-static ActArgs make_act(int64_t rows, int relu, float p, uint64_t seed) {
-    ActArgs a{};
-    a.rows = rows; a.relu = relu; a.p = p; a.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
-    return a;
-}
-
 int eg_bn_act_fwd(const float* z, int64_t rows, const float* scale, const float* shift, const float* residual,
                   int relu, float dropout_p, uint64_t seed, float* out, eg_stream_t stream) {
     if (!z || !scale || !shift || !out || rows < 1) return set_error(EG_ERR_ARG, "bad argument");
@@ -313,33 +464,58 @@ int eg_bn_act_fwd(const float* z, int64_t rows, const float* scale, const float*
 
 int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* mean, const float* invstd,
                   const float* gamma, const float* beta, int relu, float dropout_p, uint64_t seed, void* workspace,
-                  float* dz, float* dgamma, float* dbeta, eg_stream_t stream_) {
-    if (!dy || !z || !mean || !invstd || !gamma || !beta || !workspace || !dz || !dgamma || !dbeta || rows < 1)
-        return set_error(EG_ERR_ARG, "bad argument");
-    if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
-    hipStream_t stream = (hipStream_t)stream_;
-    const ActArgs a = make_act(rows, relu, dropout_p, seed);
-    double* partial = (double*)workspace;
-    const int nb = red_blocks(rows);
-    double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
-    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nb), dim3(RED_THREADS), 0, stream, dy, z, mean, invstd, gamma, beta, partial, a);
-    hipLaunchKernelGGL(k_reduce_partials<2>, dim3(2 * C / 8), dim3(256), 0, stream, partial, nb, totals);
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(128), 0, stream, totals, dgamma, dbeta);
-    long long blocks = (rows + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, stream, dy, z, mean, invstd, gamma, beta, totals, dz, a);
-    EG_HIP_TRY(hipGetLastError());
-    return EG_OK;
+                  float* dz, float* dgamma, float* dbeta, eg_stream_t stream) {
+    return eg_launch_bn_bwd(dy, z, rows, mean, invstd, gamma, beta, relu, dropout_p, seed, workspace, dz, dgamma, dbeta, nullptr,
+                            nullptr, nullptr, (hipStream_t)stream);
 }
 
-int eg_dweight128(const float* g, const float* x, int64_t rows, void* workspace, float* dw, eg_stream_t stream_) {
-    if (!g || !x || !workspace || !dw || rows < 1) return set_error(EG_ERR_ARG, "bad argument");
+int eg_dweight128(const float* g, const float* x, int64_t rows, void* workspace, float* dw, eg_stream_t stream) {
+    return eg_launch_dweight(g, x, rows, nullptr, workspace, dw, (hipStream_t)stream);
+}
+
+// ---- one whole train-mode GNN layer: forward and backward (reference src/core/models.py:328-335, :431-435) --------------
+//   forward   z = A_hat x W^T + b (the aggregated tile A_hat x is kept: `agg`), batch statistics of z, running-stat update,
+//             out = relu?(dropout(BN(z))) + (residual ? x : 0)
+//   backward  dz = BN'(dy * mask), dgamma, dbeta;  dX = (A_hat^T dz) W + (residual ? dy : 0);  dW = dz^T (A_hat x);  db = 0
+int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* bias, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
+                           float dropout_p, uint64_t seed, int residual, void* workspace, float* z, float* agg, float* bn,
+                           float* out, eg_stream_t stream_) {
+    if (!g || !x || !W || !gamma || !beta || !workspace || !z || !bn || !out) return set_error(EG_ERR_ARG, "NULL argument");
+    if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
     hipStream_t stream = (hipStream_t)stream_;
-    long long nt = (rows + DW_ROWS - 1) / DW_ROWS;
-    const int nb = (int)(nt < DW_BLOCKS ? nt : DW_BLOCKS);
-    hipLaunchKernelGGL(k_dweight_partial, dim3(nb), dim3(256), 0, stream, g, x, (long long)rows, (float*)workspace);
-    hipLaunchKernelGGL(k_dweight_final, dim3((C * C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, dw);
+    // the layer kernel's epilogue leaves the column sums of z and z^2 per workgroup: no separate statistics pass
+    float* partial = (float*)workspace;
+    double* totals = (double*)workspace + (size_t)RED_BLOCKS * 2 * C;
+    int grid = 0;
+    int rc = eg_launch_layer_sym(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, agg, partial, &grid, stream);
+    if (rc != EG_OK) return rc;
+    const long long rows = (long long)g->n_nodes * batch;
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * C / 32), dim3(256), 0, stream, partial, grid, 2 * C, totals);
+    BnFinalize f{totals, rows, C, gamma, beta, eps, momentum, running_mean, running_var, bn, bn + C, bn + 2 * C, bn + 3 * C};
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(128), 0, stream, f);
     EG_HIP_TRY(hipGetLastError());
+    return eg_bn_act_fwd(z, rows, bn + 2 * C, bn + 3 * C, residual ? x : nullptr, relu, dropout_p, seed, out, stream_);
+}
+
+int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
+                     const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
+                     int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
+                     float* dbeta, eg_stream_t stream_) {
+    if (!g_bwd || !dy || !z || !W || !gamma || !beta || !bn || !workspace || !dz_scratch || !dgamma || !dbeta)
+        return set_error(EG_ERR_ARG, "NULL argument");
+    if (dw && !agg) return set_error(EG_ERR_ARG, "dW needs the aggregated input kept by eg_gcn_layer_train_fwd");
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long rows = (long long)g_bwd->n_nodes * batch;
+    int rc = eg_launch_bn_bwd(dy, z, rows, bn, bn + C, gamma, beta, relu, dropout_p, seed, workspace, dz_scratch, dgamma, dbeta,
+                              dw ? agg : nullptr, nullptr, dw, stream);
+    if (rc != EG_OK) return rc;
+    if (dx) {
+        rc = eg_launch_layer_sym(g_bwd, batch, dz_scratch, W, nullptr, nullptr, residual ? dy : nullptr, 0, 1, dx, nullptr, nullptr,
+                                 nullptr, stream);
+        if (rc != EG_OK) return rc;
+    }
+    if (db) EG_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * C, stream));     // a bias in front of a train-mode BatchNorm
     return EG_OK;
 }
 

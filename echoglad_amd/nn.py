@@ -127,8 +127,8 @@ _SHARED_RESOLVER = GraphResolver(None)      # every stand-alone GCNConv: the lay
 # autograd functions over the C-ABI
 # ---------------------------------------------------------------------------
 class _GCNConvFn(torch.autograd.Function):
-    """y = A_hat x W^T + b.  Backward: dx = (A_hat dy) W, dW = (A_hat dy)^T x, db = sum dy
-    (A_hat is symmetric)."""
+    """y = A_hat x W^T + b.  Backward: dx = (A_hat^T dy) W, dW = (A_hat^T dy)^T x, db = sum dy
+    (graph.bwd is the graph itself whenever A_hat is symmetric, i.e. for every undirected edge_index)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, graph, batch):
@@ -143,42 +143,14 @@ class _GCNConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gcn_layer_fwd(ctx.graph, ctx.batch, dy, weight.contiguous(), None, None, None, False,
+            dx = ops.gcn_layer_fwd(ctx.graph.bwd, ctx.batch, dy, weight.contiguous(), None, None, None, False,
                                    transpose_w=True)
         if ctx.needs_input_grad[1]:
-            g = ops.gcn_aggregate(ctx.graph, ctx.batch, dy)
+            g = ops.gcn_aggregate(ctx.graph.bwd, ctx.batch, dy)
             dw = ops.dweight128(g, x.contiguous())
         if ctx.needs_input_grad[2]:
             db = ops.colsum128(dy)
         return dx, dw, db, None, None
-
-
-class _Linear128Fn(torch.autograd.Function):
-    """y = x W^T + b on [rows,128] (no graph).  Backward: dx = dy W, dW = dy^T x, db = sum dy — all on the HIP kernels."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        x, weight = x.contiguous(), weight.contiguous()
-        ctx.save_for_backward(x, weight)
-        return ops.linear128_fwd(x, weight, None, bias.contiguous() if bias is not None else None)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = ops.linear128_fwd(dy, weight, transpose_w=True) if ctx.needs_input_grad[0] else None
-        dw = ops.dweight128(dy, x) if ctx.needs_input_grad[1] else None
-        db = ops.colsum128(dy) if ctx.needs_input_grad[2] else None
-        return dx, dw, db
-
-
-def _update_running(running_mean, running_var, mean, var, n: int, momentum) -> None:
-    """nn.BatchNorm1d's running-statistics update (unbiased variance); momentum None = nothing to update."""
-    if momentum is None or running_mean is None:
-        return
-    with torch.no_grad():
-        running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-        running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
 
 
 def _bn_step(bn: nn.BatchNorm1d):
@@ -193,73 +165,118 @@ def _bn_step(bn: nn.BatchNorm1d):
     return use_batch, factor
 
 
-class _BNActFn(torch.autograd.Function):
-    """Train-mode tail of one GNN layer in two HIP passes: BatchNorm1d with batch statistics over all rows
-    of the batch, Dropout, ReLU|Identity and the residual add (src/core/models.py:333-335, :434-435).
-    Running statistics are updated like nn.BatchNorm1d (momentum, unbiased variance)."""
-
-    @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, residual, relu, p, momentum, eps, seed):
-        z = z.contiguous()
-        mean, var = ops.bn_stats(z)
-        _update_running(running_mean, running_var, mean, var, z.shape[0], momentum)
-        invstd = torch.rsqrt(var + eps)
-        scale = (gamma * invstd).contiguous()
-        shift = (beta - mean * scale).contiguous()
-        out = ops.bn_act_fwd(z, scale, shift, residual.contiguous() if residual is not None else None, relu, p, seed)
-        ctx.save_for_backward(z, mean, invstd, gamma.detach().contiguous(), beta.detach().contiguous())
-        ctx.cfg = (relu, p, seed, residual is not None)
-        return out
-
-    @staticmethod
-    def backward(ctx, dy):
-        z, mean, invstd, gamma, beta = ctx.saved_tensors
-        relu, p, seed, has_res = ctx.cfg
-        dy = dy.contiguous()
-        dz, dgamma, dbeta = ops.bn_act_bwd(dy, z, mean, invstd, gamma, beta, relu, p, seed)
-        return dz, dgamma, dbeta, None, None, (dy if has_res else None), None, None, None, None, None
-
-
 class _LayerTrainFn(torch.autograd.Function):
-    """One whole train-mode layer as a single autograd node (models.py:328-335, :431-435):
-    z = A_hat x W^T + b;  y = relu|id(dropout(BN_batch(z))) + x.
-    Backward shares one aggregation g = A_hat dz between dX = g W and dW = g^T x, and hands the residual's gradient to
-    the dX kernel as its `residual` input, so autograd never adds two [B*N,128] tensors for this layer."""
+    """One whole train-mode layer as a single autograd node over the two C-ABI composites
+    (eg_gcn_layer_train_fwd / eg_gcn_layer_bwd; models.py:328-335, :431-435):
+        z = A_hat x W^T + b;  out = relu|id(dropout(BN_batch(z))) + x.
+    Kept for the backward: z, the aggregated input A_hat x (so that dW = dz^T (A_hat x) needs no second aggregation) and the
+    batch statistics — not x.  Returns (out, lm): lm = out's coordinate-node rows [4B,128] (``coord_rows`` = (B, n, first
+    row), else an empty tensor), i.e. the gather of models.py:447 done here so that its gradient comes back into THIS node
+    and is added into 4 rows per frame, instead of autograd summing two dense [B*N,128] gradients."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, graph, batch, relu, p, momentum, eps, seed,
-                residual):
+                residual, coord_rows):
         x = x.contiguous()
-        z = ops.gcn_layer_fwd(graph, batch, x, weight.contiguous(), None, bias.contiguous(), None, False)
-        mean, var = ops.bn_stats(z)
-        _update_running(running_mean, running_var, mean, var, z.shape[0], momentum)
-        invstd = torch.rsqrt(var + eps)
-        scale = (gamma * invstd).contiguous()
-        shift = (beta - mean * scale).contiguous()
-        out = ops.bn_act_fwd(z, scale, shift, x if residual else None, relu, p, seed)
-        ctx.save_for_backward(x, z, weight.detach().contiguous(), mean, invstd, gamma.detach().contiguous(),
-                              beta.detach().contiguous())
-        ctx.cfg = (graph, batch, relu, p, seed, residual)
-        return out
+        need_w = weight.requires_grad
+        out, z, agg, bn = ops.gcn_layer_train_fwd(graph, batch, x, weight.contiguous(), bias.contiguous(), gamma.contiguous(),
+                                                  beta.contiguous(), running_mean, running_var, momentum, eps, relu, p, seed,
+                                                  residual, want_agg=need_w)
+        ctx.save_for_backward(z, agg if agg is not None else z.new_zeros(0), weight.detach().contiguous(),
+                              gamma.detach().contiguous(), beta.detach().contiguous(), bn)
+        ctx.cfg = (graph, batch, relu, p, seed, residual, coord_rows, need_w)
+        if coord_rows is not None:
+            B, n, lo = coord_rows
+            lm = out.view(B, n, C)[:, lo:lo + 4, :].reshape(B * 4, C).clone()     # a copy: out is overwritten in place later
+        else:
+            lm = out.new_zeros(0)
+        return out, lm
+
+    @staticmethod
+    def backward(ctx, dy, dlm):
+        z, agg, weight, gamma, beta, bn = ctx.saved_tensors
+        graph, batch, relu, p, seed, residual, coord_rows, had_agg = ctx.cfg
+        dy = dy.contiguous()
+        if coord_rows is not None and dlm is not None:
+            B, n, lo = coord_rows
+            dy.view(B, n, C)[:, lo:lo + 4, :] += dlm.view(B, 4, C)        # in place: this node owns the incoming buffer
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and had_agg, ctx.needs_input_grad[2]
+        dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dy, z, agg if had_agg else None, weight, gamma, beta, bn,
+                                                      relu, p, seed, residual, need_x, need_w)
+        return (dx, dw, db if need_b else None, dgamma, dbeta) + (None,) * 11
+
+
+class _CoordScatterFn(torch.autograd.Function):
+    """models.py:455-473 in place: sample the layer output's main grid at the updated landmark coordinates
+    (bilinear_interpolation as a 4-tap gather) and overwrite the frame's 4 coordinate-node rows with the samples.
+    Backward works in place on the incoming gradient buffer as well: the coordinate rows' gradient becomes the samples'
+    gradient, those rows are zeroed (their old values were overwritten) and the 16 taps per frame are accumulated into the
+    main-grid rows; d/d coords comes from the same kernel."""
+
+    @staticmethod
+    def forward(ctx, h, coords, batch, n, main_base, frame, coord_base):
+        coords = coords.reshape(batch * 4, 2).contiguous()
+        new = ops.bilinear4_fwd(h, coords, batch, n, main_base, frame)
+        h.view(batch, n, C)[:, coord_base:coord_base + 4, :] = new.view(batch, 4, C)
+        ctx.mark_dirty(h)
+        ctx.save_for_backward(h, coords)
+        ctx.dims = (batch, n, main_base, frame, coord_base)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        h, coords = ctx.saved_tensors
+        batch, n, main_base, frame, coord_base = ctx.dims
+        dh = dh.contiguous()
+        rows = dh.view(batch, n, C)[:, coord_base:coord_base + 4, :]
+        dnew = rows.reshape(batch * 4, C).clone()
+        rows.zero_()
+        dcoords = ops.bilinear4_bwd(dnew, h, coords, batch, n, main_base, frame, dh=dh, want_dcoords=ctx.needs_input_grad[1])
+        return dh, (dcoords.view(batch, 4, 2) if dcoords is not None else None), None, None, None, None, None
+
+
+_HEAD_PARAM_IDX = ((0, "weight"), (0, "bias"), (1, "weight"), (1, "bias"), (4, "weight"), (4, "bias"), (5, "weight"),
+                   (5, "bias"), (8, "weight"), (8, "bias"))
+
+
+class _ClassifierTrainFn(torch.autograd.Function):
+    """models.py:363-377, :485-490 in train mode over eg_classifier_train_fwd / eg_classifier_bwd: node-type filter + the
+    four heads as one stacked network (first layers one [128 -> 128] product, 4 x BatchNorm1d(32) == BatchNorm1d(128) on the
+    stacked output; second layers block-diagonal [128 -> 64]; third a 16-wide dot).  ``params`` = for each head its 10
+    parameters in _HEAD_PARAM_IDX order; gradients go back to each of them."""
+
+    @staticmethod
+    def forward(ctx, h, batch, n, row_lo, n_valid, sigmoid, cfg, *params):
+        heads = [params[10 * k:10 * k + 10] for k in range(4)]
+        cat = lambda j: torch.cat([hd[j].reshape(-1) if hd[j].dim() == 1 else hd[j] for hd in heads], dim=0).contiguous()
+        P = dict(cfg)
+        P.update(w1=cat(0), b1=cat(1), gamma1=cat(2), beta1=cat(3), w2=torch.stack([hd[4] for hd in heads]).contiguous(),
+                 b2=cat(5), gamma2=cat(6), beta2=cat(7), w3=cat(8), b3=cat(9))
+        h = h.contiguous()
+        logits, z1, z2, bn = ops.classifier_train_fwd(h, batch, n, row_lo, n_valid, P, sigmoid)
+        ctx.P = {k: v for k, v in P.items() if not k.startswith("running")}
+        ctx.dims = (batch, n, row_lo, n_valid, sigmoid)
+        ctx.save_for_backward(h, z1, z2, bn, logits if sigmoid else logits.new_zeros(0))
+        return logits
 
     @staticmethod
     def backward(ctx, dy):
-        x, z, weight, mean, invstd, gamma, beta = ctx.saved_tensors
-        graph, batch, relu, p, seed, residual = ctx.cfg
-        dy = dy.contiguous()
-        dz, dgamma, dbeta = ops.bn_act_bwd(dy, z, mean, invstd, gamma, beta, relu, p, seed)
-        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        dx = dw = db = None
-        if need_w:
-            g = ops.gcn_aggregate(graph, batch, dz)
-            dw = ops.dweight128(g, x)
-            if need_x:
-                dx = ops.linear128_fwd(g, weight, None, None, dy if residual else None, False, transpose_w=True)
-        elif need_x:
-            dx = ops.gcn_layer_fwd(graph, batch, dz, weight, None, None, dy if residual else None, False, transpose_w=True)
-        if need_b:
-            db = ops.colsum128(dz)
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        h, z1, z2, bn, y = ctx.saved_tensors
+        batch, n, row_lo, n_valid, sigmoid = ctx.dims
+        dl = dy.contiguous()
+        if sigmoid:
+            dl = dl * y * (1.0 - y)
+        dh, g = ops.classifier_bwd(dl, h, batch, n, row_lo, n_valid, ctx.P, z1, z2, bn, ctx.needs_input_grad[0])
+        dw1, db1, dg1, dbe1 = g[:16384].view(4, 32, C), g[16384:16512].view(4, 32), g[16512:16640].view(4, 32), g[16640:16768].view(4, 32)
+        o = 16768
+        dw2 = g[o:o + 2048].view(4, 16, 32)
+        db2, dg2, dbe2 = (g[o + 2048 + 64 * k:o + 2048 + 64 * (k + 1)].view(4, 16) for k in range(3))
+        dw3 = g[o + 2240:o + 2304].view(4, 1, 16)
+        db3 = g[o + 2304:o + 2308].view(4, 1)
+        grads = []
+        for k in range(4):
+            grads += [dw1[k], db1[k], dg1[k], dbe1[k], dw2[k], db2[k], dg2[k], dbe2[k], dw3[k], db3[k]]
+        return (dh, None, None, None, None, None, None) + tuple(grads)
 
 
 # ---------------------------------------------------------------------------
@@ -487,8 +504,9 @@ class HierarchicalPatchModel(nn.Module):
             self._fold_cache["cls"] = hit
         return hit[1]
 
-    # ---- one GNN layer in train mode: GCNConv kernel + fused BN/Dropout/ReLU/residual kernels ----------
-    def _layer_train(self, i: int, x_in: torch.Tensor, graph: ops.Graph, gb: int) -> torch.Tensor:
+    # ---- one GNN layer in train mode: one autograd node over eg_gcn_layer_train_fwd / eg_gcn_layer_bwd ------------------
+    def _layer_train(self, i: int, x_in: torch.Tensor, graph: ops.Graph, gb: int, coord_rows=None):
+        """-> (h, lm): lm = the coordinate-node rows of h (models.py:447) when ``coord_rows`` is given, else None."""
         layer = self.gnn_layers[i]
         conv, bn, drop = layer.module_0, layer.module_1, layer.module_2
         p = float(drop.p)
@@ -497,23 +515,28 @@ class HierarchicalPatchModel(nn.Module):
         if not (bn.training and bn.affine and drop.training):
             # a frozen (eval-mode) BatchNorm / Dropout inside a training model: GCNConv kernel + the torch modules
             h = layer.forward_graph(x_in, graph, gb)
-            return h + x_in if self.residual else h
+            return (h + x_in if self.residual else h), None
         _, momentum = _bn_step(bn)
-        return _LayerTrainFn.apply(x_in, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                   graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual))
+        h, lm = _LayerTrainFn.apply(x_in, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                    graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), coord_rows)
+        return h, (lm if coord_rows is not None else None)
 
     # ---- coordinate-graph update (models.py:438-473) ---------------------------------------
-    def _coordinate_update(self, i: int, h: torch.Tensor, node_coords: torch.Tensor, batch: int):
+    def _coordinate_update(self, i: int, h: torch.Tensor, node_coords: torch.Tensor, batch: int, lm=None):
         n, _, _, main_base, coord_base = self._row_ranges()
         fs = self.frame_size
-        hv = h.view(batch, n, C)
         # pairwise (other - self) offsets per frame, flattened to 8 numbers per landmark (:441-444)
         shape_feats = (node_coords.unsqueeze(1) - node_coords.unsqueeze(2)).reshape(batch * 4, 8)
-        landmark_feats = torch.cat((hv[:, coord_base:, :].reshape(batch * 4, C), shape_feats), dim=1)
-        delta = self.node_coordinate_mlp[i](landmark_feats)
+        if lm is None:
+            lm = h.view(batch, n, C)[:, coord_base:, :].reshape(batch * 4, C).clone()
+        delta = self.node_coordinate_mlp[i](torch.cat((lm, shape_feats), dim=1))
         node_coords = torch.clamp(node_coords + delta.view(batch, 4, 2), min=0, max=fs - 1)
-        new_feats = ops.bilinear4(h, node_coords, batch, n, main_base, fs)            # [4B, 128]
-        h = ops.scatter_coord_rows(h, new_feats, batch, n, coord_base)
+        if torch.is_grad_enabled() and (h.requires_grad or node_coords.requires_grad) and h.grad_fn is not None:
+            # train step: in place on the layer output, in place on its gradient (no [B*N,128] copies, fills or adds)
+            h = _CoordScatterFn.apply(h, node_coords, batch, n, main_base, fs, coord_base)
+        else:
+            new_feats = ops.bilinear4(h, node_coords, batch, n, main_base, fs)            # [4B, 128]
+            h = ops.scatter_coord_rows(h, new_feats, batch, n, coord_base)
         return h, node_coords
 
     # ---- the hot path ------------------------------------------------------------------------
@@ -561,23 +584,24 @@ class HierarchicalPatchModel(nn.Module):
                                       relu=not last, kidsum_in=kid[(i + 1) & 1] if i > 0 else None,
                                       kidsum_out=None if last else kid[i & 1])
             elif self.training:
-                h = self._layer_train(i, x_in, graph, gb)
+                _, _, _, _, coord_base = self._row_ranges()
+                h, lm = self._layer_train(i, x_in, graph, gb, (B, n, coord_base) if self.use_coordinate_graph else None)
             else:
                 h = self.gnn_layers[i].forward_graph(x_in, graph, gb)
                 if self.residual and h.shape[1] == x_in.shape[1]:
                     h = h + x_in
             if self.use_coordinate_graph:
-                h, node_coords = self._coordinate_update(i, h, node_coords, B)
+                h, node_coords = self._coordinate_update(i, h, node_coords, B, lm if (self.training and not fused) else None)
             hidden.append(h)
         h = self.jk(hidden) if self.jk is not None else hidden[-1]
         if fused:
             out = ops.classifier_fwd(h, B, n, n_conn, n_valid, self._packed_classifier(),
                                      sigmoid=(self.output_activation == "sigmoid"))
         else:
-            hv = h.view(B, n, C)[:, n_conn:n_conn + n_valid, :].reshape(B * n_valid, C)
             if self.training and self._stacked_heads_ok():
-                out = self._classifier_train(hv)
+                out = self._classifier_train(h, B, n, n_conn, n_valid)
             else:
+                hv = h.view(B, n, C)[:, n_conn:n_conn + n_valid, :].reshape(B * n_valid, C)
                 out = torch.cat([clf(hv) for clf in self.node_classifiers], dim=1)
         if self.use_coordinate_graph:
             node_coords = node_coords.reshape(B * 4, -1)
@@ -585,57 +609,34 @@ class HierarchicalPatchModel(nn.Module):
 
     # ---- the 4 classifier heads in train mode as ONE stacked network ----------------------------------------
     def _stacked_heads_ok(self) -> bool:
-        plain_bn = all(m.training and m.affine and m.track_running_stats and m.momentum is not None
+        plain_bn = all(m.training and m.affine and m.track_running_stats and m.momentum is not None and
+                       m.momentum == self.node_classifiers[0][1].momentum and m.eps == self.node_classifiers[0][1].eps
                        for hd in self.node_classifiers for m in (hd[1], hd[5]))
         drops_on = all(m.training for hd in self.node_classifiers for m in (hd[3], hd[7]))
         return (self.num_output_channels == 4 and self.classifier_hidden_dim == 32 and self.node_embedding_dim == C
                 and plain_bn and drops_on and os.environ.get("EG_STACKED_HEADS", "1") != "0")
 
-    def _classifier_train(self, hv: torch.Tensor) -> torch.Tensor:
-        """models.py:363-377, :488-490 in train mode.  The four heads Linear(128,32)-BN-ReLU-Drop-Linear(32,16)-BN-ReLU-
-        Drop-Linear(16,1) are evaluated as one network: the first layers stacked into a [128 -> 128] product on the
-        HIP kernels (4 x BatchNorm1d(32) on the stacked output IS BatchNorm1d(128) with stacked parameters), the
-        second layers as one block-diagonal [128 -> 64] product, the third as a 16-wide weighted sum.  Running under
-        torch this replaces 12 GEMMs with N in {32, 16, 1} over all B*N rows (47 % of a training step at B=32)."""
+    def _classifier_train(self, h: torch.Tensor, B: int, n: int, row_lo: int, n_valid: int) -> torch.Tensor:
+        """models.py:363-377, :485-490 in train mode on the HIP kernels (_ClassifierTrainFn): the node-type filter is a row
+        range, the four heads run as one stacked network.  Running statistics: the kernels update stacked copies, which are
+        written back to the 8 BatchNorm modules with two multi-tensor copies."""
         heads = list(self.node_classifiers)
-        R = hv.shape[0]
-
-        def stacked_bn(idx):
-            bns = [hd[idx] for hd in heads]
-            rm = torch.cat([b.running_mean for b in bns]).clone()
-            rv = torch.cat([b.running_var for b in bns]).clone()
-            return bns, torch.cat([b.weight for b in bns]), torch.cat([b.bias for b in bns]), rm, rv
-
-        def write_back(bns, rm, rv):
-            with torch.no_grad():
-                k = bns[0].num_features
-                for i, b in enumerate(bns):
-                    b.running_mean.copy_(rm[i * k:(i + 1) * k])
-                    b.running_var.copy_(rv[i * k:(i + 1) * k])
-                    b.num_batches_tracked += 1
-
-        # layer 1: [R,128] x [128,128]^T + BN(128) + ReLU + Dropout on the HIP kernels
-        w1 = torch.cat([hd[0].weight for hd in heads], dim=0)
-        b1 = torch.cat([hd[0].bias for hd in heads], dim=0)
-        z1 = _Linear128Fn.apply(hv, w1, b1)
-        bns, g1, be1, rm, rv = stacked_bn(1)
-        p1 = float(heads[0][3].p)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p1 > 0 else 0
-        mom = 0.1 if bns[0].momentum is None else bns[0].momentum
-        h1 = _BNActFn.apply(z1, g1, be1, rm, rv, None, True, p1, mom, bns[0].eps, seed)
-        write_back(bns, rm, rv)
-        # layer 2: block-diagonal [128 -> 64]
-        w2 = torch.block_diag(*[hd[4].weight for hd in heads])
-        z2 = F.linear(h1, w2, torch.cat([hd[4].bias for hd in heads]))
-        bns, g2, be2, rm, rv = stacked_bn(5)
-        mom = 0.1 if bns[0].momentum is None else bns[0].momentum
-        h2 = F.batch_norm(z2, rm, rv, g2, be2, True, mom, bns[0].eps)
-        write_back(bns, rm, rv)
-        h2 = F.dropout(F.relu(h2), float(heads[0][7].p), True)
-        # layer 3: 16-wide weighted sum per head
-        w3 = torch.cat([hd[8].weight for hd in heads], dim=0)                      # [4,16]
-        out = (h2.view(R, 4, 16) * w3.unsqueeze(0)).sum(dim=-1) + torch.cat([hd[8].bias for hd in heads])
-        return torch.sigmoid(out) if self.output_activation == "sigmoid" else out
+        bn1, bn2 = [hd[1] for hd in heads], [hd[5] for hd in heads]
+        p1, p2 = float(heads[0][3].p), float(heads[0][7].p)
+        seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if (p1 > 0 or p2 > 0) else [0, 0]      # host RNG, like the layers
+        with torch.no_grad():
+            rm1, rv1 = torch.cat([b.running_mean for b in bn1]), torch.cat([b.running_var for b in bn1])
+            rm2, rv2 = torch.cat([b.running_mean for b in bn2]), torch.cat([b.running_var for b in bn2])
+        cfg = dict(running_mean1=rm1, running_var1=rv1, running_mean2=rm2, running_var2=rv2, eps1=bn1[0].eps, eps2=bn2[0].eps,
+                   momentum1=bn1[0].momentum, momentum2=bn2[0].momentum, p1=p1, p2=p2, seed1=seeds[0], seed2=seeds[1])
+        params = [getattr(hd[j], name) for hd in heads for j, name in _HEAD_PARAM_IDX]
+        out = _ClassifierTrainFn.apply(h, B, n, row_lo, n_valid, self.output_activation == "sigmoid", cfg, *params)
+        with torch.no_grad():
+            torch._foreach_copy_([b.running_mean for b in bn1] + [b.running_var for b in bn1] +
+                                 [b.running_mean for b in bn2] + [b.running_var for b in bn2],
+                                 list(rm1.split(32)) + list(rv1.split(32)) + list(rm2.split(16)) + list(rv2.split(16)))
+            torch._foreach_add_([b.num_batches_tracked for b in bn1 + bn2], 1)
+        return out
 
     def _kidsum_buffers(self, graph, gb):
         key = (id(graph), gb)

@@ -60,6 +60,8 @@ class Graph:
         self.kidsum_rows = int(_lib.load().eg_graph_kidsum_rows(handle)) if structured else 0
         # eg_gcn_layer_cls_fwd (last layer + classifier heads in one kernel) is available for this handle
         self.fused_classifier_ok = bool(_lib.load().eg_graph_fused_classifier_ok(handle)) if structured else False
+        # the handle whose aggregation is A_hat^T (what a backward pass needs): the handle itself unless edge_index is directed
+        self.bwd: "Graph" = self
 
     @classmethod
     def topo(cls, frame_size: int, num_aux_graphs: int, use_main_graph_only: bool = False,
@@ -82,7 +84,13 @@ class Graph:
         with torch.cuda.device(ei.device):
             _lib.check(lib.eg_csr_create(_ptr(ei), int(num_nodes), int(ei.shape[1]), _stream(), ct.byref(h)),
                        "eg_csr_create")
-        return cls(h, False, int(num_nodes), ei.device)
+            g = cls(h, False, int(num_nodes), ei.device)
+            if not lib.eg_graph_is_symmetric(h):             # directed graph: the backward aggregates over out-edges
+                ht = ct.c_void_p()
+                _lib.check(lib.eg_csr_create_transposed(h, _ptr(ei), int(ei.shape[1]), _stream(), ct.byref(ht)),
+                           "eg_csr_create_transposed")
+                g.bwd = cls(ht, False, int(num_nodes), ei.device)
+        return g
 
     def deg_inv_sqrt(self) -> torch.Tensor:
         out = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
@@ -288,6 +296,107 @@ def bn_act_bwd(dy, z, mean, invstd, gamma, beta, relu=False, dropout_p=0.0, seed
                                          _ptr(_workspace(z.device)), _ptr(dz), _ptr(dgamma), _ptr(dbeta), _stream()),
                "eg_bn_act_bwd")
     return dz, dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------
+# whole train-mode layers (eg_gcn_layer_train_fwd / _bwd, eg_classifier_train_fwd / _bwd)
+# ---------------------------------------------------------------------------
+def gcn_layer_train_fwd(graph: Graph, batch: int, x, weight, bias, gamma, beta, running_mean, running_var, momentum,
+                        eps: float, relu: bool, dropout_p: float, seed: int, residual: bool, want_agg: bool = True):
+    """-> (out, z, agg | None, bn [4,128] = mean, invstd, scale, shift).  running_* are updated in place
+    (momentum None: no update)."""
+    rows = graph.num_nodes * batch
+    _check_rows(x, "x", rows)
+    for t, n in ((bias, "bias"), (gamma, "gamma"), (beta, "beta")):
+        _check_vec(t, n, C)
+    z = torch.empty_like(x)
+    out = torch.empty_like(x)
+    agg = torch.empty_like(x) if want_agg else None
+    bn = torch.empty(4, C, dtype=torch.float32, device=x.device)
+    upd = momentum is not None and running_mean is not None
+    _lib.check(_lib.load().eg_gcn_layer_train_fwd(
+        graph._h, batch, _ptr(x), _ptr(weight), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(running_mean) if upd else None,
+        _ptr(running_var) if upd else None, float(momentum) if upd else -1.0, float(eps), int(relu), float(dropout_p),
+        int(seed) & 0xFFFFFFFFFFFFFFFF, int(residual), _ptr(_workspace(x.device)), _ptr(z), _ptr(agg), _ptr(bn), _ptr(out),
+        _stream()), "eg_gcn_layer_train_fwd")
+    return out, z, agg, bn
+
+
+def gcn_layer_bwd(graph_bwd: Graph, batch: int, dy, z, agg, weight, gamma, beta, bn, relu: bool, dropout_p: float, seed: int,
+                  residual: bool, need_dx: bool, need_dw: bool):
+    """-> (dx | None, dw | None, db | None (zeros), dgamma, dbeta)"""
+    rows = graph_bwd.num_nodes * batch
+    _check_rows(dy, "dy", rows)
+    dz = torch.empty_like(dy)
+    dx = torch.empty_like(dy) if need_dx else None
+    dw = torch.empty(C, C, dtype=torch.float32, device=dy.device) if need_dw else None
+    small = torch.empty(3, C, dtype=torch.float32, device=dy.device)           # db, dgamma, dbeta
+    _lib.check(_lib.load().eg_gcn_layer_bwd(
+        graph_bwd._h, batch, _ptr(dy), _ptr(z), _ptr(agg), _ptr(weight), _ptr(gamma), _ptr(beta), _ptr(bn), int(relu),
+        float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(residual), _ptr(_workspace(dy.device)), _ptr(dz), _ptr(dx),
+        _ptr(dw), _ptr(small[0]), _ptr(small[1]), _ptr(small[2]), _stream()), "eg_gcn_layer_bwd")
+    return dx, dw, small[0], small[1], small[2]
+
+
+CLS_GRADS_FLOATS = 19076
+_cls_workspaces = {}
+
+
+def _cls_workspace(device) -> torch.Tensor:
+    key = (torch.device(device), torch.cuda.current_stream().cuda_stream)
+    ws = _cls_workspaces.get(key)
+    if ws is None:
+        ws = torch.empty(int(_lib.load().eg_classifier_train_workspace_bytes()), dtype=torch.uint8, device=device)
+        _cls_workspaces[key] = ws
+    return ws
+
+
+def _cls_params(P: dict) -> "_lib.ClsTrainParams":
+    s = _lib.ClsTrainParams()
+    for k in ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3", "b3", "running_mean1", "running_var1",
+              "running_mean2", "running_var2"):
+        t = P.get(k)
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+            raise RuntimeError(f"classifier parameter {k} must be a contiguous CUDA float32 tensor")
+        setattr(s, k, None if t is None else t.data_ptr())
+    for k in ("eps1", "eps2", "p1", "p2"):
+        setattr(s, k, float(P[k]))
+    s.momentum1 = -1.0 if P.get("momentum1") is None else float(P["momentum1"])
+    s.momentum2 = -1.0 if P.get("momentum2") is None else float(P["momentum2"])
+    s.seed1, s.seed2 = int(P["seed1"]) & 0xFFFFFFFFFFFFFFFF, int(P["seed2"]) & 0xFFFFFFFFFFFFFFFF
+    return s
+
+
+def classifier_train_fwd(h, batch: int, n_per_frame: int, row_lo: int, n_valid: int, P: dict, sigmoid: bool):
+    """-> (logits [batch*n_valid,4], z1, z2, bn [768])"""
+    _check_rows(h, "h", batch * n_per_frame)
+    rows = batch * n_valid
+    dev = h.device
+    z1 = torch.empty(rows, C, dtype=torch.float32, device=dev)
+    z2 = torch.empty(rows, 64, dtype=torch.float32, device=dev)
+    bn = torch.empty(4 * C + 4 * 64, dtype=torch.float32, device=dev)
+    logits = torch.empty(rows, 4, dtype=torch.float32, device=dev)
+    s = _cls_params(P)
+    _lib.check(_lib.load().eg_classifier_train_fwd(_ptr(h), batch, n_per_frame, row_lo, n_valid, ct.byref(s),
+                                                   _ptr(_cls_workspace(dev)), _ptr(z1), _ptr(z2), _ptr(bn), int(sigmoid),
+                                                   _ptr(logits), _stream()), "eg_classifier_train_fwd")
+    return logits, z1, z2, bn
+
+
+def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_valid: int, P: dict, z1, z2, bn, need_dh: bool):
+    """-> (dh | None [batch*n_per_frame,128], grads [19076] packed as in include/echoglad_hip.h)"""
+    rows = batch * n_valid
+    dev = h.device
+    _check_logits(dlogits, "dlogits", rows)
+    dh1 = torch.empty(rows, C, dtype=torch.float32, device=dev)
+    dz1 = torch.empty(rows, C, dtype=torch.float32, device=dev)
+    dh = torch.empty_like(h) if need_dh else None
+    grads = torch.empty(CLS_GRADS_FLOATS, dtype=torch.float32, device=dev)
+    s = _cls_params(P)
+    _lib.check(_lib.load().eg_classifier_bwd(_ptr(dlogits), _ptr(h), batch, n_per_frame, row_lo, n_valid, ct.byref(s), _ptr(z1),
+                                             _ptr(z2), _ptr(bn), _ptr(_cls_workspace(dev)), _ptr(dh1), _ptr(dz1), _ptr(dh),
+                                             _ptr(grads), _stream()), "eg_classifier_bwd")
+    return dh, grads
 
 
 # ---------------------------------------------------------------------------

@@ -78,6 +78,14 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
 int eg_csr_create(const int64_t* edge_index_dev, int64_t n_nodes, int64_t n_edges, eg_stream_t stream,
                   eg_graph** out);
 
+/* A_hat of a DIRECTED edge_index is not symmetric, and the backward of a layer aggregates with A_hat^T
+ * (dX = (A_hat^T dY) W, dW = (A_hat^T dY)^T X).  eg_graph_is_symmetric: 1 for topology handles and for CSR handles whose
+ * kept edge multiset equals its own transpose (use the handle itself in the backward), else 0: build the transposed
+ * handle once from the SAME edge_index (rows = sources, normalisation (deg+1)^-1/2 taken from `base`). */
+int eg_graph_is_symmetric(const eg_graph* g);
+int eg_csr_create_transposed(const eg_graph* base, const int64_t* edge_index_dev, int64_t n_edges, eg_stream_t stream,
+                             eg_graph** out);
+
 int eg_graph_destroy(eg_graph* g);
 int64_t eg_graph_num_nodes(const eg_graph* g);      /* nodes per frame (topo) or total (csr) */
 int eg_graph_is_structured(const eg_graph* g);
@@ -186,6 +194,59 @@ int eg_bn_act_fwd(const float* z, int64_t rows, const float* scale, const float*
 int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* mean, const float* invstd,
                   const float* gamma, const float* beta, int relu, float dropout_p, uint64_t seed, void* workspace,
                   float* dz, float* dgamma, float* dbeta, eg_stream_t stream);
+
+/* ---- one whole train-mode GNN layer (src/core/models.py:328-335, :431-435 in train mode; backward of engine.py:271-273) ----
+ * eg_gcn_layer_train_fwd:
+ *     z   = A_hat x W^T + bias                       kept for the backward          [rows,128]
+ *     agg = A_hat x                                   kept for the weight gradient   [rows,128] (NULL: not kept)
+ *     bn  = { batch mean, 1/sqrt(var + eps), gamma * invstd, beta - mean * scale }   [4,128]
+ *     running_mean / running_var <- nn.BatchNorm1d update with `momentum` (unbiased variance); momentum < 0 or NULL: none
+ *     out = relu?(dropout(z * scale + shift)) + (residual ? x : 0)    dropout mask = pure function of (seed, element)
+ * eg_gcn_layer_bwd, given dy = d loss / d out and the tensors kept by the forward:
+ *     dz (scratch [rows,128]) = BatchNorm'(dy * dropout / ReLU mask);  dgamma, dbeta [128]
+ *     dx [rows,128] (NULL: skipped) = (A_hat^T dz) W + (residual ? dy : 0)      g_bwd: eg_graph_is_symmetric ? g : transposed handle
+ *     dw [128,128]  (NULL: skipped) = dz^T agg                                   (== (A_hat^T dz)^T x)
+ *     db [128]      (NULL: skipped) = 0: a bias in front of a train-mode BatchNorm has an identically zero gradient
+ * workspace: eg_workspace_bytes() bytes of device memory, reusable across calls on one stream. */
+int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* bias, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
+                           float dropout_p, uint64_t seed, int residual, void* workspace, float* z, float* agg, float* bn,
+                           float* out, eg_stream_t stream);
+int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
+                     const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
+                     int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
+                     float* dbeta, eg_stream_t stream);
+
+/* ---- node-type filter + the 4 classifier heads, train mode (src/core/models.py:363-377, :485-490; batch statistics in both
+ * BatchNorm layers of every head).  The four heads run as one stacked network; parameters are passed stacked:
+ *   w1 [128,128] = 4 x [32,128], b1 / gamma1 / beta1 [128];  w2 [4,16,32], b2 / gamma2 / beta2 [64];  w3 [4,16], b3 [4]
+ *   running_mean1 / running_var1 [128], running_mean2 / running_var2 [64]: updated in place (NULL or momentum < 0: not)
+ *   p1 / p2, seed1 / seed2: the two Dropout layers (mask = pure function of (seed, element))
+ * eg_classifier_train_fwd keeps z1 [batch*n_valid,128], z2 [batch*n_valid,64] and bn [4*128 + 4*64] = per layer {mean, invstd,
+ * scale, shift}, and writes logits [batch*n_valid, 4].
+ * eg_classifier_bwd, given dlogits [batch*n_valid,4]:
+ *   dh [batch*n_per_frame,128] (NULL: skipped): gradient w.r.t. h; the rows the filter drops are written as zeros
+ *   grads [19076] = dw1 [128*128], db1 [128] (= 0), dgamma1 [128], dbeta1 [128], dw2 [4*16*32], db2 [64] (= 0), dgamma2 [64],
+ *                   dbeta2 [64], dw3 [64], db3 [4]
+ *   dh1_scratch, dz1_scratch: [batch*n_valid,128] each.
+ * workspace: eg_classifier_train_workspace_bytes() bytes. */
+typedef struct eg_cls_train_params {
+    const float *w1, *b1, *gamma1, *beta1;
+    const float *w2, *b2, *gamma2, *beta2;
+    const float *w3, *b3;
+    float *running_mean1, *running_var1, *running_mean2, *running_var2;
+    float eps1, eps2, momentum1, momentum2;
+    float p1, p2;
+    uint64_t seed1, seed2;
+} eg_cls_train_params;
+#define EG_CLS_GRADS_FLOATS 19076
+size_t eg_classifier_train_workspace_bytes(void);
+int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                            const eg_cls_train_params* params, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
+                            float* logits, eg_stream_t stream);
+int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                      const eg_cls_train_params* params, const float* z1, const float* z2, const float* bn, void* workspace,
+                      float* dh1_scratch, float* dz1_scratch, float* dh, float* grads, eg_stream_t stream);
 
 /* ---- coordinate-graph resampling (src/core/models.py:539-553 as a 4-tap gather) -------------------
  * coords [batch*points, 2] in (h, w) order; out[p,:] = bilinear sample of frame p/points' main grid

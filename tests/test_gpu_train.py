@@ -211,7 +211,7 @@ def test_cfg4_train_step_vs_reference_fixture(golden_dir):
     loss.backward()
     assert np.abs(got.detach().cpu().numpy()[g["train_rows"]] - g["train_logits_rows"]).max() < 3e-4
     assert np.abs(gc.detach().cpu().numpy() - g["train_coords"]).max() < 5e-4
-    assert abs(float(loss) - float(g["train_loss"])) < 1e-4 * float(g["train_loss"])
+    assert abs(float(loss.detach()) - float(g["train_loss"])) < 1e-4 * float(g["train_loss"])
     want_norm = dict(zip([str(k) for k in g["grad_keys"]], g["grad_norms"]))
     for name, p in hip.named_parameters():
         assert p.grad is not None, name
@@ -229,3 +229,150 @@ def test_cfg4_train_step_vs_reference_fixture(golden_dir):
         rg = ref_grads[name].grad
         err = (p.grad.cpu() - rg).abs().max().item()
         assert err < 5e-3 * rg.abs().max().item() + 1e-6, (name, err, rg.abs().max().item())
+
+
+def _torch_heads(model, hv, mask1=None, mask2=None):
+    """The four heads of models.py:363-377 with torch modules in train mode; dropout replaced by the given masks."""
+    outs = []
+    for k, hd in enumerate(model.node_classifiers):
+        a = torch.relu(hd[1](hd[0](hv)))
+        if mask1 is not None:
+            a = a * mask1[:, 32 * k:32 * k + 32]
+        b = torch.relu(hd[5](hd[4](a)))
+        if mask2 is not None:
+            b = b * mask2[:, 16 * k:16 * k + 16]
+        outs.append(hd[9](hd[8](b)))
+    return torch.cat(outs, dim=1)
+
+
+@pytest.mark.parametrize("p,act", [(0.0, "logit"), (0.5, "logit"), (0.0, "sigmoid")])
+@pytest.mark.parametrize("n,row_lo,n_valid,B", [(340, 0, 340, 2), (344, 0, 340, 3), (348, 4, 340, 2), (5000, 0, 4996, 2)])
+def test_classifier_train_kernels_vs_torch_autograd(p, act, n, row_lo, n_valid, B):
+    """eg_classifier_train_fwd / eg_classifier_bwd (stacked heads, batch statistics, counter-based dropout) against the same
+    network written with torch modules under autograd, with the kernels' own dropout masks."""
+    import copy
+    from echoglad_amd import nn as egnn
+    hip, _ = model_pair(16, 3, 1, seed=n + B, output_activation=act)
+    for m in hip.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = p
+    hip.train()
+    ref = copy.deepcopy(hip)
+    # (seed chosen so that no hidden pre-activation sits within rounding of the ReLU kink: there the two implementations'
+    #  masks may legitimately differ — FMA vs mul + add — and one element's gradient with them)
+    h = (rand_rows(B * n, seed=7 + n) * 1.5).to(DEV)
+    hh = h.clone().requires_grad_(True)
+    hr = h.clone().requires_grad_(True)
+    torch.manual_seed(1234)
+    got = hip._classifier_train(hh, B, n, row_lo, n_valid)
+    torch.manual_seed(1234)
+    seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if p > 0 else [0, 0]
+    R = B * n_valid
+    m1 = m2 = None
+    if p > 0:
+        one = torch.ones(128, device=DEV)
+        zero = torch.zeros(128, device=DEV)
+        m1 = ops.bn_act_fwd(torch.ones(R, 128, device=DEV), one, zero, None, False, p, seeds[0])
+        m2 = ops.bn_act_fwd(torch.ones(R // 2, 128, device=DEV), one, zero, None, False, p, seeds[1]).view(R, 64)
+    hv = hr.view(B, n, 128)[:, row_lo:row_lo + n_valid, :].reshape(R, 128)
+    want = _torch_heads(ref, hv, m1, m2)
+    assert got.shape == want.shape == (R, 4)
+    assert (got.detach() - want.detach()).abs().max() < 2e-4
+    w = rand_rows(R, seed=9)[:, :4].to(DEV).contiguous()
+    (got * w).sum().backward()
+    (want * w).sum().backward()
+    gmax = hr.grad.abs().max()
+    assert (hh.grad - hr.grad).abs().max() < 5e-3 * gmax + 1e-7
+    if n_valid < n:                                        # rows the node-type filter drops get an exactly-zero gradient
+        drop = torch.ones(n, dtype=torch.bool); drop[row_lo:row_lo + n_valid] = False
+        assert (hh.grad.view(B, n, 128)[:, drop.to(DEV), :] == 0).all()
+    ref_grads = dict(ref.named_parameters())
+    for name, prm in hip.named_parameters():
+        if not name.startswith("node_classifiers"):
+            continue
+        rg = ref_grads[name].grad
+        if name.endswith((".0.bias", ".4.bias")):
+            # a bias in front of a train-mode BatchNorm: the gradient is analytically zero (the kernels return exact zeros,
+            # autograd returns the rounding noise of a sum that cancels)
+            wg = ref_grads[name[:-4] + "weight"].grad.abs().max().item()
+            assert prm.grad.abs().max().item() == 0 and rg.abs().max().item() < 1e-3 * wg + 1e-5, (name, rg.abs().max().item(), wg)
+            continue
+        err = (prm.grad - rg).abs().max().item()
+        assert err < 5e-3 * rg.abs().max().item() + 2e-6, (name, err, rg.abs().max().item())
+    for (n1, b1), (n2, b2) in zip(hip.named_buffers(), ref.named_buffers()):
+        if n1.startswith("node_classifiers"):
+            assert torch.allclose(b1, b2, rtol=1e-4, atol=1e-5), n1
+    if p > 0:                                              # the mask really drops about half of the hidden units
+        assert abs(float((m1 == 0).float().mean()) - p) < 0.02 and abs(float((m2 == 0).float().mean()) - p) < 0.02
+
+
+@pytest.mark.parametrize("frame,naux,coord,relu,residual,p", [(16, 3, False, True, True, 0.0), (32, 4, True, False, True, 0.5),
+                                                             (30, 3, False, True, False, 0.3)])
+def test_layer_train_composites_vs_torch_autograd(frame, naux, coord, relu, residual, p):
+    """eg_gcn_layer_train_fwd / eg_gcn_layer_bwd: one whole train-mode layer (GCNConv, batch-stat BN, dropout with the
+    kernel's own mask, ReLU, residual) against dense-A_hat torch autograd; also on a directed (asymmetric) CSR graph."""
+    B = 2
+    g = ops.Graph.topo(frame, naux, False, coord)
+    n = g.num_nodes
+    topo, ei, nt, bi = graph_tensors(frame, naux, 1, coord=coord)
+    from gpu_util import dense_ahat
+    A = dense_ahat(topo).float().to(DEV)
+    rs = np.random.RandomState(frame)
+    W = torch.from_numpy(rs.uniform(-0.15, 0.15, (128, 128)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.standard_normal(128).astype(np.float32) * 0.1).to(DEV)
+    gamma = torch.from_numpy(1 + 0.3 * rs.standard_normal(128).astype(np.float32)).to(DEV)
+    beta = torch.from_numpy(0.1 * rs.standard_normal(128).astype(np.float32)).to(DEV)
+    x = rand_rows(B * n, seed=3).to(DEV)
+    rm, rv = torch.zeros(128, device=DEV), torch.ones(128, device=DEV)
+    seed = 99
+    out, z, agg, bn = ops.gcn_layer_train_fwd(g, B, x, W, bias, gamma, beta, rm, rv, 0.1, 1e-5, relu, p, seed, residual)
+    xr, Wr, br, gr, ber = (t.clone().requires_grad_(True) for t in (x, W, bias, gamma, beta))
+    aggr = torch.cat([A @ xr[b * n:(b + 1) * n] for b in range(B)])
+    zr = aggr @ Wr.t() + br
+    mean, var = zr.mean(0), zr.var(0, unbiased=False)
+    v = (zr - mean) / torch.sqrt(var + 1e-5) * gr + ber
+    mask = ops.bn_act_fwd(torch.ones_like(x), torch.ones(128, device=DEV), torch.zeros(128, device=DEV), None, False, p, seed) \
+        if p > 0 else 1.0
+    v = v * mask
+    v = torch.relu(v) if relu else v
+    want = v + xr if residual else v
+    assert (z - zr.detach()).abs().max() < 2e-4 and (agg - aggr.detach()).abs().max() < 1e-4
+    assert (out - want.detach()).abs().max() < 3e-4
+    assert torch.allclose(rm, 0.1 * mean.detach(), atol=1e-5) and torch.allclose(rv, 0.9 + 0.1 * zr.detach().var(0), rtol=1e-4)
+    dy = rand_rows(B * n, seed=4).to(DEV)
+    dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(g.bwd, B, dy, z, agg, W, gamma, beta, bn, relu, p, seed, residual, True, True)
+    (want * dy).sum().backward()
+    for got, ref, name in ((dx, xr.grad, "dx"), (dw, Wr.grad, "dw"), (dgamma, gr.grad, "dgamma"), (dbeta, ber.grad, "dbeta")):
+        assert (got - ref).abs().max() < 5e-3 * ref.abs().max() + 1e-6, name
+    assert db.abs().max() == 0 and br.grad.abs().max() < 1e-3 * dw.abs().max()      # the bias gradient is analytically zero
+
+
+def test_layer_train_composites_on_a_directed_graph():
+    """A_hat of a directed edge_index is not symmetric: forward aggregates over in-edges, backward over out-edges
+    (eg_csr_create_transposed)."""
+    n = 300
+    rs = np.random.RandomState(1)
+    ei = torch.from_numpy(np.stack([rs.randint(0, n, 1500), rs.randint(0, n, 1500)]).astype(np.int64))
+    g = ops.Graph.csr(ei.to(DEV), n)
+    assert g.bwd is not g
+    a = torch.zeros(n, n, dtype=torch.float64)
+    keep = ei[0] != ei[1]
+    a.index_put_((ei[1][keep], ei[0][keep]), torch.ones(int(keep.sum()), dtype=torch.float64), accumulate=True)
+    a += torch.eye(n, dtype=torch.float64)
+    dis = a.sum(1).pow(-0.5)
+    A = (dis[:, None] * a * dis[None, :]).float().to(DEV)
+    assert (A - A.t()).abs().max() > 0.01
+    x = rand_rows(n, seed=1).to(DEV)
+    assert (ops.gcn_aggregate(g, 1, x) - A @ x).abs().max() < 1e-4
+    assert (ops.gcn_aggregate(g.bwd, 1, x) - A.t() @ x).abs().max() < 1e-4
+    W = torch.from_numpy(rs.uniform(-0.15, 0.15, (128, 128)).astype(np.float32)).to(DEV)
+    one, zero = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    out, z, agg, bn = ops.gcn_layer_train_fwd(g, 1, x, W, zero, one, zero, None, None, None, 1e-5, True, 0.0, 0, True)
+    xr, Wr = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    zr = (A @ xr) @ Wr.t()
+    want = torch.relu((zr - zr.mean(0)) / torch.sqrt(zr.var(0, unbiased=False) + 1e-5)) + xr
+    assert (out - want.detach()).abs().max() < 3e-4
+    dy = rand_rows(n, seed=2).to(DEV)
+    dx, dw, _, _, _ = ops.gcn_layer_bwd(g.bwd, 1, dy, z, agg, W, one, zero, bn, True, 0.0, 0, True, True, True)
+    (want * dy).sum().backward()
+    assert (dx - xr.grad).abs().max() < 5e-3 * xr.grad.abs().max() and (dw - Wr.grad).abs().max() < 5e-3 * Wr.grad.abs().max()

@@ -14,7 +14,7 @@ import csv
 n=$STEPS+$WARM
 rows=list(csv.DictReader(open("$f")))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
-for r in rows[:24]:
+for r in rows[:40]:
     print(f'{float(r["TotalDurationNs"])/n/1e6:8.3f} ms/step {float(r["Percentage"]):6.2f}% calls/step {int(r["Calls"])/n:6.1f}  {r["Name"][:100]}')
 print("total kernel ms/step", tot/n/1e6)
 PY
