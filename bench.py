@@ -278,14 +278,17 @@ def cpu_baseline(args, kw, state_dict):
                       f"(fastest of the probed thread counts {sorted(probe)} on {avail} host cores)"}, out, feats, ei
 
 
+DOMINANT_KERNEL_SOURCES = ("gcn_layer_ps.hip", "seg_wide.h", "tile.h", "common.h", "graph.hip")
+
+
 def kernel_source_digest() -> str:
-    """sha256 over the kernel sources: ties a committed PMC summary to the code it was measured on (the GPU box has no .git)."""
+    """sha256 over the sources of the dominant kernel (the chained layer kernel, its device helpers and the topology tables
+    it reads): ties a committed PMC summary to the code it was measured on (the GPU box has no .git)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "echoglad_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in DOMINANT_KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

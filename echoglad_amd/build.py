@@ -82,6 +82,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), variant: s
 
 if __name__ == "__main__":
     extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+    if "--" in sys.argv:                                   # everything after "--" goes to hipcc verbatim (experiments)
+        extra += sys.argv[sys.argv.index("--") + 1:]
     var = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")]
     p = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, extra_flags=extra,
               variant=var[0] if var else "")

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_dw(const float* __restrict
                     if (a.relu) g = v > 0.f ? g : 0.f;
                     vg[u] = ga[u] * is[u] * (g - mg[u] - xh * mgx[u]);
                 }
-                *reinterpret_cast<f32x4*>(dz + off) = vg;
+                if (dz) *reinterpret_cast<f32x4*>(dz + off) = vg;           // (NULL: only the weight gradient is wanted)
             }
             *reinterpret_cast<f32x4*>(&s_g[e * 4]) = vg;
             *reinterpret_cast<f32x4*>(&s_x[e * 4]) = vx;
@@ -392,8 +392,9 @@ static ActArgs make_act(int64_t rows, int relu, float p, uint64_t seed) {
 int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, int relu, float dropout_p, unsigned long long seed, void* workspace, float* dz,
                      float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream) {
-    if (!dy || !z || !mean || !invstd || !gamma || !beta || !workspace || !dz || !dgamma || !dbeta || rows < 1)
+    if (!dy || !z || !mean || !invstd || !gamma || !beta || !workspace || !dgamma || !dbeta || rows < 1)
         return set_error(EG_ERR_ARG, "bad argument");
+    if (!dz && !(dw && x)) return set_error(EG_ERR_ARG, "dz may only be NULL when the fused weight gradient is computed");
     if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
     const ActArgs a = make_act(rows, relu, dropout_p, seed);
     double* partial = (double*)workspace;
@@ -502,8 +503,9 @@ int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const fl
                      const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
                      int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
                      float* dbeta, eg_stream_t stream_) {
-    if (!g_bwd || !dy || !z || !W || !gamma || !beta || !bn || !workspace || !dz_scratch || !dgamma || !dbeta)
+    if (!g_bwd || !dy || !z || !W || !gamma || !beta || !bn || !workspace || !dgamma || !dbeta)
         return set_error(EG_ERR_ARG, "NULL argument");
+    if (!dz_scratch && (dx || !dw)) return set_error(EG_ERR_ARG, "dz_scratch may only be NULL when dx is not wanted and dw is");
     if (dw && !agg) return set_error(EG_ERR_ARG, "dW needs the aggregated input kept by eg_gcn_layer_train_fwd");
     hipStream_t stream = (hipStream_t)stream_;
     const long long rows = (long long)g_bwd->n_nodes * batch;

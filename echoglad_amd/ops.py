@@ -327,7 +327,7 @@ def gcn_layer_bwd(graph_bwd: Graph, batch: int, dy, z, agg, weight, gamma, beta,
     """-> (dx | None, dw | None, db | None (zeros), dgamma, dbeta)"""
     rows = graph_bwd.num_nodes * batch
     _check_rows(dy, "dy", rows)
-    dz = torch.empty_like(dy)
+    dz = torch.empty_like(dy) if (need_dx or not need_dw) else None       # dW alone comes out of the fused apply pass
     dx = torch.empty_like(dy) if need_dx else None
     dw = torch.empty(C, C, dtype=torch.float32, device=dy.device) if need_dw else None
     small = torch.empty(3, C, dtype=torch.float32, device=dy.device)           # db, dgamma, dbeta

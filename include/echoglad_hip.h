@@ -203,7 +203,8 @@ int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* me
  *     running_mean / running_var <- nn.BatchNorm1d update with `momentum` (unbiased variance); momentum < 0 or NULL: none
  *     out = relu?(dropout(z * scale + shift)) + (residual ? x : 0)    dropout mask = pure function of (seed, element)
  * eg_gcn_layer_bwd, given dy = d loss / d out and the tensors kept by the forward:
- *     dz (scratch [rows,128]) = BatchNorm'(dy * dropout / ReLU mask);  dgamma, dbeta [128]
+ *     dz (scratch [rows,128]; may be NULL when dx is NULL and dw is not: the first layer of a stack whose input needs no
+ *         gradient never writes it) = BatchNorm'(dy * dropout / ReLU mask);  dgamma, dbeta [128]
  *     dx [rows,128] (NULL: skipped) = (A_hat^T dz) W + (residual ? dy : 0)      g_bwd: eg_graph_is_symmetric ? g : transposed handle
  *     dw [128,128]  (NULL: skipped) = dz^T agg                                   (== (A_hat^T dz)^T x)
  *     db [128]      (NULL: skipped) = 0: a bias in front of a train-mode BatchNorm has an identically zero gradient
