@@ -347,6 +347,34 @@ def other_configs(args, device):
             out[key] = {"workload": what, "error": repr(ex)}
         gc.collect()
         torch.cuda.empty_cache()
+    what = ("configs[1] through the GENERIC path: the same 224x224 / 7-aux-level batch of 8 with its edge_index turned into a CSR "
+            "handle (what grid-diagonal graphs, connection nodes or arbitrary edge_index take): 3 x eg_gcn_layer_fwd + eg_classifier_fwd")
+    try:
+        from echoglad_amd import ops
+        model, kw, topo, feats, ei, _ = infer_workload(224, 7, args.layers, False, 8, device, 0, hip_graph=False)
+        g = ops.Graph.csr(ei, feats.shape[0])
+        folded, packed = model._folded_layers(), model._packed_classifier()
+
+        def csr_step():
+            h = feats
+            for i, (w, sc, sh) in enumerate(folded):
+                h = ops.gcn_layer_fwd(g, 1, h, w, sc, sh, h, relu=i < len(folded) - 1)
+            return ops.classifier_fwd(h, 8, topo.num_nodes, 0, topo.num_nodes, packed)
+
+        with torch.no_grad():
+            ms = time_steps(csr_step, iters=20, warm=5)
+            same = float((csr_step() - model.forward_nodes(feats, ei, 8)[0]).abs().max())
+        sb, sf = stack_work(topo, args.layers)
+        fps = 8 / (ms * 1e-3)
+        out["cfg2_csr_fallback"] = {"workload": what, "ms_per_step": round(ms, 4), "frames_s": round(fps, 1),
+                                    "mfma_frac": round(fps * sf / 1e12 / PEAK_F32_MFMA_TF, 4),
+                                    "hbm_frac": round(fps * (sb + 8 * 2 * topo.num_undirected_edges * args.layers) / 1e9 / PEAK_HBM_GBS, 4),
+                                    "max_abs_diff_vs_stencil_path": same}
+        del model, feats, ei, g
+    except Exception as ex:
+        out["cfg2_csr_fallback"] = {"workload": what, "error": repr(ex)}
+    gc.collect()
+    torch.cuda.empty_cache()
     what = ("configs[3]: 224x224, 7 aux levels + coordinate graph, batch 32 per GPU, one training step "
             "(fwd + 3 losses + bwd + Adam; dropout 0.5, batch-stat BN)")
     try:
