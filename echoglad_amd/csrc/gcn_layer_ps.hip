@@ -161,6 +161,10 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         }
         __syncthreads();                                   // tile 0 is in buffer 0
         PSTAMP_INIT;
+#ifdef EG_STAMP
+        // in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): shader cycles / 100 MHz ticks around the tile loop
+        const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int k = 0;; ++k) {
             const int t_cur = __builtin_amdgcn_readfirstlane(s_tile[k & 7]);
             if (t_cur < 0) break;
@@ -348,6 +352,13 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             PSTAMP(2);
         }
         PSTAMP_FLUSH(0);
+#ifdef EG_STAMP
+        if (wave == 0 && lane_k == 0) {
+            unsigned long long* stats = reinterpret_cast<unsigned long long*>(counters + WALK_GROUPS * WALK_CTR_STRIDE);
+            atomicAdd(&stats[9], __builtin_amdgcn_s_memtime() - clk0);
+            atomicAdd(&stats[10], __builtin_amdgcn_s_memrealtime() - rt0);
+        }
+#endif
     } else {
         // =========================== PRODUCER: patch rows 2p, 2p+1 of every tile ================================
         const int p = wave - 4;

@@ -530,7 +530,7 @@ int eg_debug_phase_cycles(eg_graph* g, uint64_t* out_host, int reset) {
     if (!g || !out_host) return set_error(EG_ERR_ARG, "NULL argument");
     EG_HIP_TRY(hipDeviceSynchronize());
     int* const tail = g->walk_counters + (size_t)QUEUE_SLOTS * QUEUE_SLICE_INTS;
-    EG_HIP_TRY(hipMemcpy(out_host, tail, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    EG_HIP_TRY(hipMemcpy(out_host, tail, 11 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (reset) EG_HIP_TRY(hipMemset(tail, 0, 16 * sizeof(uint64_t)));
     return EG_OK;
 }

@@ -94,8 +94,9 @@ int64_t eg_graph_num_tiles(const eg_graph* g);      /* 64-row work tiles per fra
 int eg_graph_deg_inv_sqrt(const eg_graph* g, float* out_dev, eg_stream_t stream);
 
 /* Diagnostic (stamp builds only, -DEG_STAMP): per-phase cycle sums of the layer kernel accumulated in
- * the handle since the last reset: out_host[0..7] = phase sums over all waves, out_host[8] = waves.
- * Synchronises the device. */
+ * the handle since the last reset: out_host[0..7] = phase sums over all waves, out_host[8] = waves,
+ * out_host[9] / out_host[10] = shader cycles / 100-MHz ticks around the tile loops (their ratio x 100 MHz = the clock the
+ * chip held inside the kernel).  out_host must hold 11 values.  Synchronises the device. */
 int eg_debug_phase_cycles(eg_graph* g, uint64_t* out_host, int reset);
 
 /* Diagnostic: out_dev[b] = XCC (XCD) id workgroup b ran on, out_dev[nblocks + b] = its start time stamp. */

@@ -10,7 +10,7 @@ g = ops.Graph.topo(224, 7)
 x = synthetic_node_feats(B * g.num_nodes, 128, 1).cuda()
 w = (synthetic_node_feats(128, 128, 2) * 0.1).cuda()
 out = torch.empty_like(x)
-buf = (ct.c_uint64 * 9)()
+buf = (ct.c_uint64 * 11)()
 lib = _lib.load()
 form = os.environ.get("EG_STAMP_FORM", "")          # "", "kin", "kout", "kin+kout", "kin+cls": chained forms run the producer/consumer kernel
 kw = {}
@@ -20,6 +20,17 @@ packed = None
 if "cls" in form:                                    # last layer + fused classifier heads (k_gcn_layer_ps<true>)
     f = lambda *shape: (synthetic_node_feats(int(torch.tensor(shape).prod()), 1, 7).reshape(shape) * 0.1).cuda().contiguous()
     packed = {"w1": f(128, 128), "s1": f(128) + 1, "t1": f(128), "w2": f(4, 16, 32), "s2": f(64) + 1, "t2": f(64), "w3": f(4, 16), "b3": f(4)}
+import time
+warm = float(os.environ.get("EG_STAMP_WARM", "0"))        # seconds of back-to-back launches first (DVFS steady state)
+t_end = time.time() + warm
+while time.time() < t_end:
+    for _ in range(50):
+        if packed is not None:
+            ops.gcn_layer_cls_fwd(g, B, x, w, None, None, x, False, packed, kidsum_in=kw.get("kidsum_in"))
+        else:
+            ops.gcn_layer_fwd(g, B, x, w, None, None, x, relu=True, out=out, **kw)
+    torch.cuda.synchronize()
+lib.eg_debug_phase_cycles(g._h, buf, 1)
 for it in range(3):
     if packed is not None:
         ops.gcn_layer_cls_fwd(g, B, x, w, None, None, x, False, packed, kidsum_in=kw.get("kidsum_in"))
@@ -31,6 +42,8 @@ names = ["c_mfma", "c_epilogue", "c_barrier", "c_loop", "p_issue", "p_main(wait+
 tot = sum(v[:8]); waves = max(v[8], 1)
 tiles = 1128 * B
 print(f"waves(counted)={waves} tiles={tiles}")
+if v[10]:
+    print(f"in-kernel clock = {v[9] / v[10] * 0.1:.3f} GHz  (shader cycles / 100-MHz ticks around the tile loop, stamp build)")
 wgs = 256 if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else waves / 8
 waves = wgs * 4 if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else waves
 for n, c in zip(names, v[:8]):
