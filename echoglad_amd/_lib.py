@@ -69,6 +69,8 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_classifier_train_workspace_bytes": (ct.c_size_t, []),
     "eg_classifier_train_fwd": (_i, [_p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _i, _p, _p]),
     "eg_classifier_bwd": (_i, [_p, _p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "eg_coord_mlp_fwd": (_i, [_p, _p, _i, _pp, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "eg_coord_mlp_bwd": (_i, [_p, _p, _p, _i, _pp, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "eg_bilinear4_fwd": (_i, [_p, _p, _i, _i, _i64, _i64, _i, _p, _p]),
     "eg_bilinear4_bwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i, _p, _p, _p]),
     "eg_pack_levels": (_i, [ct.POINTER(_p), ct.POINTER(_i), _i, _i, _i64, _i64, _p, _p]),

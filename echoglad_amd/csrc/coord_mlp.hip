@@ -1,0 +1,469 @@
+// Coordinate-graph landmark update for gfx950 (reference src/core/models.py:438-453):
+//     shape_feats[(f,j)] = coords[f,:,:] - coords[f,j,:]                                   (8 numbers per landmark)
+//     delta = node_coordinate_mlp[i](cat(lm, shape_feats))        Linear(136,32)-BN-ReLU-Drop-Linear(32,16)-BN-ReLU-Drop-Linear(16,2)
+//     coords <- clamp(coords + delta, 0, frame - 1)
+// on the 4 landmark rows of every frame: R = 4 * batch rows in all (128 at batch 32).  That is far too little work for the
+// chip -- what matters is launch count: the reference's module list is ~15 launches forward and ~35 backward per GNN layer
+// (three of them rocBLAS GEMMs with 2..32 output columns).  Here the forward is ONE single-workgroup kernel and the backward
+// another; BatchNorm uses batch statistics over the R rows (train) or the running ones (eval), Dropout is the same
+// counter-based mask as everywhere else (train_common.h), hidden activations are recomputed from the saved pre-BatchNorm
+// z1 / z2.  All reductions run in a fixed order inside the workgroup: bitwise reproducible.
+#include "train_common.h"
+
+namespace eg {
+
+constexpr int CM_IN = 136, CM_H1 = 32, CM_H2 = 16, CM_OUT = 2;
+constexpr int CM_THREADS = 1024, CM_WAVES = CM_THREADS / 64;
+constexpr int CM_TILE = 64;                     // rows staged in LDS at a time
+constexpr int CM_LDI = 140;                     // LDS row stride of an input tile (16-byte aligned rows)
+constexpr int CM_LDW1 = CM_IN + 1, CM_LDW2 = CM_H1 + 1, CM_LDH = CM_H1 + 1, CM_LDZ2 = CM_H2 + 1;
+constexpr int CM_SCR = 56;                      // backward scratch floats per row: dz2[16] | dz1[32] | d shape_feats[8]
+// gradient vector layout (floats)
+constexpr int CG_DW1 = 0, CG_DB1 = CG_DW1 + CM_H1 * CM_IN, CG_DG1 = CG_DB1 + CM_H1, CG_DBE1 = CG_DG1 + CM_H1;
+constexpr int CG_DW2 = CG_DBE1 + CM_H1, CG_DB2 = CG_DW2 + CM_H2 * CM_H1, CG_DG2 = CG_DB2 + CM_H2, CG_DBE2 = CG_DG2 + CM_H2;
+constexpr int CG_DW3 = CG_DBE2 + CM_H2, CG_DB3 = CG_DW3 + CM_OUT * CM_H2, CG_TOTAL = CG_DB3 + CM_OUT;
+static_assert(CG_TOTAL == EG_COORD_MLP_GRADS_FLOATS, "header and kernel disagree on the gradient layout");
+
+struct CoordMlpW {
+    const float *w1, *b1, *gamma1, *beta1, *w2, *b2, *gamma2, *beta2, *w3, *b3;
+    float p1, ik1, p2, ik2;
+    unsigned long long seed1, seed2;
+};
+
+struct CoordMlpFwd {
+    const float *lm, *coords;                   // [R,128], [R,2]
+    int rows, train;
+    CoordMlpW w;
+    float *rm1, *rv1, *rm2, *rv2;
+    float eps1, eps2, mom1, mom2, cmax;
+    float *z1, *z2, *bn, *pre, *newc;           // [R,32], [R,16], [96], [R,2], [R,2]
+};
+
+struct CoordMlpBwd {
+    const float *dnew, *lm, *coords, *pre, *z1, *z2, *bn;
+    int rows;
+    CoordMlpW w;
+    float cmax;
+    float *scratch, *dlm, *dcoords, *grads;     // [R,56], [R,128] | NULL, [R,2] | NULL, [CG_TOTAL]
+};
+
+// input column i of row r = (frame f, landmark j): the landmark's features, then the offsets to the frame's 4 landmarks
+__device__ inline float mlp_in(const float* __restrict__ lm, const float* __restrict__ coords, int r, int i) {
+    if (i < C) return lm[(size_t)r * C + i];
+    const int k = (i - C) >> 1, d = i & 1;
+    return coords[((r & ~3) + k) * 2 + d] - coords[r * 2 + d];
+}
+
+// rows row0 .. row0 + 63 of cat(lm, shape_feats) -> s_in[64][CM_LDI] (rows past the end: zeros)
+__device__ inline void stage_inputs(const float* __restrict__ lm, const float* __restrict__ coords, int row0, int R, float* s_in) {
+    for (int e = threadIdx.x; e < CM_TILE * CM_IN; e += CM_THREADS) {
+        const int r = e / CM_IN, i = e - r * CM_IN, row = row0 + r;
+        s_in[r * CM_LDI + i] = row < R ? mlp_in(lm, coords, row, i) : 0.f;
+    }
+}
+
+__device__ inline float hidden_act(float z, float scale, float shift, unsigned long long seed, unsigned long long idx, float p,
+                                   float ik, float* keep_out) {
+    const float y = z * scale + shift;
+    const float k = p > 0.f ? keep_scale(seed, idx, p, ik) : 1.0f;
+    *keep_out = y > 0.f ? k : 0.f;              // d act / d y
+    return y > 0.f ? y * k : 0.f;
+}
+
+__device__ inline void load_weights(const CoordMlpW& w, float* s_w1, float* s_w2, float* s_w3) {
+    for (int i = threadIdx.x; i < CM_H1 * CM_IN; i += CM_THREADS) s_w1[(i / CM_IN) * CM_LDW1 + i % CM_IN] = w.w1[i];
+    for (int i = threadIdx.x; i < CM_H2 * CM_H1; i += CM_THREADS) s_w2[(i / CM_H1) * CM_LDW2 + i % CM_H1] = w.w2[i];
+    if (threadIdx.x < CM_OUT * CM_H2) s_w3[threadIdx.x] = w.w3[threadIdx.x];
+}
+
+// s_red[PARTS][W] -> sum for column c, fixed order (threads < W call this after a barrier)
+template <int W>
+__device__ inline float reduce_parts(const float* s_red, int c) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < CM_THREADS / W; ++p) t += s_red[p * W + c];
+    return t;
+}
+
+// sum of v over the whole workgroup (fixed order: lanes by xor-shuffle, then waves 0..15), returned to every thread
+__device__ inline float block_sum(float v, float* s_part) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    __syncthreads();                            // s_part may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < CM_WAVES; ++w) t += s_part[w];
+    return t;
+}
+
+// mean and biased variance of every column of z [rows][W] (two passes, fixed order) -> s_mean, s_var
+template <int W>
+__device__ inline void column_stats(const float* __restrict__ z, int rows, float* s_red, float* s_mean, float* s_var) {
+    constexpr int PARTS = CM_THREADS / W;
+    const int c = threadIdx.x % W, part = threadIdx.x / W;
+    float s = 0.f;
+    for (int r = part; r < rows; r += PARTS) s += z[r * W + c];
+    s_red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < W) s_mean[c] = reduce_parts<W>(s_red, c) / (float)rows;
+    __syncthreads();
+    const float m = s_mean[c];
+    float q = 0.f;
+    for (int r = part; r < rows; r += PARTS) {
+        const float d = z[r * W + c] - m;
+        q += d * d;
+    }
+    s_red[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < W) s_var[c] = reduce_parts<W>(s_red, c) / (float)rows;
+    __syncthreads();
+}
+
+// BatchNorm1d bookkeeping of one layer: statistics -> (mean, invstd) saved in bn, affine (scale, shift) in LDS
+template <int W>
+__device__ inline void bn_setup(const float* __restrict__ z, int rows, int train, const float* gamma, const float* beta, float eps,
+                                float mom, float* rm, float* rv, float* bn_mean, float* bn_inv, float* s_red, float* s_mean,
+                                float* s_var, float* s_scale, float* s_shift) {
+    if (train) column_stats<W>(z, rows, s_red, s_mean, s_var);
+    if (threadIdx.x < W) {
+        const int c = threadIdx.x;
+        float mean, var;
+        if (train) {
+            mean = s_mean[c];
+            var = s_var[c];
+            if (rm && mom >= 0.f) {
+                const float unbiased = rows > 1 ? var * (float)rows / (float)(rows - 1) : var;
+                rm[c] = (1.0f - mom) * rm[c] + mom * mean;
+                rv[c] = (1.0f - mom) * rv[c] + mom * unbiased;
+            }
+        } else {
+            mean = rm[c];
+            var = rv[c];
+        }
+        const float inv = 1.0f / sqrtf(var + eps);
+        bn_mean[c] = mean;
+        bn_inv[c] = inv;
+        const float sc = gamma[c] * inv;
+        s_scale[c] = sc;
+        s_shift[c] = beta[c] - mean * sc;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd a) {
+    __shared__ __attribute__((aligned(16))) float s_in[CM_TILE * CM_LDI];       // input tile, later the h1 tile
+    __shared__ float s_w1[CM_H1 * CM_LDW1], s_w2[CM_H2 * CM_LDW2], s_w3[CM_OUT * CM_H2];
+    __shared__ float s_red[CM_THREADS], s_mean[CM_H1], s_var[CM_H1], s_sc1[CM_H1], s_sh1[CM_H1], s_sc2[CM_H2], s_sh2[CM_H2];
+    const int t = threadIdx.x, R = a.rows;
+    const float* __restrict__ lm = a.lm;
+    const float* __restrict__ coords = a.coords;
+    load_weights(a.w, s_w1, s_w2, s_w3);
+    // ---- z1 = in W1^T + b1, 64 rows at a time: thread -> (row t >> 5 and +32, output channel t & 31)
+    for (int row0 = 0; row0 < R; row0 += CM_TILE) {
+        __syncthreads();
+        stage_inputs(lm, coords, row0, R, s_in);
+        __syncthreads();
+        const int o = t & 31;
+        const float b = a.w.b1[o];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int r = (t >> 5) + 32 * half;
+            float acc = b;
+#pragma unroll 8
+            for (int i = 0; i < CM_IN; ++i) acc += s_w1[o * CM_LDW1 + i] * s_in[r * CM_LDI + i];
+            if (row0 + r < R) a.z1[(row0 + r) * CM_H1 + o] = acc;
+        }
+    }
+    __syncthreads();
+    bn_setup<CM_H1>(a.z1, R, a.train, a.w.gamma1, a.w.beta1, a.eps1, a.mom1, a.rm1, a.rv1, a.bn, a.bn + CM_H1, s_red, s_mean, s_var,
+                    s_sc1, s_sh1);
+    // ---- z2 = h1 W2^T + b2: h1 tile [64][33] in LDS, thread -> (row t >> 4, output channel t & 15)
+    float* s_h1 = s_in;
+    for (int row0 = 0; row0 < R; row0 += CM_TILE) {
+        __syncthreads();
+        for (int e = t; e < CM_TILE * CM_H1; e += CM_THREADS) {
+            const int r = e >> 5, i = e & 31, row = row0 + r;
+            float k, h = 0.f;
+            if (row < R)
+                h = hidden_act(a.z1[row * CM_H1 + i], s_sc1[i], s_sh1[i], a.w.seed1, (unsigned long long)row * CM_H1 + i, a.w.p1,
+                               a.w.ik1, &k);
+            s_h1[r * CM_LDH + i] = h;
+        }
+        __syncthreads();
+        const int r = t >> 4, o = t & 15;
+        float acc = a.w.b2[o];
+#pragma unroll
+        for (int i = 0; i < CM_H1; ++i) acc += s_w2[o * CM_LDW2 + i] * s_h1[r * CM_LDH + i];
+        if (row0 + r < R) a.z2[(row0 + r) * CM_H2 + o] = acc;
+    }
+    __syncthreads();
+    bn_setup<CM_H2>(a.z2, R, a.train, a.w.gamma2, a.w.beta2, a.eps2, a.mom2, a.rm2, a.rv2, a.bn + 2 * CM_H1, a.bn + 2 * CM_H1 + CM_H2,
+                    s_red, s_mean, s_var, s_sc2, s_sh2);
+    // ---- delta = h2 W3^T + b3; coords <- clamp(coords + delta)
+    for (int e = t; e < R * CM_OUT; e += CM_THREADS) {
+        const int r = e >> 1, d = e & 1;
+        float acc = a.w.b3[d];
+#pragma unroll
+        for (int i = 0; i < CM_H2; ++i) {
+            float k;
+            const float h = hidden_act(a.z2[r * CM_H2 + i], s_sc2[i], s_sh2[i], a.w.seed2, (unsigned long long)r * CM_H2 + i,
+                                       a.w.p2, a.w.ik2, &k);
+            acc += s_w3[d * CM_H2 + i] * h;
+        }
+        const float pre = coords[e] + acc;
+        if (a.pre) a.pre[e] = pre;
+        a.newc[e] = fminf(fmaxf(pre, 0.f), a.cmax);
+    }
+}
+
+__global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd a) {
+    __shared__ __attribute__((aligned(16))) float s_in[CM_TILE * CM_LDI];       // input tile; before that h1 | keep1 | xhat1 tiles
+    __shared__ float s_w1[CM_H1 * CM_LDW1], s_w2[CM_H2 * CM_LDW2], s_w3[CM_OUT * CM_H2];
+    __shared__ float s_dz[CM_TILE * CM_LDH];                                    // dz2 tile [64][17], later dz1 tile [64][33]
+    __shared__ float s_red[4][CM_THREADS], s_part[CM_WAVES];
+    __shared__ float s_gm[CM_H1], s_gxm[CM_H1], s_sc1[CM_H1], s_sh1[CM_H1], s_sc2[CM_H2], s_sh2[CM_H2];
+    const int t = threadIdx.x, R = a.rows;
+    const float* __restrict__ lm = a.lm;
+    const float* __restrict__ coords = a.coords;
+    const float* __restrict__ z1 = a.z1;
+    const float* __restrict__ z2 = a.z2;
+    const float* mean1 = a.bn;
+    const float* inv1 = a.bn + CM_H1;
+    const float* mean2 = a.bn + 2 * CM_H1;
+    const float* inv2 = a.bn + 2 * CM_H1 + CM_H2;
+    load_weights(a.w, s_w1, s_w2, s_w3);
+    if (t < CM_H1) {
+        const float sc = a.w.gamma1[t] * inv1[t];
+        s_sc1[t] = sc;
+        s_sh1[t] = a.w.beta1[t] - mean1[t] * sc;
+    } else if (t < CM_H1 + CM_H2) {
+        const int c = t - CM_H1;
+        const float sc = a.w.gamma2[c] * inv2[c];
+        s_sc2[c] = sc;
+        s_sh2[c] = a.w.beta2[c] - mean2[c] * sc;
+    }
+    __syncthreads();
+    // gradient of the clamp (torch.clamp: passes where min <= x <= max)
+    auto dd = [&](int r, int d) -> float {
+        const float pre = a.pre[r * 2 + d];
+        return (pre >= 0.f && pre <= a.cmax) ? a.dnew[r * 2 + d] : 0.f;
+    };
+    // ---- output layer: g2 = (dd W3) mask2, its BatchNorm sums, dW3, db3
+    {
+        const int c = t & 15, part = t >> 4;
+        float sg = 0.f, sgx = 0.f, dw0 = 0.f, dw1 = 0.f;
+        for (int r = part; r < R; r += CM_THREADS / CM_H2) {
+            const float z = z2[r * CM_H2 + c], d0 = dd(r, 0), d1 = dd(r, 1);
+            float k;
+            const float h = hidden_act(z, s_sc2[c], s_sh2[c], a.w.seed2, (unsigned long long)r * CM_H2 + c, a.w.p2, a.w.ik2, &k);
+            const float g = (d0 * s_w3[c] + d1 * s_w3[CM_H2 + c]) * k;
+            sg += g;
+            sgx += g * ((z - mean2[c]) * inv2[c]);
+            dw0 += d0 * h;
+            dw1 += d1 * h;
+        }
+        s_red[0][t] = sg; s_red[1][t] = sgx; s_red[2][t] = dw0; s_red[3][t] = dw1;
+        __syncthreads();
+        if (t < CM_H2) {
+            const float g = reduce_parts<CM_H2>(s_red[0], t), gx = reduce_parts<CM_H2>(s_red[1], t);
+            s_gm[t] = g / (float)R;
+            s_gxm[t] = gx / (float)R;
+            a.grads[CG_DG2 + t] = gx;
+            a.grads[CG_DBE2 + t] = g;
+            a.grads[CG_DB2 + t] = 0.f;                       // a bias in front of a train-mode BatchNorm
+        } else if (t >= 64 && t < 64 + CM_H2) {
+            a.grads[CG_DW3 + t - 64] = reduce_parts<CM_H2>(s_red[2], t - 64);
+        } else if (t >= 128 && t < 128 + CM_H2) {
+            a.grads[CG_DW3 + CM_H2 + t - 128] = reduce_parts<CM_H2>(s_red[3], t - 128);
+        }
+        float v = 0.f;                                       // db3[d] = sum_r dd(r, d): element parity == thread parity
+        for (int e = t; e < R * 2; e += CM_THREADS) v += dd(e >> 1, e & 1);
+        const float db0 = block_sum((t & 1) ? 0.f : v, s_part);
+        const float db1 = block_sum((t & 1) ? v : 0.f, s_part);
+        if (t == 0) { a.grads[CG_DB3] = db0; a.grads[CG_DB3 + 1] = db1; }
+        // dz2 = gamma2 invstd2 (g2 - mean g2 - xhat2 mean(g2 xhat2))
+        for (int e = t; e < R * CM_H2; e += CM_THREADS) {
+            const int r = e >> 4, cc = e & 15;
+            const float z = z2[e];
+            float k;
+            hidden_act(z, s_sc2[cc], s_sh2[cc], a.w.seed2, (unsigned long long)e, a.w.p2, a.w.ik2, &k);
+            const float g = (dd(r, 0) * s_w3[cc] + dd(r, 1) * s_w3[CM_H2 + cc]) * k;
+            const float xh = (z - mean2[cc]) * inv2[cc];
+            a.scratch[r * CM_SCR + cc] = a.w.gamma2[cc] * inv2[cc] * (g - s_gm[cc] - xh * s_gxm[cc]);
+        }
+        __syncthreads();
+    }
+    // ---- hidden layer 2, 64 rows at a time: dW2 = dz2^T h1;  g1 = (dz2 W2) mask1 (-> scratch) and its BatchNorm sums
+    {
+        float* s_h1 = s_in;
+        float* s_k1 = s_in + CM_TILE * CM_LDH;
+        float* s_x1 = s_in + 2 * CM_TILE * CM_LDH;
+        const int wo = (t & 511) >> 5, wi = t & 31, whalf = t >> 9;         // dW2[wo][wi], rows 32 * whalf .. + 32 of the tile
+        const int c = t & 31, part = t >> 5;                                 // g1 column c, rows part and part + 32 of the tile
+        float dw2 = 0.f, sg = 0.f, sgx = 0.f;
+        for (int row0 = 0; row0 < R; row0 += CM_TILE) {
+            __syncthreads();
+            for (int e = t; e < CM_TILE * CM_H1; e += CM_THREADS) {
+                const int r = e >> 5, i = e & 31, row = row0 + r;
+                float k = 0.f, h = 0.f, xh = 0.f;
+                if (row < R) {
+                    const float z = z1[row * CM_H1 + i];
+                    h = hidden_act(z, s_sc1[i], s_sh1[i], a.w.seed1, (unsigned long long)row * CM_H1 + i, a.w.p1, a.w.ik1, &k);
+                    xh = (z - mean1[i]) * inv1[i];
+                }
+                s_h1[r * CM_LDH + i] = h;
+                s_k1[r * CM_LDH + i] = k;
+                s_x1[r * CM_LDH + i] = xh;
+            }
+            {
+                const int r = t >> 4, o = t & 15;
+                s_dz[r * CM_LDZ2 + o] = row0 + r < R ? a.scratch[(row0 + r) * CM_SCR + o] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int r = 32 * whalf; r < 32 * whalf + 32; ++r) dw2 += s_dz[r * CM_LDZ2 + wo] * s_h1[r * CM_LDH + wi];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int r = part + 32 * half;
+                float gp = 0.f;
+#pragma unroll
+                for (int o = 0; o < CM_H2; ++o) gp += s_dz[r * CM_LDZ2 + o] * s_w2[o * CM_LDW2 + c];
+                const float g = gp * s_k1[r * CM_LDH + c];
+                sg += g;
+                sgx += g * s_x1[r * CM_LDH + c];
+                if (row0 + r < R) a.scratch[(row0 + r) * CM_SCR + CM_H2 + c] = g;
+            }
+        }
+        s_red[0][t] = sg; s_red[1][t] = sgx; s_red[2][t] = dw2;
+        __syncthreads();
+        if (t < CM_H1) {
+            const float g = reduce_parts<CM_H1>(s_red[0], t), gx = reduce_parts<CM_H1>(s_red[1], t);
+            s_gm[t] = g / (float)R;
+            s_gxm[t] = gx / (float)R;
+            a.grads[CG_DG1 + t] = gx;
+            a.grads[CG_DBE1 + t] = g;
+            a.grads[CG_DB1 + t] = 0.f;
+        }
+        if (t < 512) a.grads[CG_DW2 + t] = s_red[2][t] + s_red[2][t + 512];
+        __syncthreads();
+        // dz1 = gamma1 invstd1 (g1 - mean g1 - xhat1 mean(g1 xhat1)), in place in the scratch
+        for (int e = t; e < R * CM_H1; e += CM_THREADS) {
+            const int r = e >> 5, cc = e & 31;
+            const float xh = (z1[e] - mean1[cc]) * inv1[cc];
+            float* p = a.scratch + r * CM_SCR + CM_H2 + cc;
+            *p = a.w.gamma1[cc] * inv1[cc] * (*p - s_gm[cc] - xh * s_gxm[cc]);
+        }
+    }
+    // ---- first layer, 64 rows at a time: dW1 = dz1^T in;  d in = dz1 W1 -> d lm, d shape_feats
+    {
+        // dW1 work item = (o, 4 consecutive inputs): 32 * 34 = 1088 items; threads 0..63 take a second one
+        const int it0 = t, it1 = CM_THREADS + t;
+        const bool two = it1 < CM_H1 * (CM_IN / 4);
+        const int o0 = it0 / 34, q0 = it0 - 34 * o0, o1 = two ? it1 / 34 : 0, q1 = two ? it1 - 34 * o1 : 0;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int row0 = 0; row0 < R; row0 += CM_TILE) {
+            __syncthreads();
+            stage_inputs(lm, coords, row0, R, s_in);
+            for (int e = t; e < CM_TILE * CM_H1; e += CM_THREADS) {
+                const int r = e >> 5, i = e & 31;
+                s_dz[r * CM_LDH + i] = row0 + r < R ? a.scratch[(row0 + r) * CM_SCR + CM_H2 + i] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int r = 0; r < CM_TILE; ++r) {
+                acc0 += s_dz[r * CM_LDH + o0] * *reinterpret_cast<const f32x4*>(&s_in[r * CM_LDI + 4 * q0]);
+                if (two) acc1 += s_dz[r * CM_LDH + o1] * *reinterpret_cast<const f32x4*>(&s_in[r * CM_LDI + 4 * q1]);
+            }
+            if (a.dlm) {                                  // thread -> column t & 127, rows (t >> 7) + 8 j
+                const int i = t & 127;
+                for (int r = t >> 7; r < CM_TILE && row0 + r < R; r += 8) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int o = 0; o < CM_H1; ++o) acc += s_dz[r * CM_LDH + o] * s_w1[o * CM_LDW1 + i];
+                    a.dlm[(size_t)(row0 + r) * C + i] = acc;
+                }
+            }
+            if (t < CM_TILE * 8) {
+                const int r = t >> 3, i = C + (t & 7);
+                float acc = 0.f;
+#pragma unroll
+                for (int o = 0; o < CM_H1; ++o) acc += s_dz[r * CM_LDH + o] * s_w1[o * CM_LDW1 + i];
+                if (row0 + r < R) a.scratch[(row0 + r) * CM_SCR + CM_H2 + CM_H1 + (t & 7)] = acc;
+            }
+        }
+        *reinterpret_cast<f32x4*>(a.grads + CG_DW1 + o0 * CM_IN + 4 * q0) = acc0;
+        if (two) *reinterpret_cast<f32x4*>(a.grads + CG_DW1 + o1 * CM_IN + 4 * q1) = acc1;
+        __syncthreads();
+    }
+    // ---- d coords: through the clamp directly, as "the other landmark" k = m of all 4 rows of the frame (+), and as
+    //      "self" of row m for all k (-)
+    if (a.dcoords) {
+        const float* dsf = a.scratch + CM_H2 + CM_H1;
+        for (int e = t; e < R * 2; e += CM_THREADS) {
+            const int r = e >> 1, d = e & 1, f4 = r & ~3, m = r & 3;
+            float acc = dd(r, d);
+            for (int j = 0; j < 4; ++j) acc += dsf[(f4 + j) * CM_SCR + 2 * m + d];
+            for (int k = 0; k < 4; ++k) acc -= dsf[r * CM_SCR + 2 * k + d];
+            a.dcoords[e] = acc;
+        }
+    }
+}
+
+static CoordMlpW weights_of(const eg_cls_train_params* P, bool train) {
+    CoordMlpW w{P->w1, P->b1, P->gamma1, P->beta1, P->w2, P->b2, P->gamma2, P->beta2, P->w3, P->b3};
+    w.p1 = train ? P->p1 : 0.f;
+    w.p2 = train ? P->p2 : 0.f;
+    w.ik1 = w.p1 > 0.f ? 1.0f / (1.0f - w.p1) : 1.0f;
+    w.ik2 = w.p2 > 0.f ? 1.0f / (1.0f - w.p2) : 1.0f;
+    w.seed1 = P->seed1;
+    w.seed2 = P->seed2;
+    return w;
+}
+
+static bool params_ok(const eg_cls_train_params* P) {
+    return P && P->w1 && P->b1 && P->gamma1 && P->beta1 && P->w2 && P->b2 && P->gamma2 && P->beta2 && P->w3 && P->b3;
+}
+
+}  // namespace eg
+
+using namespace eg;
+
+extern "C" {
+
+int eg_coord_mlp_fwd(const float* lm, const float* coords, int batch, const eg_cls_train_params* P, int train, int frame,
+                     float* z1, float* z2, float* bn, float* pre, float* new_coords, eg_stream_t stream) {
+    if (!lm || !coords || !z1 || !z2 || !bn || !new_coords || !params_ok(P)) return set_error(EG_ERR_ARG, "NULL argument");
+    if (batch < 1 || frame < 1 || batch > (1 << 20)) return set_error(EG_ERR_ARG, "bad batch / frame");
+    if (!train && (!P->running_mean1 || !P->running_var1 || !P->running_mean2 || !P->running_var2))
+        return set_error(EG_ERR_ARG, "eval mode needs the running statistics");
+    if (!(P->p1 >= 0.f && P->p1 < 1.f && P->p2 >= 0.f && P->p2 < 1.f)) return set_error(EG_ERR_ARG, "dropout p must be in [0, 1)");
+    CoordMlpFwd a{};
+    a.lm = lm; a.coords = coords; a.rows = 4 * batch; a.train = train ? 1 : 0;
+    a.w = weights_of(P, train != 0);
+    a.rm1 = P->running_mean1; a.rv1 = P->running_var1; a.rm2 = P->running_mean2; a.rv2 = P->running_var2;
+    a.eps1 = P->eps1; a.eps2 = P->eps2; a.mom1 = P->momentum1; a.mom2 = P->momentum2; a.cmax = (float)(frame - 1);
+    a.z1 = z1; a.z2 = z2; a.bn = bn; a.pre = pre; a.newc = new_coords;
+    hipLaunchKernelGGL(k_coord_mlp_fwd, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_coord_mlp_bwd(const float* dnew_coords, const float* lm, const float* coords, int batch, const eg_cls_train_params* P,
+                     int frame, const float* z1, const float* z2, const float* bn, const float* pre, float* scratch, float* dlm,
+                     float* dcoords, float* grads, eg_stream_t stream) {
+    if (!dnew_coords || !lm || !coords || !z1 || !z2 || !bn || !pre || !scratch || !grads || !params_ok(P))
+        return set_error(EG_ERR_ARG, "NULL argument");
+    if (batch < 1 || frame < 1 || batch > (1 << 20)) return set_error(EG_ERR_ARG, "bad batch / frame");
+    CoordMlpBwd a{};
+    a.dnew = dnew_coords; a.lm = lm; a.coords = coords; a.pre = pre; a.z1 = z1; a.z2 = z2; a.bn = bn; a.rows = 4 * batch;
+    a.w = weights_of(P, true);
+    a.cmax = (float)(frame - 1);
+    a.scratch = scratch; a.dlm = dlm; a.dcoords = dcoords; a.grads = grads;
+    hipLaunchKernelGGL(k_coord_mlp_bwd, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+}  // extern "C"

@@ -279,6 +279,39 @@ class _ClassifierTrainFn(torch.autograd.Function):
         return (dh, None, None, None, None, None, None) + tuple(grads)
 
 
+_MLP_NAMES = ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3", "b3")
+
+
+class _CoordMlpFn(torch.autograd.Function):
+    """models.py:441-453 in train mode as one autograd node over eg_coord_mlp_fwd / eg_coord_mlp_bwd:
+    (landmark rows [4B,128], coords [B,4,2]) -> clamp(coords + node_coordinate_mlp(cat(lm, pairwise offsets)), 0, frame-1).
+    ``params`` = the head's 10 parameters in _HEAD_PARAM_IDX order."""
+
+    @staticmethod
+    def forward(ctx, lm, coords, batch, frame, cfg, *params):
+        P = dict(cfg)
+        P.update({k: p.detach().contiguous() for k, p in zip(_MLP_NAMES, params)})
+        lm = lm.contiguous()
+        flat = coords.reshape(batch * 4, 2).contiguous()
+        new, saved = ops.coord_mlp_fwd(lm, flat, batch, P, True, frame, True)
+        ctx.P = {k: v for k, v in P.items() if not k.startswith("running")}
+        ctx.dims = (batch, frame)
+        ctx.save_for_backward(lm, flat, *saved)
+        return new.view(batch, 4, 2)
+
+    @staticmethod
+    def backward(ctx, dnew):
+        lm, flat, z1, z2, bn, pre = ctx.saved_tensors
+        batch, frame = ctx.dims
+        dlm, dc, g = ops.coord_mlp_bwd(dnew.contiguous().view(batch * 4, 2), lm, flat, batch, ctx.P, frame, (z1, z2, bn, pre),
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        sizes = (32 * 136, 32, 32, 32, 16 * 32, 16, 16, 16, 2 * 16, 2)
+        parts = torch.split(g, sizes)
+        grads = (parts[0].view(32, 136), parts[1], parts[2], parts[3], parts[4].view(16, 32), parts[5], parts[6], parts[7],
+                 parts[8].view(2, 16), parts[9])
+        return (dlm, dc.view(batch, 4, 2) if dc is not None else None, None, None, None) + grads
+
+
 # ---------------------------------------------------------------------------
 # torch_geometric-compatible modules
 # ---------------------------------------------------------------------------
@@ -526,11 +559,15 @@ class HierarchicalPatchModel(nn.Module):
         n, _, _, main_base, coord_base = self._row_ranges()
         fs = self.frame_size
         # pairwise (other - self) offsets per frame, flattened to 8 numbers per landmark (:441-444)
-        shape_feats = (node_coords.unsqueeze(1) - node_coords.unsqueeze(2)).reshape(batch * 4, 8)
         if lm is None:
             lm = h.view(batch, n, C)[:, coord_base:, :].reshape(batch * 4, C).clone()
-        delta = self.node_coordinate_mlp[i](torch.cat((lm, shape_feats), dim=1))
-        node_coords = torch.clamp(node_coords + delta.view(batch, 4, 2), min=0, max=fs - 1)
+        new_coords = self._coord_mlp_kernel(self.node_coordinate_mlp[i], lm, node_coords, batch, fs)
+        if new_coords is None:
+            # a mix of frozen and training sub-modules, or eval mode with gradients: the torch modules, op by op
+            shape_feats = (node_coords.unsqueeze(1) - node_coords.unsqueeze(2)).reshape(batch * 4, 8)
+            delta = self.node_coordinate_mlp[i](torch.cat((lm, shape_feats), dim=1))
+            new_coords = torch.clamp(node_coords + delta.view(batch, 4, 2), min=0, max=fs - 1)
+        node_coords = new_coords
         if torch.is_grad_enabled() and (h.requires_grad or node_coords.requires_grad) and h.grad_fn is not None:
             # train step: in place on the layer output, in place on its gradient (no [B*N,128] copies, fills or adds)
             h = _CoordScatterFn.apply(h, node_coords, batch, n, main_base, fs, coord_base)
@@ -538,6 +575,36 @@ class HierarchicalPatchModel(nn.Module):
             new_feats = ops.bilinear4(h, node_coords, batch, n, main_base, fs)            # [4B, 128]
             h = ops.scatter_coord_rows(h, new_feats, batch, n, coord_base)
         return h, node_coords
+
+    def _coord_mlp_kernel(self, mlp: nn.Sequential, lm: torch.Tensor, node_coords: torch.Tensor, batch: int, frame: int):
+        """models.py:441-453 on eg_coord_mlp_fwd / _bwd (one launch each way) -> new coords [B,4,2], or None when the
+        module states are not ones the kernel implements."""
+        if self.classifier_hidden_dim != 32 or self.node_embedding_dim != C or node_coords.shape[-1] != 2 or node_coords.dtype != torch.float32 or \
+                os.environ.get("EG_COORD_MLP_KERNEL", "1") == "0":
+            return None
+        bn1, bn2, d1, d2 = mlp[1], mlp[5], mlp[3], mlp[7]
+        if not (bn1.affine and bn2.affine):
+            return None
+        params = [getattr(mlp[j], name) for j, name in _HEAD_PARAM_IDX]
+        cfg = dict(eps1=bn1.eps, eps2=bn2.eps, p1=float(d1.p), p2=float(d2.p), seed1=0, seed2=0,
+                   running_mean1=bn1.running_mean, running_var1=bn1.running_var, running_mean2=bn2.running_mean,
+                   running_var2=bn2.running_var)
+        if bn1.training and bn2.training and d1.training and d2.training:
+            if cfg["p1"] > 0 or cfg["p2"] > 0:
+                cfg["seed1"], cfg["seed2"] = torch.randint(0, 2 ** 62, (2,)).tolist()     # host RNG, like the layers
+            _, cfg["momentum1"] = _bn_step(bn1)
+            _, cfg["momentum2"] = _bn_step(bn2)
+            return _CoordMlpFn.apply(lm, node_coords, batch, frame, cfg, *params)
+        frozen = not (bn1.training or bn2.training or d1.training or d2.training)
+        needs_grad = torch.is_grad_enabled() and (lm.requires_grad or node_coords.requires_grad or
+                                                  any(p.requires_grad for p in params))
+        if frozen and not needs_grad and bn1.running_mean is not None and bn2.running_mean is not None:
+            P = dict(cfg, momentum1=None, momentum2=None)
+            P.update({k: p.detach().contiguous() for k, p in zip(_MLP_NAMES, params)})
+            new, _ = ops.coord_mlp_fwd(lm.contiguous(), node_coords.reshape(batch * 4, 2).contiguous(), batch, P, False, frame,
+                                       False)
+            return new.view(batch, 4, 2)
+        return None
 
     # ---- the hot path ------------------------------------------------------------------------
     def forward_nodes(self, node_feats: torch.Tensor, edge_index: torch.Tensor, batch: Optional[int] = None,

@@ -400,6 +400,52 @@ def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_vali
 
 
 # ---------------------------------------------------------------------------
+# coordinate-graph landmark update (models.py:438-453)
+# ---------------------------------------------------------------------------
+COORD_MLP_GRADS_FLOATS = 5042
+
+
+def coord_mlp_fwd(lm, coords, batch: int, P: dict, train: bool, frame: int, want_backward: bool):
+    """lm [4*batch,128], coords [4*batch,2] -> (new_coords [4*batch,2], saved = (z1, z2, bn, pre) | None).
+    P: the _cls_params dictionary with the 136-32-16-2 head's tensors."""
+    rows = 4 * batch
+    if not lm.is_cuda or lm.dtype != torch.float32 or not lm.is_contiguous() or tuple(lm.shape) != (rows, C):
+        raise RuntimeError(f"lm must be a contiguous CUDA float32 [{rows}, {C}] tensor")
+    _check_coords(coords, batch, 4)
+    for k, shape in (("w1", (32, C + 8)), ("w2", (16, 32)), ("w3", (2, 16))):
+        if tuple(P[k].shape) != shape:
+            raise RuntimeError(f"coordinate MLP {k} must be {shape}, got {tuple(P[k].shape)}")
+    dev = lm.device
+    z1 = torch.empty(rows, 32, dtype=torch.float32, device=dev)
+    z2 = torch.empty(rows, 16, dtype=torch.float32, device=dev)
+    bn = torch.empty(96, dtype=torch.float32, device=dev)
+    pre = torch.empty(rows, 2, dtype=torch.float32, device=dev) if want_backward else None
+    new = torch.empty(rows, 2, dtype=torch.float32, device=dev)
+    s = _cls_params(P)
+    _lib.check(_lib.load().eg_coord_mlp_fwd(_ptr(lm), _ptr(coords), batch, ct.byref(s), int(train), frame, _ptr(z1), _ptr(z2),
+                                            _ptr(bn), _ptr(pre), _ptr(new), _stream()), "eg_coord_mlp_fwd")
+    return new, ((z1, z2, bn, pre) if want_backward else None)
+
+
+def coord_mlp_bwd(dnew, lm, coords, batch: int, P: dict, frame: int, saved, need_dlm: bool, need_dcoords: bool):
+    """-> (dlm | None, dcoords | None, grads [5042] packed as in include/echoglad_hip.h)"""
+    rows = 4 * batch
+    z1, z2, bn, pre = saved
+    dev = lm.device
+    if not dnew.is_cuda or dnew.dtype != torch.float32 or not dnew.is_contiguous() or dnew.numel() != rows * 2:
+        raise RuntimeError(f"dnew must be contiguous CUDA float32 with {rows * 2} elements")
+    scratch = torch.empty(rows, 56, dtype=torch.float32, device=dev)
+    dlm = torch.empty(rows, C, dtype=torch.float32, device=dev) if need_dlm else None
+    dcoords = torch.empty(rows, 2, dtype=torch.float32, device=dev) if need_dcoords else None
+    grads = torch.empty(COORD_MLP_GRADS_FLOATS, dtype=torch.float32, device=dev)
+    s = _cls_params(P)
+    _lib.check(_lib.load().eg_coord_mlp_bwd(_ptr(dnew), _ptr(lm), _ptr(coords), batch, ct.byref(s), frame, _ptr(z1), _ptr(z2),
+                                            _ptr(bn), _ptr(pre), _ptr(scratch), _ptr(dlm), _ptr(dcoords), _ptr(grads),
+                                            _stream()), "eg_coord_mlp_bwd")
+    return dlm, dcoords, grads
+
+
+# ---------------------------------------------------------------------------
 # coordinate-graph resampling
 # ---------------------------------------------------------------------------
 def _check_coords(coords, batch, points):

@@ -250,6 +250,26 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
                       const eg_cls_train_params* params, const float* z1, const float* z2, const float* bn, void* workspace,
                       float* dh1_scratch, float* dz1_scratch, float* dh, float* grads, eg_stream_t stream);
 
+/* ---- coordinate-graph landmark update (src/core/models.py:438-453) -----------------------------------
+ * For the 4 landmark rows of every frame (R = 4 * batch rows):
+ *   shape_feats[(f,j), 2k+d] = coords[f,k,d] - coords[f,j,d]                                   (models.py:441-444)
+ *   delta = node_coordinate_mlp[i](cat(lm, shape_feats))   Linear(136,32)-BN-ReLU-Drop-Linear(32,16)-BN-ReLU-Drop-Linear(16,2)
+ *   new_coords = clamp(coords + delta, 0, frame - 1)                                            (models.py:449-453)
+ * in one single-workgroup launch.  params: the eg_cls_train_params struct with w1 [32,136], w2 [16,32], w3 [2,16] and
+ * 32 / 16-long BatchNorm vectors.  train != 0: batch statistics, running-stat update (momentum < 0 or NULL: none) and
+ * Dropout(p1, p2) with the counter-based masks (seed1, seed2); train == 0: running statistics, no dropout.
+ *   lm [R,128], coords [R,2] (h, w);  saved for the backward: z1 [R,32], z2 [R,16], bn [96] = mean1, invstd1 [32 each],
+ *   mean2, invstd2 [16 each], pre [R,2] = coords + delta before the clamp (nullable when no backward follows).
+ * eg_coord_mlp_bwd (train-mode statistics only): d new_coords -> dlm [R,128] (nullable), dcoords [R,2] (nullable) and
+ *   grads [EG_COORD_MLP_GRADS_FLOATS] = dw1 [32*136], db1 [32] (= 0), dgamma1, dbeta1 [32 each], dw2 [16*32], db2 [16] (= 0),
+ *   dgamma2, dbeta2 [16 each], dw3 [2*16], db3 [2];   scratch: [R,56] floats. */
+#define EG_COORD_MLP_GRADS_FLOATS 5042
+int eg_coord_mlp_fwd(const float* lm, const float* coords, int batch, const eg_cls_train_params* params, int train, int frame,
+                     float* z1, float* z2, float* bn, float* pre, float* new_coords, eg_stream_t stream);
+int eg_coord_mlp_bwd(const float* dnew_coords, const float* lm, const float* coords, int batch,
+                     const eg_cls_train_params* params, int frame, const float* z1, const float* z2, const float* bn,
+                     const float* pre, float* scratch, float* dlm, float* dcoords, float* grads, eg_stream_t stream);
+
 /* ---- coordinate-graph resampling (src/core/models.py:539-553 as a 4-tap gather) -------------------
  * coords [batch*points, 2] in (h, w) order; out[p,:] = bilinear sample of frame p/points' main grid
  * (rows main_base .. main_base + frame*frame of each frame's node block), zero outside the grid. */

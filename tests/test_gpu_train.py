@@ -306,6 +306,86 @@ def test_classifier_train_kernels_vs_torch_autograd(p, act, n, row_lo, n_valid, 
         assert abs(float((m1 == 0).float().mean()) - p) < 0.02 and abs(float((m2 == 0).float().mean()) - p) < 0.02
 
 
+def _kernel_mask(rows, width, p, seed):
+    """The counter-based dropout mask (element index = row * width + column) the kernels apply, read back through
+    eg_bn_act_fwd on an all-ones input."""
+    n = rows * width
+    one, zero = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    m = ops.bn_act_fwd(torch.ones((n + 127) // 128, 128, device=DEV), one, zero, None, False, p, seed)
+    return m.reshape(-1)[:n].view(rows, width)
+
+
+@pytest.mark.parametrize("p,B,frame", [(0.0, 2, 16), (0.5, 8, 16), (0.3, 32, 224), (0.5, 5, 30)])
+def test_coordinate_mlp_kernels_vs_torch_autograd(p, B, frame):
+    """eg_coord_mlp_fwd / eg_coord_mlp_bwd (models.py:441-453: pairwise offsets, the 136-32-16-2 head with batch statistics
+    and counter-based dropout, clamp) against the same steps written with torch ops under autograd, kernel masks."""
+    import copy
+    hip, _ = model_pair(16, 3, 1, coord=True, seed=3 + B)
+    mlp = hip.node_coordinate_mlp[0]
+    mlp[3].p = mlp[7].p = p
+    hip.train()
+    ref = copy.deepcopy(mlp)
+    R = 4 * B
+    rs = np.random.RandomState(11 + B)
+    lm0 = torch.from_numpy(rs.standard_normal((R, 128)).astype(np.float32)).to(DEV)
+    # some landmarks near / outside the borders so that the clamp cuts gradients
+    c0 = torch.from_numpy((rs.uniform(-0.5, frame - 0.5, (B, 4, 2))).astype(np.float32)).to(DEV)
+    lm_a, c_a = lm0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    lm_b, c_b = lm0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    torch.manual_seed(77)
+    got = hip._coord_mlp_kernel(mlp, lm_a, c_a, B, frame)
+    assert got is not None and got.shape == (B, 4, 2)
+    torch.manual_seed(77)
+    seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if p > 0 else [0, 0]
+    sf = (c_b.unsqueeze(1) - c_b.unsqueeze(2)).reshape(R, 8)
+    a = torch.relu(ref[1](ref[0](torch.cat((lm_b, sf), dim=1))))
+    if p > 0:
+        a = a * _kernel_mask(R, 32, p, seeds[0])
+    b = torch.relu(ref[5](ref[4](a)))
+    if p > 0:
+        b = b * _kernel_mask(R, 16, p, seeds[1])
+    want = torch.clamp(c_b + ref[8](b).view(B, 4, 2), min=0, max=frame - 1)
+    assert (got.detach() - want.detach()).abs().max() < 2e-4 * max(1.0, float(want.detach().abs().max()))
+    clamped = (want.detach() == 0) | (want.detach() == frame - 1)
+    assert clamped.any() and not clamped.all()
+    w = torch.from_numpy(rs.standard_normal((B, 4, 2)).astype(np.float32)).to(DEV)
+    (got * w).sum().backward()
+    (want * w).sum().backward()
+    assert (lm_a.grad - lm_b.grad).abs().max() < 5e-3 * lm_b.grad.abs().max() + 1e-7
+    assert (c_a.grad - c_b.grad).abs().max() < 5e-3 * c_b.grad.abs().max() + 1e-7
+    ref_grads = dict(ref.named_parameters())
+    for name, prm in mlp.named_parameters():
+        rg = ref_grads[name].grad
+        if name in ("0.bias", "4.bias"):                   # in front of a train-mode BatchNorm: exactly zero here
+            wg = ref_grads[name[:-4] + "weight"].grad.abs().max().item()
+            assert prm.grad.abs().max().item() == 0 and rg.abs().max().item() < 1e-3 * wg + 1e-5, name
+            continue
+        err = (prm.grad - rg).abs().max().item()
+        assert err < 5e-3 * rg.abs().max().item() + 2e-6, (name, err, rg.abs().max().item())
+    for (n1, b1), (n2, b2) in zip(mlp.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(b1, b2, rtol=1e-4, atol=1e-5), n1
+
+
+def test_coordinate_mlp_kernel_eval_mode_and_fallbacks():
+    """train == 0: running statistics, no dropout (== the torch modules in eval mode); module states the kernel does not
+    implement fall back to the modules (None)."""
+    hip, _ = model_pair(16, 3, 1, coord=True, seed=5)
+    mlp = hip.node_coordinate_mlp[0]
+    B, frame = 6, 16
+    rs = np.random.RandomState(2)
+    lm = torch.from_numpy(rs.standard_normal((4 * B, 128)).astype(np.float32)).to(DEV)
+    c = torch.from_numpy(rs.uniform(-0.5, frame - 0.5, (B, 4, 2)).astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        got = hip._coord_mlp_kernel(mlp, lm, c, B, frame)
+        sf = (c.unsqueeze(1) - c.unsqueeze(2)).reshape(4 * B, 8)
+        want = torch.clamp(c + mlp(torch.cat((lm, sf), dim=1)).view(B, 4, 2), min=0, max=frame - 1)
+    assert (got - want).abs().max() < 1e-4
+    assert hip._coord_mlp_kernel(mlp, lm.clone().requires_grad_(True), c, B, frame) is None     # eval mode with gradients
+    mlp[1].train()                                                                              # mixed module states
+    with torch.no_grad():
+        assert hip._coord_mlp_kernel(mlp, lm, c, B, frame) is None
+
+
 @pytest.mark.parametrize("frame,naux,coord,relu,residual,p", [(16, 3, False, True, True, 0.0), (32, 4, True, False, True, 0.5),
                                                              (30, 3, False, True, False, 0.3)])
 def test_layer_train_composites_vs_torch_autograd(frame, naux, coord, relu, residual, p):
