@@ -101,7 +101,8 @@ def spawn_ranks(n: int) -> int:
 # models / workloads
 # ---------------------------------------------------------------------------------------------------------------------
 def model_kwargs(frame, naux, layers, main_only=False, coord=False):
-    return dict(frame_size=frame, gnn_dropout_p=0.5, classifier_dropout_p=0.5, node_embedding_dim=C,
+    drop = float(os.environ.get("EG_BENCH_DROPOUT", "0.5"))          # diagnostic knob; the reported workloads use 0.5
+    return dict(frame_size=frame, gnn_dropout_p=drop, classifier_dropout_p=drop, node_embedding_dim=C,
                 node_hidden_dim=C, num_output_channels=4, num_gnn_layers=layers, num_aux_graphs=naux,
                 gnn_jk_mode="last", classifier_hidden_dim=32, residual=True, use_coordinate_graph=coord,
                 output_activation="logit", use_main_graph_only=main_only)

@@ -121,9 +121,12 @@ __global__ __launch_bounds__(512, 4) void k_lin128_map(const float* __restrict__
 }
 
 // ---- hidden activation of a BN-ReLU-Dropout block, recomputed from z ------------------------------------------------
-__device__ inline float hidden_act(float z, float scale, float shift, const ClsDrop& d, unsigned long long idx) {
-    float v = fmaxf(z * scale + shift, 0.f);
-    if (d.p > 0.f) v *= keep_scale(d.seed, idx, d.p, d.inv_keep);
+// (4 consecutive channels; idx = element index of the first, a multiple of 4)
+__device__ inline f32x4 hidden_act4(const f32x4& z, const f32x4& scale, const f32x4& shift, const ClsDrop& d, unsigned long long idx) {
+    f32x4 v = z * scale + shift;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+    if (d.p > 0.f) v *= keep_scale4(d.seed, idx, d.p, d.inv_keep);
     return v;
 }
 
@@ -140,10 +143,7 @@ __device__ inline void load_h1_tile(const float* __restrict__ z1, long long row0
             const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4);
             const unsigned long long idx = (unsigned long long)(row0 + r) * H1 + c4;
-            v.x = hidden_act(zz.x, sc.x, sh.x, d, idx + 0);
-            v.y = hidden_act(zz.y, sc.y, sh.y, d, idx + 1);
-            v.z = hidden_act(zz.z, sc.z, sh.z, d, idx + 2);
-            v.w = hidden_act(zz.w, sc.w, sh.w, d, idx + 3);
+            v = hidden_act4(zz, sc, sh, d, idx);
         }
         *reinterpret_cast<f32x4*>(&s_h[r * LDA + c4]) = v;
     }
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(CT_THREADS) void k_cls_out_fwd(const float* __restr
             const f32x4 sh = *reinterpret_cast<const f32x4*>(bn2.shift + 16 * head + 4 * q);
             const f32x4 ww = *reinterpret_cast<const f32x4*>(w3 + 16 * head + 4 * q);
             const unsigned long long idx = (unsigned long long)row * H2 + 16 * head + 4 * q;
-            y += ww.x * hidden_act(zz.x, sc.x, sh.x, d2, idx + 0) + ww.y * hidden_act(zz.y, sc.y, sh.y, d2, idx + 1) +
-                 ww.z * hidden_act(zz.z, sc.z, sh.z, d2, idx + 2) + ww.w * hidden_act(zz.w, sc.w, sh.w, d2, idx + 3);
+            const f32x4 hh = hidden_act4(zz, sc, sh, d2, idx);
+            y += ww.x * hh.x + ww.y * hh.y + ww.z * hh.z + ww.w * hh.w;
         }
         if (sigmoid) y = 1.0f / (1.0f + __expf(-y));
         logits[i] = y;
@@ -266,13 +266,15 @@ __global__ __launch_bounds__(CT_THREADS) void k_cls_out_bwd_sums(const float* __
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 zq = *reinterpret_cast<const f32x4*>(zp + 4 * q);
+            const f32x4 kq = d2.p > 0.f ? keep_scale4(d2.seed, (unsigned long long)row * H2 + 16 * head + 4 * q, d2.p, d2.inv_keep)
+                                        : f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int c = 4 * q + u;
                 const float zz = zq[u];
                 const float xh = (zz - mean[c]) * istd[c];
                 const float v = zz * scl[c] + sft[c];
-                const float k = d2.p > 0.f ? keep_scale(d2.seed, (unsigned long long)row * H2 + 16 * head + c, d2.p, d2.inv_keep) : 1.0f;
+                const float k = kq[u];
                 const float m = v > 0.f ? k : 0.f;
                 const float g = dl * w3v[c] * m;
                 sg[c] += g; sgx[c] += g * xh; sw[c] += dl * v * m;
@@ -346,13 +348,15 @@ __global__ __launch_bounds__(CT_THREADS) void k_cls_mid_bwd(const float* __restr
                 const f32x4 mn = *reinterpret_cast<const f32x4*>(bn2.mean + c4), is = *reinterpret_cast<const f32x4*>(bn2.invstd + c4);
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(bn2.scale + c4), sh = *reinterpret_cast<const f32x4*>(bn2.shift + c4);
                 const f32x4 ww = *reinterpret_cast<const f32x4*>(w3 + c4);
+                const f32x4 kk = d2.p > 0.f ? keep_scale4(d2.seed, (unsigned long long)row * H2 + c4, d2.p, d2.inv_keep)
+                                            : f32x4{1.f, 1.f, 1.f, 1.f};
                 float ov[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int ch = c4 + u;
                     const float xh = (zz[u] - mn[u]) * is[u];
                     const float v = zz[u] * sc[u] + sh[u];
-                    const float k = d2.p > 0.f ? keep_scale(d2.seed, (unsigned long long)row * H2 + ch, d2.p, d2.inv_keep) : 1.0f;
+                    const float k = kk[u];
                     const float g = v > 0.f ? dl * ww[u] * k : 0.f;
                     ov[u] = s_c[0][ch] * (g - s_c[1][ch] - xh * s_c[2][ch]);
                 }

@@ -140,12 +140,7 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ z,
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4);
         f32x4 v = zz * sc + sh;
-        if (a.p > 0.f) {
-            v.x *= keep_scale(a.seed, (unsigned long long)i * 4 + 0, a.p, a.inv_keep);
-            v.y *= keep_scale(a.seed, (unsigned long long)i * 4 + 1, a.p, a.inv_keep);
-            v.z *= keep_scale(a.seed, (unsigned long long)i * 4 + 2, a.p, a.inv_keep);
-            v.w *= keep_scale(a.seed, (unsigned long long)i * 4 + 3, a.p, a.inv_keep);
-        }
+        if (a.p > 0.f) v *= keep_scale4(a.seed, (unsigned long long)i * 4, a.p, a.inv_keep);
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
         *reinterpret_cast<f32x4*>(out + i * 4) = v;
@@ -166,10 +161,7 @@ __device__ inline f32x2 act_grad2(const float* __restrict__ dy, const float* __r
     xhat = (zz - m) * is;
     const f32x2 v = xhat * ga + be;
     f32x2 g = d;
-    if (a.p > 0.f) {
-        g.x *= keep_scale(a.seed, (unsigned long long)off, a.p, a.inv_keep);
-        g.y *= keep_scale(a.seed, (unsigned long long)off + 1, a.p, a.inv_keep);
-    }
+    if (a.p > 0.f) g *= keep_scale2(a.seed, (unsigned long long)off, a.p, a.inv_keep);
     if (a.relu) { g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f; }
     return g;
 }
@@ -215,7 +207,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 // 32 x 128 slab dW[32w..32w+31][:] as four 32x32 accumulators.  Row tiles of 32 rows of g and x go through
 // LDS; v_mfma_f32_32x32x2_f32: A[i][k] = g[row k][32w + i] (lane i = l&31, k = l>>5), B[k][j] = x[row k][32jb + j].
 constexpr int DW_ROWS = 32;
-constexpr int DW_BLOCKS = 512;
+constexpr int DW_BLOCKS = 768;            // 3 workgroups per CU (k_bn_bwd_apply_dw: 168 VGPRs)
 // workspace layout: [0, WS_RED_BYTES) column-reduction partials (doubles) + totals; then DW_BLOCKS slabs of [128,128] floats
 constexpr size_t WS_RED_BYTES = (((size_t)RED_BLOCKS * 2 * C + 2 * C) * sizeof(double) + 4095) / 4096 * 4096;
 
@@ -288,7 +280,7 @@ __global__ __launch_bounds__(256) void k_dweight_final(const float* __restrict__
 
 // ---- BN backward apply fused with the weight gradient: dz = BN'(dy * mask) is written AND fed (through LDS) to
 // dW += dz^T x, so dz is not read back for the weight gradient.  Same tiling as k_dweight_partial.
-__global__ __launch_bounds__(256) void k_bn_bwd_apply_dw(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 3) void k_bn_bwd_apply_dw(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ x,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const double* __restrict__ totals, float* __restrict__ dz,
@@ -311,34 +303,52 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_dw(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
     const long long n_tiles = (a.rows + DW_ROWS - 1) / DW_ROWS;
+    // The 12 row loads of a tile (dy, z, x: 4 float4 each per thread) are issued one tile ahead, right before the MFMA
+    // phase of the current tile, so that the memory round trip runs under the 64 MFMAs instead of in front of them.
+    f32x4 pd[4], pz[4], px[4];
+    auto issue = [&](long long t) {
+        const long long r0 = t * DW_ROWS + (tid >> 5);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long r = r0 + 8 * q;
+            pd[q] = pz[q] = px[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < a.rows) {
+                const size_t off = (size_t)r * C + c4;
+                pd[q] = *reinterpret_cast<const f32x4*>(dy + off);
+                pz[q] = *reinterpret_cast<const f32x4*>(z + off);
+                const long long rx = xm.n_valid > 0 ? map_row(xm, r) : r;
+                px[q] = *reinterpret_cast<const f32x4*>(x + (size_t)rx * C + c4);
+            }
+        }
+    };
+    if ((long long)blockIdx.x < n_tiles) issue(blockIdx.x);
     for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const long long r0 = t * DW_ROWS;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = tid + 256 * q;
             const long long r = r0 + e / 32;
-            f32x4 vg = {0.f, 0.f, 0.f, 0.f}, vx = vg;
+            f32x4 vg = {0.f, 0.f, 0.f, 0.f};
             if (r < a.rows) {
                 const size_t off = (size_t)r * C + c4;
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + off);
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + off);
-                const long long rx = xm.n_valid > 0 ? map_row(xm, r) : r;
-                vx = *reinterpret_cast<const f32x4*>(x + (size_t)rx * C + c4);
+                const f32x4 zz = pz[q];
+                f32x4 d = pd[q];
+                if (a.p > 0.f) d *= keep_scale4(a.seed, (unsigned long long)off, a.p, a.inv_keep);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float xh = (zz[u] - mn[u]) * is[u];
                     const float v = xh * ga[u] + be[u];
                     float g = d[u];
-                    if (a.p > 0.f) g *= keep_scale(a.seed, (unsigned long long)off + u, a.p, a.inv_keep);
                     if (a.relu) g = v > 0.f ? g : 0.f;
                     vg[u] = ga[u] * is[u] * (g - mg[u] - xh * mgx[u]);
                 }
                 if (dz) *reinterpret_cast<f32x4*>(dz + off) = vg;           // (NULL: only the weight gradient is wanted)
             }
             *reinterpret_cast<f32x4*>(&s_g[e * 4]) = vg;
-            *reinterpret_cast<f32x4*>(&s_x[e * 4]) = vx;
+            *reinterpret_cast<f32x4*>(&s_x[e * 4]) = px[q];
         }
         __syncthreads();
+        if (t + gridDim.x < n_tiles) issue(t + gridDim.x);
 #pragma unroll 4
         for (int s = 0; s < DW_ROWS / 2; ++s) {
             const int r = 2 * s + kh;
