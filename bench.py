@@ -17,6 +17,7 @@ environment's RANK / LOCAL_RANK / WORLD_SIZE are used as they are.
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel, measured live with HIP events on
 the launch stream), `cpu_baseline` (the CPU oracle = port of the reference PyG op sequence,
 timed on this box's host cores on a bounded sample), `repeats` (the timed loop repeated) and — at N = 1 —
+`experiments` (opt-in bf16x3 layer product, with its error against the exact path) and
 `other_configs`: BASELINE configs[2] (main grid only, batch 32), configs[4] (448x448, 8 aux levels, batch 8) and one
 configs[3] training step (coordinate graph, batch 32), each timed the same way; they never enter `value`."""
 from __future__ import annotations
@@ -326,6 +327,34 @@ def time_steps(step, iters=20, warm=5):
     return e0.elapsed_time(e1) / iters
 
 
+def bf16x3_experiment(model, graph, step, exact_out, B, frame):
+    """OPT-IN experiment, never part of `value` (which stays exact fp32): the same step with the layer product of the
+    producer/consumer kernel switched to the split-operand bf16 form (eg_graph_set_precision, include/echoglad_hip.h)."""
+    import torch
+
+    def landmark_argmax(logits):                  # hard arg-max over the main-grid rows of each frame, per channel
+        return logits.view(B, -1, logits.shape[-1])[:, -frame * frame:, :].argmax(dim=1)
+
+    what = ("same workload and weights as the headline; 128x128 layer product as 3 bf16 MFMAs on hi/lo-split operands, fp32 "
+            "accumulate; classifier heads fp32")
+    exact = exact_out.detach().clone()
+    try:
+        graph.set_precision("bf16x3")
+        model.enable_hip_graph(model.use_hip_graph)          # drop the captured fp32 launches
+        got = step().detach().clone()
+        ms = time_steps(step, 50, 5)
+        return {"what": what, "ms_per_step": round(ms, 4), "frames_s": round(B / (ms * 1e-3), 1),
+                "max_abs_logit_diff_vs_f32": float((got - exact).abs().max()),
+                "max_abs_logit": float(exact.abs().max()),
+                "landmark_argmax_equal": bool(torch.equal(landmark_argmax(got), landmark_argmax(exact))),
+                "dtype": "bf16x3 (opt-in)"}
+    except Exception as ex:
+        return {"what": what, "error": repr(ex)}
+    finally:
+        graph.set_precision("f32")
+        model.enable_hip_graph(model.use_hip_graph)
+
+
 def other_configs(args, device):
     """The BASELINE configs the metric is not quoted on, timed like the headline (HIP-graph replay, inputs in HBM);
     reported beside it, never inside `value`."""
@@ -482,12 +511,12 @@ def main_infer(args, world, rank, device, dist_info):
         forms = [dict(kidsum_out=ka)] + [dict(kidsum_in=ka, kidsum_out=kb)] * max(args.layers - 2, 0)
         fused_cls = bool(model.fuse_classifier) and topo.n_conn == 0 and topo.num_valid_nodes == N
         if not fused_cls:
-            forms.append(dict(kidsum_in=ka))          # (with the classifier fused, the last layer is k_gcn_layer_ps<true>)
-        kname = "k_gcn_layer_ps<false>" if fused_cls else "k_gcn_layer_ps"
+            forms.append(dict(kidsum_in=ka))          # (with the classifier fused, the last layer is k_gcn_layer_ps<true, false>)
+        kname = "k_gcn_layer_ps<false, false>" if fused_cls else "k_gcn_layer_ps"
     else:
         forms = [dict()]
         flat = graph.structured and graph.kidsum_rows == 0 and graph.fused_classifier_ok       # single-level topology
-        kname = "k_gcn_layer_ps<false>" if flat else ("k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>")
+        kname = "k_gcn_layer_ps<false, false>" if flat else ("k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>")
 
     def layer_launches():
         for f in forms:
@@ -521,7 +550,7 @@ def main_infer(args, world, rank, device, dist_info):
                    "nodes_per_frame": N, "directed_edges_per_frame": e_dir, "global_batch": B * world,
                    "parallelism": f"dp{world} (batch-sharded frames, no data-path collective)",
                    "launch": "eager" if args.no_hip_graph else "hipGraph replay of the step's kernels",
-                   "kernels_per_step": ("2 x k_gcn_layer_ps<false> (chained layers) + k_gcn_layer_ps<true> (last layer + "
+                   "kernels_per_step": ("2 x k_gcn_layer_ps<false, false> (chained layers) + k_gcn_layer_ps<true, false> (last layer + "
                                         "classifier heads)") if (graph.kidsum_rows > 0 and model.chain_layers and
                                                                   model.fuse_classifier) else "3 layer launches + k_classifier"},
         "distributed": dist_info,
@@ -575,6 +604,7 @@ def main_infer(args, world, rank, device, dist_info):
                                 O.landmark_argmax(cpu_out, args.cpu_frames, args.frame)))}
     if world == 1 and not args.no_other_configs:
         del buf
+        result["experiments"] = {"bf16x3": bf16x3_experiment(model, graph, step, out, B, args.frame)}
         result["other_configs"] = other_configs(args, device)
     print(json.dumps(result), flush=True)
 

@@ -69,7 +69,7 @@ __device__ inline void ps_claim(int* __restrict__ counters, int group, int n_til
 // Linear(32,16)-BN-ReLU-Linear(16,1)] of src/core/models.py:363-377, :485-490, eval-mode BN folded by the caller
 // (same packing as eg_classifier_fwd).  The layer's output tile never leaves LDS.
 
-template <bool CLS>
+template <bool CLS, bool BF3 = false>
 __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ out, const float* __restrict__ dis,
@@ -115,8 +115,11 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
     // exactly one workgroup barrier per tile, in lock step:   [prologue barrier]  (tile k work)  [barrier k] ...
     if (wave < 4) {
         // =========================== CONSUMER: channels 32*wave .. 32*wave+31 ===================================
-        float wreg[64];
-        load_w_slice(W, wave, lane_k, a.transpose_w, wreg);
+        // the wave's slice of W: fp32 (exact, the default) or split into bf16 hi / lo parts (opt-in bf16x3 product, tile.h)
+        float wreg[BF3 ? 1 : 64];
+        WSliceBf wbf;
+        if constexpr (BF3) load_w_slice_bf(W, wave, lane_k, a.transpose_w, wbf);
+        else load_w_slice(W, wave, lane_k, a.transpose_w, wreg);
         f32x4 sc[4], sh[4];
         if (!CLS) {
 #pragma unroll
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         // CLS: wave = classifier head.  First-layer slice of the stacked [128,128] weight in 64 more VGPRs (the per-channel
         // scale / shift vectors of both stages then live in LDS, not in registers); second layer as in classifier.hip:
         // MFMA 16x16x4 A operand lane (o = l & 15, kq = l >> 4) holds W2[head][o][8 kq + s].
-        float wreg2[64];
+        float wreg2[64];                                // (stays exact fp32 in the bf16x3 experiment too: the heads amplify the error)
         float w2a[8];
         f32x4 s2v, t2v, w3v;
         float b3v = 0.f;
@@ -251,17 +254,23 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(ob + (size_t)node[e] * C) = o[e];
             };
 #ifndef EG_ABL_NO_MFMA
-            mfma_rowblock(s_a, 0, lane, wreg, acc0);
             // rows 32..63: the MFMA chain leaves ~60 issue cycles per instruction free; the epilogue of rows 0..31
             // (VALU, LDS, and its global stores) is placed between the chunks of the chain, every LDS read one chunk
             // ahead of its use
-            mfma_rowblock_with(s_a, 32, lane, wreg, acc1, [&](int c) {
+            auto between = [&](int c) {
                 if (c < 2) { finish_group(acc0, 0, 2 * c); finish_group(acc0, 0, 2 * c + 1); }
                 else if (!CLS && c == 2) read_segments(0);
                 else if (!CLS) store_segments();
-            });
+            };
+            if constexpr (BF3) {
+                mfma_rowblock_bf(s_a, 0, lane, wbf, acc0);
+                mfma_rowblock_bf_with(s_a, 32, lane, wbf, acc1, between);
+            } else {
+                mfma_rowblock(s_a, 0, lane, wreg, acc0);
+                mfma_rowblock_with(s_a, 32, lane, wreg, acc1, between);
+            }
 #else
-            acc0[0] = wreg[0] + s_a[lane]; acc1[0] = wreg[63];
+            acc0[0] = wreg[0] + s_a[lane]; acc1[0] = wreg[BF3 ? 0 : 63];
 #pragma unroll
             for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
             if (!CLS) { read_segments(0); store_segments(); }
@@ -522,20 +531,26 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
             EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
     }
     int* const queue = g->next_queue_slice();
     EG_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
     long long grid = n_tiles < 256 ? n_tiles : g->knobs.ps_grid;      // one persistent workgroup per CU
-    if (cls)
-        hipLaunchKernelGGL(k_gcn_layer_ps<true>, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out,
-                           g->dis, g->topo_dev, g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout,
-                           queue, a, *cls);
-    else
-        hipLaunchKernelGGL(k_gcn_layer_ps<false>, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out,
-                           g->dis, g->topo_dev, g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout,
-                           queue, a, ClsArgs{});
+    const ClsArgs none{};
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out, g->dis, g->topo_dev,
+                           g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, queue, a, cls ? *cls : none);
+    };
+    if (g->knobs.bf16x3) {                                            // opt-in experiment (EG_LAYER_PRECISION=bf16x3)
+        if (cls) launch(k_gcn_layer_ps<true, true>);
+        else launch(k_gcn_layer_ps<false, true>);
+    } else {
+        if (cls) launch(k_gcn_layer_ps<true, false>);
+        else launch(k_gcn_layer_ps<false, false>);
+    }
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

@@ -538,6 +538,100 @@ __device__ inline void mfma_rowblock_with(const float* s_a, int row0, int lane, 
     between(3);
 }
 
+// ---- opt-in bf16x3 form of the same product (EG_LAYER_PRECISION=bf16x3; never the default) -------------------------
+// Every fp32 operand is split into a = hi + lo with hi = bf16(a), lo = bf16(a - hi) (16 significant bits together) and
+//   a b  ~=  hi_a hi_b + hi_a lo_b + lo_a hi_b          (the dropped lo lo term is <= 2^-16 |a b|)
+// runs as three v_mfma_f32_32x32x16_bf16 (8 passes each for 16 k-values: 3/16 of the fp32 MFMA time), accumulated in
+// fp32.  Same lane <-> (row, channel, k-half) assignment and the same accumulator layout as the fp32 chain above, so the
+// epilogues are shared: MFMA step t of lane (., h) covers k = 64 h + 8 t .. + 7.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));          // v_cvt_pk_bf16_f32, round to nearest even
+    const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+__device__ inline void split_bf16_8(const f32x4& p, const f32x4& q, u32x4& hi, u32x4& lo) {
+    unsigned h[4], l[4];
+    split_bf16_pair(p.x, p.y, h[0], l[0]);
+    split_bf16_pair(p.z, p.w, h[1], l[1]);
+    split_bf16_pair(q.x, q.y, h[2], l[2]);
+    split_bf16_pair(q.z, q.w, h[3], l[3]);
+    hi = u32x4{h[0], h[1], h[2], h[3]};
+    lo = u32x4{l[0], l[1], l[2], l[3]};
+}
+
+struct WSliceBf { u32x4 hi[8], lo[8]; };                 // the wave's W slice, split once: 64 VGPRs like the fp32 slice
+
+__device__ inline void load_w_slice_bf(const float* __restrict__ W, int wave, int lane, int transpose, WSliceBf& w) {
+    float wreg[64];
+    load_w_slice(W, wave, lane, transpose, wreg);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        split_bf16_8(f32x4{wreg[8 * t], wreg[8 * t + 1], wreg[8 * t + 2], wreg[8 * t + 3]},
+                     f32x4{wreg[8 * t + 4], wreg[8 * t + 5], wreg[8 * t + 6], wreg[8 * t + 7]}, w.hi[t], w.lo[t]);
+}
+
+// two MFMA steps (16 k-values per lane half) from 4 float4 fragments of the fp32 LDS tile
+__device__ inline void mfma_chunk_bf(const f32x4 (&av)[4], const WSliceBf& w, int t0, f32x16& acc) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        u32x4 ahi, alo;
+        split_bf16_8(av[2 * u], av[2 * u + 1], ahi, alo);
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, w.hi[t0 + u]), wl = __builtin_bit_cast(bf16x8, w.lo[t0 + u]);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi), al = __builtin_bit_cast(bf16x8, alo);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
+    }
+    // Measured on MI355X (tools/tools_bf16x3.py): without this guard the NEXT fragment loads (ds_read_b128 into
+    // the registers the last MFMA above just used as its B operand -- the allocator reuses them at once) corrupted that operand
+    // on ~1 row in 2000, only when the co-resident producer wave was stalled so that this wave issued back to back.  A VALU
+    // read of the accumulator (the compiler adds the XDL-write -> VALU-read wait states) plus 64 idle issue cycles between the
+    // last MFMA of a chunk and anything that may overwrite its sources made 300 launches bit-identical.
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        float probe = acc[0];
+        asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7" : "+v"(probe));
+        acc[0] = probe;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename F>
+__device__ inline void mfma_rowblock_bf_with(const float* s_a, int row0, int lane, const WSliceBf& w, f32x16& acc, F between) {
+    const int j = lane & 31, h = lane >> 5;
+    const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
+    f32x4 a0[4], a1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a0[t] = ap[t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk_bf(a0, w, 0, acc);
+    between(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk_bf(a1, w, 2, acc);
+    between(1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk_bf(a0, w, 4, acc);
+    between(2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk_bf(a1, w, 6, acc);
+    between(3);
+}
+
+__device__ inline void mfma_rowblock_bf(const float* s_a, int row0, int lane, const WSliceBf& w, f32x16& acc) {
+    mfma_rowblock_bf_with(s_a, row0, lane, w, acc, [](int) {});
+}
+
 // ---- 8-wave layout: wave w owns 16 output channels, v_mfma_f32_16x16x4_f32 ------------------------
 // A operand = W slice (32 VGPRs for the lifetime of the workgroup): lane (i = l&15, kq = l>>4) holds
 // W[16w+i][koff(kq) + s], s = 0..31.  B operand = LDS tile: lane (j = l&15, kq) reads a[row0+j][koff(kq)+s]

@@ -92,6 +92,18 @@ class Graph:
                 g.bwd = cls(ht, False, int(num_nodes), ei.device)
         return g
 
+    def set_precision(self, mode: str) -> None:
+        """OPT-IN experiment (include/echoglad_hip.h eg_graph_set_precision): "f32" = exact fp32 MFMA (default),
+        "bf16x3" = split-operand bf16 product inside the producer/consumer layer kernel."""
+        modes = {"f32": 0, "bf16x3": 1}
+        if mode not in modes:
+            raise ValueError(f"precision must be one of {sorted(modes)}")
+        _lib.check(_lib.load().eg_graph_set_precision(self._h, modes[mode]), "eg_graph_set_precision")
+
+    @property
+    def precision(self) -> str:
+        return "bf16x3" if _lib.load().eg_graph_precision(self._h) == 1 else "f32"
+
     def deg_inv_sqrt(self) -> torch.Tensor:
         out = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
         _lib.check(_lib.load().eg_graph_deg_inv_sqrt(self._h, _ptr(out), _stream()), "eg_graph_deg_inv_sqrt")
