@@ -575,30 +575,37 @@ __device__ inline void load_w_slice_bf(const float* __restrict__ W, int wave, in
                      f32x4{wreg[8 * t + 4], wreg[8 * t + 5], wreg[8 * t + 6], wreg[8 * t + 7]}, w.hi[t], w.lo[t]);
 }
 
-// two MFMA steps (16 k-values per lane half) from 4 float4 fragments of the fp32 LDS tile
+// two MFMA steps (16 k-values per lane half) from 4 float4 fragments of the fp32 LDS tile.
+// Register discipline (measured on MI355X): v_mfma_f32_32x32x16_bf16 reads its 4-VGPR A / B operands
+// progressively while it executes, and neither the hardware nor the compiler's hazard tables keep a VALU instruction issued
+// right behind it from overwriting them -- a v_cvt_pk_bf16_f32 of the NEXT step into the same registers corrupted the last
+// sub-block the MFMA reads (k-group 1, even elements, columns n = 3 mod 8) on ~1 row in 2000, only with every CU busy and the
+// co-resident wave stalled.  So: all 16 operand registers of a chunk are written BEFORE its six MFMAs and are live across all of
+// them, and nothing may write them again until a VALU read of the accumulator (the compiler adds the XDL-write -> VALU-read
+// wait states) plus 64 idle issue cycles have passed.
 __device__ inline void mfma_chunk_bf(const f32x4 (&av)[4], const WSliceBf& w, int t0, f32x16& acc) {
+    u32x4 ahi[2], alo[2];
+    split_bf16_8(av[0], av[1], ahi[0], alo[0]);
+    split_bf16_8(av[2], av[3], ahi[1], alo[1]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        u32x4 ahi, alo;
-        split_bf16_8(av[2 * u], av[2 * u + 1], ahi, alo);
         const bf16x8 wh = __builtin_bit_cast(bf16x8, w.hi[t0 + u]), wl = __builtin_bit_cast(bf16x8, w.lo[t0 + u]);
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi), al = __builtin_bit_cast(bf16x8, alo);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi[u]), al = __builtin_bit_cast(bf16x8, alo[u]);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
     }
-    // Measured on MI355X (tools/tools_bf16x3.py): without this guard the NEXT fragment loads (ds_read_b128 into
-    // the registers the last MFMA above just used as its B operand -- the allocator reuses them at once) corrupted that operand
-    // on ~1 row in 2000, only when the co-resident producer wave was stalled so that this wave issued back to back.  A VALU
-    // read of the accumulator (the compiler adds the XDL-write -> VALU-read wait states) plus 64 idle issue cycles between the
-    // last MFMA of a chunk and anything that may overwrite its sources made 300 launches bit-identical.
+#ifndef EG_BF3_NOGUARD
     __builtin_amdgcn_sched_barrier(0);
     {
         float probe = acc[0];
-        asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7" : "+v"(probe));
+        asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7"
+                     : "+v"(probe), "+v"(ahi[0]), "+v"(alo[0]), "+v"(ahi[1]), "+v"(alo[1]));      // (operands stay allocated up to here)
         acc[0] = probe;
     }
     __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 template <typename F>

@@ -184,7 +184,8 @@ def test_cfg5_448_full_batch_8():
 def test_bf16x3_experiment_is_opt_in_close_and_deterministic():
     """The split-operand bf16 product (eg_graph_set_precision, include/echoglad_hip.h) is OFF by default; switched on it stays
     within north_star's 1e-4 of the exact fp32 path at configs[1] with identical per-level arg-max, and repeated launches
-    are bit-identical (the kernel carries a guard for a register-reuse hazard found on hardware, tile.h)."""
+    are bit-identical (the kernel carries a guard for an MFMA operand-read hazard found on hardware, tile.h; the long soak is
+    tools/tools_determinism.py)."""
     from echoglad_amd import ops
     frame, naux, B = 224, 7, 8
     hip, _ = model_pair(frame, naux, 3, seed=11)
