@@ -17,7 +17,7 @@ environment's RANK / LOCAL_RANK / WORLD_SIZE are used as they are.
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel, measured live with HIP events on
 the launch stream), `cpu_baseline` (the CPU oracle = port of the reference PyG op sequence,
 timed on this box's host cores on a bounded sample), `repeats` (the timed loop repeated) and — at N = 1 —
-`experiments` (opt-in bf16x3 layer product, with its error against the exact path) and
+`experiments` (opt-in bf16x3 / bf16x6 layer products, with their error against the exact path) and
 `other_configs`: BASELINE configs[2] (main grid only, batch 32), configs[4] (448x448, 8 aux levels, batch 8) and one
 configs[3] training step (coordinate graph, batch 32), each timed the same way; they never enter `value`."""
 from __future__ import annotations
@@ -327,19 +327,21 @@ def time_steps(step, iters=20, warm=5):
     return e0.elapsed_time(e1) / iters
 
 
-def bf16x3_experiment(model, graph, step, exact_out, B, frame):
+def split_bf16_experiment(mode, model, graph, step, exact_out, B, frame):
     """OPT-IN experiment, never part of `value` (which stays exact fp32): the same step with the layer product of the
-    producer/consumer kernel switched to the split-operand bf16 form (eg_graph_set_precision, include/echoglad_hip.h)."""
+    producer/consumer kernel switched to a split-operand bf16 form (eg_graph_set_precision, include/echoglad_hip.h)."""
     import torch
 
     def landmark_argmax(logits):                  # hard arg-max over the main-grid rows of each frame, per channel
         return logits.view(B, -1, logits.shape[-1])[:, -frame * frame:, :].argmax(dim=1)
 
-    what = ("same workload and weights as the headline; 128x128 layer product as 3 bf16 MFMAs on hi/lo-split operands, fp32 "
-            "accumulate; classifier heads fp32")
+    what = {"bf16x3": "same workload and weights as the headline; 128x128 layer product as 3 bf16 MFMAs on operands split into 2 "
+                      "bf16 parts, fp32 accumulate; classifier heads fp32",
+            "bf16x6": "same; 6 bf16 MFMAs on operands split into 3 bf16 parts (exact 24-bit split, dropped terms <= 2^-23 of a "
+                      "product); classifier heads fp32 and not fused into the last layer in this mode"}[mode]
     exact = exact_out.detach().clone()
     try:
-        graph.set_precision("bf16x3")
+        graph.set_precision(mode)
         model.enable_hip_graph(model.use_hip_graph)          # drop the captured fp32 launches
         got = step().detach().clone()
         ms = time_steps(step, 50, 5)
@@ -347,7 +349,7 @@ def bf16x3_experiment(model, graph, step, exact_out, B, frame):
                 "max_abs_logit_diff_vs_f32": float((got - exact).abs().max()),
                 "max_abs_logit": float(exact.abs().max()),
                 "landmark_argmax_equal": bool(torch.equal(landmark_argmax(got), landmark_argmax(exact))),
-                "dtype": "bf16x3 (opt-in)"}
+                "dtype": mode + " (opt-in)"}
     except Exception as ex:
         return {"what": what, "error": repr(ex)}
     finally:
@@ -604,7 +606,7 @@ def main_infer(args, world, rank, device, dist_info):
                                 O.landmark_argmax(cpu_out, args.cpu_frames, args.frame)))}
     if world == 1 and not args.no_other_configs:
         del buf
-        result["experiments"] = {"bf16x3": bf16x3_experiment(model, graph, step, out, B, args.frame)}
+        result["experiments"] = {m: split_bf16_experiment(m, model, graph, step, out, B, args.frame) for m in ("bf16x3", "bf16x6")}
         result["other_configs"] = other_configs(args, device)
     print(json.dumps(result), flush=True)
 

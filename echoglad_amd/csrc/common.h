@@ -167,8 +167,8 @@ struct Knobs {
     int grid_cap;       // EG_GRID        persistent grid of the symmetric kernel (default 512 = 2 workgroups per CU)
     int layer_impl;     // EG_LAYER_IMPL  -1 auto, 0 symmetric kernel, 1 producer/consumer kernel for plain calls
     int ps_grid;        // EG_PS_GRID     persistent grid of the producer/consumer kernel (default 256 = 1 per CU)
-    int bf16x3;         // EG_LAYER_PRECISION=bf16x3  opt-in experiment: the layer product of the producer/consumer kernel as three
-                        //                bf16 MFMAs on split operands instead of the exact fp32 MFMA (default off)
+    int precision;      // EG_LAYER_PRECISION=bf16x3|bf16x6  opt-in experiment (EG_PRECISION_*): the layer product of the producer/
+                        //                consumer kernel as 3 / 6 bf16 MFMAs on split operands instead of the exact fp32 MFMA
 };
 Knobs read_knobs();
 const Knobs& process_knobs();

@@ -69,7 +69,8 @@ __device__ inline void ps_claim(int* __restrict__ counters, int group, int n_til
 // Linear(32,16)-BN-ReLU-Linear(16,1)] of src/core/models.py:363-377, :485-490, eval-mode BN folded by the caller
 // (same packing as eg_classifier_fwd).  The layer's output tile never leaves LDS.
 
-template <bool CLS, bool BF3 = false>
+// PREC: 0 = exact fp32 MFMA (default), 2 / 3 = opt-in bf16 product with 2 / 3 parts per operand (bf16x3 / bf16x6, tile.h)
+template <bool CLS, int PREC = 0>
 __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ out, const float* __restrict__ dis,
@@ -116,9 +117,13 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
     if (wave < 4) {
         // =========================== CONSUMER: channels 32*wave .. 32*wave+31 ===================================
         // the wave's slice of W: fp32 (exact, the default) or split into bf16 hi / lo parts (opt-in bf16x3 product, tile.h)
-        float wreg[BF3 ? 1 : 64];
-        WSliceBf wbf;
-        if constexpr (BF3) load_w_slice_bf(W, wave, lane_k, a.transpose_w, wbf);
+        constexpr bool BF = PREC != 0;
+        constexpr int BFP = BF ? PREC : 2;
+        // (bf16x6 needs 96 VGPRs for W: the 32 registers of the residual prefetch go, the residual is read in the epilogue)
+        constexpr bool RES_LATE = CLS || PREC == 3;
+        float wreg[BF ? 1 : 64];
+        WSliceBf<BFP> wbf;
+        if constexpr (BF) load_w_slice_bf<BFP>(W, wave, lane_k, a.transpose_w, wbf);
         else load_w_slice(W, wave, lane_k, a.transpose_w, wreg);
         f32x4 sc[4], sh[4];
         if (!CLS) {
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             // residual rows of both 32-row blocks, read BEFORE the MFMA chains: an LDS wait inside a chain stalls the
             // wave's next MFMA as well (in-order issue)
             f32x4 res[2][4];
-            if (!CLS) {                                                       // (the fused-classifier variant has no registers to spare)
+            if (!RES_LATE) {                                                  // (the fused-classifier variant has no registers to spare)
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     v = v * sc[g] + sh[g];
                 }
                 v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-                const f32x4 r = CLS ? *reinterpret_cast<const f32x4*>(xp) : res[rb][g];
+                const f32x4 r = RES_LATE ? *reinterpret_cast<const f32x4*>(xp) : res[rb][g];
                 v.x += has_res ? r.x : 0.f; v.y += has_res ? r.y : 0.f; v.z += has_res ? r.z : 0.f; v.w += has_res ? r.w : 0.f;
                 *reinterpret_cast<f32x4*>(xp) = v;
             };
@@ -262,15 +267,15 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 else if (!CLS && c == 2) read_segments(0);
                 else if (!CLS) store_segments();
             };
-            if constexpr (BF3) {
-                mfma_rowblock_bf(s_a, 0, lane, wbf, acc0);
-                mfma_rowblock_bf_with(s_a, 32, lane, wbf, acc1, between);
+            if constexpr (BF) {
+                mfma_rowblock_bf<BFP>(s_a, 0, lane, wbf, acc0);
+                mfma_rowblock_bf_with<BFP>(s_a, 32, lane, wbf, acc1, between);
             } else {
                 mfma_rowblock(s_a, 0, lane, wreg, acc0);
                 mfma_rowblock_with(s_a, 32, lane, wreg, acc1, between);
             }
 #else
-            acc0[0] = wreg[0] + s_a[lane]; acc1[0] = wreg[BF3 ? 0 : 63];
+            acc0[0] = wreg[0] + s_a[lane]; acc1[0] = wreg[BF ? 0 : 63];
 #pragma unroll
             for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
             if (!CLS) { read_segments(0); store_segments(); }
@@ -529,10 +534,11 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         int dev = 0;
         EG_HIP_TRY(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
     }
@@ -544,12 +550,15 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out, g->dis, g->topo_dev,
                            g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, queue, a, cls ? *cls : none);
     };
-    if (g->knobs.bf16x3) {                                            // opt-in experiment (EG_LAYER_PRECISION=bf16x3)
-        if (cls) launch(k_gcn_layer_ps<true, true>);
-        else launch(k_gcn_layer_ps<false, true>);
+    if (g->knobs.precision == EG_PRECISION_BF16X3) {                  // opt-in experiments (eg_graph_set_precision)
+        if (cls) launch(k_gcn_layer_ps<true, 2>);
+        else launch(k_gcn_layer_ps<false, 2>);
+    } else if (g->knobs.precision == EG_PRECISION_BF16X6) {
+        if (cls) return EG_ERR_UNSUPPORTED;                           // (96 VGPRs of W parts + the heads' 64 do not fit: unfused there)
+        launch(k_gcn_layer_ps<false, 3>);
     } else {
-        if (cls) launch(k_gcn_layer_ps<true, false>);
-        else launch(k_gcn_layer_ps<false, false>);
+        if (cls) launch(k_gcn_layer_ps<true, 0>);
+        else launch(k_gcn_layer_ps<false, 0>);
     }
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;

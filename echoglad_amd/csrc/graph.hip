@@ -30,7 +30,8 @@ Knobs read_knobs() {
     k.layer_impl = env_int("EG_LAYER_IMPL", -1);
     k.ps_grid = env_int("EG_PS_GRID", 256);
     const char* prec = getenv("EG_LAYER_PRECISION");
-    k.bf16x3 = (prec && strcmp(prec, "bf16x3") == 0) ? 1 : 0;
+    k.precision = !prec ? EG_PRECISION_F32 : strcmp(prec, "bf16x3") == 0 ? EG_PRECISION_BF16X3
+                        : strcmp(prec, "bf16x6") == 0 ? EG_PRECISION_BF16X6 : EG_PRECISION_F32;
     return k;
 }
 
@@ -397,12 +398,13 @@ int eg_csr_create_transposed(const eg_graph* base, const int64_t* ei, int64_t n_
 
 int eg_graph_set_precision(eg_graph* g, int mode) {
     if (!g) return set_error(EG_ERR_ARG, "NULL graph handle");
-    if (mode != EG_PRECISION_F32 && mode != EG_PRECISION_BF16X3) return set_error(EG_ERR_ARG, "unknown precision mode");
-    g->knobs.bf16x3 = mode == EG_PRECISION_BF16X3 ? 1 : 0;
+    if (mode != EG_PRECISION_F32 && mode != EG_PRECISION_BF16X3 && mode != EG_PRECISION_BF16X6)
+        return set_error(EG_ERR_ARG, "unknown precision mode");
+    g->knobs.precision = mode;
     return EG_OK;
 }
 
-int eg_graph_precision(const eg_graph* g) { return g && g->knobs.bf16x3 ? EG_PRECISION_BF16X3 : EG_PRECISION_F32; }
+int eg_graph_precision(const eg_graph* g) { return g ? g->knobs.precision : EG_PRECISION_F32; }
 
 int eg_graph_is_symmetric(const eg_graph* g) { return g && (g->kind == GRAPH_TOPO || g->symmetric); }
 

@@ -538,78 +538,98 @@ __device__ inline void mfma_rowblock_with(const float* s_a, int row0, int lane, 
     between(3);
 }
 
-// ---- opt-in bf16x3 form of the same product (EG_LAYER_PRECISION=bf16x3; never the default) -------------------------
-// Every fp32 operand is split into a = hi + lo with hi = bf16(a), lo = bf16(a - hi) (16 significant bits together) and
-//   a b  ~=  hi_a hi_b + hi_a lo_b + lo_a hi_b          (the dropped lo lo term is <= 2^-16 |a b|)
-// runs as three v_mfma_f32_32x32x16_bf16 (8 passes each for 16 k-values: 3/16 of the fp32 MFMA time), accumulated in
-// fp32.  Same lane <-> (row, channel, k-half) assignment and the same accumulator layout as the fp32 chain above, so the
+// ---- opt-in split-bf16 forms of the same product (eg_graph_set_precision; never the default) ---------------------------
+// bf16x3: every fp32 operand is split into a = a0 + a1 with a0 = bf16(a), a1 = bf16(a - a0) (16 significant bits together) and
+//   a b  ~=  a0 b0 + a0 b1 + a1 b0                      (the dropped a1 b1 term is <= 2^-16 |a b|)
+// runs as three v_mfma_f32_32x32x16_bf16 (8 passes each for 16 k-values: 3/16 of the fp32 MFMA time), accumulated in fp32.
+// bf16x6: three parts (a = a0 + a1 + a2 EXACTLY: 3 x 8 = 24 bits) and the six products a_i b_j with i + j <= 2; the dropped
+//   terms are <= 2^-23 |a b| together -- the size of one fp32 rounding -- at 6/16 of the fp32 MFMA time.  Same lane <-> (row, channel, k-half) assignment and the same accumulator layout as the fp32 chain above, so the
 // epilogues are shared: MFMA step t of lane (., h) covers k = 64 h + 8 t .. + 7.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ inline void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
-    const f32x2 v = {a, b};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));          // v_cvt_pk_bf16_f32, round to nearest even
-    const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-}
-__device__ inline void split_bf16_8(const f32x4& p, const f32x4& q, u32x4& hi, u32x4& lo) {
-    unsigned h[4], l[4];
-    split_bf16_pair(p.x, p.y, h[0], l[0]);
-    split_bf16_pair(p.z, p.w, h[1], l[1]);
-    split_bf16_pair(q.x, q.y, h[2], l[2]);
-    split_bf16_pair(q.z, q.w, h[3], l[3]);
-    hi = u32x4{h[0], h[1], h[2], h[3]};
-    lo = u32x4{l[0], l[1], l[2], l[3]};
+// P-way split of 8 floats: part[0] = bf16(a), part[1] = bf16(a - part[0]), part[2] = bf16(a - part[0] - part[1]) (exact: 3 x 8 = 24 bits)
+template <int P>
+__device__ inline void split_bf16_parts(const f32x4& p, const f32x4& q, u32x4 (&part)[P]) {
+    f32x4 rp = p, rq = q;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        unsigned h[4];
+        const f32x2 v0 = {rp.x, rp.y}, v1 = {rp.z, rp.w}, v2 = {rq.x, rq.y}, v3 = {rq.z, rq.w};
+        h[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf16x2));
+        h[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf16x2));
+        h[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2));
+        h[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(v3, bf16x2));
+        part[i] = u32x4{h[0], h[1], h[2], h[3]};
+        if (i + 1 < P) {
+            rp -= f32x4{__uint_as_float(h[0] << 16), __uint_as_float(h[0] & 0xffff0000u), __uint_as_float(h[1] << 16),
+                        __uint_as_float(h[1] & 0xffff0000u)};
+            rq -= f32x4{__uint_as_float(h[2] << 16), __uint_as_float(h[2] & 0xffff0000u), __uint_as_float(h[3] << 16),
+                        __uint_as_float(h[3] & 0xffff0000u)};
+        }
+    }
 }
 
-struct WSliceBf { u32x4 hi[8], lo[8]; };                 // the wave's W slice, split once: 64 VGPRs like the fp32 slice
+// the wave's W slice, split once: P x 32 VGPRs (the fp32 slice takes 64)
+template <int P>
+struct WSliceBf { u32x4 part[P][8]; };
 
-__device__ inline void load_w_slice_bf(const float* __restrict__ W, int wave, int lane, int transpose, WSliceBf& w) {
+template <int P>
+__device__ inline void load_w_slice_bf(const float* __restrict__ W, int wave, int lane, int transpose, WSliceBf<P>& w) {
     float wreg[64];
     load_w_slice(W, wave, lane, transpose, wreg);
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-        split_bf16_8(f32x4{wreg[8 * t], wreg[8 * t + 1], wreg[8 * t + 2], wreg[8 * t + 3]},
-                     f32x4{wreg[8 * t + 4], wreg[8 * t + 5], wreg[8 * t + 6], wreg[8 * t + 7]}, w.hi[t], w.lo[t]);
+    for (int t = 0; t < 8; ++t) {
+        u32x4 parts[P];
+        split_bf16_parts<P>(f32x4{wreg[8 * t], wreg[8 * t + 1], wreg[8 * t + 2], wreg[8 * t + 3]},
+                            f32x4{wreg[8 * t + 4], wreg[8 * t + 5], wreg[8 * t + 6], wreg[8 * t + 7]}, parts);
+#pragma unroll
+        for (int i = 0; i < P; ++i) w.part[i][t] = parts[i];
+    }
 }
 
-// two MFMA steps (16 k-values per lane half) from 4 float4 fragments of the fp32 LDS tile.
+// two MFMA steps (16 k-values per lane half) from 4 float4 fragments of the fp32 LDS tile: every product w_i a_j with
+// i + j < P (3 for P = 2, 6 for P = 3), smallest terms first.
 // Register discipline (measured on MI355X): v_mfma_f32_32x32x16_bf16 reads its 4-VGPR A / B operands
 // progressively while it executes, and neither the hardware nor the compiler's hazard tables keep a VALU instruction issued
 // right behind it from overwriting them -- a v_cvt_pk_bf16_f32 of the NEXT step into the same registers corrupted the last
 // sub-block the MFMA reads (k-group 1, even elements, columns n = 3 mod 8) on ~1 row in 2000, only with every CU busy and the
-// co-resident wave stalled.  So: all 16 operand registers of a chunk are written BEFORE its six MFMAs and are live across all of
+// co-resident wave stalled.  So: all operand registers of a chunk are written BEFORE its MFMAs and are live across all of
 // them, and nothing may write them again until a VALU read of the accumulator (the compiler adds the XDL-write -> VALU-read
 // wait states) plus 64 idle issue cycles have passed.
-__device__ inline void mfma_chunk_bf(const f32x4 (&av)[4], const WSliceBf& w, int t0, f32x16& acc) {
-    u32x4 ahi[2], alo[2];
-    split_bf16_8(av[0], av[1], ahi[0], alo[0]);
-    split_bf16_8(av[2], av[3], ahi[1], alo[1]);
+template <int P>
+__device__ inline void mfma_chunk_bf(const f32x4 (&av)[4], const WSliceBf<P>& w, int t0, f32x16& acc) {
+    u32x4 ap[2][P];
+    split_bf16_parts<P>(av[0], av[1], ap[0]);
+    split_bf16_parts<P>(av[2], av[3], ap[1]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, w.hi[t0 + u]), wl = __builtin_bit_cast(bf16x8, w.lo[t0 + u]);
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, ahi[u]), al = __builtin_bit_cast(bf16x8, alo[u]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
-    }
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int order = P - 1; order >= 0; --order)            // order = i + j
+#pragma unroll
+            for (int i = order; i >= 0; --i)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.part[i][t0 + u]),
+                                                              __builtin_bit_cast(bf16x8, ap[u][order - i]), acc, 0, 0, 0);
 #ifndef EG_BF3_NOGUARD
     __builtin_amdgcn_sched_barrier(0);
     {
         float probe = acc[0];
-        asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7"
-                     : "+v"(probe), "+v"(ahi[0]), "+v"(alo[0]), "+v"(ahi[1]), "+v"(alo[1]));      // (operands stay allocated up to here)
+        if constexpr (P == 2)
+            asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7"
+                         : "+v"(probe), "+v"(ap[0][0]), "+v"(ap[0][1]), "+v"(ap[1][0]), "+v"(ap[1][1]));      // (operands stay allocated up to here)
+        else
+            asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7"
+                         : "+v"(probe), "+v"(ap[0][0]), "+v"(ap[0][1]), "+v"(ap[0][2]), "+v"(ap[1][0]), "+v"(ap[1][1]), "+v"(ap[1][2]));
         acc[0] = probe;
     }
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
 
-template <typename F>
-__device__ inline void mfma_rowblock_bf_with(const float* s_a, int row0, int lane, const WSliceBf& w, f32x16& acc, F between) {
+template <int P, typename F>
+__device__ inline void mfma_rowblock_bf_with(const float* s_a, int row0, int lane, const WSliceBf<P>& w, f32x16& acc, F between) {
     const int j = lane & 31, h = lane >> 5;
     const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
     f32x4 a0[4], a1[4];
@@ -618,25 +638,26 @@ __device__ inline void mfma_rowblock_bf_with(const float* s_a, int row0, int lan
 #pragma unroll
     for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk_bf(a0, w, 0, acc);
+    mfma_chunk_bf<P>(a0, w, 0, acc);
     between(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk_bf(a1, w, 2, acc);
+    mfma_chunk_bf<P>(a1, w, 2, acc);
     between(1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk_bf(a0, w, 4, acc);
+    mfma_chunk_bf<P>(a0, w, 4, acc);
     between(2);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk_bf(a1, w, 6, acc);
+    mfma_chunk_bf<P>(a1, w, 6, acc);
     between(3);
 }
 
-__device__ inline void mfma_rowblock_bf(const float* s_a, int row0, int lane, const WSliceBf& w, f32x16& acc) {
-    mfma_rowblock_bf_with(s_a, row0, lane, w, acc, [](int) {});
+template <int P>
+__device__ inline void mfma_rowblock_bf(const float* s_a, int row0, int lane, const WSliceBf<P>& w, f32x16& acc) {
+    mfma_rowblock_bf_with<P>(s_a, row0, lane, w, acc, [](int) {});
 }
 
 // ---- 8-wave layout: wave w owns 16 output channels, v_mfma_f32_16x16x4_f32 ------------------------

@@ -138,12 +138,15 @@ int eg_graph_fused_classifier_ok(const eg_graph* g);
  *   EG_PRECISION_F32     (default) exact fp32 MFMA (v_mfma_f32_32x32x2_f32): what every parity test and the bench headline use
  *   EG_PRECISION_BF16X3  both operands split into bf16 hi + lo parts, three bf16 MFMAs per product (hi hi + hi lo + lo hi),
  *                        fp32 accumulation: ~2^-16 relative error per product (measured: logits within 5e-5 of the fp32
- *                        path at configs[1], arg-max identical), 3/16 of the MFMA time.  The classifier heads of
- *                        eg_gcn_layer_cls_fwd stay fp32.
- * A handle created while the environment holds EG_LAYER_PRECISION=bf16x3 starts in the second mode.  Not thread-safe
+ *                        path at configs[1], arg-max identical), 3/16 of the MFMA time.
+ *   EG_PRECISION_BF16X6  three parts per operand (an exact 24-bit split), the six products a_i b_j with i + j <= 2: the
+ *                        dropped terms are <= 2^-23 of a product, the size of one fp32 rounding; 6/16 of the MFMA time.
+ * The classifier heads of eg_gcn_layer_cls_fwd stay fp32 in every mode.
+ * A handle created while the environment holds EG_LAYER_PRECISION=bf16x3 | bf16x6 starts in that mode.  Not thread-safe
  * against launches in flight on the same handle; kernels captured into a HIP graph keep the mode they were captured with. */
 #define EG_PRECISION_F32 0
 #define EG_PRECISION_BF16X3 1
+#define EG_PRECISION_BF16X6 2
 int eg_graph_set_precision(eg_graph* g, int mode);
 int eg_graph_precision(const eg_graph* g);
 int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,

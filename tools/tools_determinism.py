@@ -45,7 +45,7 @@ def soak(frame, naux, B, mode, reps, main_only=False):
 if __name__ == "__main__":
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     total = 0
-    for mode in ("f32", "bf16x3"):
+    for mode in ("f32", "bf16x3", "bf16x6"):
         total += soak(224, 7, 8, mode, reps)
         total += soak(224, 7, 32, mode, reps, main_only=True)
         total += soak(448, 8, 8, mode, max(reps // 4, 2))
