@@ -173,7 +173,7 @@ using namespace eg;
 
 extern "C" {
 
-int eg_version(void) { return 110; }
+int eg_version(void) { return 120; }
 
 const char* eg_last_error(void) { return g_last_error.c_str(); }
 
