@@ -353,6 +353,10 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out
     if (grid_out) *grid_out = (int)grid.x;
     const bool train = a.agg_out || a.stats_partial;
     a.d.walk_mode = a.walk_counters ? a.knobs.walk_mode : WALK_MOD8;
+    // Batch statistics are summed per WORKGROUP over the tiles it walks: with the dynamic queue the set of tiles behind each
+    // partial sum, hence the rounding of the totals, would change from launch to launch.  A static walk keeps a training step
+    // bit-reproducible (tests/test_gpu_train.py::test_cfg4_train_full_batch_32_properties).
+    if (a.stats_partial && a.d.walk_mode == WALK_QUEUE) a.d.walk_mode = WALK_MOD8;
     a.d.stagger = a.knobs.stagger;
     if (a.d.walk_mode == WALK_QUEUE)
         EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));

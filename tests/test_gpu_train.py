@@ -456,3 +456,68 @@ def test_layer_train_composites_on_a_directed_graph():
     dx, dw, _, _, _ = ops.gcn_layer_bwd(g.bwd, 1, dy, z, agg, W, one, zero, bn, True, 0.0, 0, True, True, True)
     (want * dy).sum().backward()
     assert (dx - xr.grad).abs().max() < 5e-3 * xr.grad.abs().max() and (dw - Wr.grad).abs().max() < 5e-3 * Wr.grad.abs().max()
+
+
+def test_cfg4_train_full_batch_32_properties():
+    """BASELINE configs[3] at its full per-GPU batch (224x224, 7 aux levels + coordinate graph, 32 frames, train mode):
+    size-independent properties of one forward + backward.
+      * determinism: the same step twice (same weights, same host RNG state, dropout 0.5 on) gives bit-identical logits,
+        coordinates and parameter gradients -- the dropout masks are regenerated, every reduction has a fixed order;
+      * frame-permutation invariance (dropout off): batch statistics, losses that are means over the batch and parameter
+        gradients do not depend on the order of the frames; logits and coordinates move with their frames;
+      * one frame's rows depend on the other frames only through the BatchNorm statistics: with the statistics frozen
+        (eval mode) frame 5 of the batch equals the same frame run alone."""
+    import copy
+    frame, naux, B = 224, 7, 32
+    hip, _ = model_pair(frame, naux, 3, coord=True, seed=17)
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+    n, nv = topo.num_nodes, topo.num_valid_nodes
+    x = synthetic_node_feats(B * n, 128, seed=31).to(DEV)
+    jitter = torch.from_numpy(np.random.RandomState(9).uniform(-20, 20, (B * 4, 2)).astype(np.float32))
+    coords0 = (initial_coords(B, frame) + jitter).clamp(0, frame - 1).to(DEV)       # a different landmark set per frame
+    eid = ei.to(DEV)
+
+    def step(model, feats, coords, seed):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(seed)
+        logits, c = model.forward_nodes(feats, eid, B, coords.clone())
+        loss = (logits ** 2).mean() + (c ** 2).mean() * 1e-3
+        loss.backward()
+        return logits.detach(), c.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, float(loss.detach())
+
+    # ---- determinism with dropout on
+    hip.train()
+    state = copy.deepcopy(hip.state_dict())
+    l1, c1, g1, loss1 = step(hip, x, coords0, 5)
+    hip.load_state_dict(state)                                  # (running statistics back to where they were)
+    l2, c2, g2, loss2 = step(hip, x, coords0, 5)
+    assert torch.equal(l1, l2) and torch.equal(c1, c2) and loss1 == loss2
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    assert all(torch.isfinite(v).all() for v in g1.values())
+    # ---- frame-permutation invariance, dropout off
+    for m in hip.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    hip.load_state_dict(state)
+    la, ca, ga, lossa = step(hip, x, coords0, 1)
+    perm = torch.from_numpy(np.random.RandomState(3).permutation(B)).to(DEV)
+    xp = x.view(B, n, 128)[perm].reshape(B * n, 128).contiguous()
+    cp = coords0.view(B, 4, 2)[perm].reshape(coords0.shape).contiguous()
+    hip.load_state_dict(state)
+    lb, cb, gb, lossb = step(hip, xp, cp, 1)
+    assert abs(lossa - lossb) < 1e-5 * abs(lossa)
+    assert (la.view(B, nv, 4)[perm] - lb.view(B, nv, 4)).abs().max() < 2e-4 * la.abs().max()
+    assert (ca.view(B, 4, 2)[perm] - cb.view(B, 4, 2)).abs().max() < 1e-3
+    for k in ga:
+        gm = ga[k].abs().max().item()
+        assert (ga[k] - gb[k]).abs().max().item() < 2e-3 * gm + 1e-7, (k, gm)
+    # ---- eval mode: a frame of the batch == the same frame alone
+    hip.eval()
+    f = 5
+    ei1 = torch.from_numpy(topo.edge_index()).to(DEV)
+    with torch.no_grad():
+        full, cfull = hip.forward_nodes(x, eid, B, coords0.clone())
+        one, cone = hip.forward_nodes(x[f * n:(f + 1) * n].contiguous(), ei1, 1, coords0.view(B, 4, 2)[f:f + 1].reshape(4, 2).clone())
+    assert torch.equal(full[f * nv:(f + 1) * nv], one)
+    assert torch.equal(cfull.view(B, 4, 2)[f], cone.view(4, 2))
