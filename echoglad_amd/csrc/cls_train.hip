@@ -28,6 +28,7 @@ constexpr int H2 = 64;              // 4 heads x 16
 constexpr int LDZ = H2 + 4;         // LDS row stride of a [64][64] tile
 constexpr int CT_THREADS = 256;
 constexpr int CT_MAX_BLOCKS = 1024; // partial slabs per kernel
+constexpr int LIN_GRID = 512;        // k_lin128_map: 2 workgroups of 8 waves per CU (124 VGPRs; at 3 per CU it spills and is 20 % slower)
 
 struct ClsBn {                      // per-channel vectors of one BatchNorm layer (device pointers)
     const float *mean, *invstd, *scale, *shift, *gamma;
@@ -309,7 +310,9 @@ __global__ __launch_bounds__(CT_THREADS) void k_cls_out_bwd_sums(const float* __
 // ---- backward of the second layers ------------------------------------------------------------------------------------------
 // per 64-row tile: dz2 = gamma2 invstd2 (g2 - mean(g2) - xhat2 mean(g2 xhat2));  dW2[head] += dz2^T h1 (K = rows, MFMA);
 // dh1 = dz2 W2 (MFMA), written as whole rows.  tot = the reduced sums of k_cls_out_bwd_sums (double).
-__global__ __launch_bounds__(CT_THREADS) void k_cls_mid_bwd(const float* __restrict__ dlogits, const float* __restrict__ z2,
+// (3 waves per SIMD = the 3 workgroups per CU the 768-block grid counts on: 150 VGPRs, no spills; left to itself the
+//  compiler took 182 and the third of the grid that was not resident ran as a tail: 1.06 -> 0.71 ms at B = 32)
+__global__ __launch_bounds__(CT_THREADS, 3) void k_cls_mid_bwd(const float* __restrict__ dlogits, const float* __restrict__ z2,
                                                             const float* __restrict__ z1, long long rows, const ClsBn bn1, const ClsDrop d1,
                                                             const ClsBn bn2, const ClsDrop d2, const float* __restrict__ w2,
                                                             const float* __restrict__ w3, const double* __restrict__ tot,
@@ -477,7 +480,7 @@ int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int6
     d.n_valid = (int)n_valid; d.tiles_per_frame = (int)((n_valid + TILE - 1) / TILE); d.batch = batch; d.transpose_w = 0;
     d.in_stride = (int)n_per_frame; d.in_lo = (int)row_lo; d.out_stride = (int)n_valid; d.out_lo = 0;
     const long long n_tiles = (long long)d.tiles_per_frame * batch;
-    const int g1 = (int)(n_tiles < 512 ? n_tiles : 512);
+    const int g1 = (int)(n_tiles < LIN_GRID ? n_tiles : LIN_GRID);
     hipLaunchKernelGGL(k_lin128_map<true>, dim3(g1), dim3(512), 0, stream, h, P->w1, P->b1, z1, partial, d);
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3(8), dim3(256), 0, stream, partial, g1, 256, totals);
     BnFinalize f1{totals, rows, H1, P->gamma1, P->beta1, P->eps1, P->momentum1, P->running_mean1, P->running_var1,
@@ -546,7 +549,7 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
         d.n_valid = (int)n_valid; d.tiles_per_frame = (int)((n_valid + TILE - 1) / TILE); d.batch = batch; d.transpose_w = 1;
         d.in_stride = (int)n_valid; d.in_lo = 0; d.out_stride = (int)n_per_frame; d.out_lo = (int)row_lo;
         const long long n_tiles = (long long)d.tiles_per_frame * batch;
-        hipLaunchKernelGGL(k_lin128_map<false>, dim3((unsigned)(n_tiles < 512 ? n_tiles : 512)), dim3(512), 0, stream, dz1_scratch,
+        hipLaunchKernelGGL(k_lin128_map<false>, dim3((unsigned)(n_tiles < LIN_GRID ? n_tiles : LIN_GRID)), dim3(512), 0, stream, dz1_scratch,
                            P->w1, (const float*)nullptr, dh, (float*)nullptr, d);
         EG_HIP_TRY(hipGetLastError());
     }
