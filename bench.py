@@ -513,12 +513,12 @@ def main_infer(args, world, rank, device, dist_info):
         forms = [dict(kidsum_out=ka)] + [dict(kidsum_in=ka, kidsum_out=kb)] * max(args.layers - 2, 0)
         fused_cls = bool(model.fuse_classifier) and topo.n_conn == 0 and topo.num_valid_nodes == N
         if not fused_cls:
-            forms.append(dict(kidsum_in=ka))          # (with the classifier fused, the last layer is k_gcn_layer_ps<true, false>)
-        kname = "k_gcn_layer_ps<false, false>" if fused_cls else "k_gcn_layer_ps"
+            forms.append(dict(kidsum_in=ka))          # (with the classifier fused, the last layer is k_gcn_layer_ps<true, 0>)
+        kname = "k_gcn_layer_ps<false, 0>" if fused_cls else "k_gcn_layer_ps"
     else:
         forms = [dict()]
         flat = graph.structured and graph.kidsum_rows == 0 and graph.fused_classifier_ok       # single-level topology
-        kname = "k_gcn_layer_ps<false, false>" if flat else ("k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>")
+        kname = "k_gcn_layer_ps<false, 0>" if flat else ("k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>")
 
     def layer_launches():
         for f in forms:
@@ -552,7 +552,7 @@ def main_infer(args, world, rank, device, dist_info):
                    "nodes_per_frame": N, "directed_edges_per_frame": e_dir, "global_batch": B * world,
                    "parallelism": f"dp{world} (batch-sharded frames, no data-path collective)",
                    "launch": "eager" if args.no_hip_graph else "hipGraph replay of the step's kernels",
-                   "kernels_per_step": ("2 x k_gcn_layer_ps<false, false> (chained layers) + k_gcn_layer_ps<true, false> (last layer + "
+                   "kernels_per_step": ("2 x k_gcn_layer_ps<false, 0> (chained layers) + k_gcn_layer_ps<true, 0> (last layer + "
                                         "classifier heads)") if (graph.kidsum_rows > 0 and model.chain_layers and
                                                                   model.fuse_classifier) else "3 layer launches + k_classifier"},
         "distributed": dist_info,
