@@ -1,5 +1,5 @@
 """Diagnostic: soak test for launch-to-launch determinism of the fused layer kernels at FULL grid size (the register-reuse
-hazard of DESIGN.md section 5 item 14 only showed with every CU busy).  Runs each form `reps` times and compares bits.
+hazard of DESIGN.md section 5 item 14 only showed with every CU busy).  Runs each form `reps` times and compares bits; then a whole training step `reps / 10` times.
 usage (GPU box, repo root): python3 tools/tools_determinism.py [reps]"""
 import os
 import sys
@@ -42,6 +42,36 @@ def soak(frame, naux, B, mode, reps, main_only=False):
     return bad
 
 
+def soak_train(reps):
+    """One configs[3] training step (224/7 + coordinate graph, batch 32, dropout 0.5) repeated from the same state and host
+    RNG seed: logits, coordinates and every parameter gradient must come out bit-identical."""
+    import copy
+    from fixtures_util import initial_coords
+    from gpu_util import graph_tensors, model_pair
+    frame, naux, B = 224, 7, 32
+    hip, _ = model_pair(frame, naux, 3, coord=True, seed=17)
+    hip.train()
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+    x = synthetic_node_feats(B * topo.num_nodes, 128, seed=31).to(DEV)
+    coords0 = initial_coords(B, frame).to(DEV)
+    eid = ei.to(DEV)
+    state = copy.deepcopy(hip.state_dict())
+    first, bad = None, 0
+    for _ in range(reps):
+        hip.load_state_dict(state)
+        hip.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        logits, c = hip.forward_nodes(x, eid, B, coords0.clone())
+        ((logits ** 2).mean() + (c ** 2).mean() * 1e-3).backward()
+        cur = [logits.detach().clone(), c.detach().clone()] + [p.grad.detach().clone() for p in hip.parameters()]
+        if first is None:
+            first = cur
+        elif not all(torch.equal(a, b) for a, b in zip(cur, first)):
+            bad += 1
+    print(f"train step 224/7+coord B=32: {bad} of {reps - 1} repetitions differ from the first")
+    return bad
+
+
 if __name__ == "__main__":
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     total = 0
@@ -49,4 +79,5 @@ if __name__ == "__main__":
         total += soak(224, 7, 8, mode, reps)
         total += soak(224, 7, 32, mode, reps, main_only=True)
         total += soak(448, 8, 8, mode, max(reps // 4, 2))
+    total += soak_train(max(reps // 10, 3))
     sys.exit(1 if total else 0)
