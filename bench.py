@@ -26,6 +26,7 @@ import argparse
 import hashlib
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -281,35 +282,65 @@ def cpu_baseline(args, kw, state_dict):
 
 
 DOMINANT_KERNEL_SOURCES = ("gcn_layer_ps.hip", "seg_wide.h", "tile.h", "common.h", "graph.hip")
+TRAIN_KERNEL_SOURCES = ("gcn_layer.hip", "gcn_layer_ps.hip", "train.hip", "cls_train.hip", "train_common.h", "seg_wide.h",
+                        "tile.h", "common.h", "graph.hip")
 
 
-def kernel_source_digest() -> str:
+def kernel_source_digest(sources=DOMINANT_KERNEL_SOURCES) -> str:
     """sha256 over the sources of the dominant kernel (the chained layer kernel, its device helpers and the topology tables
-    it reads): ties a committed PMC summary to the code it was measured on (the GPU box has no .git)."""
+    it reads): ties a committed PMC summary to the code it was measured on (the GPU box has no .git).  With
+    TRAIN_KERNEL_SOURCES: the same for the kernels of the training step."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "echoglad_amd", "csrc")
-    for f in DOMINANT_KERNEL_SOURCES:
+    for f in sources:
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_key: str):
-    """HBM bytes per launch of the dominant kernel from the newest profiles/*_pmc.json (tools/profile_round.sh:
-    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  A summary measured
-    on other kernel sources is NOT used: `traffic` stays null and the source says why."""
+def _pmc_summary(pattern: str, sources):
+    """Newest profiles/<pattern> (r{NN}_pmc.json: the inference step; r{NN}_train_pmc.json: the training step) whose
+    `kernel_source_digest` equals the current sources'.  Files of the other kind, or any other *_pmc.json that happens to
+    lie in profiles/, are never candidates.  Returns (summary | None, source-or-reason)."""
     pdir = os.path.join(ROOT, "profiles")
-    cands = sorted([f for f in os.listdir(pdir) if f.endswith("_pmc.json")], reverse=True) if os.path.isdir(pdir) else []
+    rx = re.compile(pattern)
+    cands = sorted([f for f in os.listdir(pdir) if rx.fullmatch(f)], reverse=True) if os.path.isdir(pdir) else []
     if not cands:
-        return None, "no profiles/*_pmc.json"
+        return None, f"no profiles/{pattern}"
+    want = kernel_source_digest(sources)
     try:
         pm = json.load(open(os.path.join(pdir, cands[0])))
-        if pm.get("kernel_source_digest") != kernel_source_digest():
-            return None, (f"profiles/{cands[0]} is stale (measured on kernel sources {pm.get('kernel_source_digest')}, "
-                          f"current {kernel_source_digest()}): re-run tools/profile_round.sh")
-        return int(pm[kernel_key]["hbm_bytes_per_launch"]), "profiles/" + cands[0]
     except Exception as ex:
         return None, f"profiles/{cands[0]}: {ex!r}"
+    if pm.get("kernel_source_digest") != want:
+        return None, (f"profiles/{cands[0]} is stale (measured on kernel sources {pm.get('kernel_source_digest')}, "
+                      f"current {want}): re-run tools/profile_round.sh")
+    return pm, "profiles/" + cands[0]
+
+
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch of the dominant kernel from the newest profiles/r{NN}_pmc.json (tools/profile_round.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  A summary measured
+    on other kernel sources is NOT used: `traffic` stays null and the source says why."""
+    pm, src = _pmc_summary(r"r\d+_pmc\.json", DOMINANT_KERNEL_SOURCES)
+    if pm is None:
+        return None, src
+    try:
+        return int(pm[kernel_key]["hbm_bytes_per_launch"]), src
+    except Exception as ex:
+        return None, f"{src}: {ex!r}"
+
+
+def train_pmc_traffic():
+    """HBM bytes of one configs[3] training step (batch 32 per GPU) from the newest profiles/r{NN}_train_pmc.json
+    (tools/profile_train_pmc.sh; per-kernel bytes per launch x launches per step), same staleness rule."""
+    pm, src = _pmc_summary(r"r\d+_train_pmc\.json", TRAIN_KERNEL_SOURCES)
+    if pm is None:
+        return None, src
+    try:
+        return int(pm["hbm_bytes_per_step"]), src
+    except Exception as ex:
+        return None, f"{src}: {ex!r}"
 
 
 def time_steps(step, iters=20, warm=5):
@@ -427,6 +458,9 @@ def other_configs(args, device):
                              "mfma_frac": round(fps * 3 * sf / 1e12 / PEAK_F32_MFMA_TF, 4),
                              "hbm_frac": round(fps * 3 * sb / 1e9 / PEAK_HBM_GBS, 4), "nodes_per_frame": topo.num_nodes,
                              "floor": "3 x the forward's algorithmic bytes / FLOPs (SURVEY 8d)"}
+        tb, tsrc = train_pmc_traffic()
+        out["cfg4_train"].update({"traffic_bytes_per_step": tb, "traffic_source": tsrc,
+                                  "algorithmic_bytes_per_step": 3 * sb * B})
         del step
     except Exception as ex:
         out["cfg4_train"] = {"workload": what, "error": repr(ex)}

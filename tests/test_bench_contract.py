@@ -33,6 +33,17 @@ def test_pmc_summary_is_used_only_for_the_sources_it_was_measured_on(tmp_path, m
     assert traffic is None and "stale" in why
     (prof / "r09_pmc.json").write_text(json.dumps({"kernel_source_digest": digest, "k_gcn_layer": {"hbm_bytes_per_launch": 7.5e8}}))
     assert b.pmc_traffic("k_gcn_layer") == (750000000, "profiles/r09_pmc.json")
+    # other *_pmc.json files next to the real one (the training step's summary sorts AFTER r09_pmc.json; round 2's HEAD
+    # picked it and reported traffic = null) are never candidates for the inference kernel's traffic
+    (prof / "r09_train_pmc.json").write_text(json.dumps({"k_bn_act_fwd": {"hbm_bytes_per_launch": 3.5e9}}))
+    (prof / "zz_pmc.json").write_text("{}")
+    assert b.pmc_traffic("k_gcn_layer") == (750000000, "profiles/r09_pmc.json")
+    # ... and the training summary has its own digest (over the training kernels' sources) and its own reader
+    assert b.train_pmc_traffic()[0] is None and "stale" in b.train_pmc_traffic()[1]
+    (prof / "r09_train_pmc.json").write_text(json.dumps({"kernel_source_digest": b.kernel_source_digest(b.TRAIN_KERNEL_SOURCES),
+                                                         "hbm_bytes_per_step": 5.0e10}))
+    assert b.train_pmc_traffic() == (50000000000, "profiles/r09_train_pmc.json")
+    assert b.pmc_traffic("k_gcn_layer") == (750000000, "profiles/r09_pmc.json")
 
 
 def test_committed_pmc_summary_matches_the_committed_kernel_sources():
