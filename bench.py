@@ -17,7 +17,6 @@ environment's RANK / LOCAL_RANK / WORLD_SIZE are used as they are.
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel, measured live with HIP events on
 the launch stream), `cpu_baseline` (the CPU oracle = port of the reference PyG op sequence,
 timed on this box's host cores on a bounded sample), `repeats` (the timed loop repeated) and — at N = 1 —
-`experiments` (opt-in bf16x3 / bf16x6 layer products, with their error against the exact path) and
 `other_configs`: BASELINE configs[2] (main grid only, batch 32), configs[4] (448x448, 8 aux levels, batch 8) and one
 configs[3] training step (coordinate graph, batch 32), each timed the same way; they never enter `value`."""
 from __future__ import annotations
@@ -57,6 +56,9 @@ def parse():
     p.add_argument("--repeats", type=int, default=5, help="extra repeats of the K-step timed loop (reported under `repeats`)")
     p.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed steps before the warm-up steps")
     p.add_argument("--no-hip-graph", action="store_true", help="launch the 4 kernels of a step eagerly from Python")
+    p.add_argument("--force-collective", action="store_true",
+                   help="train mode: initialise torch.distributed (nccl = RCCL) and run the gradient reducer's collectives even "
+                        "at world size 1 -- the single-GPU way through the code path the multi-GPU step takes")
     p.add_argument("--mode", choices=["infer", "train"], default="infer",
                    help="infer (default): BASELINE configs[1], the metric's configuration.  train: one full training "
                         "step of the GNN stack on configs[3] (coordinate graph; SURVEY 8d), reported under its own metric name")
@@ -144,7 +146,7 @@ def infer_workload(frame, naux, layers, main_only, B, device, rank, hip_graph=Tr
     return model, kw, topo, feats, edge_index, step
 
 
-def train_workload(frame, naux, layers, B, device, world, rank):
+def train_workload(frame, naux, layers, B, device, world, rank, force_collective=False):
     """forward + losses + backward + gradient all-reduce + Adam on the stack's parameters,
     node features [B*N,128] resident in HBM, B frames per GPU (32 in BASELINE's cfg4), coordinate graph on."""
     import numpy as np
@@ -170,9 +172,9 @@ def train_workload(frame, naux, layers, B, device, world, rank):
     params = list(model.parameters())
     opt = torch.optim.Adam(params, lr=1e-4)
     reducer = None
-    if world > 1:
+    if world > 1 or force_collective:
         broadcast_parameters(model)
-        reducer = GradientAllReducer(params)
+        reducer = GradientAllReducer(params, force_collective=force_collective)
         reducer.attach_hooks()
 
     def step():
@@ -186,6 +188,7 @@ def train_workload(frame, naux, layers, B, device, world, rank):
         opt.step()
         return loss
 
+    step.reducer = reducer
     return step, topo
 
 
@@ -211,9 +214,9 @@ def timed_loop(step, steps, world, device):
     return elapsed, out
 
 
-def main_train(args, world, rank, device):
+def main_train(args, world, rank, device, dist_info):
     B = args.batch
-    step, topo = train_workload(args.frame, args.naux, args.layers, B, device, world, rank)
+    step, topo = train_workload(args.frame, args.naux, args.layers, B, device, world, rank, args.force_collective)
     for _ in range(max(args.warmup, 2)):
         loss = step()
     elapsed, loss = timed_loop(step, args.steps, world, device)
@@ -232,7 +235,9 @@ def main_train(args, world, rank, device):
                        "parallelism": f"dp{world} (batch-sharded frames, gradient all-reduce overlapped with backward)"},
             # train-step floor = 3 x the forward's algorithmic bytes / FLOPs
             "stack_hbm_frac": round(fps / world * 3 * sb / 1e9 / PEAK_HBM_GBS, 4),
-            "stack_mfma_frac": round(fps / world * 3 * sf / 1e12 / PEAK_F32_MFMA_TF, 4), "final_loss": float(loss.detach())}), flush=True)
+            "stack_mfma_frac": round(fps / world * 3 * sf / 1e12 / PEAK_F32_MFMA_TF, 4), "final_loss": float(loss.detach()),
+            "distributed": dict(dist_info, gradient_collectives_issued=(step.reducer.collectives_issued if step.reducer else 0),
+                                gradient_buckets=(len(step.reducer._buckets) if step.reducer else 0))}), flush=True)
 
 
 def cpu_baseline(args, kw, state_dict):
@@ -358,36 +363,6 @@ def time_steps(step, iters=20, warm=5):
     return e0.elapsed_time(e1) / iters
 
 
-def split_bf16_experiment(mode, model, graph, step, exact_out, B, frame):
-    """OPT-IN experiment, never part of `value` (which stays exact fp32): the same step with the layer product of the
-    producer/consumer kernel switched to a split-operand bf16 form (eg_graph_set_precision, include/echoglad_hip.h)."""
-    import torch
-
-    def landmark_argmax(logits):                  # hard arg-max over the main-grid rows of each frame, per channel
-        return logits.view(B, -1, logits.shape[-1])[:, -frame * frame:, :].argmax(dim=1)
-
-    what = {"bf16x3": "same workload and weights as the headline; 128x128 layer product as 3 bf16 MFMAs on operands split into 2 "
-                      "bf16 parts, fp32 accumulate; classifier heads fp32",
-            "bf16x6": "same; 6 bf16 MFMAs on operands split into 3 bf16 parts (exact 24-bit split, dropped terms <= 2^-23 of a "
-                      "product); classifier heads fp32 and not fused into the last layer in this mode"}[mode]
-    exact = exact_out.detach().clone()
-    try:
-        graph.set_precision(mode)
-        model.enable_hip_graph(model.use_hip_graph)          # drop the captured fp32 launches
-        got = step().detach().clone()
-        ms = time_steps(step, 50, 5)
-        return {"what": what, "ms_per_step": round(ms, 4), "frames_s": round(B / (ms * 1e-3), 1),
-                "max_abs_logit_diff_vs_f32": float((got - exact).abs().max()),
-                "max_abs_logit": float(exact.abs().max()),
-                "landmark_argmax_equal": bool(torch.equal(landmark_argmax(got), landmark_argmax(exact))),
-                "dtype": mode + " (opt-in)"}
-    except Exception as ex:
-        return {"what": what, "error": repr(ex)}
-    finally:
-        graph.set_precision("f32")
-        model.enable_hip_graph(model.use_hip_graph)
-
-
 def other_configs(args, device):
     """The BASELINE configs the metric is not quoted on, timed like the headline (HIP-graph replay, inputs in HBM);
     reported beside it, never inside `value`."""
@@ -485,9 +460,17 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist_info = {"world_size": 1, "backend": None, "allreduce_check": None}
-    if world > 1:
+    use_dist = world > 1 or (args.force_collective and args.mode == "train")
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                              # --force-collective on one GPU: a one-rank RCCL group
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)          # "nccl" IS RCCL on ROCm
         one = torch.ones(1, device=device)
         dist.all_reduce(one)
@@ -499,11 +482,11 @@ def main():
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
     try:
         if args.mode == "train":
-            main_train(args, world, rank, device)
+            main_train(args, world, rank, device, dist_info)
         else:
             main_infer(args, world, rank, device, dist_info)
     finally:
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
 
@@ -640,7 +623,6 @@ def main_infer(args, world, rank, device, dist_info):
                                 O.landmark_argmax(cpu_out, args.cpu_frames, args.frame)))}
     if world == 1 and not args.no_other_configs:
         del buf
-        result["experiments"] = {m: split_bf16_experiment(m, model, graph, step, out, B, args.frame) for m in ("bf16x3", "bf16x6")}
         result["other_configs"] = other_configs(args, device)
     print(json.dumps(result), flush=True)
 

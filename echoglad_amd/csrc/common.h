@@ -167,8 +167,6 @@ struct Knobs {
     int grid_cap;       // EG_GRID        persistent grid of the symmetric kernel (default 512 = 2 workgroups per CU)
     int layer_impl;     // EG_LAYER_IMPL  -1 auto, 0 symmetric kernel, 1 producer/consumer kernel for plain calls
     int ps_grid;        // EG_PS_GRID     persistent grid of the producer/consumer kernel (default 256 = 1 per CU)
-    int precision;      // EG_LAYER_PRECISION=bf16x3|bf16x6  opt-in experiment (EG_PRECISION_*): the layer product of the producer/
-                        //                consumer kernel as 3 / 6 bf16 MFMAs on split operands instead of the exact fp32 MFMA
 };
 Knobs read_knobs();
 const Knobs& process_knobs();
@@ -183,6 +181,16 @@ constexpr int QUEUE_SLOTS = 1;          // stamp builds keep their cycle sums ri
 constexpr int QUEUE_SLOTS = 64;
 #endif
 constexpr int QUEUE_TAIL_INTS = 64;     // stamp statistics (diagnostic builds)
+
+// Producer/consumer layer kernel (gcn_layer_ps.hip): dynamic LDS = 2 aggregated tiles + 2 stashes of raw rows, the tile-id ring,
+// a ring of per-tile (deg+1)^-1/2 slices (read one tile late by the deferred epilogue), the weight-pattern table and, with the
+// classifier heads fused in, 4 x 128 per-channel constants.
+constexpr int PS_DIS_RING = 4;
+constexpr int PS_MAX_GRID = 1024;       // persistent workgroups at most (EG_PS_GRID is clamped to it)
+constexpr int PS_SINK_FLOATS = 8 * C;   // per workgroup: dump area for the epilogue stores of tiles that have nothing to store
+inline size_t ps_lds_bytes(int n_pats, bool cls) {
+    return (size_t)(4 * TILE * LDA + 16 + 64 + PS_DIS_RING * TILE + n_pats * 64 + (cls ? 4 * C : 0)) * sizeof(float);
+}
 
 }  // namespace eg
 
@@ -206,6 +214,7 @@ struct eg_graph {
     int* colidx;              // device [nnz]
     int64_t nnz;
     int symmetric;            // kind == GRAPH_CSR: the kept edge multiset equals its transpose (A_hat^T == A_hat)
+    float* sink;              // device [PS_MAX_GRID][PS_SINK_FLOATS] dump area of the producer/consumer kernel (kind == GRAPH_TOPO)
     int* walk_counters;       // device [QUEUE_SLOTS][8 x 32] ring of per-launch tile-queue heads (+ QUEUE_TAIL_INTS)
     mutable std::atomic<unsigned> launch_seq;   // next slice of the ring (the only host state a launch touches)
     eg::Knobs knobs;          // environment knobs, read once at creation

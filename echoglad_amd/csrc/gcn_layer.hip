@@ -458,8 +458,7 @@ int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const f
 }
 
 int eg_graph_fused_classifier_ok(const eg_graph* g) {
-    return g && g->kind == GRAPH_TOPO && (g->kid_rows > 0 || g->flat) && g->topo.coord_base >= g->n_nodes &&
-           g->knobs.precision != EG_PRECISION_BF16X6;
+    return g && g->kind == GRAPH_TOPO && (g->kid_rows > 0 || g->flat) && g->topo.coord_base >= g->n_nodes;
 }
 
 int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,

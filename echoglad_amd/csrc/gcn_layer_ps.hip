@@ -4,8 +4,11 @@
 //   waves 4..7  PRODUCERS  aggregate tile k+1 (two 8-node segments each, all row loads of both segments in flight
 //               at once) into LDS buffer (k+1)&1: the aggregated tile [64][128] and the raw self rows (residual);
 //   waves 0..3  CONSUMERS  one per SIMD: output channels 32c..32c+31, W slice in 64 VGPRs, 128 chained
-//               v_mfma_f32_32x32x2_f32 per tile on buffer k&1, then the epilogue straight from the accumulators
-//               (scale/shift, ReLU, residual from the LDS stash, 16-B stores).
+//               v_mfma_f32_32x32x2_f32 per tile on buffer k&1 in the rows x channels orientation (tile.h, SWAP): an
+//               accumulator register is 2 x 128 contiguous bytes of two output rows, so the epilogue (scale/shift, ReLU,
+//               residual, child sums) runs on the accumulators and stores them as they stand -- no LDS round trip, no
+//               consumer-side synchronisation; it is issued between the MFMAs of the NEXT 32-row block (of the next tile,
+//               for the second block: its residual rows are read before the barrier, the rest lives in registers).
 // ONE workgroup barrier per tile hands buffer (k+1)&1 to the consumers and buffer k&1 back to the producers, so
 // memory traffic of tile k+1 always overlaps the matrix work of tile k instead of relying on two workgroups
 // drifting apart.  Tile ids come from the per-XCD queues (tile.h), claimed two tiles ahead by one producer lane.
@@ -16,8 +19,8 @@
 namespace eg {
 
 constexpr int PS_THREADS = 512;
-constexpr int PS_LDS_DIS = 4 * TILE * LDA + 16;       // float offsets inside the dynamic LDS block
-constexpr int PS_LDS_PAT = PS_LDS_DIS + 2 * TILE;
+constexpr int PS_LDS_DIS = 4 * TILE * LDA + 16 + 64;  // float offsets inside the dynamic LDS block (tile-id ring, CLS counter, descriptor ring)
+constexpr int PS_LDS_PAT = PS_LDS_DIS + PS_DIS_RING * TILE;
 
 struct PsDims {
     int n_per_frame, batch, tiles_per_frame, relu, transpose_w, has_res;
@@ -69,28 +72,30 @@ __device__ inline void ps_claim(int* __restrict__ counters, int group, int n_til
 // Linear(32,16)-BN-ReLU-Linear(16,1)] of src/core/models.py:363-377, :485-490, eval-mode BN folded by the caller
 // (same packing as eg_classifier_fwd).  The layer's output tile never leaves LDS.
 
-// PREC: 0 = exact fp32 MFMA (default), 2 / 3 = opt-in bf16 product with 2 / 3 parts per operand (bf16x3 / bf16x6, tile.h)
-template <bool CLS, int PREC = 0>
+// KOUT: the launch writes the child sums of its output (kout != NULL), a launch-uniform property compiled in so that the
+// epilogue stays branch-free inside the MFMA chains.
+template <bool CLS, bool KOUT>
 __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ out, const float* __restrict__ dis,
                                                                 const Topo* __restrict__ T, const TileDesc* __restrict__ tiles,
                                                                 const SegDesc* __restrict__ segs, const float* __restrict__ pats,
                                                                 const float* __restrict__ patsq, const float* __restrict__ kin, float* __restrict__ kout,
-                                                                int* __restrict__ counters, const PsDims a, const ClsArgs ca) {
+                                                                float* __restrict__ sink_base, int* __restrict__ counters, const PsDims a,
+                                                                const ClsArgs ca) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_a0 = smem;                               // [2][TILE * LDA]  aggregated tiles
-    float* s_x0 = smem + 2 * TILE * LDA;              // [2][TILE * LDA]  raw self rows (residual); then the output tile
+    float* s_x0 = smem + 2 * TILE * LDA;              // [2][TILE * LDA]  raw self rows (residual)
     int* s_tile = reinterpret_cast<int*>(smem + 4 * TILE * LDA);                  // [8] ring of tile ids
     int* s_sync = s_tile + 8;                         // consumer-only tile counter (CLS)
-    float* s_dis0 = smem + PS_LDS_DIS;                // [2][TILE] (deg+1)^-1/2 of the tile's rows (child sums of the output)
+    int* s_cd = s_tile + 16;                          // [2][8 segments][4] descriptor words of the consumers' epilogue (below)
+    float* s_dis0 = smem + PS_LDS_DIS;                // [PS_DIS_RING][TILE] (deg+1)^-1/2 of the tile's rows (child sums of the output)
     float* s_pat = smem + PS_LDS_PAT;                 // [n_pats][64] weight patterns, quad layout (seg_wide.h)
     float* s_bn = s_pat + a.n_pats * PATQ;            // CLS only: [4][128] layer scale, shift, classifier s1, t1
 
     const int tid = threadIdx.x;
     const int lane_k = tid & 63;
     const int wave = wave_id();
-    const bool consumer = wave < 4;
     const int n_tiles = a.tiles_per_frame * a.batch;
     const int group = xcc_id();
 
@@ -115,16 +120,210 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
     // The two roles run separate loops (so that neither carries the other's persistent registers); both execute
     // exactly one workgroup barrier per tile, in lock step:   [prologue barrier]  (tile k work)  [barrier k] ...
     if (wave < 4) {
+        // Descriptor words the epilogue needs -- {n_first, cnt, par0, pad1} of the tile's 8 segments: first node and count,
+        // parent row and parent count of the segment pair -- come through an LDS ring the producers fill from the
+        // descriptors they hold anyway (slot = buffer parity).  The consumers issue NO vector-memory load: a load whose
+        // result is needed at the top of the next tile made the compiler drain vmcnt there, i.e. wait for every output
+        // store of the tile before.
+        if constexpr (!CLS) {
+        // =========================== CONSUMER: channels 32*wave .. 32*wave+31 ===================================
+        float wreg[64];
+        load_w_slice(W, wave, lane_k, a.transpose_w, wreg);
+        // lane (j, h): channel 32 wave + j; accumulator register e of the 32-row block rb is tile row
+        // 32 rb + (e & 3) + 8 (e >> 2) + 4 h  =  patch row 4 rb + (e >> 2), column (e & 3) + 4 h
+        const int ch = 32 * wave + (lane_k & 31);
+        const float scj = scale ? scale[ch] : 1.0f;
+        const float shj = shift ? shift[ch] : 0.0f;
+        const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+        const bool has_res = a.has_res != 0;
+        __syncthreads();                                   // tile 0 is in buffer 0
+        PSTAMP_INIT;
+#ifdef EG_STAMP
+        // in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): shader cycles / 100 MHz ticks around the tile loop
+        const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        // The second 32-row block of a tile is finished one tile late (inside the first MFMA chain of the next tile, after
+        // the barrier that hands its LDS buffers back to the producers): everything it needs is in registers by then.
+        // Both chains of a tile carry an epilogue UNCONDITIONALLY (a second instance of a chain for "nothing pending" costs
+        // an accumulator copy behind every chain): when there is nothing to finish -- first tile of the workgroup, or a
+        // ragged tile, whose two blocks take the conditional-store path below -- the row pointers aim at this workgroup's
+        // slice of a dump area (eg_graph::sink) and the values stored are never read.
+        float* const sink = sink_base + (size_t)blockIdx.x * PS_SINK_FLOATS;
+        float* p_orow[4] = {sink, sink, sink, sink};       // out + (frame rows + first node of patch rows 4..7) * C
+        float* p_krow[2] = {sink, sink};                   // kout + (frame kid rows + first parent row of patch-row pairs 2, 3) * C
+        int p_slot = 0;                                    // slice of the s_dis ring that holds the pending tile's (deg+1)^-1/2
+        f32x16 acc0, acc1;
+        float res0[16], res1[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; res0[e] = 0.f; res1[e] = 0.f; }
+        const int hq = lane_k >> 5;
+        const unsigned lane_off = (unsigned)(4 * hq * C + ch);                        // + first node * C + (e & 3) * C
+        const unsigned kid_off = (unsigned)(2 * hq * C + ch);                         // + first parent row * C + (0 | 1) * C
+
+        // one patch row (accumulator registers 4c .. 4c+3) of a block, straight from the accumulators; d = (deg+1)^-1/2 of
+        // the lane's 4 nodes of that patch row
+        float ks[2] = {0.f, 0.f};
+        auto epi_row = [&](const f32x16& acc, const float (&res)[16], int c, float* orow, float* krow, const f32x4& d) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = fmaf(acc[4 * c + e], scj, shj);
+                t = fmaxf(t, relu_floor);
+                t += has_res ? res[4 * c + e] : 0.f;
+                v[e] = t;
+                orow[lane_off + e * C] = t;
+            }
+            if (KOUT) {
+                // children (2 pr, 2 pc), (2 pr, 2 pc + 1), (2 pr + 1, 2 pc), (2 pr + 1, 2 pc + 1) of parent (pr, pc = 2 h + e2)
+                // are registers 2 e2, 2 e2 + 1 of this patch row and of the next one, in THIS lane; summed in that order
+                if ((c & 1) == 0) {
+                    ks[0] = fmaf(d[1], v[1], d[0] * v[0]);
+                    ks[1] = fmaf(d[3], v[3], d[2] * v[2]);
+                } else {
+                    ks[0] = fmaf(d[1], v[1], fmaf(d[0], v[0], ks[0]));
+                    ks[1] = fmaf(d[3], v[3], fmaf(d[2], v[2], ks[1]));
+                    krow[kid_off] = ks[0];
+                    krow[kid_off + C] = ks[1];
+                }
+            }
+        };
+
+        for (int k = 0;; ++k) {
+            const int t_cur = __builtin_amdgcn_readfirstlane(s_tile[k & 7]);
+            if (t_cur < 0) break;
+            int lane = lane_k;
+            asm volatile("" : "+v"(lane));
+            const int cd = s_cd[(k & 1) * 32 + (lane & 31)];
+            const float* s_a = s_a0 + (k & 1) * TILE * LDA;
+            const float* s_x = s_x0 + (k & 1) * TILE * LDA;
+            const int frame = t_cur / a.tiles_per_frame;
+            const int h = lane >> 5;
+            int seg_first[8], seg_cnt[8], par0[4], npar[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                seg_first[i] = __builtin_amdgcn_readlane(cd, 4 * i);
+                seg_cnt[i] = __builtin_amdgcn_readlane(cd, 4 * i + 1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                par0[i] = __builtin_amdgcn_readlane(cd, 8 * i + 2);
+                npar[i] = __builtin_amdgcn_readlane(cd, 8 * i + 3);
+            }
+            // fast tile: a full 8x8 patch (and, when child sums are written, every 2x2 block of it has its parent)
+            bool fast = true;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fast = fast && seg_cnt[i] == 8;
+            if (KOUT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fast = fast && npar[i] == 4;
+            }
+            float* const ofr = out + (size_t)frame * a.n_per_frame * C;
+            float* const kfr = KOUT ? kout + (size_t)frame * a.kid_rows * C : sink;
+            const float* const resp = s_x + (4 * h) * LDA + ch;               // + tile row * LDA
+            const float* const disp = s_dis0 + 4 * h;                         // + ring slot * TILE + 8 * patch row
+            auto read_res = [&](float (&res)[16], int rb, int c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) res[4 * c + e] = resp[(32 * rb + 8 * c + e) * LDA];
+            };
+            auto read_dis = [&](int slot, int prow) -> f32x4 {
+                return KOUT ? *reinterpret_cast<const f32x4*>(disp + slot * TILE + 8 * prow) : f32x4{0.f, 0.f, 0.f, 0.f};
+            };
+            const int slot = k & (PS_DIS_RING - 1);
+
+            // ---- rows 0..31: MFMA chain; in its issue gaps the residual rows of this block are read and the deferred
+            // second block of the previous tile is finished (every LDS value is read one chunk ahead of its use)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc0[e] = 0.f;
+            f32x4 dq[4];
+            dq[0] = read_dis(p_slot, 4);
+            mfma_rowblock_with<true>(s_a, 0, lane, wreg, acc0, [&](int c) {
+                if (c < 3) dq[c + 1] = read_dis(p_slot, 5 + c);
+                read_res(res0, 0, c);
+                epi_row(acc1, res1, c, p_orow[c], p_krow[c >> 1], dq[c]);
+            });
+            PSTAMP(0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+            // ---- rows 32..63: MFMA chain with the epilogue of rows 0..31 in its gaps
+            float* orow0[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) orow0[c] = fast ? ofr + (size_t)seg_first[c] * C : sink;
+            float* krow0[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) krow0[c] = (fast && KOUT) ? kfr + (size_t)par0[c] * C : sink;
+            dq[0] = read_dis(slot, 0);
+            mfma_rowblock_with<true>(s_a, 32, lane, wreg, acc1, [&](int c) {
+                if (c < 3) dq[c + 1] = read_dis(slot, 1 + c);
+                read_res(res1, 1, c);
+                epi_row(acc0, res0, c, orow0[c], krow0[c >> 1], dq[c]);
+            });
+            PSTAMP(1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p_orow[c] = fast ? ofr + (size_t)seg_first[4 + c] * C : sink;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) p_krow[c] = (fast && KOUT) ? kfr + (size_t)par0[2 + c] * C : sink;
+            p_slot = slot;
+            if (!fast) {
+                // ---- ragged patches, levels without parents (rare): both blocks finished here with conditional stores (the
+                // unconditional epilogues of this tile went / go to the dump area); the child sums go through this wave's own
+                // channel slice of the stash
+                float* s_xw = s_x0 + (k & 1) * TILE * LDA;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int p = 4 * rb + (e >> 2), col = (e & 3) + 4 * h;
+                        float t = fmaf(rb ? acc1[e] : acc0[e], scj, shj);
+                        t = fmaxf(t, relu_floor);
+                        t += has_res ? (rb ? res1[e] : res0[e]) : 0.f;
+                        if (KOUT) s_xw[(8 * p + col) * LDA + ch] = t;
+                        if (col < seg_cnt[p]) ofr[(size_t)(seg_first[p] + col) * C + ch] = t;
+                    }
+                }
+                if (KOUT) {
+                    // lane -> (parent q = (lane >> 3) + 8 i, 16-B chunk lane & 7) of the wave's 32 channels
+                    const int c4 = 4 * (lane & 7);
+                    const float* dsl = s_dis0 + slot * TILE;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int q = (lane >> 3) + 8 * i, pr = q >> 2, pc = q & 3;
+                        const int np = pr == 0 ? npar[0] : (pr == 1 ? npar[1] : (pr == 2 ? npar[2] : npar[3]));
+                        const int pb = pr == 0 ? par0[0] : (pr == 1 ? par0[1] : (pr == 2 ? par0[2] : par0[3]));
+                        const int ra = 16 * pr + 2 * pc;                       // LDS row of child (2 pr, 2 pc)
+                        const float* sp = s_xw + ra * LDA + 32 * wave + c4;
+                        const float* dp = dsl + ra;
+                        f32x4 kk = dp[0] * *reinterpret_cast<const f32x4*>(sp);
+                        kk += dp[1] * *reinterpret_cast<const f32x4*>(sp + LDA);
+                        kk += dp[8] * *reinterpret_cast<const f32x4*>(sp + 8 * LDA);
+                        kk += dp[9] * *reinterpret_cast<const f32x4*>(sp + 9 * LDA);
+                        if (pc < np) *reinterpret_cast<f32x4*>(kfr + (size_t)(pb + pc) * C + 32 * wave + c4) = kk;
+                    }
+                }
+            }
+            __syncthreads();                               // barrier k+1: buffer (k+1)&1 is full, buffer k&1 is free
+            PSTAMP(2);
+        }
+        {   // the last tile's second block (or the dump area)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 d = KOUT ? *reinterpret_cast<const f32x4*>(s_dis0 + 4 * hq + p_slot * TILE + 8 * (4 + c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                epi_row(acc1, res1, c, p_orow[c], p_krow[c >> 1], d);
+            }
+        }
+        PSTAMP_FLUSH(0);
+#ifdef EG_STAMP
+        if (wave == 0 && lane_k == 0) {
+            unsigned long long* stats = reinterpret_cast<unsigned long long*>(counters + WALK_GROUPS * WALK_CTR_STRIDE);
+            atomicAdd(&stats[9], __builtin_amdgcn_s_memtime() - clk0);
+            atomicAdd(&stats[10], __builtin_amdgcn_s_memrealtime() - rt0);
+        }
+#endif
+        } else {
         // =========================== CONSUMER: channels 32*wave .. 32*wave+31 ===================================
         // the wave's slice of W: fp32 (exact, the default) or split into bf16 hi / lo parts (opt-in bf16x3 product, tile.h)
-        constexpr bool BF = PREC != 0;
-        constexpr int BFP = BF ? PREC : 2;
-        // (bf16x6 needs 96 VGPRs for W: the 32 registers of the residual prefetch go, the residual is read in the epilogue)
-        constexpr bool RES_LATE = CLS || PREC == 3;
-        float wreg[BF ? 1 : 64];
-        WSliceBf<BFP> wbf;
-        if constexpr (BF) load_w_slice_bf<BFP>(W, wave, lane_k, a.transpose_w, wbf);
-        else load_w_slice(W, wave, lane_k, a.transpose_w, wreg);
+        constexpr bool RES_LATE = true;
+        float wreg[64];
+        load_w_slice(W, wave, lane_k, a.transpose_w, wreg);
         f32x4 sc[4], sh[4];
         if (!CLS) {
 #pragma unroll
@@ -152,21 +351,6 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             w3v = *reinterpret_cast<const f32x4*>(ca.w3 + o4);
             b3v = ca.b3[wave];
         }
-        // Descriptor words the epilogue needs (first node and count of the 8 segments, parent row and parent count of
-        // the 4 segment pairs) travel in one VGPR, fetched a tile ahead like the producers' (lane l: segment l >> 2,
-        // word {n_first, cnt, par0, pad1}[l & 3]).
-        auto load_cdesc = [&](int tile_i, int lane) -> int {
-            const int frame = tile_i / a.tiles_per_frame;
-            const int t_in = tile_i - frame * a.tiles_per_frame;
-            const int f = lane & 3;
-            const int word = f == 0 ? 0 : (f == 1 ? 1 : (f == 2 ? 6 : 15));
-            return reinterpret_cast<const int*>(segs)[(t_in * 8 + ((lane >> 2) & 7)) * 16 + word];
-        };
-        int cd_next = 0;
-        {
-            const int t0 = __builtin_amdgcn_readfirstlane(s_tile[0]);
-            if (t0 >= 0) cd_next = load_cdesc(t0, lane_k);
-        }
         __syncthreads();                                   // tile 0 is in buffer 0
         PSTAMP_INIT;
 #ifdef EG_STAMP
@@ -179,8 +363,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             const int t_nx = __builtin_amdgcn_readfirstlane(s_tile[(k + 1) & 7]);
             int lane = lane_k;
             asm volatile("" : "+v"(lane));
-            const int cd = cd_next;
-            if (t_nx >= 0) cd_next = load_cdesc(t_nx, lane);
+            const int cd = s_cd[(k & 1) * 32 + (lane & 31)];
             PSTAMP(3);
             float* s_a = s_a0 + (k & 1) * TILE * LDA;
             float* s_x = s_x0 + (k & 1) * TILE * LDA;
@@ -267,15 +450,10 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 else if (!CLS && c == 2) read_segments(0);
                 else if (!CLS) store_segments();
             };
-            if constexpr (BF) {
-                mfma_rowblock_bf<BFP>(s_a, 0, lane, wbf, acc0);
-                mfma_rowblock_bf_with<BFP>(s_a, 32, lane, wbf, acc1, between);
-            } else {
-                mfma_rowblock(s_a, 0, lane, wreg, acc0);
-                mfma_rowblock_with(s_a, 32, lane, wreg, acc1, between);
-            }
+            mfma_rowblock(s_a, 0, lane, wreg, acc0);
+            mfma_rowblock_with(s_a, 32, lane, wreg, acc1, between);
 #else
-            acc0[0] = wreg[0] + s_a[lane]; acc1[0] = wreg[BF ? 0 : 63];
+            acc0[0] = wreg[0] + s_a[lane]; acc1[0] = wreg[63];
 #pragma unroll
             for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
             if (!CLS) { read_segments(0); store_segments(); }
@@ -293,7 +471,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                         const int q = (lane >> 3) + 8 * i;
                         const int ra = 16 * (q >> 2) + 2 * (q & 3);            // LDS row of child (2 pr, 2 pc)
                         const float* sp = s_x + ra * LDA + 32 * wave + c4;
-                        const float* dp = s_dis0 + (k & 1) * TILE + ra;
+                        const float* dp = s_dis0 + (k & (PS_DIS_RING - 1)) * TILE + ra;
                         f32x4 ks = dp[0] * *reinterpret_cast<const f32x4*>(sp);
                         ks += dp[1] * *reinterpret_cast<const f32x4*>(sp + LDA);
                         ks += dp[8] * *reinterpret_cast<const f32x4*>(sp + 8 * LDA);
@@ -373,6 +551,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             atomicAdd(&stats[10], __builtin_amdgcn_s_memrealtime() - rt0);
         }
 #endif
+        }
     } else {
         // =========================== PRODUCER: patch rows 2p, 2p+1 of every tile ================================
         const int p = wave - 4;
@@ -400,11 +579,16 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             d.pad0 = __builtin_amdgcn_readlane(dv, o + 14);    d.pad1 = __builtin_amdgcn_readlane(dv, o + 15);
             return d;
         };
-        auto produce = [&](int tile_i, int buf, int lane, int dv) {
+        auto produce = [&](int tile_i, int buf, int dslot, int lane, int dv) {
             const int frame = tile_i / a.tiles_per_frame;
             const float* __restrict__ xf = x + (size_t)frame * a.n_per_frame * C;
             const SegDesc sd0 = desc_of(dv, 0);
             const SegDesc sd1 = desc_of(dv, 16);
+            {   // the consumers' descriptor words of this tile (segments 2p, 2p+1: words 0, 1, 6, 15 -> ring slot [seg][0..3])
+                const int w = lane & 15;
+                const int f = w == 0 ? 0 : (w == 1 ? 1 : (w == 6 ? 2 : (w == 15 ? 3 : -1)));
+                if (lane < 32 && f >= 0) s_cd[buf * 32 + (2 * p + (lane >> 4)) * 4 + f] = dv;
+            }
             float* s_a = s_a0 + buf * TILE * LDA;
             float* s_x = a.has_res ? s_x0 + buf * TILE * LDA : nullptr;
             f32x4 acc0[4], acc1[4];
@@ -457,8 +641,8 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     const f32x4 da = quad_w(wqa, SLOT_SELF), db = quad_w(wqb, SLOT_SELF);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        s_dis0[buf * TILE + 16 * p + 2 * k + (lane >> 5)] = da[k];
-                        s_dis0[buf * TILE + 16 * p + 8 + 2 * k + (lane >> 5)] = db[k];
+                        s_dis0[dslot * TILE + 16 * p + 2 * k + (lane >> 5)] = da[k];
+                        s_dis0[dslot * TILE + 16 * p + 8 + 2 * k + (lane >> 5)] = db[k];
                     }
                 }
             } else {
@@ -480,7 +664,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         {
             const int t0 = __builtin_amdgcn_readfirstlane(s_tile[0]);
             const int t1 = __builtin_amdgcn_readfirstlane(s_tile[1]);
-            if (t0 >= 0) produce(t0, 0, lane_k, load_desc(t0, lane_k));
+            if (t0 >= 0) produce(t0, 0, 0, lane_k, load_desc(t0, lane_k));
             if (t1 >= 0) dv_next = load_desc(t1, lane_k);
         }
         __syncthreads();                                   // tile 0 is in buffer 0
@@ -496,7 +680,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             int got = 0;
             if (tid == 256) got = ps_claim_issue(counters, group);                          // three tiles ahead, asynchronous
             PSTAMP(3);
-            if (t_next >= 0) produce(t_next, (k + 1) & 1, lane, dv_cur);
+            if (t_next >= 0) produce(t_next, (k + 1) & 1, (k + 1) & (PS_DIS_RING - 1), lane, dv_cur);
             if (tid == 256) ps_claim_commit(counters, group, n_tiles, got, &s_tile[(k + 3) & 7]);
             __syncthreads();                               // barrier k+1
             PSTAMP(3);
@@ -527,39 +711,31 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     a.kid_rows = g->kid_rows; a.n_pats = g->n_pats;
     const long long n_tiles = (long long)a.tiles_per_frame * batch;
     if (n_tiles <= 0) return EG_OK;
-    const size_t lds = (size_t)(PS_LDS_PAT + g->n_pats * PATQ + (cls ? 4 * C : 0)) * sizeof(float);
+    const size_t lds = ps_lds_bytes(g->n_pats, cls != nullptr);
     if (lds > 160 * 1024) return EG_ERR_UNSUPPORTED;             // more weight patterns than fit beside the tile buffers
     {   // 160 KB of dynamic LDS needs the attribute once per device (idempotent, so a benign race sets it twice at worst)
         static std::atomic<bool> attr_set[64];
         int dev = 0;
         EG_HIP_TRY(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
     }
     int* const queue = g->next_queue_slice();
     EG_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
     long long grid = n_tiles < 256 ? n_tiles : g->knobs.ps_grid;      // one persistent workgroup per CU
+    if (grid > PS_MAX_GRID) grid = PS_MAX_GRID;
     const ClsArgs none{};
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out, g->dis, g->topo_dev,
-                           g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, queue, a, cls ? *cls : none);
+                           g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, g->sink, queue, a, cls ? *cls : none);
     };
-    if (g->knobs.precision == EG_PRECISION_BF16X3) {                  // opt-in experiments (eg_graph_set_precision)
-        if (cls) launch(k_gcn_layer_ps<true, 2>);
-        else launch(k_gcn_layer_ps<false, 2>);
-    } else if (g->knobs.precision == EG_PRECISION_BF16X6) {
-        if (cls) return EG_ERR_UNSUPPORTED;                           // (96 VGPRs of W parts + the heads' 64 do not fit: unfused there)
-        launch(k_gcn_layer_ps<false, 3>);
-    } else {
-        if (cls) launch(k_gcn_layer_ps<true, 0>);
-        else launch(k_gcn_layer_ps<false, 0>);
-    }
+    if (cls) launch(k_gcn_layer_ps<true, false>);
+    else if (kout) launch(k_gcn_layer_ps<false, true>);
+    else launch(k_gcn_layer_ps<false, false>);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

@@ -29,9 +29,6 @@ Knobs read_knobs() {
     k.grid_cap = env_int("EG_GRID", 512);
     k.layer_impl = env_int("EG_LAYER_IMPL", -1);
     k.ps_grid = env_int("EG_PS_GRID", 256);
-    const char* prec = getenv("EG_LAYER_PRECISION");
-    k.precision = !prec ? EG_PRECISION_F32 : strcmp(prec, "bf16x3") == 0 ? EG_PRECISION_BF16X3
-                        : strcmp(prec, "bf16x6") == 0 ? EG_PRECISION_BF16X6 : EG_PRECISION_F32;
     return k;
 }
 
@@ -353,7 +350,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
                     patsq[(size_t)pi * 64 + h * 32 + sl * 4 + k] = sl < 6 ? w : (w != 0.0f ? 1.0f : 0.0f);
                 }
     // chained layers run the producer/consumer kernel, which keeps the pattern table in LDS beside its tile buffers
-    const size_t ps_lds = (size_t)(4 * TILE * LDA + 16 + 2 * TILE + (pats.size() / 128) * 64 + 4 * C) * sizeof(float);   // incl. the fused-classifier tables
+    const size_t ps_lds = ps_lds_bytes((int)(pats.size() / 128), true);   // incl. the fused-classifier tables
     g->kid_rows = (kidsum_ok && ps_lds <= 160 * 1024) ? kid_rows : 0;
     g->flat = (T.n_levels == 1 && T.n_desc == 1 && ps_lds <= 160 * 1024) ? 1 : 0;
     g->topo = T;
@@ -362,6 +359,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
     if (e == hipSuccess) e = hipMemcpy(g->dis, dis.data(), sizeof(float) * T.n_nodes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&g->walk_counters, QUEUE_RING_BYTES);
     if (e == hipSuccess) e = hipMemset(g->walk_counters, 0, QUEUE_RING_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->sink, sizeof(float) * PS_MAX_GRID * PS_SINK_FLOATS);
     if (e == hipSuccess) e = hipMalloc((void**)&g->topo_dev, sizeof(Topo));
     if (e == hipSuccess) e = hipMemcpy(g->topo_dev, &T, sizeof(Topo), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&g->tiles_dev, sizeof(TileDesc) * tiles.size());
@@ -380,6 +378,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
         if (g->topo_dev) (void)hipFree(g->topo_dev);
         if (g->tiles_dev) (void)hipFree(g->tiles_dev);
         if (g->walk_counters) (void)hipFree(g->walk_counters);
+        if (g->sink) (void)hipFree(g->sink);
         delete g;
         return set_error(EG_ERR_HIP, std::string("eg_topo_create: ") + hipGetErrorString(e));
     }
@@ -395,16 +394,6 @@ int eg_csr_create_transposed(const eg_graph* base, const int64_t* ei, int64_t n_
     if (!base || base->kind != GRAPH_CSR) return set_error(EG_ERR_ARG, "base must be a CSR handle");
     return csr_build(ei, base->n_nodes, n_edges, (hipStream_t)stream, base, out);
 }
-
-int eg_graph_set_precision(eg_graph* g, int mode) {
-    if (!g) return set_error(EG_ERR_ARG, "NULL graph handle");
-    if (mode != EG_PRECISION_F32 && mode != EG_PRECISION_BF16X3 && mode != EG_PRECISION_BF16X6)
-        return set_error(EG_ERR_ARG, "unknown precision mode");
-    g->knobs.precision = mode;
-    return EG_OK;
-}
-
-int eg_graph_precision(const eg_graph* g) { return g ? g->knobs.precision : EG_PRECISION_F32; }
 
 int eg_graph_is_symmetric(const eg_graph* g) { return g && (g->kind == GRAPH_TOPO || g->symmetric); }
 
@@ -520,6 +509,7 @@ int eg_graph_destroy(eg_graph* g) {
     if (g->patsq_dev) (void)hipFree(g->patsq_dev);
     if (g->tiles_dev) (void)hipFree(g->tiles_dev);
     if (g->walk_counters) (void)hipFree(g->walk_counters);
+    if (g->sink) (void)hipFree(g->sink);
     if (g->rowptr) (void)hipFree(g->rowptr);
     if (g->colidx) (void)hipFree(g->colidx);
     delete g;

@@ -474,44 +474,39 @@ __device__ inline void load_w_slice(const float* __restrict__ W, int wave, int l
     }
 }
 
-// acc[m][n]: n = lane&31 = row (row0 + n), m = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel within the wave's 32.
+// SWAP = false:  D^T[32 channels x 32 rows] = W_slice * A^T   acc[m][n]: n = lane&31 = row (row0 + n),
+//                m = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel within the wave's 32 (a lane holds 16 channels of ONE row).
+// SWAP = true:   D[32 rows x 32 channels] = A * W_slice^T (the same two operand registers in the other order, so every output
+//                element is the same sum in the same order): n = lane&31 = channel within the wave's 32,
+//                m = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = row (row0 + m): a wave register is 2 x 128 contiguous bytes of two
+//                output rows, so the epilogue can store it as it stands.
 // The 16 ds_read_b128 are software-pipelined in chunks of 4 (two named fragment sets) so that at most
 // 32 VGPRs hold A fragments while the 64-cycle MFMAs of the previous chunk cover the LDS latency.
-__device__ inline void mfma_chunk(const f32x4 (&av)[4], const float (&wreg)[64], int t0, f32x16& acc) {
+template <bool SWAP = false>
+__device__ inline void mfma_chunk(const f32x4 (&av)[4], const float (&wreg)[64], int t0, f32x16& acc, int t_lo = 0, int t_hi = 4) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 0], av[t].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 1], av[t].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 2], av[t].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 3], av[t].w, acc, 0, 0, 0);
+    for (int t = t_lo; t < t_hi; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float w = wreg[4 * (t0 + t) + e], v = av[t][e];
+            acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(v, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w, v, acc, 0, 0, 0);
+        }
     }
 }
 
-__device__ inline void mfma_rowblock(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc) {
-    const int j = lane & 31, h = lane >> 5;
-    const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
-    f32x4 a0[4], a1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a0[t] = ap[t];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
+// One 32-row block: 64 chained MFMAs.  between(c) is emitted in the scheduling region of chunk c (c = 0..3) so that
+// independent VALU / LDS / store work of the caller fills the issue slots the dependent 64-cycle MFMAs leave free.  The
+// first four MFMAs of a chunk are fenced off in front of it: left to itself the scheduler may place between(c) BEFORE the
+// chunk's MFMAs, and work that reads the previous chain's accumulator then waits out that chain's tail (an 18-wait-state
+// s_nop plus the VALU block, with the matrix pipe idle).
+// (a pure MFMA has no place in the instruction-selection order of its own: a scheduling barrier alone does not keep it on its
+// side; tying the accumulator to an empty volatile asm does)
+__device__ inline void pin_mfma(f32x16& acc) {
+    asm volatile("" : "+v"(acc));
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a0, wreg, 0, acc);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a1, wreg, 4, acc);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a0, wreg, 8, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a1, wreg, 12, acc);
 }
 
-// Same chain; between(c) is emitted in the scheduling region of chunk c (c = 0..3) so that independent VALU / LDS /
-// store work of the caller fills the issue slots the dependent 64-cycle MFMAs leave free.
-template <typename F>
+template <bool SWAP = false, typename F>
 __device__ inline void mfma_rowblock_with(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc, F between) {
     const int j = lane & 31, h = lane >> 5;
     const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
@@ -521,143 +516,34 @@ __device__ inline void mfma_rowblock_with(const float* s_a, int row0, int lane, 
 #pragma unroll
     for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a0, wreg, 0, acc);
+    mfma_chunk<SWAP>(a0, wreg, 0, acc, 0, 1);
+    pin_mfma(acc);
+    mfma_chunk<SWAP>(a0, wreg, 0, acc, 1, 4);
     between(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a1, wreg, 4, acc);
+    mfma_chunk<SWAP>(a1, wreg, 4, acc, 0, 1);
+    pin_mfma(acc);
+    mfma_chunk<SWAP>(a1, wreg, 4, acc, 1, 4);
     between(1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a0, wreg, 8, acc);
+    mfma_chunk<SWAP>(a0, wreg, 8, acc, 0, 1);
+    pin_mfma(acc);
+    mfma_chunk<SWAP>(a0, wreg, 8, acc, 1, 4);
     between(2);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a1, wreg, 12, acc);
+    mfma_chunk<SWAP>(a1, wreg, 12, acc, 0, 1);
+    pin_mfma(acc);
+    mfma_chunk<SWAP>(a1, wreg, 12, acc, 1, 4);
     between(3);
 }
 
-// ---- opt-in split-bf16 forms of the same product (eg_graph_set_precision; never the default) ---------------------------
-// bf16x3: every fp32 operand is split into a = a0 + a1 with a0 = bf16(a), a1 = bf16(a - a0) (16 significant bits together) and
-//   a b  ~=  a0 b0 + a0 b1 + a1 b0                      (the dropped a1 b1 term is <= 2^-16 |a b|)
-// runs as three v_mfma_f32_32x32x16_bf16 (8 passes each for 16 k-values: 3/16 of the fp32 MFMA time), accumulated in fp32.
-// bf16x6: three parts (a = a0 + a1 + a2 EXACTLY: 3 x 8 = 24 bits) and the six products a_i b_j with i + j <= 2; the dropped
-//   terms are <= 2^-23 |a b| together -- the size of one fp32 rounding -- at 6/16 of the fp32 MFMA time.  Same lane <-> (row, channel, k-half) assignment and the same accumulator layout as the fp32 chain above, so the
-// epilogues are shared: MFMA step t of lane (., h) covers k = 64 h + 8 t .. + 7.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// P-way split of 8 floats: part[0] = bf16(a), part[1] = bf16(a - part[0]), part[2] = bf16(a - part[0] - part[1]) (exact: 3 x 8 = 24 bits)
-template <int P>
-__device__ inline void split_bf16_parts(const f32x4& p, const f32x4& q, u32x4 (&part)[P]) {
-    f32x4 rp = p, rq = q;
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        unsigned h[4];
-        const f32x2 v0 = {rp.x, rp.y}, v1 = {rp.z, rp.w}, v2 = {rq.x, rq.y}, v3 = {rq.z, rq.w};
-        h[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf16x2));
-        h[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf16x2));
-        h[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2));
-        h[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(v3, bf16x2));
-        part[i] = u32x4{h[0], h[1], h[2], h[3]};
-        if (i + 1 < P) {
-            rp -= f32x4{__uint_as_float(h[0] << 16), __uint_as_float(h[0] & 0xffff0000u), __uint_as_float(h[1] << 16),
-                        __uint_as_float(h[1] & 0xffff0000u)};
-            rq -= f32x4{__uint_as_float(h[2] << 16), __uint_as_float(h[2] & 0xffff0000u), __uint_as_float(h[3] << 16),
-                        __uint_as_float(h[3] & 0xffff0000u)};
-        }
-    }
-}
-
-// the wave's W slice, split once: P x 32 VGPRs (the fp32 slice takes 64)
-template <int P>
-struct WSliceBf { u32x4 part[P][8]; };
-
-template <int P>
-__device__ inline void load_w_slice_bf(const float* __restrict__ W, int wave, int lane, int transpose, WSliceBf<P>& w) {
-    float wreg[64];
-    load_w_slice(W, wave, lane, transpose, wreg);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        u32x4 parts[P];
-        split_bf16_parts<P>(f32x4{wreg[8 * t], wreg[8 * t + 1], wreg[8 * t + 2], wreg[8 * t + 3]},
-                            f32x4{wreg[8 * t + 4], wreg[8 * t + 5], wreg[8 * t + 6], wreg[8 * t + 7]}, parts);
-#pragma unroll
-        for (int i = 0; i < P; ++i) w.part[i][t] = parts[i];
-    }
-}
-
-// two MFMA steps (16 k-values per lane half) from 4 float4 fragments of the fp32 LDS tile: every product w_i a_j with
-// i + j < P (3 for P = 2, 6 for P = 3), smallest terms first.
-// Register discipline (measured on MI355X): v_mfma_f32_32x32x16_bf16 reads its 4-VGPR A / B operands
-// progressively while it executes, and neither the hardware nor the compiler's hazard tables keep a VALU instruction issued
-// right behind it from overwriting them -- a v_cvt_pk_bf16_f32 of the NEXT step into the same registers corrupted the last
-// sub-block the MFMA reads (k-group 1, even elements, columns n = 3 mod 8) on ~1 row in 2000, only with every CU busy and the
-// co-resident wave stalled.  So: all operand registers of a chunk are written BEFORE its MFMAs and are live across all of
-// them, and nothing may write them again until a VALU read of the accumulator (the compiler adds the XDL-write -> VALU-read
-// wait states) plus 64 idle issue cycles have passed.
-template <int P>
-__device__ inline void mfma_chunk_bf(const f32x4 (&av)[4], const WSliceBf<P>& w, int t0, f32x16& acc) {
-    u32x4 ap[2][P];
-    split_bf16_parts<P>(av[0], av[1], ap[0]);
-    split_bf16_parts<P>(av[2], av[3], ap[1]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int order = P - 1; order >= 0; --order)            // order = i + j
-#pragma unroll
-            for (int i = order; i >= 0; --i)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.part[i][t0 + u]),
-                                                              __builtin_bit_cast(bf16x8, ap[u][order - i]), acc, 0, 0, 0);
-#ifndef EG_BF3_NOGUARD
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        float probe = acc[0];
-        if constexpr (P == 2)
-            asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7"
-                         : "+v"(probe), "+v"(ap[0][0]), "+v"(ap[0][1]), "+v"(ap[1][0]), "+v"(ap[1][1]));      // (operands stay allocated up to here)
-        else
-            asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7"
-                         : "+v"(probe), "+v"(ap[0][0]), "+v"(ap[0][1]), "+v"(ap[0][2]), "+v"(ap[1][0]), "+v"(ap[1][1]), "+v"(ap[1][2]));
-        acc[0] = probe;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
-template <int P, typename F>
-__device__ inline void mfma_rowblock_bf_with(const float* s_a, int row0, int lane, const WSliceBf<P>& w, f32x16& acc, F between) {
-    const int j = lane & 31, h = lane >> 5;
-    const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
-    f32x4 a0[4], a1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a0[t] = ap[t];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk_bf<P>(a0, w, 0, acc);
-    between(0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk_bf<P>(a1, w, 2, acc);
-    between(1);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk_bf<P>(a0, w, 4, acc);
-    between(2);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk_bf<P>(a1, w, 6, acc);
-    between(3);
-}
-
-template <int P>
-__device__ inline void mfma_rowblock_bf(const float* s_a, int row0, int lane, const WSliceBf<P>& w, f32x16& acc) {
-    mfma_rowblock_bf_with<P>(s_a, row0, lane, w, acc, [](int) {});
+template <bool SWAP = false>
+__device__ inline void mfma_rowblock(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc) {
+    mfma_rowblock_with<SWAP>(s_a, row0, lane, wreg, acc, [](int) {});
 }
 
 // ---- 8-wave layout: wave w owns 16 output channels, v_mfma_f32_16x16x4_f32 ------------------------

@@ -92,21 +92,8 @@ class Graph:
 
     @property
     def fused_classifier_ok(self) -> bool:
-        """eg_gcn_layer_cls_fwd (last layer + classifier heads in one kernel) is available for this handle (in its current
-        precision mode)."""
+        """eg_gcn_layer_cls_fwd (last layer + classifier heads in one kernel) is available for this handle."""
         return bool(_lib.load().eg_graph_fused_classifier_ok(self._h)) if self.structured else False
-
-    def set_precision(self, mode: str) -> None:
-        """OPT-IN experiment (include/echoglad_hip.h eg_graph_set_precision): "f32" = exact fp32 MFMA (default),
-        "bf16x3" / "bf16x6" = split-operand bf16 products inside the producer/consumer layer kernel."""
-        modes = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
-        if mode not in modes:
-            raise ValueError(f"precision must be one of {sorted(modes)}")
-        _lib.check(_lib.load().eg_graph_set_precision(self._h, modes[mode]), "eg_graph_set_precision")
-
-    @property
-    def precision(self) -> str:
-        return {1: "bf16x3", 2: "bf16x6"}.get(int(_lib.load().eg_graph_precision(self._h)), "f32")
 
     def deg_inv_sqrt(self) -> torch.Tensor:
         out = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)

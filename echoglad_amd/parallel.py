@@ -64,20 +64,29 @@ class GradientAllReducer:
     The parameters are laid out in ONE flat fp32 buffer in REVERSE registration order (the order backward finishes
     them: classifier heads first, the first GNN layer last) and cut into a few contiguous buckets.  With
     ``attach_hooks()`` every parameter's post-accumulate-grad hook counts its bucket down; the moment a bucket is
-    complete it is packed (one ``torch.cat`` into its slice) on the producing stream and its sum all-reduce is issued on
-    a SIDE stream behind an event, so RCCL moves the finished layers' gradients over xGMI while the kernels of the
-    remaining backward keep running.  ``finish()`` (after ``loss.backward()``) issues whatever never fired (parameters
-    without a gradient contribute zeros), waits for the collectives, divides by the world size and hands the reduced
-    values back as ``p.grad``.  Replaces torch_geometric's DataParallel reduce-to-GPU-0 (src/engine.py:105-110).
+    complete AND every bucket before it has gone out, it is packed (one ``torch.cat`` into its slice) on the producing
+    stream and its sum all-reduce is issued on a SIDE stream behind an event, so RCCL moves the finished layers'
+    gradients over xGMI while the kernels of the remaining backward keep running.  Buckets leave strictly in index
+    order on every rank: RCCL and gloo pair collectives by ISSUE ORDER, not by tensor, so a bucket that completes early on
+    one rank (a parameter without a gradient there) must not overtake.  ``finish()`` (after ``loss.backward()``) issues
+    whatever never fired, in order (parameters without a gradient contribute zeros), waits for the collectives, divides
+    by the world size and hands the reduced values back as ``p.grad``.  If backward raised, call ``reset()`` before the
+    next step.  Replaces torch_geometric's DataParallel reduce-to-GPU-0 (src/engine.py:105-110).
+
+    ``force_collective=True`` issues the collectives (side stream, event, async all-reduce) at world size 1 as well: the
+    single-GPU way to run the exact code path the multi-GPU step takes.
 
     Sizing for xGMI (point-to-point links, ~20 us per collective): the 277 KB of GNN + classifier gradients go out as
     at most ~5 collectives; with a 32 MB front-end the buckets grow to total / 8 (4 MB), capped at 8 MB."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None, average: bool = True,
-                 bucket_bytes: Optional[int] = None):
+                 bucket_bytes: Optional[int] = None, force_collective: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.average = average
+        self.force_collective = bool(force_collective)
+        self._next = 0                      # index of the next bucket to go out (strict order)
+        self.collectives_issued = 0         # all-reduces issued so far (diagnostics / tests)
         order = list(reversed(self.params))
         total = sum(p.numel() for p in order)
         if bucket_bytes is None:
@@ -127,10 +136,24 @@ class GradientAllReducer:
         self._hooks = []
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
-        b = self._buckets[self._where[id(p)]]
-        b.ready += 1
-        if b.ready == len(b.params) and not b.launched:
-            self._launch(b)
+        self._buckets[self._where[id(p)]].ready += 1
+        # every complete bucket at the head of the line goes out; a complete bucket behind an incomplete one waits
+        while self._next < len(self._buckets) and self._buckets[self._next].ready >= len(self._buckets[self._next].params):
+            self._launch(self._buckets[self._next])
+
+    def _flush(self) -> None:
+        while self._next < len(self._buckets):
+            self._launch(self._buckets[self._next])
+
+    def reset(self) -> None:
+        """Drop the state of a step that did not reach ``finish()`` (backward raised): waits for what is in flight."""
+        for w in self._works:
+            w.wait()
+        if self._flat is not None and self._flat.is_cuda and self._side is not None:
+            torch.cuda.current_stream(self._flat.device).wait_stream(self._side)
+        for b in self._buckets:
+            b.ready, b.launched = 0, False
+        self._works, self._next = [], 0
 
     def _launch(self, b: _Bucket) -> None:
         flat = self._buffer()
@@ -138,8 +161,11 @@ class GradientAllReducer:
         parts = [(p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), dtype=flat.dtype, device=flat.device))
                  for p in b.params]
         torch.cat(parts, out=piece)                          # pack: one kernel per bucket, on the producing stream
+        assert self._buckets[self._next] is b, "buckets leave in index order"
         b.launched = True
-        if self._world() > 1:
+        self._next += 1
+        if self._world() > 1 or (self.force_collective and dist.is_initialized()):
+            self.collectives_issued += 1
             if flat.is_cuda:
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=flat.device)
@@ -155,9 +181,7 @@ class GradientAllReducer:
         """After backward: flush, wait, average, unpack into ``p.grad``.  Every rank must call it every step."""
         if not self.params:
             return
-        for b in self._buckets:
-            if not b.launched:
-                self._launch(b)
+        self._flush()
         for w in self._works:
             w.wait()
         flat = self._buffer()
@@ -180,7 +204,7 @@ class GradientAllReducer:
             b.ready, b.launched = 0, False
         if have:
             torch._foreach_copy_(have, views)
-        self._works = []
+        self._works, self._next = [], 0
 
     # ---- hook-less form (kept for callers that reduce after backward has returned) ---------------------------------
     def allreduce(self, async_op: bool = False):
@@ -188,9 +212,7 @@ class GradientAllReducer:
         gradient on this rank contribute zeros (every rank must call this with the same parameter list)."""
         if not self.params:
             return None
-        for b in self._buckets:
-            if not b.launched:
-                self._launch(b)
+        self._flush()
         if async_op:
             return _Pending(self)
         self.finish()

@@ -133,22 +133,6 @@ int64_t eg_graph_kidsum_rows(const eg_graph* g);    /* rows per frame of a child
 /* 1 when eg_gcn_layer_cls_fwd (below) covers this handle: a topology handle without coordinate / connection rows
  * whose layer kernel is the producer/consumer form (child sums available, or a single-level grid); else 0. */
 int eg_graph_fused_classifier_ok(const eg_graph* g);
-/* OPT-IN EXPERIMENT, never the default: arithmetic of the 128x128 product inside the producer/consumer layer kernel
- * (eg_gcn_layer_fwd / _chain / _cls_fwd on topology handles).
- *   EG_PRECISION_F32     (default) exact fp32 MFMA (v_mfma_f32_32x32x2_f32): what every parity test and the bench headline use
- *   EG_PRECISION_BF16X3  both operands split into bf16 hi + lo parts, three bf16 MFMAs per product (hi hi + hi lo + lo hi),
- *                        fp32 accumulation: ~2^-16 relative error per product (measured: logits within 5e-5 of the fp32
- *                        path at configs[1], arg-max identical), 3/16 of the MFMA time.
- *   EG_PRECISION_BF16X6  three parts per operand (an exact 24-bit split), the six products a_i b_j with i + j <= 2: the
- *                        dropped terms are <= 2^-23 of a product, the size of one fp32 rounding; 6/16 of the MFMA time.
- * The classifier heads of eg_gcn_layer_cls_fwd stay fp32 in every mode.
- * A handle created while the environment holds EG_LAYER_PRECISION=bf16x3 | bf16x6 starts in that mode.  Not thread-safe
- * against launches in flight on the same handle; kernels captured into a HIP graph keep the mode they were captured with. */
-#define EG_PRECISION_F32 0
-#define EG_PRECISION_BF16X3 1
-#define EG_PRECISION_BF16X6 2
-int eg_graph_set_precision(eg_graph* g, int mode);
-int eg_graph_precision(const eg_graph* g);
 int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                            const float* shift, const float* residual, int relu, int transpose_w, float* out,
                            const float* kidsum_in, float* kidsum_out, eg_stream_t stream);

@@ -1,0 +1,102 @@
+"""-m gpu: the GPU branch of the gradient reducer (side stream + event + asynchronous RCCL all-reduce, echoglad_amd/parallel.py)
+on ONE GPU: a one-rank "nccl" process group with ``force_collective=True`` runs exactly the calls the multi-GPU step makes
+(replaces the reference's DataParallel gradient reduce, src/engine.py:105-110).  Each case runs in a child process: a process
+group is process-global state the other tests must not see."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _child_env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def test_reducer_hooks_on_rccl_world_1_leave_the_gradients_bit_identical():
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], capture_output=True, text=True, timeout=600, env=_child_env())
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["world_size"] == 1
+    assert d["collectives_issued"] == d["buckets"] >= 2 and d["fired_inside_backward"] >= d["buckets"] - 1
+    assert d["bit_identical"] is True and d["params_compared"] > 40 and d["side_stream_used"] is True
+
+
+def test_bench_train_step_with_the_reducer_attached_on_one_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--batch", "4", "--steps", "3", "--warmup", "2",
+                        "--force-collective"], capture_output=True, text=True, timeout=900, env=_child_env())
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    dist = d["distributed"]
+    assert dist["backend"] == "nccl" and dist["world_size"] == 1 and dist["allreduce_check"] is True
+    assert dist["gradient_buckets"] >= 1 and dist["gradient_collectives_issued"] == dist["gradient_buckets"] * 5      # 2 warm-up + 3 timed steps
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["final_loss"] == d["final_loss"]                                  # (not NaN)
+
+
+def _main():
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from fixtures_util import initial_coords, synthetic_node_feats
+    from gpu_util import DEV, graph_tensors, model_pair
+    from echoglad_amd.parallel import GradientAllReducer
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    frame, naux, B = 32, 4, 3
+    hip, _ = model_pair(frame, naux, 3, coord=True, seed=23)
+    hip.train()
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+    x = synthetic_node_feats(B * topo.num_nodes, 128, seed=41).to(DEV)
+    eid = ei.to(DEV)
+    coords0 = initial_coords(B, frame).to(DEV)
+    state = {k: v.clone() for k, v in hip.state_dict().items()}
+
+    def step(reducer):
+        hip.load_state_dict(state)
+        for p in hip.parameters():
+            p.grad = None
+        torch.manual_seed(7)                                   # the dropout seeds come from the host RNG
+        logits, coords = hip.forward_nodes(x, eid, B, coords0.clone())
+        loss = (logits ** 2).mean() + (coords ** 2).mean() * 1e-3
+        loss.backward()
+        inside.append(len(fired))                              # buckets that went out from inside backward
+        if reducer is not None:
+            reducer.finish()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in hip.named_parameters() if p.grad is not None}
+
+    fired, inside = [], []
+    plain = step(None)
+    red = GradientAllReducer(hip.parameters(), bucket_bytes=32 << 10, force_collective=True).attach_hooks()
+    orig = red._launch
+    red._launch = lambda b: (fired.append(b), orig(b))[1]
+    reduced = step(red)
+    reduced2 = step(red)                                        # second step through the same reducer: counters reset
+    same = set(plain) == set(reduced) and all(torch.equal(plain[k], reduced[k]) and torch.equal(plain[k], reduced2[k]) for k in plain)
+    print(json.dumps({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "buckets": len(red._buckets),
+                      "collectives_issued": red.collectives_issued // 2, "fired_inside_backward": inside[1],
+                      "bit_identical": bool(same), "params_compared": len(plain), "side_stream_used": red._side is not None}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    _main()

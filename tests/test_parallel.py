@@ -61,9 +61,29 @@ def _worker(rank, world, port, frame, naux, B, out_dir, mode="after"):
     parallel.broadcast_parameters(model, src=0)
     ei = torch.from_numpy(topo.batched_edge_index(b))
     nt = torch.from_numpy(np.tile(topo.node_type(), b))
+    if mode == "missing" and rank == 1:
+        # withheld BEFORE the forward builds the graph: no AccumulateGrad node, the hook never fires on this rank, so the
+        # bucket that holds this parameter completes inside backward on rank 0 and only in finish() on rank 1
+        model.node_classifiers[3][8].bias.requires_grad_(False)
     logits, _ = model.forward_nodes(shard["node_feats"], ei, nt, b)
     loss = (logits ** 2).sum() / (B * n)            # global mean written as a sum of shard sums
-    if mode == "after":                             # reduce once backward has returned
+    if mode == "missing":
+        # (the parameter list must be the same on both ranks: the flag is re-enabled for the list, not for the graph)
+        model.node_classifiers[3][8].bias.requires_grad_(True)
+        red = parallel.GradientAllReducer(model.parameters(), average=False, bucket_bytes=16 << 10).attach_hooks()
+        fired = []
+        orig = red._launch
+        red._launch = lambda bk: (fired.append(bk), orig(bk))[1]
+        loss.backward()
+        in_backward = len(fired)
+        red.finish()
+        order = [red._buckets.index(bk) for bk in fired]
+        assert order == list(range(len(red._buckets))), order          # strictly in index order on every rank
+        if rank == 0:
+            assert in_backward >= len(red._buckets) - 1
+        else:
+            assert in_backward == 0                                     # bucket 0 never completed: everything waits for finish()
+    elif mode == "after":                             # reduce once backward has returned
         loss.backward()
         red = parallel.GradientAllReducer(model.parameters(), average=False)
         pending = red.allreduce(async_op=True)
@@ -74,11 +94,8 @@ def _worker(rank, world, port, frame, naux, B, out_dir, mode="after"):
         fired = []
         orig = red._launch
         red._launch = lambda b: (fired.append(b), orig(b))[1]
-        if rank == 1:                               # a parameter that gets no gradient on one rank contributes zeros
-            model.node_classifiers[3][8].bias.requires_grad_(False)
         loss.backward()
         n_in_backward = len(fired)
-        model.node_classifiers[3][8].bias.requires_grad_(True)
         red.finish()
         assert n_in_backward >= len(red._buckets) - 1 and len(fired) == len(red._buckets)
         # the classifier heads' bucket goes out first, the first GNN layer's last
@@ -97,7 +114,7 @@ def _worker(rank, world, port, frame, naux, B, out_dir, mode="after"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["after", "overlapped"])
+@pytest.mark.parametrize("mode", ["after", "overlapped", "missing"])
 def test_two_rank_gradients_match_single_process(tmp_path, mode):
     frame, naux, B, world = 8, 2, 4, 2
     with socket.socket() as s:
@@ -113,8 +130,19 @@ def test_two_rank_gradients_match_single_process(tmp_path, mode):
     nt = torch.from_numpy(np.tile(topo.node_type(), B))
     logits, _ = model.forward_nodes(feats, ei, nt, B)
     ((logits ** 2).sum() / (B * n)).backward()
-    for k, p in model.named_parameters():
-        assert torch.allclose(got[k], p.grad, rtol=1e-4, atol=1e-6), k
+    want = {k: p.grad.clone() for k, p in model.named_parameters()}
+    if mode == "missing":
+        # rank 1 contributed zeros for the withheld parameter: its reduced gradient is rank 0's shard alone
+        # (round 2's reducer paired the wrong buckets here and returned silently wrong sums for EVERY bucket)
+        half = B // 2
+        for p in model.parameters():
+            p.grad = None
+        ei0 = torch.from_numpy(topo.batched_edge_index(half))
+        logits, _ = model.forward_nodes(feats[:half * n], ei0, nt[:half * n], half)
+        ((logits ** 2).sum() / (B * n)).backward()
+        want["node_classifiers.3.8.bias"] = model.node_classifiers[3][8].bias.grad.clone()
+    for k in want:
+        assert torch.allclose(got[k], want[k], rtol=1e-4, atol=1e-6), k
 
 
 def test_bench_starts_its_own_ranks_and_propagates_failure():

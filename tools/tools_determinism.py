@@ -18,7 +18,6 @@ DEV = "cuda:0"
 
 def soak(frame, naux, B, mode, reps, main_only=False):
     g = ops.Graph.topo(frame, naux, main_only)
-    g.set_precision(mode)
     n = g.num_nodes
     x = synthetic_node_feats(B * n, 128, seed=1).to(DEV)
     w = (synthetic_node_feats(128, 128, seed=2) * 0.1).to(DEV)
@@ -37,7 +36,6 @@ def soak(frame, naux, B, mode, reps, main_only=False):
             first = out.clone()
         elif not torch.equal(out, first):
             bad += 1
-    g.set_precision("f32")
     print(f"{frame}x{frame} naux={naux} main_only={main_only} B={B} {mode}: {bad} of {reps - 1} launches differ from the first")
     return bad
 
@@ -75,7 +73,7 @@ def soak_train(reps):
 if __name__ == "__main__":
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     total = 0
-    for mode in ("f32", "bf16x3", "bf16x6"):
+    for mode in ("f32",):
         total += soak(224, 7, 8, mode, reps)
         total += soak(224, 7, 32, mode, reps, main_only=True)
         total += soak(448, 8, 8, mode, max(reps // 4, 2))
