@@ -74,7 +74,9 @@ __device__ inline void ps_claim(int* __restrict__ counters, int group, int n_til
 
 // KOUT: the launch writes the child sums of its output (kout != NULL), a launch-uniform property compiled in so that the
 // epilogue stays branch-free inside the MFMA chains.
-template <bool CLS, bool KOUT>
+// KIN: the launch reads the child sums of its input (kin != NULL), likewise compiled in: a launch without them pulls the
+// children of aux nodes as rows, which takes the registers the child-sum rows of the next tile would travel in.
+template <bool CLS, bool KOUT, bool KIN>
 __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ out, const float* __restrict__ dis,
@@ -99,11 +101,12 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
     const int n_tiles = a.tiles_per_frame * a.batch;
     const int group = xcc_id();
 
-    // ---- prologue: tiles 0, 1 and 2 claimed (before anyone reads the ring) -------------------------------------
+    // ---- prologue: tiles 0 .. 3 claimed (before anyone reads the ring) -----------------------------------------
     if (tid == 256) {
         ps_claim(counters, group, n_tiles, &s_tile[0]);
         ps_claim(counters, group, n_tiles, &s_tile[1]);
         ps_claim(counters, group, n_tiles, &s_tile[2]);
+        ps_claim(counters, group, n_tiles, &s_tile[3]);
     }
     for (int i = tid; i < a.n_pats * PATQ; i += PS_THREADS) s_pat[i] = patsq[i];
     if (CLS) {
@@ -579,7 +582,31 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             d.pad0 = __builtin_amdgcn_readlane(dv, o + 14);    d.pad1 = __builtin_amdgcn_readlane(dv, o + 15);
             return d;
         };
-        auto produce = [&](int tile_i, int buf, int dslot, int lane, int dv) {
+        // The rows of a tile sit in R (112 VGPRs); `have` = R holds -- in flight since the previous period -- the rows of the
+        // tile about to be produced.  produce() aggregates tile_i into buffer `buf` and, stage by stage, re-issues every
+        // register group for tile_n (descriptors dvn) right after its last use; returns whether R now holds tile_n.
+#ifdef EG_ABL_HALO      // timing-only ablation (results wrong): the rows above / below a pair are loaded only where no other wave
+                        // of the workgroup loads them as its own rows -- the bytes a halo exchange through LDS would save
+        const bool HALO_U = p == 0, HALO_D = p == 3;
+#else
+        const bool HALO_U = true, HALO_D = true;
+#endif
+        PairRegs R;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            R.Sa[k] = R.Sb[k] = R.U[k] = R.D[k] = R.Ka[k] = R.Kb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        R.LRa = R.LRb = R.P[0] = R.P[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto pick = [](bool c, const SegDesc& u, const SegDesc& v) -> SegDesc {          // wave-uniform select, field by field
+            SegDesc d;
+            d.n_first = c ? u.n_first : v.n_first;  d.cnt = c ? u.cnt : v.cnt;      d.mode = c ? u.mode : v.mode;
+            d.pat = c ? u.pat : v.pat;              d.up0 = c ? u.up0 : v.up0;      d.down0 = c ? u.down0 : v.down0;
+            d.par0 = c ? u.par0 : v.par0;           d.left = c ? u.left : v.left;   d.right = c ? u.right : v.right;
+            d.c0 = c ? u.c0 : v.c0;  d.c1 = c ? u.c1 : v.c1;  d.c2 = c ? u.c2 : v.c2;  d.c3 = c ? u.c3 : v.c3;
+            d.aux = c ? u.aux : v.aux;              d.pad0 = c ? u.pad0 : v.pad0;   d.pad1 = c ? u.pad1 : v.pad1;
+            return d;
+        };
+        auto produce = [&](int tile_i, int buf, int dslot, int lane, int dv, bool have, int tile_n, int dvn) -> bool {
             const int frame = tile_i / a.tiles_per_frame;
             const float* __restrict__ xf = x + (size_t)frame * a.n_per_frame * C;
             const SegDesc sd0 = desc_of(dv, 0);
@@ -589,40 +616,166 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 const int f = w == 0 ? 0 : (w == 1 ? 1 : (w == 6 ? 2 : (w == 15 ? 3 : -1)));
                 if (lane < 32 && f >= 0) s_cd[buf * 32 + (2 * p + (lane >> 4)) * 4 + f] = dv;
             }
+            // the tile after this one: pipe-able when both of its segments are on the pair path; otherwise the re-issued
+            // loads simply fetch this tile's rows again (no branch around a write to the loop-carried register set: the
+            // allocator would keep both generations alive) and the next call starts from scratch
+            const SegDesc m0 = desc_of(dvn, 0), m1 = desc_of(dvn, 16);
+            const bool nxt = tile_n >= 0 && m0.pad0 != 0;
+            const SegDesc n0 = pick(nxt, m0, sd0), n1 = pick(nxt, m1, sd1);
+            const int frame_n = nxt ? tile_n / a.tiles_per_frame : frame;
+            const float* __restrict__ xfn = x + (size_t)frame_n * a.n_per_frame * C;
+            const bool kin_n = KIN && nxt && n0.aux;
+            const float* __restrict__ kfn = KIN ? kin + (size_t)frame_n * a.kid_rows * C : xfn;
+            const PairLane pl{lane >> 5, lane & 31};
             float* s_a = s_a0 + buf * TILE * LDA;
             float* s_x = a.has_res ? s_x0 + buf * TILE * LDA : nullptr;
             f32x4 acc0[4], acc1[4];
+            // everything of a pair at once, in the order the stages consume it (vmcnt counts in issue order)
+            auto issue_all = [&](const SegDesc& u0, const SegDesc& u1, const float* __restrict__ xf_, const float* __restrict__ kf_, bool k_) {
+                R.LRa = *reinterpret_cast<const f32x4*>(xf_ + bcast_off(pl.h ? u0.left : u0.right, pl));
+                if constexpr (KIN) {
+                    if (k_) {
+                        const unsigned oa = pair_off(u0.n_first, pl);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) R.Ka[k] = ld4(kf_, oa, k);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) R.Ka[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                if (HALO_U) pair_issue_u(u0, xf_, pl, R);
+                R.LRb = *reinterpret_cast<const f32x4*>(xf_ + bcast_off(pl.h ? u1.left : u1.right, pl));
+                if constexpr (KIN) {
+                    if (k_) {
+                        const unsigned ob = pair_off(u1.n_first, pl);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) R.Kb[k] = ld4(kf_, ob, k);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) R.Kb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                pair_issue_s(u0, u1, xf_, pl, R);
+                if (HALO_D) pair_issue_d(u1, xf_, pl, R);
+                pair_issue_p(u0, xf_, pl, R);
+            };
             if (sd0.pad0) {
-#ifdef EG_STAMP2              // finer producer stamps: 0 = descriptor wait, 1 = load issue, 2 = fma + kids + store, 3 = claim + barrier
-                PSTAMP(0);
-#define PS_ISSUE 1
-#define PS_MAIN 2
-#else
-#define PS_ISSUE 0
-#define PS_MAIN 1
-#endif
                 // ---- usual case: both segments on the fast path, vertically adjacent, same parents ----
-                SegPair A;
-                const bool use_kin = sd0.aux && kin;                // uniform: children already summed by the previous layer
-                segp_issue(sd0, sd1, xf, lane, A);
-#ifdef EG_ABL_NO_LOADS        // timing-only ablation: producers do nothing (results wrong)
-                return;
-#endif
-                __builtin_amdgcn_sched_barrier(0);                  // every load of both segments is issued above this line
-                PSTAMP(PS_ISSUE);
+                const bool use_kin = KIN && sd0.aux;                // uniform: children already summed by the previous layer
+                if (!have) issue_all(sd0, sd1, xf, KIN ? kin + (size_t)frame * a.kid_rows * C : xf, use_kin);    // nothing in flight for this tile
+                __builtin_amdgcn_sched_barrier(0);
+                PSTAMP(0);
                 const float* wqa = s_pat + sd0.pat * PATQ + 32 * (lane >> 5);      // this lane's weights (LDS, quad layout)
                 const float* wqb = s_pat + sd1.pat * PATQ + 32 * (lane >> 5);
-                segw_rows(lane, wqa, A.Sa, A.LRa, A.LRa, A.U, A.Sb, A.P, acc0, s_x, 16 * p);
-                segw_rows(lane, wqb, A.Sb, A.LRb, A.LRb, A.Sa, A.D, A.P, acc1, s_x, 16 * p + 8);
-                pin_acc4(acc0);
-                pin_acc4(acc1);                                     // the 40 main-stage registers are dead from here on
-                __builtin_amdgcn_sched_barrier(0);
-                PSTAMP(PS_MAIN);
-                if (use_kin) {                                      // (issued here, not with the first batch: registers)
-                    SegKidsum KS;
-                    segp_kidsum_issue(sd0, sd1, kin + (size_t)frame * a.kid_rows * C, lane, KS);
-                    segp_kidsum_add(KS, wqa, wqb, acc0, acc1);
-                } else if (sd0.aux) {                               // uniform: aux level, children pulled as rows
+                if (KIN || !sd0.aux) {
+                    // ---- pipelined form: segment a is finished before segment b (one accumulator set live at a time), and
+                    // every register group goes out again for the next tile right after its last use
+                    // segment a: self + left + right (raw rows into the stash), child sums, above, below (= segment b), parents
+                    pair_stage_self(lane, wqa, R.Sa, R.LRa, acc0, s_x, 16 * p);
+                    pin_acc4(acc0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    R.LRa = *reinterpret_cast<const f32x4*>(xfn + bcast_off(pl.h ? n0.left : n0.right, pl));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (KIN) {
+                        if (use_kin) {
+                            const f32x4 fa = quad_w(wqa, SLOT_HASKIDS);            // 1.0 / 0.0
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc0[k] += fa[k] * R.Ka[k];
+                        }
+                        pin_acc4(acc0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kin_n) {
+                            const unsigned oa = pair_off(n0.n_first, pl);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) R.Ka[k] = ld4(kfn, oa, k);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) R.Ka[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    pair_stage_rows(wqa, SLOT_UP, R.U, acc0);
+                    pin_acc4(acc0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (HALO_U) pair_issue_u(n0, xfn, pl, R);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pair_stage_rows(wqa, SLOT_DOWN, R.Sb, acc0);
+                    {
+                        const f32x4 w5 = quad_w(wqa, SLOT_PARENT);
+                        f32x4 plo[2], pup[2];
+                        halves(R.P[0], plo[0], pup[0]);
+                        halves(R.P[1], plo[1], pup[1]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc0[k] += w5[k] * ((k & 1) ? pup[k >> 1] : plo[k >> 1]);
+                    }
+                    segw_store(lane, wqa, acc0, s_a, 16 * p);
+                    pin_acc4(acc0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // segment b: self + left + right, child sums, above (= segment a), below, parents
+                    pair_stage_self(lane, wqb, R.Sb, R.LRb, acc1, s_x, 16 * p + 8);
+                    pin_acc4(acc1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    R.LRb = *reinterpret_cast<const f32x4*>(xfn + bcast_off(pl.h ? n1.left : n1.right, pl));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (KIN) {
+                        if (use_kin) {
+                            const f32x4 fb = quad_w(wqb, SLOT_HASKIDS);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc1[k] += fb[k] * R.Kb[k];
+                        }
+                        pin_acc4(acc1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kin_n) {
+                            const unsigned ob = pair_off(n1.n_first, pl);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) R.Kb[k] = ld4(kfn, ob, k);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) R.Kb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    pair_stage_rows(wqb, SLOT_UP, R.Sa, acc1);
+                    pin_acc4(acc1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    {   // both segments' self rows are dead now
+                        const unsigned osa = pair_off(n0.n_first, pl), osb = pair_off(n1.n_first, pl);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) R.Sa[k] = ld4(xfn, osa, k);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) R.Sb[k] = ld4(xfn, osb, k);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    pair_stage_rows(wqb, SLOT_DOWN, R.D, acc1);
+                    pin_acc4(acc1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (HALO_D) pair_issue_d(n1, xfn, pl, R);
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const f32x4 w5 = quad_w(wqb, SLOT_PARENT);
+                        f32x4 plo[2], pup[2];
+                        halves(R.P[0], plo[0], pup[0]);
+                        halves(R.P[1], plo[1], pup[1]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc1[k] += w5[k] * ((k & 1) ? pup[k >> 1] : plo[k >> 1]);
+                    }
+                    pin_acc4(acc1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pair_issue_p(n0, xfn, pl, R);
+                    __builtin_amdgcn_sched_barrier(0);
+                    segw_store(lane, wqb, acc1, s_a, 16 * p + 8);
+                    PSTAMP(1);
+                } else if constexpr (!KIN) {
+                    // ---- aux level of an unchained / first layer: the children are pulled as rows (64 more registers), so the
+                    // next tile's rows go out only when this tile is done
+                    pair_stage_self(lane, wqa, R.Sa, R.LRa, acc0, s_x, 16 * p);
+                    pair_stage_self(lane, wqb, R.Sb, R.LRb, acc1, s_x, 16 * p + 8);
+                    pair_stage_rows(wqa, SLOT_UP, R.U, acc0);
+                    pair_stage_rows(wqb, SLOT_UP, R.Sa, acc1);
+                    pair_stage_rows(wqa, SLOT_DOWN, R.Sb, acc0);
+                    pair_stage_rows(wqb, SLOT_DOWN, R.D, acc1);
+                    pair_stage_par(wqa, wqb, R.P, acc0, acc1);
+                    pair_pin(acc0, acc1);                           // the main-stage registers are dead from here on
                     {
                         SegKids K;
                         segw_kids_issue(sd0, pats, xf, lane, K);
@@ -634,9 +787,13 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                         segw_kids_issue(sd1, pats, xf, lane, K);
                         segw_kids_add(lane, K, acc1);
                     }
+                    pair_pin(acc0, acc1);
+                    PSTAMP(1);
+                    issue_all(n0, n1, xfn, kfn, kin_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                    segw_store(lane, wqa, acc0, s_a, 16 * p);
+                    segw_store(lane, wqb, acc1, s_a, 16 * p + 8);
                 }
-                segw_store(lane, wqa, acc0, s_a, 16 * p);
-                segw_store(lane, wqb, acc1, s_a, 16 * p + 8);
                 if (kout && (lane & 31) == 0) {                     // (deg+1)^-1/2 of the 16 nodes, for the consumers' child sums
                     const f32x4 da = quad_w(wqa, SLOT_SELF), db = quad_w(wqb, SLOT_SELF);
 #pragma unroll
@@ -649,23 +806,31 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 // ---- ragged patches, coordinate nodes, frame end (rare): node by node, scalar neighbour decode ----
 #pragma unroll 1
                 for (int e = 0; e < 2; ++e) {
-                    const int n0 = e ? sd1.n_first : sd0.n_first, cnt = e ? sd1.cnt : sd0.cnt;
+                    const int n0f = e ? sd1.n_first : sd0.n_first, cnt = e ? sd1.cnt : sd0.cnt;
                     const int rl = 16 * p + 8 * e;
 #pragma unroll 1
                     for (int u = 0; u < cnt; ++u) {
-                        *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = agg_stencil(T, xf, dis, n0 + u, lane);
-                        if (s_x) *reinterpret_cast<f32x2*>(&s_x[(rl + u) * LDA + 2 * lane]) = load_row2(xf, n0 + u, lane);
+                        *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = agg_stencil(T, xf, dis, n0f + u, lane);
+                        if (s_x) *reinterpret_cast<f32x2*>(&s_x[(rl + u) * LDA + 2 * lane]) = load_row2(xf, n0f + u, lane);
                     }
                 }
+                issue_all(n0, n1, xfn, kfn, kin_n);                 // (nothing to pipe: this tile's own rows again, never used)
             }
             PSTAMP(2);
+            return nxt;
         };
-        int dv_next = 0;
+        // descriptors travel two tiles ahead (dv_a: the tile produced next, dv_b: the one after it, whose rows are issued)
+        int dv_a = 0, dv_b = 0;
+        bool have = false;
         {
             const int t0 = __builtin_amdgcn_readfirstlane(s_tile[0]);
             const int t1 = __builtin_amdgcn_readfirstlane(s_tile[1]);
-            if (t0 >= 0) produce(t0, 0, 0, lane_k, load_desc(t0, lane_k));
-            if (t1 >= 0) dv_next = load_desc(t1, lane_k);
+            const int t2 = __builtin_amdgcn_readfirstlane(s_tile[2]);
+            int dv0 = 0;
+            if (t0 >= 0) dv0 = load_desc(t0, lane_k);
+            if (t1 >= 0) dv_a = load_desc(t1, lane_k);
+            if (t2 >= 0) dv_b = load_desc(t2, lane_k);
+            if (t0 >= 0) have = produce(t0, 0, 0, lane_k, dv0, false, t1, dv_a);
         }
         __syncthreads();                                   // tile 0 is in buffer 0
         for (int k = 0;; ++k) {
@@ -673,15 +838,17 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             if (t_cur < 0) break;
             const int t_next = __builtin_amdgcn_readfirstlane(s_tile[(k + 1) & 7]);
             const int t_nn = __builtin_amdgcn_readfirstlane(s_tile[(k + 2) & 7]);
+            const int t_n3 = __builtin_amdgcn_readfirstlane(s_tile[(k + 3) & 7]);
             int lane = lane_k;
             asm volatile("" : "+v"(lane));
-            const int dv_cur = dv_next;
-            if (t_nn >= 0) dv_next = load_desc(t_nn, lane);                                 // used by the NEXT iteration
+            const int dv_cur = dv_a, dv_nxt = dv_b;
+            dv_a = dv_b;
+            if (t_n3 >= 0) dv_b = load_desc(t_n3, lane);                                    // used two iterations from now
             int got = 0;
-            if (tid == 256) got = ps_claim_issue(counters, group);                          // three tiles ahead, asynchronous
+            if (tid == 256) got = ps_claim_issue(counters, group);                          // four tiles ahead, asynchronous
             PSTAMP(3);
-            if (t_next >= 0) produce(t_next, (k + 1) & 1, (k + 1) & (PS_DIS_RING - 1), lane, dv_cur);
-            if (tid == 256) ps_claim_commit(counters, group, n_tiles, got, &s_tile[(k + 3) & 7]);
+            if (t_next >= 0) have = produce(t_next, (k + 1) & 1, (k + 1) & (PS_DIS_RING - 1), lane, dv_cur, have, t_nn, dv_nxt);
+            if (tid == 256) ps_claim_commit(counters, group, n_tiles, got, &s_tile[(k + 4) & 7]);
             __syncthreads();                               // barrier k+1
             PSTAMP(3);
         }
@@ -718,9 +885,10 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         int dev = 0;
         EG_HIP_TRY(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            const void* kernels[] = {(const void*)k_gcn_layer_ps<false, false, false>, (const void*)k_gcn_layer_ps<false, false, true>,
+                                     (const void*)k_gcn_layer_ps<false, true, false>, (const void*)k_gcn_layer_ps<false, true, true>,
+                                     (const void*)k_gcn_layer_ps<true, false, false>, (const void*)k_gcn_layer_ps<true, false, true>};
+            for (const void* f : kernels) EG_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
     }
@@ -733,9 +901,9 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out, g->dis, g->topo_dev,
                            g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, g->sink, queue, a, cls ? *cls : none);
     };
-    if (cls) launch(k_gcn_layer_ps<true, false>);
-    else if (kout) launch(k_gcn_layer_ps<false, true>);
-    else launch(k_gcn_layer_ps<false, false>);
+    if (cls) { if (kin) launch(k_gcn_layer_ps<true, false, true>); else launch(k_gcn_layer_ps<true, false, false>); }
+    else if (kout) { if (kin) launch(k_gcn_layer_ps<false, true, true>); else launch(k_gcn_layer_ps<false, true, false>); }
+    else { if (kin) launch(k_gcn_layer_ps<false, false, true>); else launch(k_gcn_layer_ps<false, false, false>); }
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

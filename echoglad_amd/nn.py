@@ -16,6 +16,7 @@ per-landmark coordinate MLP (4 rows per frame).  There is no CPU fallback."""
 from __future__ import annotations
 
 import os
+import sys
 import weakref
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -153,6 +154,63 @@ class _GCNConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+# ---- who owns an incoming gradient buffer? -------------------------------------------------------------------------------
+# _LayerTrainFn.backward and _CoordScatterFn.backward work IN PLACE on the gradient they receive (4 coordinate rows per frame
+# are patched; nothing of [B*N,128] size is cloned, filled or added).  Autograd does not promise that the buffer is theirs
+# alone: Add hands ONE tensor to both inputs (as an expanded view), a tensor hook may keep the very object, a later consumer
+# may read it.  The exclusive case has a fixed signature in a given torch build -- (python references, TensorImpl use count,
+# storage use count, no view base) -- which is measured once on a toy function of the same arity; anything else is cloned.
+def _grad_signature(t: torch.Tensor) -> tuple:
+    return (sys.getrefcount(t), t._use_count(), torch._C._storage_Use_Count(t.untyped_storage()._cdata))
+
+
+_OWN_SIG: Dict[int, Optional[tuple]] = {}
+
+
+def _probe_entry(dy: torch.Tensor, n_out: int, seen: list) -> None:
+    seen.append(_grad_signature(dy))
+
+
+def _calibrate_ownership(n_out: int) -> Optional[tuple]:
+    seen = []
+
+    class _Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return tuple(x * float(k + 2) for k in range(n_out)) if n_out > 1 else x * 2.0
+
+        @staticmethod
+        def backward(ctx, dy, *rest):
+            _probe_entry(dy, n_out, seen)              # same call depth as _own_or_clone below (the frames hold references too)
+            return dy
+
+    try:
+        with torch.enable_grad():
+            x = torch.zeros(2, 2, requires_grad=True)
+            y = _Probe.apply(x)
+            first = y[0] if n_out > 1 else y
+            loss = (first * 3.0).sum()                # a fresh, exclusively owned gradient reaches the probe
+            for other in (y[1:] if n_out > 1 else ()):
+                loss = loss + (other * 5.0).sum()
+            loss.backward()
+        return seen[0]
+    except Exception:                               # an unknown torch build: never assume ownership
+        return None
+
+
+def _own_or_clone(dy: torch.Tensor, n_out: int) -> torch.Tensor:
+    """``dy`` itself when this backward provably holds the only references to it, else a contiguous copy."""
+    if n_out not in _OWN_SIG:
+        _OWN_SIG[n_out] = _calibrate_ownership(n_out)
+    base = _OWN_SIG[n_out]
+    if base is None or dy._base is not None or not dy.is_contiguous():
+        return dy.contiguous() if (dy._base is None and not dy.is_contiguous()) else dy.clone(memory_format=torch.contiguous_format)
+    sig = _grad_signature(dy)
+    if sig[0] > base[0] or sig[1] > base[1] or sig[2] > base[2]:
+        return dy.clone(memory_format=torch.contiguous_format)
+    return dy
+
+
 def _bn_step(bn: nn.BatchNorm1d):
     """What nn.BatchNorm1d.forward decides before calling F.batch_norm: (use batch statistics?, update factor | None).
     Counts the batch in ``num_batches_tracked``; ``momentum=None`` is the cumulative moving average."""
@@ -196,10 +254,12 @@ class _LayerTrainFn(torch.autograd.Function):
     def backward(ctx, dy, dlm):
         z, agg, weight, gamma, beta, bn = ctx.saved_tensors
         graph, batch, relu, p, seed, residual, coord_rows, had_agg = ctx.cfg
-        dy = dy.contiguous()
         if coord_rows is not None and dlm is not None:
+            dy = _own_or_clone(dy, 2)                                     # in place only on a buffer that is provably ours
             B, n, lo = coord_rows
-            dy.view(B, n, C)[:, lo:lo + 4, :] += dlm.view(B, 4, C)        # in place: this node owns the incoming buffer
+            dy.view(B, n, C)[:, lo:lo + 4, :] += dlm.view(B, 4, C)
+        else:
+            dy = dy.contiguous()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and had_agg, ctx.needs_input_grad[2]
         dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dy, z, agg if had_agg else None, weight, gamma, beta, bn,
                                                       relu, p, seed, residual, need_x, need_w)
@@ -227,7 +287,7 @@ class _CoordScatterFn(torch.autograd.Function):
     def backward(ctx, dh):
         h, coords = ctx.saved_tensors
         batch, n, main_base, frame, coord_base = ctx.dims
-        dh = dh.contiguous()
+        dh = _own_or_clone(dh, 1)                                          # in place only on a buffer that is provably ours
         rows = dh.view(batch, n, C)[:, coord_base:coord_base + 4, :]
         dnew = rows.reshape(batch * 4, C).clone()
         rows.zero_()
@@ -485,6 +545,8 @@ class HierarchicalPatchModel(nn.Module):
         # ... and the last layer runs the classifier heads on its output tile inside the kernel (EG_FUSE_CLS=0: separate)
         self.fuse_classifier = os.environ.get("EG_FUSE_CLS", "1") != "0"
         self._kidsum: Dict[tuple, tuple] = {}
+        # optional callable (layer index, layer output incl. residual and coordinate rows) -> None, called by forward_nodes
+        self.layer_output_hook = None
 
     def enable_hip_graph(self, flag: bool = True) -> "HierarchicalPatchModel":
         """Inference only: capture the kernel sequence of ``forward_nodes`` (3 fused layers + classifier
@@ -558,6 +620,10 @@ class HierarchicalPatchModel(nn.Module):
     def _coordinate_update(self, i: int, h: torch.Tensor, node_coords: torch.Tensor, batch: int, lm=None):
         n, _, _, main_base, coord_base = self._row_ranges()
         fs = self.frame_size
+        # lm given: h is the fresh output of _LayerTrainFn, which nothing else has saved for its backward -- only then may
+        # the resampled rows overwrite it in place (the output of a torch module, e.g. the ReLU of the frozen-BatchNorm
+        # fallback, is saved by that module and must not be written to)
+        fresh_layer_output = lm is not None
         # pairwise (other - self) offsets per frame, flattened to 8 numbers per landmark (:441-444)
         if lm is None:
             lm = h.view(batch, n, C)[:, coord_base:, :].reshape(batch * 4, C).clone()
@@ -568,7 +634,7 @@ class HierarchicalPatchModel(nn.Module):
             delta = self.node_coordinate_mlp[i](torch.cat((lm, shape_feats), dim=1))
             new_coords = torch.clamp(node_coords + delta.view(batch, 4, 2), min=0, max=fs - 1)
         node_coords = new_coords
-        if torch.is_grad_enabled() and (h.requires_grad or node_coords.requires_grad) and h.grad_fn is not None:
+        if fresh_layer_output and torch.is_grad_enabled() and (h.requires_grad or node_coords.requires_grad) and h.grad_fn is not None:
             # train step: in place on the layer output, in place on its gradient (no [B*N,128] copies, fills or adds)
             h = _CoordScatterFn.apply(h, node_coords, batch, n, main_base, fs, coord_base)
         else:
@@ -622,8 +688,8 @@ class HierarchicalPatchModel(nn.Module):
         else:
             node_coords = None
         fused = (not self.training) and (not torch.is_grad_enabled() or not node_feats.requires_grad)
-        fused = fused and self.jk is None and not any(p.requires_grad and torch.is_grad_enabled()
-                                                      for p in self.parameters())
+        fused = fused and self.jk is None and self.layer_output_hook is None and not any(
+            p.requires_grad and torch.is_grad_enabled() for p in self.parameters())
         if fused and self.use_hip_graph and not self.use_coordinate_graph and not torch.cuda.is_current_stream_capturing():
             return self._forward_nodes_graphed(node_feats, edge_index, B), None
         hidden = [node_feats.contiguous()]
@@ -659,6 +725,8 @@ class HierarchicalPatchModel(nn.Module):
                     h = h + x_in
             if self.use_coordinate_graph:
                 h, node_coords = self._coordinate_update(i, h, node_coords, B, lm if (self.training and not fused) else None)
+            if self.layer_output_hook is not None:
+                self.layer_output_hook(i, h)              # e.g. h.retain_grad() / h.register_hook(...) in a test
             hidden.append(h)
         h = self.jk(hidden) if self.jk is not None else hidden[-1]
         if fused:

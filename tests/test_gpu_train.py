@@ -521,3 +521,53 @@ def test_cfg4_train_full_batch_32_properties():
         one, cone = hip.forward_nodes(x[f * n:(f + 1) * n].contiguous(), ei1, 1, coords0.view(B, 4, 2)[f:f + 1].reshape(4, 2).clone())
     assert torch.equal(full[f * nv:(f + 1) * nv], one)
     assert torch.equal(cfull.view(B, 4, 2)[f], cone.view(4, 2))
+
+
+def test_in_place_backward_leaves_retained_and_hooked_gradients_intact():
+    """_LayerTrainFn / _CoordScatterFn patch the gradient they receive IN PLACE, but only when the buffer is provably theirs
+    (nn._own_or_clone).  A middle layer's output with retain_grad() and with a hook that KEEPS the gradient object -- the case
+    where the in-place patch would corrupt somebody else's tensor -- must give the oracle's dL/dh, and must not change the
+    parameter gradients."""
+    frame, naux, B, L = 32, 4, 2, 3
+    hip, ref = model_pair(frame, naux, L, coord=True, seed=37)
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    hip.train(); ref.train()
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+    x = synthetic_node_feats(B * topo.num_nodes, 128, seed=3)
+    coords0 = initial_coords(B, frame)
+    state = {k: v.clone() for k, v in hip.state_dict().items()}
+
+    def run(hook):
+        hip.load_state_dict(state)
+        for p in hip.parameters():
+            p.grad = None
+        hip.layer_output_hook = hook
+        try:
+            got, gc = hip.forward_nodes(x.to(DEV), ei.to(DEV), B, coords0.clone().to(DEV))
+            ((got ** 2).mean() + (gc ** 2).mean() * 1e-3).backward()
+        finally:
+            hip.layer_output_hook = None
+        return {k: p.grad.clone() for k, p in hip.named_parameters()}
+
+    plain = run(None)
+    kept, retained = {}, {}
+
+    def hook(i, h):
+        if i == 1:                                                    # middle layer, coordinate rows already resampled
+            h.retain_grad()
+            retained[i] = h
+            h.register_hook(lambda g: kept.setdefault(i, g))          # keeps the very tensor autograd hands on
+    hooked = run(hook)
+    for k in plain:
+        assert torch.allclose(plain[k], hooked[k], rtol=1e-5, atol=1e-7), k       # (a cloned buffer changes no value)
+    # the oracle's gradient w.r.t. the same hidden state
+    want, wc, hidden = ref.forward_nodes(x, ei, nt, B, coords0.clone(), return_hidden=True)
+    hidden[2].retain_grad()
+    ((want ** 2).mean() + (wc ** 2).mean() * 1e-3).backward()
+    g_ref = hidden[2].grad
+    scale = float(g_ref.abs().max())
+    for name, g in (("hook-kept", kept[1]), ("retain_grad", retained[1].grad)):
+        err = float((g.cpu() - g_ref).abs().max())
+        assert err < 5e-3 * scale + 1e-7, (name, err, scale)
