@@ -32,7 +32,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_MFMA_TF = 157.3       # MI355X_MICROARCH.md: dense fp32 MFMA peak
@@ -114,7 +113,7 @@ def model_kwargs(frame, naux, layers, main_only=False, coord=False):
 
 def build_model(kw, device, train=False):
     from echoglad_amd import nn as egnn
-    from fixtures_util import fill_state_dict
+    from echoglad_amd.synthetic import fill_state_dict
     model = egnn.HierarchicalPatchModel(**kw)
     fill_state_dict(model, seed=200)          # glorot-like weights, trained-like BN stats (seed: default.yml:24)
     model = model.to(device)
@@ -130,7 +129,7 @@ def stack_work(topo, layers):
 def infer_workload(frame, naux, layers, main_only, B, device, rank, hip_graph=True):
     import torch
     from echoglad_amd.topology import TopologySpec, get_topology
-    from fixtures_util import synthetic_node_feats
+    from echoglad_amd.synthetic import synthetic_node_feats
     kw = model_kwargs(frame, naux, layers, main_only)
     model = build_model(kw, device)
     model.enable_hip_graph(hip_graph)
@@ -155,7 +154,7 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
     from echoglad_amd.data import node_labels
     from echoglad_amd.parallel import GradientAllReducer, broadcast_parameters
     from echoglad_amd.topology import TopologySpec, get_topology
-    from fixtures_util import initial_coords, synthetic_node_feats
+    from echoglad_amd.synthetic import initial_coords, synthetic_node_feats
     model = build_model(model_kwargs(frame, naux, layers, coord=True), device, train=True)
     topo = get_topology(TopologySpec(frame, naux, False, True))
     N, n_valid = topo.num_nodes, topo.num_valid_nodes
@@ -248,7 +247,7 @@ def cpu_baseline(args, kw, state_dict):
     import torch
     from oracle import gnn_oracle as O
     from echoglad_amd.topology import TopologySpec, get_topology
-    from fixtures_util import synthetic_node_feats
+    from echoglad_amd.synthetic import synthetic_node_feats
     avail = os.cpu_count() or 1
     ref = O.OracleHierarchicalPatchModel(**kw)
     ref.load_state_dict({k: v.cpu() for k, v in state_dict.items()}, strict=True)

@@ -230,9 +230,9 @@ struct eg_graph {
 namespace eg {
 // Classifier heads fused behind the LAST layer of a stack: node-type filter + 4 x [Linear(128,32)-BN-ReLU-Linear(32,16)-
 // BN-ReLU-Linear(16,1)] of src/core/models.py:363-377, :485-490, eval-mode BN folded by the caller (same packing as
-// eg_classifier_fwd).  The layer's output tile never leaves LDS.
+// eg_classifier_fwd); the layer itself is folded into the heads' first layers (eg_cls_fold): its output is never formed.
 struct ClsArgs {
-    const float *w1, *s1, *t1, *w2, *s2, *t2, *w3, *b3;
+    const float *wc, *w1, *s1, *t1c, *w2, *s2, *t2, *w3, *b3;     // wc, t1c: eg_cls_fold
     float* logits;
     int sigmoid;
 };

@@ -89,11 +89,10 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
     float* s_a0 = smem;                               // [2][TILE * LDA]  aggregated tiles
     float* s_x0 = smem + 2 * TILE * LDA;              // [2][TILE * LDA]  raw self rows (residual)
     int* s_tile = reinterpret_cast<int*>(smem + 4 * TILE * LDA);                  // [8] ring of tile ids
-    int* s_sync = s_tile + 8;                         // consumer-only tile counter (CLS)
     int* s_cd = s_tile + 16;                          // [2][8 segments][4] descriptor words of the consumers' epilogue (below)
     float* s_dis0 = smem + PS_LDS_DIS;                // [PS_DIS_RING][TILE] (deg+1)^-1/2 of the tile's rows (child sums of the output)
     float* s_pat = smem + PS_LDS_PAT;                 // [n_pats][64] weight patterns, quad layout (seg_wide.h)
-    float* s_bn = s_pat + a.n_pats * PATQ;            // CLS only: [4][128] layer scale, shift, classifier s1, t1
+    float* s_bn = s_pat + a.n_pats * PATQ;            // CLS only: [2][128] first classifier layers: scale s1, folded shift t1c
 
     const int tid = threadIdx.x;
     const int lane_k = tid & 63;
@@ -111,12 +110,14 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
     for (int i = tid; i < a.n_pats * PATQ; i += PS_THREADS) s_pat[i] = patsq[i];
     if (CLS) {
         if (tid < C) {
-            s_bn[tid] = scale ? scale[tid] : 1.0f;
-            s_bn[C + tid] = shift ? shift[tid] : 0.0f;
-            s_bn[2 * C + tid] = ca.s1[tid];
-            s_bn[3 * C + tid] = ca.t1[tid];
+            s_bn[tid] = ca.s1[tid];
+            s_bn[C + tid] = ca.t1c[tid];
         }
-        if (tid == 0) *s_sync = 0;
+        if (tid < 64) {                                    // second / third classifier layers: [s2 | t2 | w3] x [4 heads x 16]
+            s_bn[2 * C + tid] = ca.s2[tid];
+            s_bn[2 * C + 64 + tid] = ca.t2[tid];
+            s_bn[2 * C + 128 + tid] = ca.w3[tid];
+        }
     }
     __syncthreads();
 
@@ -322,230 +323,124 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         }
 #endif
         } else {
-        // =========================== CONSUMER: channels 32*wave .. 32*wave+31 ===================================
-        // the wave's slice of W: fp32 (exact, the default) or split into bf16 hi / lo parts (opt-in bf16x3 product, tile.h)
-        constexpr bool RES_LATE = true;
-        float wreg[64];
-        load_w_slice(W, wave, lane_k, a.transpose_w, wreg);
-        f32x4 sc[4], sh[4];
-        if (!CLS) {
+        // =========================== CONSUMER with the classifier heads: wave = head ==============================
+        // The stack's last layer has no activation (models.py:335), so layer + residual + first classifier layer are ONE
+        // linear map of what is in LDS anyway:
+        //     hidden_pre = (A_hat x) Wc^T + x W1^T + const,    Wc = W1 diag(scale) W,   const = W1 shift   (eg_cls_fold)
+        // i.e. a K = 256 product over the aggregated tile and the stash of raw rows: no output tile, no LDS round trip, no
+        // meeting point of the four waves.  Orientation channels x rows (lane = tile row, 16 hidden channels per lane), so
+        // Linear(32,16) runs straight from the accumulator: step t of v_mfma_f32_32x32x2_f32 takes accumulator register t as its
+        // B operand (k = lane half <-> hidden channel (t & 3) + 8 (t >> 2) + 4 h) against W2 laid out the same way; BN + ReLU +
+        // the 16-wide dot follow on the result (8 outputs per lane, one cross-half add).
+        float wA[64], wB[64];
+        load_w_slice(ca.wc, wave, lane_k, 0, wA);
+        const bool has_res = a.has_res != 0;
+        if (has_res) load_w_slice(ca.w1, wave, lane_k, 0, wB);
+        else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch0 = 32 * wave + 8 * g + 4 * (lane_k >> 5);
-                sc[g] = scale ? *reinterpret_cast<const f32x4*>(scale + ch0) : f32x4{1.f, 1.f, 1.f, 1.f};
-                sh[g] = shift ? *reinterpret_cast<const f32x4*>(shift + ch0) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int i = 0; i < 64; ++i) wB[i] = 0.f;
         }
-        // CLS: wave = classifier head.  First-layer slice of the stacked [128,128] weight in 64 more VGPRs (the per-channel
-        // scale / shift vectors of both stages then live in LDS, not in registers); second layer as in classifier.hip:
-        // MFMA 16x16x4 A operand lane (o = l & 15, kq = l >> 4) holds W2[head][o][8 kq + s].
-        float wreg2[64];                                // (stays exact fp32 in the bf16x3 experiment too: the heads amplify the error)
-        float w2a[8];
-        f32x4 s2v, t2v, w3v;
-        float b3v = 0.f;
-        if (CLS) {
-            load_w_slice(ca.w1, wave, lane_k, 0, wreg2);
-            const f32x4* pw = reinterpret_cast<const f32x4*>(ca.w2 + (size_t)(wave * 16 + (lane_k & 15)) * 32 + 8 * (lane_k >> 4));
-            const f32x4 q0 = pw[0], q1 = pw[1];
-            w2a[0] = q0.x; w2a[1] = q0.y; w2a[2] = q0.z; w2a[3] = q0.w; w2a[4] = q1.x; w2a[5] = q1.y; w2a[6] = q1.z; w2a[7] = q1.w;
-            const int o4 = wave * 16 + 4 * (lane_k >> 4);
-            s2v = *reinterpret_cast<const f32x4*>(ca.s2 + o4);
-            t2v = *reinterpret_cast<const f32x4*>(ca.t2 + o4);
-            w3v = *reinterpret_cast<const f32x4*>(ca.w3 + o4);
-            b3v = ca.b3[wave];
+        const int j = lane_k & 31, hq = lane_k >> 5;
+        float w2r[16];                                    // W2[head][o = j][hidden channel of (step t, half hq)], 0 for o >= 16
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int c = (t & 3) + 8 * (t >> 2) + 4 * hq;
+            w2r[t] = j < 16 ? ca.w2[(size_t)(wave * 16 + j) * 32 + c] : 0.f;
         }
         __syncthreads();                                   // tile 0 is in buffer 0
         PSTAMP_INIT;
 #ifdef EG_STAMP
-        // in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): shader cycles / 100 MHz ticks around the tile loop
         const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+        // s_bn: [0,128) s1, [128,256) t1c (first-layer scale / shift per hidden channel); second-layer constants per head
+        const float* const s1p = s_bn + 32 * wave + 4 * hq;               // + 8 g: the lane's hidden channels 4g .. 4g+3 of group g
+        const float* const t1p = s1p + C;
+        // second-layer result: lane (row, half hq') holds outputs o = (e & 3) + 8 (e >> 2) + 4 hq', e = 0..7
+        const float* const l2p = s_bn + 2 * C + wave * 16 + 4 * hq;      // s2 | t2 | w3 ([3][64]) at this lane's outputs
+        const float b3v = ca.b3[wave];
+        // hidden = relu(s1 * pre + t1c) in place on an accumulator (group g = registers 4g .. 4g+3)
+        auto hidden_group = [&](f32x16& acc, int g) {
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(s1p + 8 * g), tv = *reinterpret_cast<const f32x4*>(t1p + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * g + e] = fmaxf(fmaf(acc[4 * g + e], sv[e], tv[e]), 0.f);
+        };
+        auto second_layer = [&](const f32x16& hid, float (&zs)[8]) {       // (only outputs 0..15 = registers 0..7 are kept)
+            f32x16 z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) z = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[t], hid[t], z, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zs[e] = z[e];
+        };
+        // BN + ReLU + Linear(16,1) (+ sigmoid) of one 32-row block and its store; lg: this lane's logit address (a word of the
+        // dump area for lanes without a node: no branch inside an MFMA chain)
+        const bool sigm = ca.sigmoid != 0;
+        auto third_layer = [&](const float (&z)[8], int node) {          // node: frame rows + node id of this lane's row, -1: none
+            const f32x4 s2a = *reinterpret_cast<const f32x4*>(l2p), s2b = *reinterpret_cast<const f32x4*>(l2p + 8);
+            const f32x4 t2a = *reinterpret_cast<const f32x4*>(l2p + 64), t2b = *reinterpret_cast<const f32x4*>(l2p + 72);
+            const f32x4 w3a = *reinterpret_cast<const f32x4*>(l2p + 128), w3b = *reinterpret_cast<const f32x4*>(l2p + 136);
+            float y = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y = fmaf(w3a[e], fmaxf(fmaf(z[e], s2a[e], t2a[e]), 0.f), y);
+                y = fmaf(w3b[e], fmaxf(fmaf(z[4 + e], s2b[e], t2b[e]), 0.f), y);
+            }
+            y += __shfl_xor(y, 32);
+            y += b3v;
+            const float ys = 1.0f / (1.0f + __expf(-y));
+            float* const lg = node >= 0 ? ca.logits + ((size_t)(unsigned)node * 4 + wave)
+                                        : sink_base + ((size_t)blockIdx.x * PS_SINK_FLOATS + lane_k);
+            *lg = sigm ? ys : y;
+        };
+        f32x16 acc0, acc1;
+        float z0[8], z1[8];
+        int lg0 = -1, lg1 = -1;                           // logit rows of the previous tile's two blocks (finished one tile late)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { z0[e] = 0.f; z1[e] = 0.f; }
         for (int k = 0;; ++k) {
             const int t_cur = __builtin_amdgcn_readfirstlane(s_tile[k & 7]);
             if (t_cur < 0) break;
-            const int t_nx = __builtin_amdgcn_readfirstlane(s_tile[(k + 1) & 7]);
             int lane = lane_k;
             asm volatile("" : "+v"(lane));
-            const int cd = s_cd[(k & 1) * 32 + (lane & 31)];
-            PSTAMP(3);
-            float* s_a = s_a0 + (k & 1) * TILE * LDA;
-            float* s_x = s_x0 + (k & 1) * TILE * LDA;
+            const float* s_a = s_a0 + (k & 1) * TILE * LDA;
+            const float* s_x = s_x0 + (k & 1) * TILE * LDA;
             const int frame = t_cur / a.tiles_per_frame;
-            int seg_first[8], seg_cnt[8];
+            // this lane's node of each block: patch row 4 rb + (j >> 3), column j & 7 (descriptor ring: {n_first, cnt, ., .})
+            const int* cdp = s_cd + (k & 1) * 32 + 4 * (j >> 3);
+            const int f0 = cdp[0], c0 = cdp[1], f1 = cdp[16], c1 = cdp[17];
+            const int nlg0 = (hq == 0 && (j & 7) < c0) ? frame * a.n_per_frame + f0 + (j & 7) : -1;
+            const int nlg1 = (hq == 0 && (j & 7) < c1) ? frame * a.n_per_frame + f1 + (j & 7) : -1;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                seg_first[i] = __builtin_amdgcn_readlane(cd, 4 * i);
-                seg_cnt[i] = __builtin_amdgcn_readlane(cd, 4 * i + 1);
-            }
-            // Child sums of the OUTPUT for the next layer (kout): lane -> (parent q = (lane >> 3) + 8 i, 16-B chunk lane & 7);
-            // the parent's four children are rows 2 pr, 2 pr + 1, columns 2 pc, 2 pc + 1 of this patch.
-            int kout_row[2];
-            if (kout) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bool odd = (lane >> 5) != 0;                  // pr = 2 i + odd: segments 4 i (even pr) / 4 i + 2
-                    const int pc = (lane >> 3) & 3;
-                    const int npar = odd ? __builtin_amdgcn_readlane(cd, 4 * (4 * i + 2) + 3) : __builtin_amdgcn_readlane(cd, 4 * (4 * i) + 3);
-                    const int par0 = odd ? __builtin_amdgcn_readlane(cd, 4 * (4 * i + 2) + 2) : __builtin_amdgcn_readlane(cd, 4 * (4 * i) + 2);
-                    kout_row[i] = pc < npar ? par0 + pc : -1;
-                }
-            }
-            f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            f32x16 acc1 = acc0;
-            // Epilogue pieces, all branch-free so that they can sit in one scheduling region with MFMAs.
-            // Lane (row j of a 32-row block, half h) holds 16 channels of ONE row: stored from there a wave instruction
-            // would touch 32 rows x 32 B.  The finished values go back into this wave's own channel slice of the stash
-            // instead (where the residual was read from; no other wave touches that slice), are re-read 8 lanes per row,
-            // and leave as whole 128-B line segments: 8 stores per wave and tile.
-            const int j = lane & 31, h = lane >> 5;
-            const float relu_floor = a.relu ? 0.f : -__builtin_inff();
-            const bool has_res = a.has_res != 0;
-            // residual rows of both 32-row blocks, read BEFORE the MFMA chains: an LDS wait inside a chain stalls the
-            // wave's next MFMA as well (in-order issue)
-            f32x4 res[2][4];
-            if (!RES_LATE) {                                                  // (the fused-classifier variant has no registers to spare)
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        res[rb][g] = *reinterpret_cast<const f32x4*>(s_x + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g);
-            }
-            auto finish_group = [&](const f32x16& acc, int rb, int g) {          // 4 channels of row 32 rb + j -> LDS
-                float* xp = s_x + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g;   // LDS row = 8 * patch row + column
-                f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                if (CLS) {
-                    const float* bp = s_bn + 32 * wave + 4 * h + 8 * g;
-                    v = v * *reinterpret_cast<const f32x4*>(bp) + *reinterpret_cast<const f32x4*>(bp + C);
-                } else {
-                    v = v * sc[g] + sh[g];
-                }
-                v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-                const f32x4 r = RES_LATE ? *reinterpret_cast<const f32x4*>(xp) : res[rb][g];
-                v.x += has_res ? r.x : 0.f; v.y += has_res ? r.y : 0.f; v.z += has_res ? r.z : 0.f; v.w += has_res ? r.w : 0.f;
-                *reinterpret_cast<f32x4*>(xp) = v;
-            };
-            const int u8 = lane >> 3, c4 = 4 * (lane & 7);
-            float* ob = out + (size_t)frame * a.n_per_frame * C + 32 * wave + c4;
-            f32x4 o[4];
-            int node[4];
-            auto read_segments = [&](int i0) {                                   // patch rows i0 .. i0+3: 8 lanes per row
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // an absent segment (ragged patch) repeats segment 0, a short one its last node: identical stores
-                    const int i = seg_cnt[i0 + e] > 0 ? i0 + e : 0;
-                    const int cnt = seg_cnt[i0 + e] > 0 ? seg_cnt[i0 + e] : seg_cnt[0];
-                    const int first = seg_cnt[i0 + e] > 0 ? seg_first[i0 + e] : seg_first[0];
-                    const int u = u8 < cnt ? u8 : cnt - 1;
-                    o[e] = *reinterpret_cast<const f32x4*>(s_x + (8 * i + u) * LDA + 32 * wave + c4);
-                    node[e] = first + u;
-                }
-            };
-            auto store_segments = [&]() {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(ob + (size_t)node[e] * C) = o[e];
-            };
-#ifndef EG_ABL_NO_MFMA
-            // rows 32..63: the MFMA chain leaves ~60 issue cycles per instruction free; the epilogue of rows 0..31
-            // (VALU, LDS, and its global stores) is placed between the chunks of the chain, every LDS read one chunk
-            // ahead of its use
-            auto between = [&](int c) {
-                if (c < 2) { finish_group(acc0, 0, 2 * c); finish_group(acc0, 0, 2 * c + 1); }
-                else if (!CLS && c == 2) read_segments(0);
-                else if (!CLS) store_segments();
-            };
-            mfma_rowblock(s_a, 0, lane, wreg, acc0);
-            mfma_rowblock_with(s_a, 32, lane, wreg, acc1, between);
-#else
-            acc0[0] = wreg[0] + s_a[lane]; acc1[0] = wreg[63];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
-            if (!CLS) { read_segments(0); store_segments(); }
-#endif
+            for (int e = 0; e < 16; ++e) acc0[e] = 0.f;
+            // rows 0..31: K = 128 over the aggregated tile (third layers of the previous tile in the gaps), K = 128 over the raw rows
+            mfma_rowblock_lean<false>(s_a, 0, lane, wA, acc0, [&](int c) {
+                if (c == 0) third_layer(z0, lg0);
+                if (c == 1) third_layer(z1, lg1);
+            });
+            if (has_res) mfma_rowblock_lean<false>(s_x, 0, lane, wB, acc0, [](int) {});
             PSTAMP(0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) finish_group(acc1, 1, g);
-            if (!CLS) {
-                read_segments(4);
-                store_segments();
-                if (kout) {
-                    float* kb = kout + (size_t)frame * a.kid_rows * C + 32 * wave + c4;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int q = (lane >> 3) + 8 * i;
-                        const int ra = 16 * (q >> 2) + 2 * (q & 3);            // LDS row of child (2 pr, 2 pc)
-                        const float* sp = s_x + ra * LDA + 32 * wave + c4;
-                        const float* dp = s_dis0 + (k & (PS_DIS_RING - 1)) * TILE + ra;
-                        f32x4 ks = dp[0] * *reinterpret_cast<const f32x4*>(sp);
-                        ks += dp[1] * *reinterpret_cast<const f32x4*>(sp + LDA);
-                        ks += dp[8] * *reinterpret_cast<const f32x4*>(sp + 8 * LDA);
-                        ks += dp[9] * *reinterpret_cast<const f32x4*>(sp + 9 * LDA);
-                        if (kout_row[i] >= 0) *reinterpret_cast<f32x4*>(kb + (size_t)kout_row[i] * C) = ks;
-                    }
-                }
-            } else {
-                // ---- classifier heads on the finished tile (all 128 channels of it are needed: the four consumer waves
-                // meet on an LDS counter; the producers are not involved and keep filling the other buffer) -------------
-                PSTAMP(1);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_fetch_add(s_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int target = 4 * (k + 1);
-                while (__hip_atomic_load(s_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                PSTAMP(2);                                 // (stamp builds: the consumers' wait for each other counts as barrier time)
-                // first layers: hidden[row][32 wave + c] = relu(bn(h3[row][:] . W1[32 wave + c][:])), into this wave's column
-                // slice of the A tile (dead now: every wave is past its MFMAs on it)
-                f32x16& hc0 = acc0;
-                f32x16& hc1 = acc1;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { hc0[i] = 0.f; hc1[i] = 0.f; }
-                auto hidden_group = [&](const f32x16& hc, int rb, int g) {
-                    const float* bp = s_bn + 2 * C + 32 * wave + 4 * h + 8 * g;
-                    f32x4 v = f32x4{hc[4 * g], hc[4 * g + 1], hc[4 * g + 2], hc[4 * g + 3]};
-                    v = v * *reinterpret_cast<const f32x4*>(bp) + *reinterpret_cast<const f32x4*>(bp + C);
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    *reinterpret_cast<f32x4*>(s_a + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g) = v;
-                };
-                mfma_rowblock(s_x, 0, lane, wreg2, hc0);
-                mfma_rowblock_with(s_x, 32, lane, wreg2, hc1, [&](int c) { hidden_group(hc0, 0, c); });
-                PSTAMP(3);                                 // (stamp builds: the second GEMM counts as "loop")
-#pragma unroll
-                for (int g = 0; g < 4; ++g) hidden_group(hc1, 1, g);
-                // second / third layers per 16-row block: K = 32 on the MFMA (8 x 16x16x4), BN + ReLU + the 16-wide dot
-                // on the accumulator (4 outputs per lane, two cross-lane adds), as in classifier.hip
-                const int j16 = lane & 15, kq = lane >> 4;
-                float* lg = ca.logits + ((size_t)frame * a.n_per_frame) * 4 + wave;
-                f32x4 hb[4][2];
-#pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4) {
-                    const f32x4* hp = reinterpret_cast<const f32x4*>(s_a + (16 * b4 + j16) * LDA + 32 * wave + 8 * kq);
-                    hb[b4][0] = hp[0]; hb[b4][1] = hp[1];
-                }
-                f32x4v z[4];
-#pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4) z[b4] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 8; ++t)                       // the four 16-row blocks interleaved: independent chains
-#pragma unroll
-                    for (int b4 = 0; b4 < 4; ++b4)
-                        z[b4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[t], hb[b4][t >> 2][t & 3], z[b4], 0, 0, 0);
-#pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4) {
-                    float y = w3v.x * fmaxf(z[b4].x * s2v.x + t2v.x, 0.f) + w3v.y * fmaxf(z[b4].y * s2v.y + t2v.y, 0.f) +
-                              w3v.z * fmaxf(z[b4].z * s2v.z + t2v.z, 0.f) + w3v.w * fmaxf(z[b4].w * s2v.w + t2v.w, 0.f);
-                    y += __shfl_xor(y, 16);
-                    y += __shfl_xor(y, 32);
-                    y += b3v;
-                    if (ca.sigmoid) y = 1.0f / (1.0f + __expf(-y));
-                    const bool hi = (j16 >> 3) != 0;                     // patch row 2 b4 + hi, column j16 & 7
-                    const int first = hi ? seg_first[2 * b4 + 1] : seg_first[2 * b4];
-                    const int cnt = hi ? seg_cnt[2 * b4 + 1] : seg_cnt[2 * b4];
-                    if (kq == 0 && (j16 & 7) < cnt) lg[(size_t)(first + (j16 & 7)) * 4] = y;
-                }
-            }
+            for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+            // rows 32..63, with BN + ReLU of rows 0..31 in the gaps
+            mfma_rowblock_lean<false>(s_a, 32, lane, wA, acc1, [&](int c) { hidden_group(acc0, c); });
+            if (has_res) mfma_rowblock_lean<false>(s_x, 32, lane, wB, acc1, [](int) {});
             PSTAMP(1);
+            // second layers (16 MFMAs per block); BN + ReLU of rows 32..63 runs beside those of rows 0..31
+            second_layer(acc0, z0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) hidden_group(acc1, g);
+            second_layer(acc1, z1);
+            lg0 = nlg0;
+            lg1 = nlg1;
+            PSTAMP(3);
             __syncthreads();                               // barrier k+1: buffer (k+1)&1 is full, buffer k&1 is free
             PSTAMP(2);
         }
+        third_layer(z0, lg0);                              // the last tile's blocks
+        third_layer(z1, lg1);
         PSTAMP_FLUSH(0);
 #ifdef EG_STAMP
         if (wave == 0 && lane_k == 0) {
@@ -847,7 +742,9 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             int got = 0;
             if (tid == 256) got = ps_claim_issue(counters, group);                          // four tiles ahead, asynchronous
             PSTAMP(3);
+#ifndef EG_ABL_NO_PROD       // timing-only ablation (results wrong): the consumers alone, on whatever is in LDS
             if (t_next >= 0) have = produce(t_next, (k + 1) & 1, (k + 1) & (PS_DIS_RING - 1), lane, dv_cur, have, t_nn, dv_nxt);
+#endif
             if (tid == 256) ps_claim_commit(counters, group, n_tiles, got, &s_tile[(k + 4) & 7]);
             __syncthreads();                               // barrier k+1
             PSTAMP(3);

@@ -327,6 +327,9 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph
                     if (npar > 0 && (!sa.pad0 || par_raw != sa.par0 || par_raw + npar > kid_rows)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: parent t=%zu tr=%d level=%d pad0=%d par_raw=%d par0=%d npar=%d kid_rows=%d modes %d %d\n", t, tr, td.level, sa.pad0, par_raw, sa.par0, npar, kid_rows, sa.mode, sb.mode); }
                     sa.pad1 = npar;
                     const bool kids = d.kind == KIND_AUX && ((r >= d.clo && r < d.chi) || (r + 1 >= d.clo && r + 1 < d.chi)) && c0 < d.chi && c0 + 8 > d.clo;
+                    // the pair path reads runs of 8 child-sum rows from each segment's first node: they must stay inside the
+                    // frame's slice of the side buffer (tiny pyramids only: a 2x2 or 4x4 level right at its end)
+                    if (kids && (sa.n_first + 8 > kid_rows || sb.n_first + 8 > kid_rows)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: 8-row run past the side buffer t=%zu tr=%d\n", t, tr); }
                     if (kids && !sa.pad0) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: kids unpaired t=%zu tr=%d level=%d\n", t, tr, td.level); }      // a segment that would read the side buffer is not on the pair path
                 }
             }

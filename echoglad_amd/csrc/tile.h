@@ -489,7 +489,11 @@ __device__ inline void mfma_chunk(const f32x4 (&av)[4], const float (&wreg)[64],
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float w = wreg[4 * (t0 + t) + e], v = av[t][e];
+#ifdef EG_ABL_NO_MFMA       // timing-only ablation (results wrong): the memory side and the epilogue without the matrix work
+            acc[e] += w + v;
+#else
             acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(v, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w, v, acc, 0, 0, 0);
+#endif
         }
     }
 }
@@ -539,6 +543,36 @@ __device__ inline void mfma_rowblock_with(const float* s_a, int row0, int lane, 
     pin_mfma(acc);
     mfma_chunk<SWAP>(a1, wreg, 12, acc, 1, 4);
     between(3);
+}
+
+// Register-lean form of the same chain: the fragments live in 2 x 8 registers (half-chunks of two ds_read_b128, re-read 8 MFMAs
+// = 512 cycles ahead of their use) instead of 2 x 16.  between(c), c = 0..3, as above.
+template <bool SWAP = false, typename F>
+__device__ inline void mfma_rowblock_lean(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc, F between) {
+    const int j = lane & 31, h = lane >> 5;
+    const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
+    f32x4 af[2][2];
+    af[0][0] = ap[0]; af[0][1] = ap[1];
+    af[1][0] = ap[2]; af[1][1] = ap[3];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int hc = 0; hc < 8; ++hc) {
+        const int b = hc & 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float w = wreg[8 * hc + e], v = af[b][0][e];
+            acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(v, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w, v, acc, 0, 0, 0);
+        }
+        pin_mfma(acc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float w = wreg[8 * hc + 4 + e], v = af[b][1][e];
+            acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(v, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w, v, acc, 0, 0, 0);
+        }
+        if (hc & 1) between(hc >> 1);
+        if (hc + 2 < 8) { af[b][0] = ap[2 * (hc + 2)]; af[b][1] = ap[2 * (hc + 2) + 1]; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <bool SWAP = false>

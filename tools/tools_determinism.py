@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(R, "tests", "golden"))
 import torch  # noqa: E402
 
 from echoglad_amd import ops  # noqa: E402
-from fixtures_util import synthetic_node_feats  # noqa: E402
+from echoglad_amd.synthetic import synthetic_node_feats  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -44,7 +44,7 @@ def soak_train(reps):
     """One configs[3] training step (224/7 + coordinate graph, batch 32, dropout 0.5) repeated from the same state and host
     RNG seed: logits, coordinates and every parameter gradient must come out bit-identical."""
     import copy
-    from fixtures_util import initial_coords
+    from echoglad_amd.synthetic import initial_coords
     from gpu_util import graph_tensors, model_pair
     frame, naux, B = 224, 7, 32
     hip, _ = model_pair(frame, naux, 3, coord=True, seed=17)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 from echoglad_amd import ops
 from echoglad_amd.topology import TopologySpec, get_topology
-from fixtures_util import synthetic_node_feats
+from echoglad_amd.synthetic import synthetic_node_feats
 
 def timeit(fn, iters=20):
     for _ in range(3): fn()

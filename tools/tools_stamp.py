@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 import torch
 from echoglad_amd import ops, _lib
-from fixtures_util import synthetic_node_feats
+from echoglad_amd.synthetic import synthetic_node_feats
 B = 8
 g = ops.Graph.topo(224, 7)
 x = synthetic_node_feats(B * g.num_nodes, 128, 1).cuda()

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 from echoglad_amd import nn as egnn
 from echoglad_amd.topology import TopologySpec, get_topology
-from fixtures_util import fill_state_dict, synthetic_node_feats
+from echoglad_amd.synthetic import fill_state_dict, synthetic_node_feats
 B = 8
 kw = dict(frame_size=224, gnn_dropout_p=0.5, classifier_dropout_p=0.5, node_embedding_dim=128, node_hidden_dim=128,
           num_output_channels=4, num_gnn_layers=3, num_aux_graphs=7, classifier_hidden_dim=32, output_activation="logit")
