@@ -54,8 +54,7 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_graph_kidsum_rows": (_i64, [_p]),
     "eg_graph_fused_classifier_ok": (_i, [_p]),
     "eg_gcn_layer_fwd_chain": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
-    "eg_cls_fold": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "eg_gcn_layer_cls_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "eg_gcn_layer_cls_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "eg_gcn_aggregate": (_i, [_p, _i, _p, _p, _p]),
     "eg_linear128_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _i, _i, _p, _p]),
     "eg_classifier_fwd": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),

@@ -130,39 +130,9 @@ __global__ __launch_bounds__(CLS_THREADS, 4) void k_classifier(const float* __re
     }
 }
 
-// ---- eg_cls_fold: the stack's last layer folded into the heads' first layers (gcn_layer_ps.hip, CLS) ---------------------
-//   h3 = (A_hat x) W^T * scale + shift (+ x),   hidden_pre = h3 W1^T   ==>   hidden_pre = (A_hat x) Wc^T (+ x W1^T) + W1 shift
-//   Wc[c][k] = sum_ch W1[c][ch] scale[ch] W[ch][k]          t1c[c] = t1[c] + s1[c] * sum_ch W1[c][ch] shift[ch]
-// One workgroup per hidden channel c, thread = k; fp64 accumulation, one rounding to fp32 at the end.
-__global__ __launch_bounds__(128) void k_cls_fold(const float* __restrict__ W, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                  const float* __restrict__ w1, const float* __restrict__ s1, const float* __restrict__ t1,
-                                                  float* __restrict__ wc, float* __restrict__ t1c) {
-    __shared__ double s_red[128];
-    const int c = blockIdx.x, k = threadIdx.x;
-    double acc = 0.0;
-    for (int ch = 0; ch < C; ++ch)
-        acc += (double)w1[c * C + ch] * (double)(scale ? scale[ch] : 1.0f) * (double)W[ch * C + k];
-    wc[c * C + k] = (float)acc;
-    s_red[k] = (double)w1[c * C + k] * (double)(shift ? shift[k] : 0.0f);
-    __syncthreads();
-    for (int st = 64; st > 0; st >>= 1) {
-        if (k < st) s_red[k] += s_red[k + st];
-        __syncthreads();
-    }
-    if (k == 0) t1c[c] = (float)((double)t1[c] + (double)s1[c] * s_red[0]);
-}
-
 }  // namespace eg
 
 using namespace eg;
-
-extern "C" int eg_cls_fold(const float* W, const float* scale, const float* shift, const float* w1, const float* s1, const float* t1,
-                           float* wc, float* t1c, eg_stream_t stream) {
-    if (!W || !w1 || !s1 || !t1 || !wc || !t1c) return set_error(EG_ERR_ARG, "NULL argument");
-    hipLaunchKernelGGL(k_cls_fold, dim3(C), dim3(128), 0, (hipStream_t)stream, W, scale, shift, w1, s1, t1, wc, t1c);
-    EG_HIP_TRY(hipGetLastError());
-    return EG_OK;
-}
 
 extern "C" int eg_classifier_fwd(const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                                  const float* w1, const float* s1, const float* t1, const float* w2, const float* s2,

@@ -182,16 +182,6 @@ constexpr int QUEUE_SLOTS = 64;
 #endif
 constexpr int QUEUE_TAIL_INTS = 64;     // stamp statistics (diagnostic builds)
 
-// Producer/consumer layer kernel (gcn_layer_ps.hip): dynamic LDS = 2 aggregated tiles + 2 stashes of raw rows, the tile-id ring,
-// a ring of per-tile (deg+1)^-1/2 slices (read one tile late by the deferred epilogue), the weight-pattern table and, with the
-// classifier heads fused in, 4 x 128 per-channel constants.
-constexpr int PS_DIS_RING = 4;
-constexpr int PS_MAX_GRID = 1024;       // persistent workgroups at most (EG_PS_GRID is clamped to it)
-constexpr int PS_SINK_FLOATS = 8 * C;   // per workgroup: dump area for the epilogue stores of tiles that have nothing to store
-inline size_t ps_lds_bytes(int n_pats, bool cls) {
-    return (size_t)(4 * TILE * LDA + 16 + 64 + PS_DIS_RING * TILE + n_pats * 64 + (cls ? 4 * C : 0)) * sizeof(float);
-}
-
 }  // namespace eg
 
 // The opaque handle of the public ABI.
@@ -214,7 +204,6 @@ struct eg_graph {
     int* colidx;              // device [nnz]
     int64_t nnz;
     int symmetric;            // kind == GRAPH_CSR: the kept edge multiset equals its transpose (A_hat^T == A_hat)
-    float* sink;              // device [PS_MAX_GRID][PS_SINK_FLOATS] dump area of the producer/consumer kernel (kind == GRAPH_TOPO)
     int* walk_counters;       // device [QUEUE_SLOTS][8 x 32] ring of per-launch tile-queue heads (+ QUEUE_TAIL_INTS)
     mutable std::atomic<unsigned> launch_seq;   // next slice of the ring (the only host state a launch touches)
     eg::Knobs knobs;          // environment knobs, read once at creation
@@ -230,9 +219,9 @@ struct eg_graph {
 namespace eg {
 // Classifier heads fused behind the LAST layer of a stack: node-type filter + 4 x [Linear(128,32)-BN-ReLU-Linear(32,16)-
 // BN-ReLU-Linear(16,1)] of src/core/models.py:363-377, :485-490, eval-mode BN folded by the caller (same packing as
-// eg_classifier_fwd); the layer itself is folded into the heads' first layers (eg_cls_fold): its output is never formed.
+// eg_classifier_fwd).  The layer's output tile never leaves LDS.
 struct ClsArgs {
-    const float *wc, *w1, *s1, *t1c, *w2, *s2, *t2, *w3, *b3;     // wc, t1c: eg_cls_fold
+    const float *w1, *s1, *t1, *w2, *s2, *t2, *w3, *b3;
     float* logits;
     int sigmoid;
 };

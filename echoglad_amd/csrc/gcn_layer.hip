@@ -461,15 +461,16 @@ int eg_graph_fused_classifier_ok(const eg_graph* g) {
     return g && g->kind == GRAPH_TOPO && (g->kid_rows > 0 || g->flat) && g->topo.coord_base >= g->n_nodes;
 }
 
-int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* wc, const float* residual, const float* kidsum_in,
-                         const float* w1, const float* s1, const float* t1c, const float* w2, const float* s2, const float* t2,
+int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
+                         const float* shift, const float* residual, int relu, const float* kidsum_in, const float* w1,
+                         const float* s1, const float* t1, const float* w2, const float* s2, const float* t2,
                          const float* w3, const float* b3, int sigmoid, float* logits, eg_stream_t stream) {
-    if (!x || !wc || !logits || !w1 || !s1 || !t1c || !w2 || !s2 || !t2 || !w3 || !b3) return set_error(EG_ERR_ARG, "NULL argument");
+    if (!x || !W || !logits || !w1 || !s1 || !t1 || !w2 || !s2 || !t2 || !w3 || !b3) return set_error(EG_ERR_ARG, "NULL argument");
     if (!g || batch <= 0) return set_error(EG_ERR_ARG, "bad graph handle or batch");
     if (g->kind != GRAPH_TOPO || g->topo.coord_base < g->n_nodes)
         return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs a topology handle whose rows are all valid nodes (no coordinate nodes)");
-    eg::ClsArgs c{wc, w1, s1, t1c, w2, s2, t2, w3, b3, logits, sigmoid};
-    const int rc = eg_launch_layer_ps(g, batch, x, wc, nullptr, nullptr, residual, 0, 0, nullptr, kidsum_in, nullptr, &c,
+    eg::ClsArgs c{w1, s1, t1, w2, s2, t2, w3, b3, logits, sigmoid};
+    const int rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, 0, nullptr, kidsum_in, nullptr, &c,
                                       (hipStream_t)stream);
     if (rc == EG_ERR_UNSUPPORTED)
         return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs eg_graph_fused_classifier_ok() and residual in {NULL, x}");

@@ -161,99 +161,4 @@ __device__ inline void segw_store(int lane, const float* wq, const f32x4 (&acc)[
     }
 }
 
-// ---- register-resident pair, one tile ahead -------------------------------------------------------------------------
-// The producers keep the rows of the NEXT tile in flight while they aggregate the current one: every group of registers is
-// re-issued for the next tile right after its last use, so a load has a whole tile period to land (a CU sustains its share
-// of HBM only with ~60 KB in flight all the time; issued in one burst in front of the FMAs that need them, the loads cost
-// an exposed round trip per tile and leave the memory pipe idle for the rest of the period).
-// Stage order (the same order of additions per node as segw_rows): self + left + right, above, below, parents, child sums.
-struct PairRegs {
-    f32x4 Sa[4], Sb[4], LRa, LRb, U[4], D[4], P[2];      // as SegPair
-    f32x4 Ka[4], Kb[4];                                  // child-sum rows of the two segments (aux levels, chained layers)
-};
-
-__device__ inline void pair_issue_lr(const SegDesc& sa, const SegDesc& sb, const float* __restrict__ xf, const PairLane& pl, PairRegs& R) {
-    R.LRa = *reinterpret_cast<const f32x4*>(xf + bcast_off(pl.h ? sa.left : sa.right, pl));
-    R.LRb = *reinterpret_cast<const f32x4*>(xf + bcast_off(pl.h ? sb.left : sb.right, pl));
-}
-__device__ inline void pair_issue_u(const SegDesc& sa, const float* __restrict__ xf, const PairLane& pl, PairRegs& R) {
-    const unsigned ou = pair_off(sa.up0, pl);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) R.U[k] = ld4(xf, ou, k);
-}
-__device__ inline void pair_issue_s(const SegDesc& sa, const SegDesc& sb, const float* __restrict__ xf, const PairLane& pl, PairRegs& R) {
-    const unsigned osa = pair_off(sa.n_first, pl), osb = pair_off(sb.n_first, pl);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) R.Sa[k] = ld4(xf, osa, k);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) R.Sb[k] = ld4(xf, osb, k);
-}
-__device__ inline void pair_issue_d(const SegDesc& sb, const float* __restrict__ xf, const PairLane& pl, PairRegs& R) {
-    const unsigned od = pair_off(sb.down0, pl);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) R.D[k] = ld4(xf, od, k);
-}
-__device__ inline void pair_issue_p(const SegDesc& sa, const float* __restrict__ xf, const PairLane& pl, PairRegs& R) {
-    const unsigned op = pair_off(sa.par0, pl);
-    R.P[0] = ld4(xf, op, 0);
-    R.P[1] = ld4(xf, op, 1);
-}
-__device__ inline void pair_issue_k(const SegDesc& sa, const SegDesc& sb, const float* __restrict__ kf, const PairLane& pl, PairRegs& R) {
-    const unsigned oa = pair_off(sa.n_first, pl), ob = pair_off(sb.n_first, pl);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { R.Ka[k] = ld4(kf, oa, k); R.Kb[k] = ld4(kf, ob, k); }
-}
-
-// self + left + right of one segment (and the raw rows into the stash)
-__device__ inline void pair_stage_self(int lane, const float* wq, const f32x4 (&S)[4], const f32x4& LR, f32x4 (&acc)[4], float* s_x, int rl) {
-    const PairLane pl{lane >> 5, lane & 31};
-    const bool up_half = pl.h != 0;
-    const f32x4 w0 = quad_w(wq, SLOT_SELF), w3 = quad_w(wq, SLOT_LEFT), w4 = quad_w(wq, SLOT_RIGHT);
-    f32x4 Mk = seam(LR, S[0], up_half);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const f32x4 Mn = seam(S[k], k < 3 ? S[k < 3 ? k + 1 : 3] : LR, up_half);
-        f32x4 a = w4[k] * Mn;
-        a += w3[k] * Mk;
-        a += w0[k] * S[k];
-        acc[k] = a;
-        Mk = Mn;
-    }
-    if (s_x) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(&s_x[(rl + 2 * k + pl.h) * LDA + 4 * pl.q]) = S[k];
-    }
-}
-__device__ inline void pair_stage_rows(const float* wq, int slot, const f32x4 (&V)[4], f32x4 (&acc)[4]) {
-    const f32x4 w = quad_w(wq, slot);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] += w[k] * V[k];
-}
-__device__ inline void pair_stage_par(const float* wqa, const float* wqb, const f32x4 (&P)[2], f32x4 (&acc0)[4], f32x4 (&acc1)[4]) {
-    const f32x4 wa = quad_w(wqa, SLOT_PARENT), wb = quad_w(wqb, SLOT_PARENT);
-    f32x4 plo[2], pup[2];
-    halves(P[0], plo[0], pup[0]);
-    halves(P[1], plo[1], pup[1]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const f32x4 v = (k & 1) ? pup[k >> 1] : plo[k >> 1];
-        acc0[k] += wa[k] * v;
-        acc1[k] += wb[k] * v;
-    }
-}
-__device__ inline void pair_stage_kids(const float* wqa, const float* wqb, const PairRegs& R, f32x4 (&acc0)[4], f32x4 (&acc1)[4]) {
-    const f32x4 fa = quad_w(wqa, SLOT_HASKIDS), fb = quad_w(wqb, SLOT_HASKIDS);       // 1.0 / 0.0
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        acc0[k] += fa[k] * R.Ka[k];
-        acc1[k] += fb[k] * R.Kb[k];
-    }
-}
-// everything between two stages is complete at this point: accumulators updated, re-issued loads below it
-__device__ inline void pair_pin(f32x4 (&acc0)[4], f32x4 (&acc1)[4]) {
-    pin_acc4(acc0);
-    pin_acc4(acc1);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
 }  // namespace eg

@@ -474,43 +474,44 @@ __device__ inline void load_w_slice(const float* __restrict__ W, int wave, int l
     }
 }
 
-// SWAP = false:  D^T[32 channels x 32 rows] = W_slice * A^T   acc[m][n]: n = lane&31 = row (row0 + n),
-//                m = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel within the wave's 32 (a lane holds 16 channels of ONE row).
-// SWAP = true:   D[32 rows x 32 channels] = A * W_slice^T (the same two operand registers in the other order, so every output
-//                element is the same sum in the same order): n = lane&31 = channel within the wave's 32,
-//                m = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = row (row0 + m): a wave register is 2 x 128 contiguous bytes of two
-//                output rows, so the epilogue can store it as it stands.
+// acc[m][n]: n = lane&31 = row (row0 + n), m = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel within the wave's 32.
 // The 16 ds_read_b128 are software-pipelined in chunks of 4 (two named fragment sets) so that at most
 // 32 VGPRs hold A fragments while the 64-cycle MFMAs of the previous chunk cover the LDS latency.
-template <bool SWAP = false>
-__device__ inline void mfma_chunk(const f32x4 (&av)[4], const float (&wreg)[64], int t0, f32x16& acc, int t_lo = 0, int t_hi = 4) {
+__device__ inline void mfma_chunk(const f32x4 (&av)[4], const float (&wreg)[64], int t0, f32x16& acc) {
 #pragma unroll
-    for (int t = t_lo; t < t_hi; ++t) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float w = wreg[4 * (t0 + t) + e], v = av[t][e];
-#ifdef EG_ABL_NO_MFMA       // timing-only ablation (results wrong): the memory side and the epilogue without the matrix work
-            acc[e] += w + v;
-#else
-            acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(v, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w, v, acc, 0, 0, 0);
-#endif
-        }
+    for (int t = 0; t < 4; ++t) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 0], av[t].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 1], av[t].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 2], av[t].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 3], av[t].w, acc, 0, 0, 0);
     }
 }
 
-// One 32-row block: 64 chained MFMAs.  between(c) is emitted in the scheduling region of chunk c (c = 0..3) so that
-// independent VALU / LDS / store work of the caller fills the issue slots the dependent 64-cycle MFMAs leave free.  The
-// first four MFMAs of a chunk are fenced off in front of it: left to itself the scheduler may place between(c) BEFORE the
-// chunk's MFMAs, and work that reads the previous chain's accumulator then waits out that chain's tail (an 18-wait-state
-// s_nop plus the VALU block, with the matrix pipe idle).
-// (a pure MFMA has no place in the instruction-selection order of its own: a scheduling barrier alone does not keep it on its
-// side; tying the accumulator to an empty volatile asm does)
-__device__ inline void pin_mfma(f32x16& acc) {
-    asm volatile("" : "+v"(acc));
+__device__ inline void mfma_rowblock(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc) {
+    const int j = lane & 31, h = lane >> 5;
+    const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
+    f32x4 a0[4], a1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a0[t] = ap[t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
     __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a0, wreg, 0, acc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a1, wreg, 4, acc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a0, wreg, 8, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(a1, wreg, 12, acc);
 }
 
-template <bool SWAP = false, typename F>
+// Same chain; between(c) is emitted in the scheduling region of chunk c (c = 0..3) so that independent VALU / LDS /
+// store work of the caller fills the issue slots the dependent 64-cycle MFMAs leave free.
+template <typename F>
 __device__ inline void mfma_rowblock_with(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc, F between) {
     const int j = lane & 31, h = lane >> 5;
     const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
@@ -520,64 +521,21 @@ __device__ inline void mfma_rowblock_with(const float* s_a, int row0, int lane, 
 #pragma unroll
     for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk<SWAP>(a0, wreg, 0, acc, 0, 1);
-    pin_mfma(acc);
-    mfma_chunk<SWAP>(a0, wreg, 0, acc, 1, 4);
+    mfma_chunk(a0, wreg, 0, acc);
     between(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk<SWAP>(a1, wreg, 4, acc, 0, 1);
-    pin_mfma(acc);
-    mfma_chunk<SWAP>(a1, wreg, 4, acc, 1, 4);
+    mfma_chunk(a1, wreg, 4, acc);
     between(1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk<SWAP>(a0, wreg, 8, acc, 0, 1);
-    pin_mfma(acc);
-    mfma_chunk<SWAP>(a0, wreg, 8, acc, 1, 4);
+    mfma_chunk(a0, wreg, 8, acc);
     between(2);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk<SWAP>(a1, wreg, 12, acc, 0, 1);
-    pin_mfma(acc);
-    mfma_chunk<SWAP>(a1, wreg, 12, acc, 1, 4);
+    mfma_chunk(a1, wreg, 12, acc);
     between(3);
-}
-
-// Register-lean form of the same chain: the fragments live in 2 x 8 registers (half-chunks of two ds_read_b128, re-read 8 MFMAs
-// = 512 cycles ahead of their use) instead of 2 x 16.  between(c), c = 0..3, as above.
-template <bool SWAP = false, typename F>
-__device__ inline void mfma_rowblock_lean(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc, F between) {
-    const int j = lane & 31, h = lane >> 5;
-    const f32x4* ap = reinterpret_cast<const f32x4*>(s_a + (row0 + j) * LDA + 64 * h);
-    f32x4 af[2][2];
-    af[0][0] = ap[0]; af[0][1] = ap[1];
-    af[1][0] = ap[2]; af[1][1] = ap[3];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int hc = 0; hc < 8; ++hc) {
-        const int b = hc & 1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float w = wreg[8 * hc + e], v = af[b][0][e];
-            acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(v, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w, v, acc, 0, 0, 0);
-        }
-        pin_mfma(acc);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float w = wreg[8 * hc + 4 + e], v = af[b][1][e];
-            acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(v, w, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w, v, acc, 0, 0, 0);
-        }
-        if (hc & 1) between(hc >> 1);
-        if (hc + 2 < 8) { af[b][0] = ap[2 * (hc + 2)]; af[b][1] = ap[2 * (hc + 2) + 1]; }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <bool SWAP = false>
-__device__ inline void mfma_rowblock(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc) {
-    mfma_rowblock_with<SWAP>(s_a, row0, lane, wreg, acc, [](int) {});
 }
 
 // ---- 8-wave layout: wave w owns 16 output channels, v_mfma_f32_16x16x4_f32 ------------------------

@@ -161,35 +161,9 @@ def gcn_layer_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tenso
     return out
 
 
-_cls_folds: dict = {}
-
-
-def cls_fold(weight: torch.Tensor, scale, shift, packed: dict):
-    """(wc [128,128], t1c [128]) of eg_cls_fold for this layer / classifier parameter set, cached on the tensors' identity
-    and versions (a handful of entries; the folded tensors of a captured HIP graph are kept alive by the model)."""
-    srcs = (weight, scale, shift, packed["w1"], packed["s1"], packed["t1"])
-    key = tuple((id(t), t._version, t.data_ptr()) if t is not None else None for t in srcs)
-    hit = _cls_folds.get(key)
-    if hit is None or any(r() is not t for r, t in zip(hit[2], srcs) if t is not None):
-        import weakref
-        wc = torch.empty(C, C, dtype=torch.float32, device=weight.device)
-        t1c = torch.empty(C, dtype=torch.float32, device=weight.device)
-        _lib.check(_lib.load().eg_cls_fold(_ptr(weight), _ptr(scale), _ptr(shift), _ptr(packed["w1"]), _ptr(packed["s1"]),
-                                           _ptr(packed["t1"]), _ptr(wc), _ptr(t1c), _stream()), "eg_cls_fold")
-        if len(_cls_folds) > 16:
-            _cls_folds.clear()
-        hit = (wc, t1c, tuple(weakref.ref(t) if t is not None else None for t in srcs))
-        _cls_folds[key] = hit
-    return hit[0], hit[1]
-
-
 def gcn_layer_cls_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tensor, scale, shift, residual, relu: bool,
                       packed: dict, sigmoid: bool = False, kidsum_in: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Last layer + node-type filter + 4 classifier heads in one kernel -> logits [batch * num_nodes, 4].  The layer is folded
-    into the heads' first layers (eg_cls_fold), which needs a last layer without activation (relu=False, as the reference
-    builds it)."""
-    if relu:
-        raise RuntimeError("the fused last layer + classifier needs a last layer without activation (models.py:335)")
+    """Last layer + node-type filter + 4 classifier heads in one kernel -> logits [batch * num_nodes, 4]."""
     rows = graph.num_nodes * batch
     _check_rows(x, "x", rows)
     if weight.shape != (C, C) or not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous():
@@ -202,10 +176,10 @@ def gcn_layer_cls_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.T
         _check_rows(kidsum_in, "kidsum_in", graph.kidsum_rows * batch)
     out = torch.empty(rows, 4, dtype=torch.float32, device=x.device)
     p = packed
-    wc, t1c = cls_fold(weight, scale, shift, packed)
-    _lib.check(_lib.load().eg_gcn_layer_cls_fwd(graph._h, batch, _ptr(x), _ptr(wc), _ptr(residual), _ptr(kidsum_in), _ptr(p["w1"]),
-                                                _ptr(p["s1"]), _ptr(t1c), _ptr(p["w2"]), _ptr(p["s2"]), _ptr(p["t2"]), _ptr(p["w3"]),
-                                                _ptr(p["b3"]), int(sigmoid), _ptr(out), _stream()), "eg_gcn_layer_cls_fwd")
+    _lib.check(_lib.load().eg_gcn_layer_cls_fwd(graph._h, batch, _ptr(x), _ptr(weight), _ptr(scale), _ptr(shift), _ptr(residual),
+                                                int(relu), _ptr(kidsum_in), _ptr(p["w1"]), _ptr(p["s1"]), _ptr(p["t1"]),
+                                                _ptr(p["w2"]), _ptr(p["s2"]), _ptr(p["t2"]), _ptr(p["w3"]), _ptr(p["b3"]),
+                                                int(sigmoid), _ptr(out), _stream()), "eg_gcn_layer_cls_fwd")
     return out
 
 

@@ -138,20 +138,15 @@ int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const f
                            const float* kidsum_in, float* kidsum_out, eg_stream_t stream);
 
 /* Last layer of a stack + node-type filter + the 4 classifier heads in ONE kernel (models.py:431-435 last iteration,
- * :485-490).  The stack's last layer has no activation (models.py:335: Identity), so layer, residual and the heads' first
- * layers are one linear map of the aggregated rows and the raw rows; eg_cls_fold prepares it once per parameter set:
- *     wc  [128,128] = W1 diag(scale) W          (W: the layer's lin.weight, scale / shift: bias + eval BatchNorm folded,
- *     t1c [128]     = t1 + s1 * (W1 shift)       W1 / s1 / t1: the stacked first classifier layers as in eg_classifier_fwd)
- * eg_gcn_layer_cls_fwd then computes logits [batch * num_nodes, 4] = heads((A_hat x) W^T * scale + shift + (residual ? x : 0))
- * without ever forming the layer's output.  residual in {NULL, x}; kidsum_in as eg_gcn_layer_fwd_chain (or NULL); w1 is read
- * only when residual != NULL.  Needs eg_graph_fused_classifier_ok(g); EG_ERR_UNSUPPORTED otherwise (run eg_gcn_layer_fwd +
- * eg_classifier_fwd instead -- also the route for a last layer WITH an activation, which the reference never builds). */
-int eg_cls_fold(const float* W, const float* scale, const float* shift, const float* w1, const float* s1, const float* t1,
-                float* wc, float* t1c, eg_stream_t stream);
-int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* wc, const float* residual,
-                         const float* kidsum_in, const float* w1, const float* s1, const float* t1c, const float* w2,
-                         const float* s2, const float* t2, const float* w3, const float* b3, int sigmoid, float* logits,
-                         eg_stream_t stream);
+ * :485-490): the layer's output tile never leaves the chip, logits [batch * num_nodes, 4] are the only output.
+ * Layer arguments as eg_gcn_layer_fwd (W^T form), kidsum_in as eg_gcn_layer_fwd_chain (or NULL); classifier
+ * arguments as eg_classifier_fwd.  Needs a topology handle with eg_graph_kidsum_rows(g) > 0 whose rows are all
+ * valid nodes (no coordinate / connection nodes) and residual in {NULL, x}; EG_ERR_UNSUPPORTED otherwise (run
+ * eg_gcn_layer_fwd + eg_classifier_fwd instead). */
+int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
+                         const float* shift, const float* residual, int relu, const float* kidsum_in, const float* w1,
+                         const float* s1, const float* t1, const float* w2, const float* s2, const float* t2,
+                         const float* w3, const float* b3, int sigmoid, float* logits, eg_stream_t stream);
 
 /* out = A_hat x  (aggregation only; training / backward building block) */
 int eg_gcn_aggregate(const eg_graph* g, int batch, const float* x, float* out, eg_stream_t stream);

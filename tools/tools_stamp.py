@@ -10,7 +10,7 @@ g = ops.Graph.topo(224, 7)
 x = synthetic_node_feats(B * g.num_nodes, 128, 1).cuda()
 w = (synthetic_node_feats(128, 128, 2) * 0.1).cuda()
 out = torch.empty_like(x)
-buf = (ct.c_uint64 * 11)()
+buf = (ct.c_uint64 * 32)()
 lib = _lib.load()
 form = os.environ.get("EG_STAMP_FORM", "")          # "", "kin", "kout", "kin+kout", "kin+cls": chained forms run the producer/consumer kernel
 kw = {}
@@ -48,3 +48,8 @@ wgs = 256 if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else waves / 
 waves = wgs * 4 if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else waves
 for n, c in zip(names, v[:8]):
     print(f"{n:10s} {100*c/tot:6.2f}%  {c/waves/(tiles/wgs):9.0f} cyc/tile")
+
+if len(v) >= 32 and form:
+    print("per wave: cycles per tile waiting at the barrier / in all (waves 0-3 consumers, 4-7 producers)")
+    for w in range(8):
+        print(f"  wave {w}: {v[16 + w] / 256 / (tiles / 256):8.0f} / {v[24 + w] / 256 / (tiles / 256):8.0f}")
