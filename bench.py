@@ -529,12 +529,12 @@ def main_infer(args, world, rank, device, dist_info):
         forms = [dict(kidsum_out=ka)] + [dict(kidsum_in=ka, kidsum_out=kb)] * max(args.layers - 2, 0)
         fused_cls = bool(model.fuse_classifier) and topo.n_conn == 0 and topo.num_valid_nodes == N
         if not fused_cls:
-            forms.append(dict(kidsum_in=ka))          # (with the classifier fused, the last layer is k_gcn_layer_ps<true, 0>)
-        kname = "k_gcn_layer_ps<false, 0>" if fused_cls else "k_gcn_layer_ps"
+            forms.append(dict(kidsum_in=ka))          # (with the classifier fused, the last layer is k_gcn_layer_ps<true>)
+        kname = "k_gcn_layer_ps<false>" if fused_cls else "k_gcn_layer_ps"
     else:
         forms = [dict()]
         flat = graph.structured and graph.kidsum_rows == 0 and graph.fused_classifier_ok       # single-level topology
-        kname = "k_gcn_layer_ps<false, 0>" if flat else ("k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>")
+        kname = "k_gcn_layer_ps<false>" if flat else ("k_gcn_layer<AGG_STENCIL>" if graph.structured else "k_gcn_layer<AGG_CSR>")
 
     def layer_launches():
         for f in forms:
@@ -568,7 +568,7 @@ def main_infer(args, world, rank, device, dist_info):
                    "nodes_per_frame": N, "directed_edges_per_frame": e_dir, "global_batch": B * world,
                    "parallelism": f"dp{world} (batch-sharded frames, no data-path collective)",
                    "launch": "eager" if args.no_hip_graph else "hipGraph replay of the step's kernels",
-                   "kernels_per_step": ("2 x k_gcn_layer_ps<false, 0> (chained layers) + k_gcn_layer_ps<true, 0> (last layer + "
+                   "kernels_per_step": ("2 x k_gcn_layer_ps<false> (chained layers) + k_gcn_layer_ps<true> (last layer + "
                                         "classifier heads)") if (graph.kidsum_rows > 0 and model.chain_layers and
                                                                   model.fuse_classifier) else "3 layer launches + k_classifier"},
         "distributed": dist_info,
@@ -602,7 +602,22 @@ def main_infer(args, world, rank, device, dist_info):
             result["before_path"] = {"pack_levels_ms": pack_ms,
                                      "pack_levels_GBs": round(2 * B * N * C * 4 / (pack_ms * 1e-3) / 1e9, 1),
                                      "note": "SURVEY f-1: NCHW level maps -> node-major [B*N,128] in one launch (reads + writes B*N*512 B)"}
-            del pm
+            # the UNet variant's tail: relu(1x1 conv to 128 channels) of every decoder map fused into the packing
+            chans = [512, 256, 128, 64, 32, 16, 8, 4][-(args.naux + 1):]
+            fm = [torch.randn(B, c, m.shape[2], m.shape[3], device=device) for c, m in zip(chans, pm)]
+            ws = [torch.randn(C, c, device=device) * (1.0 / c) ** 0.5 for c in chans]
+            bs = [torch.zeros(C, device=device) for _ in chans]
+            with torch.no_grad():
+                fused_ms = round(time_steps(lambda: ops.conv1x1_relu_pack_levels(fm, ws, bs, B, N, 0), 20, 3), 4)
+                unfused_ms = round(time_steps(lambda: ops.pack_levels(
+                    [torch.relu(torch.nn.functional.conv2d(f, w.view(C, -1, 1, 1), b)) for f, w, b in zip(fm, ws, bs)], B, N, 0), 10, 2), 4)
+            in_bytes = sum(f.numel() * 4 for f in fm)
+            result["before_path"].update({
+                "conv1x1_relu_pack_ms": fused_ms, "conv1x1_relu_then_pack_levels_ms": unfused_ms,
+                "conv1x1_relu_pack_GBs": round((in_bytes + B * N * C * 4) / (fused_ms * 1e-3) / 1e9, 1),
+                "note_fused": "models.py:707-710 + :726-756 in one launch (reads the decoder maps, writes B*N*512 B) next to torch "
+                              "conv2d + relu per level followed by eg_pack_levels"})
+            del pm, fm, ws, bs
         result["after_path"] = {"landmark_decode_ms": round(time_steps(lambda: EV.decode_landmarks(lg, B, args.frame, yl, vl), 20, 3), 4),
                                 "losses_fwd_bwd_ms": round(time_steps(loss_step, 20, 3), 4),
                                 "note": "softmax-expected + hard-argmax landmark decode of the step's logits, and "

@@ -54,7 +54,9 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_graph_kidsum_rows": (_i64, [_p]),
     "eg_graph_fused_classifier_ok": (_i, [_p]),
     "eg_gcn_layer_fwd_chain": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
-    "eg_gcn_layer_cls_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "eg_gcn_layer_cls_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "eg_gcn_layer_fwd_jk": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "eg_graph_ps_launches": (ct.c_uint, [_p]),
     "eg_gcn_aggregate": (_i, [_p, _i, _p, _p, _p]),
     "eg_linear128_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _i, _i, _p, _p]),
     "eg_classifier_fwd": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
@@ -74,6 +76,8 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_bilinear4_fwd": (_i, [_p, _p, _i, _i, _i64, _i64, _i, _p, _p]),
     "eg_bilinear4_bwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i, _p, _p, _p]),
     "eg_pack_levels": (_i, [ct.POINTER(_p), ct.POINTER(_i), _i, _i, _i64, _i64, _p, _p]),
+    "eg_conv1x1_relu_pack_levels": (_i, [ct.POINTER(_p), ct.POINTER(_p), ct.POINTER(_p), ct.POINTER(_i), ct.POINTER(_i), _i, _i,
+                                         _i64, _i64, _p, _p]),
     "eg_unpack_levels": (_i, [_p, ct.POINTER(_p), ct.POINTER(_i), _i, _i, _i64, _i64, _p]),
     "eg_heatmap_workspace_bytes": (ct.c_size_t, [_i, ct.POINTER(_i), _i]),
     "eg_heatmap_expect_fwd": (_i, [_p, _p, _p, _i, _i64, ct.POINTER(_i), ct.POINTER(_i), _i, _p, _p, _p, _p, _p, _p, _p]),

@@ -206,6 +206,7 @@ struct eg_graph {
     int symmetric;            // kind == GRAPH_CSR: the kept edge multiset equals its transpose (A_hat^T == A_hat)
     int* walk_counters;       // device [QUEUE_SLOTS][8 x 32] ring of per-launch tile-queue heads (+ QUEUE_TAIL_INTS)
     mutable std::atomic<unsigned> launch_seq;   // next slice of the ring (the only host state a launch touches)
+    mutable std::atomic<unsigned> ps_launches;  // launches of the producer/consumer kernel on this handle (eg_graph_ps_launches)
     eg::Knobs knobs;          // environment knobs, read once at creation
 
     // the slice of the queue ring for one launch
@@ -233,4 +234,5 @@ int eg_launch_layer_sym(const eg_graph* g, int batch, const float* x, const floa
                         int* grid_out, hipStream_t stream);
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
-                       const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream);
+                       const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream, const float* jk_in = nullptr,
+                       float* jk_out = nullptr);

@@ -461,9 +461,25 @@ int eg_graph_fused_classifier_ok(const eg_graph* g) {
     return g && g->kind == GRAPH_TOPO && (g->kid_rows > 0 || g->flat) && g->topo.coord_base >= g->n_nodes;
 }
 
+int eg_gcn_layer_fwd_jk(const eg_graph* g, int batch, const float* x, const float* W, const float* scale, const float* shift,
+                        const float* residual, int relu, float* out, const float* kidsum_in, float* kidsum_out, const float* jk_in,
+                        float* jk_out, eg_stream_t stream) {
+    if (!x || !W || !out || !jk_in || !jk_out) return set_error(EG_ERR_ARG, "x, W, out, jk_in and jk_out must not be NULL");
+    if (out == x || out == residual || jk_out == x || jk_out == out || jk_out == jk_in)
+        return set_error(EG_ERR_ARG, "out / jk_out must not alias the inputs or each other");
+    if (kidsum_in && kidsum_in == kidsum_out) return set_error(EG_ERR_ARG, "kidsum_out must not alias kidsum_in");
+    if (!g || batch <= 0) return set_error(EG_ERR_ARG, "bad graph handle or batch");
+    const int rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, 0, out, kidsum_in, kidsum_out, nullptr,
+                                      (hipStream_t)stream, jk_in, jk_out);
+    if (rc == EG_ERR_UNSUPPORTED)
+        return set_error(EG_ERR_UNSUPPORTED, "the running JumpingKnowledge maximum needs a topology handle on the producer/consumer kernel "
+                                             "(child sums available, or a single-level grid) and residual in {NULL, x}");
+    return rc;
+}
+
 int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
-                         const float* shift, const float* residual, int relu, const float* kidsum_in, const float* w1,
-                         const float* s1, const float* t1, const float* w2, const float* s2, const float* t2,
+                         const float* shift, const float* residual, int relu, const float* kidsum_in, const float* jk_in,
+                         const float* w1, const float* s1, const float* t1, const float* w2, const float* s2, const float* t2,
                          const float* w3, const float* b3, int sigmoid, float* logits, eg_stream_t stream) {
     if (!x || !W || !logits || !w1 || !s1 || !t1 || !w2 || !s2 || !t2 || !w3 || !b3) return set_error(EG_ERR_ARG, "NULL argument");
     if (!g || batch <= 0) return set_error(EG_ERR_ARG, "bad graph handle or batch");
@@ -471,11 +487,13 @@ int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const flo
         return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs a topology handle whose rows are all valid nodes (no coordinate nodes)");
     eg::ClsArgs c{w1, s1, t1, w2, s2, t2, w3, b3, logits, sigmoid};
     const int rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, 0, nullptr, kidsum_in, nullptr, &c,
-                                      (hipStream_t)stream);
+                                      (hipStream_t)stream, jk_in, nullptr);
     if (rc == EG_ERR_UNSUPPORTED)
         return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs eg_graph_fused_classifier_ok() and residual in {NULL, x}");
     return rc;
 }
+
+unsigned eg_graph_ps_launches(const eg_graph* g) { return g ? g->ps_launches.load(std::memory_order_relaxed) : 0u; }
 
 
 int eg_gcn_aggregate(const eg_graph* g, int batch, const float* x, float* out, eg_stream_t stream) {

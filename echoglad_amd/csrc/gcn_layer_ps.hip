@@ -69,13 +69,17 @@ __device__ inline void ps_claim(int* __restrict__ counters, int group, int n_til
 // Linear(32,16)-BN-ReLU-Linear(16,1)] of src/core/models.py:363-377, :485-490, eval-mode BN folded by the caller
 // (same packing as eg_classifier_fwd).  The layer's output tile never leaves LDS.
 
-template <bool CLS>
+// JK: JumpingKnowledge('max') of the reference (src/core/models.py:380-382, :479-482) carried through the fused stack as a
+// running element-wise maximum: jk_out = max(jk_in, out) is written beside the layer output (the first layer passes its input
+// as jk_in); with the classifier heads fused in, the heads run on max(jk_in, out) instead of out.
+template <bool CLS, bool JK = false>
 __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ out, const float* __restrict__ dis,
                                                                 const Topo* __restrict__ T, const TileDesc* __restrict__ tiles,
                                                                 const SegDesc* __restrict__ segs, const float* __restrict__ pats,
                                                                 const float* __restrict__ patsq, const float* __restrict__ kin, float* __restrict__ kout,
+                                                                const float* __restrict__ jk_in, float* __restrict__ jk_out,
                                                                 int* __restrict__ counters, const PsDims a, const ClsArgs ca) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_a0 = smem;                               // [2][TILE * LDA]  aggregated tiles
@@ -221,8 +225,10 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             };
             const int u8 = lane >> 3, c4 = 4 * (lane & 7);
             float* ob = out + (size_t)frame * a.n_per_frame * C + 32 * wave + c4;
-            f32x4 o[4];
+            f32x4 o[4], jm[4];
             int node[4];
+            const float* jb = JK ? jk_in + (size_t)frame * a.n_per_frame * C + 32 * wave + c4 : nullptr;
+            float* jo = JK ? jk_out + (size_t)frame * a.n_per_frame * C + 32 * wave + c4 : nullptr;
             auto read_segments = [&](int i0) {                                   // patch rows i0 .. i0+3: 8 lanes per row
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -233,11 +239,18 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     const int u = u8 < cnt ? u8 : cnt - 1;
                     o[e] = *reinterpret_cast<const f32x4*>(s_x + (8 * i + u) * LDA + 32 * wave + c4);
                     node[e] = first + u;
+                    if (JK) jm[e] = *reinterpret_cast<const f32x4*>(jb + (size_t)node[e] * C);
                 }
             };
             auto store_segments = [&]() {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(ob + (size_t)node[e] * C) = o[e];
+                for (int e = 0; e < 4; ++e) {
+                    *reinterpret_cast<f32x4*>(ob + (size_t)node[e] * C) = o[e];
+                    if (JK) {
+                        const f32x4 m = {fmaxf(jm[e].x, o[e].x), fmaxf(jm[e].y, o[e].y), fmaxf(jm[e].z, o[e].z), fmaxf(jm[e].w, o[e].w)};
+                        *reinterpret_cast<f32x4*>(jo + (size_t)node[e] * C) = m;
+                    }
+                }
             };
 #ifndef EG_ABL_NO_MFMA
             // rows 32..63: the MFMA chain leaves ~60 issue cycles per instruction free; the epilogue of rows 0..31
@@ -281,6 +294,31 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 // ---- classifier heads on the finished tile (all 128 channels of it are needed: the four consumer waves
                 // meet on an LDS counter; the producers are not involved and keep filling the other buffer) -------------
                 PSTAMP(1);
+                if (JK) {
+                    // this wave's 32 channels of all 64 rows, 8 lanes per row: output tile <- max(jk_in, output tile)
+                    const float* jb = jk_in + (size_t)frame * a.n_per_frame * C + 32 * wave + c4;
+#pragma unroll
+                    for (int i0 = 0; i0 < 8; i0 += 4) {
+                        f32x4 jm[4];
+                        int row[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // an absent segment repeats segment 0, a short one its last node (rows without a node are never used)
+                            const int i = seg_cnt[i0 + e] > 0 ? i0 + e : 0;
+                            const int cnt = seg_cnt[i0 + e] > 0 ? seg_cnt[i0 + e] : seg_cnt[0];
+                            const int first = seg_cnt[i0 + e] > 0 ? seg_first[i0 + e] : seg_first[0];
+                            const int u = u8 < cnt ? u8 : cnt - 1;
+                            row[e] = 8 * i + u;
+                            jm[e] = *reinterpret_cast<const f32x4*>(jb + (size_t)(first + u) * C);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float* xp = s_x + row[e] * LDA + 32 * wave + c4;
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
+                            *reinterpret_cast<f32x4*>(xp) = f32x4{fmaxf(jm[e].x, v.x), fmaxf(jm[e].y, v.y), fmaxf(jm[e].z, v.z), fmaxf(jm[e].w, v.w)};
+                        }
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_fetch_add(s_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int target = 4 * (k + 1);
@@ -494,10 +532,13 @@ using namespace eg;
 // Returns EG_ERR_UNSUPPORTED when the caller should fall back to the symmetric kernel.
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
-                       const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream) {
+                       const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream, const float* jk_in, float* jk_out) {
     if (!g || g->kind != GRAPH_TOPO || (residual != nullptr && residual != x)) return EG_ERR_UNSUPPORTED;
-    const bool chained = kin || kout;
-    if (chained && g->kid_rows == 0) return EG_ERR_UNSUPPORTED;
+    const bool jk = jk_in != nullptr;
+    if ((jk_out != nullptr) != (jk && !cls)) return set_error(EG_ERR_ARG, "jk_out goes with jk_in on a plain layer, the fused heads take jk_in alone");
+    const bool chained = kin || kout || jk;
+    if ((kin || kout) && g->kid_rows == 0) return EG_ERR_UNSUPPORTED;
+    if (jk && g->kid_rows == 0 && !g->flat) return EG_ERR_UNSUPPORTED;
     if (cls && g->kid_rows == 0 && !g->flat) return EG_ERR_UNSUPPORTED;
     // plain calls: this kernel by default on single-level topologies (no tiles that pull child rows), the symmetric
     // kernel otherwise; EG_LAYER_IMPL = 0 / 1 forces one of them
@@ -515,8 +556,9 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         int dev = 0;
         EG_HIP_TRY(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            EG_HIP_TRY(hipFuncSetAttribute((const void*)k_gcn_layer_ps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            const void* kernels[] = {(const void*)k_gcn_layer_ps<false, false>, (const void*)k_gcn_layer_ps<true, false>,
+                                     (const void*)k_gcn_layer_ps<false, true>, (const void*)k_gcn_layer_ps<true, true>};
+            for (const void* f : kernels) EG_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
     }
@@ -526,10 +568,11 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     const ClsArgs none{};
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out, g->dis, g->topo_dev,
-                           g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, queue, a, cls ? *cls : none);
+                           g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, jk_in, jk_out, queue, a, cls ? *cls : none);
     };
-    if (cls) launch(k_gcn_layer_ps<true>);
-    else launch(k_gcn_layer_ps<false>);
+    if (cls) { if (jk) launch(k_gcn_layer_ps<true, true>); else launch(k_gcn_layer_ps<true, false>); }
+    else { if (jk) launch(k_gcn_layer_ps<false, true>); else launch(k_gcn_layer_ps<false, false>); }
+    g->ps_launches.fetch_add(1u, std::memory_order_relaxed);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

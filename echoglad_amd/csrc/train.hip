@@ -130,20 +130,38 @@ struct ActArgs {
     unsigned long long seed;
 };
 
+// Streaming pass: every operand is read once (non-temporal loads keep them out of the caches' way) and four 16-B loads per
+// stream are in flight per lane before the first use.
+__device__ inline f32x4 ldnt4(const float* p) {
+    return f32x4{__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
+                 __builtin_nontemporal_load(p + 3)};
+}
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ z, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ residual,
                                                     float* __restrict__ out, const ActArgs a) {
     const long long n4 = a.rows * (C / 4);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % (C / 4)) * 4;
-        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4);
-        f32x4 v = zz * sc + sh;
-        if (a.p > 0.f) v *= keep_scale4(a.seed, (unsigned long long)i * 4, a.p, a.inv_keep);
-        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
-        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    // (stride is a multiple of 32 float4 = one row: a thread always works on the same 4 channels)
+    const int c4 = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % (C / 4)) * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4);
+    for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+        f32x4 zz[4], rr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = i0 + u * stride;
+            zz[u] = i < n4 ? ldnt4(z + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rr[u] = (residual && i < n4) ? ldnt4(residual + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = i0 + u * stride;
+            f32x4 v = zz[u] * sc + sh;
+            if (a.p > 0.f) v *= keep_scale4(a.seed, (unsigned long long)i * 4, a.p, a.inv_keep);
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            v += rr[u];
+            if (i < n4) *reinterpret_cast<f32x4*>(out + i * 4) = v;
+        }
     }
 }
 
@@ -166,16 +184,57 @@ __device__ inline f32x2 act_grad2(const float* __restrict__ dy, const float* __r
     return g;
 }
 
+// Sums pass of the BatchNorm backward: per-workgroup partials of sum g and sum g * xhat.  Paired-row accesses (one wave load =
+// two 512-B rows, 16 B per lane), two of them in flight per stream; fp64 accumulators; the four waves and the two row
+// parities are combined in a fixed order.
 __global__ __launch_bounds__(RED_THREADS) void k_bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ z,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 double* __restrict__ partial, const ActArgs a) {
-    column_partials<2>(a.rows, partial, [&](long long r, int lane, f32x2 (&v)[2]) {
-        f32x2 xhat;
-        const f32x2 g = act_grad2(dy, z, mean, invstd, gamma, beta, a, r, lane, xhat);
-        v[0] = g;
-        v[1] = g * xhat;
-    });
+    __shared__ double s_red[8][2][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, q = lane & 31;
+    const int c4 = 4 * q;
+    const f32x4 mn = *reinterpret_cast<const f32x4*>(mean + c4), is = *reinterpret_cast<const f32x4*>(invstd + c4);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c4), be = *reinterpret_cast<const f32x4*>(beta + c4);
+    double sg[4] = {0.0, 0.0, 0.0, 0.0}, sx[4] = {0.0, 0.0, 0.0, 0.0};
+    const long long pairs = (a.rows + 1) / 2;
+    const long long step = (long long)gridDim.x * 4;
+    for (long long pr = (long long)blockIdx.x * 4 + wave; pr < pairs; pr += 2 * step) {
+        f32x4 d[2], zz[2];
+        long long r[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            r[u] = 2 * (pr + u * step) + h;
+            const bool ok = r[u] < a.rows;
+            const size_t off = (size_t)(ok ? r[u] : 0) * C + c4;
+            d[u] = ok ? ldnt4(dy + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            zz[u] = ldnt4(z + off);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 g = d[u];
+            if (a.p > 0.f) g *= keep_scale4(a.seed, (unsigned long long)r[u] * C + c4, a.p, a.inv_keep);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (zz[u][e] - mn[e]) * is[e];
+                const float v = xh * ga[e] + be[e];
+                float ge = g[e];
+                if (a.relu) ge = v > 0.f ? ge : 0.f;
+                sg[e] += (double)ge;
+                sx[e] += (double)(ge * xh);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s_red[2 * wave + h][0][c4 + e] = sg[e]; s_red[2 * wave + h][1][c4 + e] = sx[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) {
+        const int qq = i / C, c = i % C;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += s_red[w][qq][c];
+        partial[((size_t)blockIdx.x * 2 + qq) * C + c] = t;
+    }
 }
 
 __global__ void k_bn_bwd_final(const double* __restrict__ totals, float* __restrict__ dgamma, float* __restrict__ dbeta) {

@@ -688,8 +688,14 @@ class HierarchicalPatchModel(nn.Module):
         else:
             node_coords = None
         fused = (not self.training) and (not torch.is_grad_enabled() or not node_feats.requires_grad)
-        fused = fused and self.jk is None and self.layer_output_hook is None and not any(
+        fused = fused and self.layer_output_hook is None and not any(
             p.requires_grad and torch.is_grad_enabled() for p in self.parameters())
+        # JumpingKnowledge('max') stays on the fused path as a running maximum written by the layer kernels
+        # (eg_gcn_layer_fwd_jk); where those do not cover the handle (CSR graphs, coordinate / connection nodes) the
+        # layers run one by one and torch takes the maximum, as before
+        jk_fused = (fused and self.jk is not None and graph.fused_classifier_ok and not self.use_coordinate_graph
+                    and os.environ.get("EG_JK_FUSED", "1") != "0")
+        fused = fused and (self.jk is None or jk_fused)
         if fused and self.use_hip_graph and not self.use_coordinate_graph and not torch.cuda.is_current_stream_capturing():
             return self._forward_nodes_graphed(node_feats, edge_index, B), None
         hidden = [node_feats.contiguous()]
@@ -702,20 +708,23 @@ class HierarchicalPatchModel(nn.Module):
         fuse_cls = (fused and self.fuse_classifier and graph.fused_classifier_ok and not self.use_coordinate_graph
                     and (kid[0] is not None or graph.kidsum_rows == 0) and n_conn == 0 and n_valid == n
                     and self.num_output_channels == 4 and self.classifier_hidden_dim == 32)
+        jkb = self._jk_buffers(graph, gb, node_feats) if jk_fused else None
         for i in range(self.num_gnn_layers):
             x_in = hidden[i]
             if fused:
                 w, scale, shift = folded[i]
                 last = i == self.num_gnn_layers - 1
+                jk_prev = None if not jk_fused else (x_in if i == 0 else jkb[(i + 1) & 1])     # max over node features, h_1 .. h_i
                 if last and fuse_cls:
                     # the last layer hands its output tile to the classifier heads inside the kernel
                     out = ops.gcn_layer_cls_fwd(graph, gb, x_in, w, scale, shift, x_in if self.residual else None, False,
                                                 self._packed_classifier(), sigmoid=(self.output_activation == "sigmoid"),
-                                                kidsum_in=kid[(i + 1) & 1] if i > 0 else None)
+                                                kidsum_in=kid[(i + 1) & 1] if i > 0 else None, jk_in=jk_prev)
                     return out.squeeze(1), None
                 h = ops.gcn_layer_fwd(graph, gb, x_in, w, scale, shift, x_in if self.residual else None,
                                       relu=not last, kidsum_in=kid[(i + 1) & 1] if i > 0 else None,
-                                      kidsum_out=None if last else kid[i & 1])
+                                      kidsum_out=None if last else kid[i & 1], jk_in=jk_prev,
+                                      jk_out=jkb[i & 1] if jk_fused else None)
             elif self.training:
                 _, _, _, _, coord_base = self._row_ranges()
                 h, lm = self._layer_train(i, x_in, graph, gb, (B, n, coord_base) if self.use_coordinate_graph else None)
@@ -728,7 +737,10 @@ class HierarchicalPatchModel(nn.Module):
             if self.layer_output_hook is not None:
                 self.layer_output_hook(i, h)              # e.g. h.retain_grad() / h.register_hook(...) in a test
             hidden.append(h)
-        h = self.jk(hidden) if self.jk is not None else hidden[-1]
+        if jk_fused:
+            h = jkb[(self.num_gnn_layers - 1) & 1]
+        else:
+            h = self.jk(hidden) if self.jk is not None else hidden[-1]
         if fused:
             out = ops.classifier_fwd(h, B, n, n_conn, n_valid, self._packed_classifier(),
                                      sigmoid=(self.output_activation == "sigmoid"))
@@ -783,6 +795,14 @@ class HierarchicalPatchModel(nn.Module):
             self._kidsum[key] = hit
         return hit[1], hit[2]
 
+    def _jk_buffers(self, graph, gb, like):
+        key = ("jk", id(graph), gb, tuple(like.shape))
+        hit = self._kidsum.get(key)
+        if hit is None or hit[0] is not graph:
+            hit = (graph, torch.empty_like(like), torch.empty_like(like))
+            self._kidsum[key] = hit
+        return hit[1], hit[2]
+
     def _forward_nodes_graphed(self, node_feats, edge_index, B):
         key = (id(node_feats), node_feats.data_ptr(), tuple(node_feats.shape), id(edge_index), edge_index._version, B,
                tuple(_versions(l) for l in self.gnn_layers), tuple(_versions(c) for c in self.node_classifiers))
@@ -808,7 +828,8 @@ class HierarchicalPatchModel(nn.Module):
             # everything the captured kernels point at stays alive with the entry: the input tensors, the graph handle,
             # the child-sum side buffers and the folded / packed parameters (their caches may evict independently)
             graph, gb = self._resolver.resolve(edge_index, node_feats.shape[0])
-            keep = (graph, self._kidsum.get((id(graph), gb)), self._fold_cache.get("layers"), self._fold_cache.get("cls"))
+            keep = (graph, self._kidsum.get((id(graph), gb)), self._kidsum.get(("jk", id(graph), gb, tuple(node_feats.shape))),
+                    self._fold_cache.get("layers"), self._fold_cache.get("cls"))
             hit = (g, out, node_feats, edge_index, keep)
             self._hip_graphs[key] = hit
         hit[0].replay()
@@ -836,6 +857,25 @@ class HierarchicalPatchModel(nn.Module):
         n, n_conn, _, main_base, coord_base = self._row_ranges()
         fs = self.frame_size
         feats = ops.pack_levels([m.float() for m in level_maps], B, n, n_conn)
+        if n_conn:
+            feats = feats.clone() if feats.requires_grad else feats
+            feats.view(B, n, C)[:, :n_conn, :] = connection_embed
+        if self.use_coordinate_graph and not self.use_main_graph_only:
+            new = ops.bilinear4(feats, node_coords.reshape(B, 4, 2).contiguous(), B, n, main_base, fs)
+            feats = ops.scatter_coord_rows(feats, new, B, n, coord_base)
+        return feats
+
+    def pack_node_features_linear(self, features, linears, num_samples_per_batch: int, node_coords=None, connection_embed=None):
+        """The UNet variant's whole tail (models.py:707-756): ``F.relu(self.linears[i](features[i]))`` for every level (1x1
+        convolutions to 128 channels) AND the node-major packing in one launch (eg_conv1x1_relu_pack_levels); the 128-channel
+        NCHW maps are never formed.  ``features``: decoder maps coarse to fine [B, C_l, p_l, p_l] (the last one frame-sized),
+        ``linears``: the matching ``nn.Conv2d(C_l, 128, kernel_size=1)`` modules.  Connection-node embeddings
+        [B, naux+1, 128] (means of the activated maps) come from the caller, as in ``pack_node_features``."""
+        B = int(num_samples_per_batch)
+        n, n_conn, _, main_base, coord_base = self._row_ranges()
+        fs = self.frame_size
+        feats = ops.conv1x1_relu_pack_levels([f.float() for f in features], [m.weight for m in linears],
+                                             [m.bias for m in linears], B, n, n_conn)
         if n_conn:
             feats = feats.clone() if feats.requires_grad else feats
             feats.view(B, n, C)[:, :n_conn, :] = connection_embed

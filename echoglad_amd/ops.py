@@ -95,6 +95,11 @@ class Graph:
         """eg_gcn_layer_cls_fwd (last layer + classifier heads in one kernel) is available for this handle."""
         return bool(_lib.load().eg_graph_fused_classifier_ok(self._h)) if self.structured else False
 
+    @property
+    def ps_launches(self) -> int:
+        """Launches of the producer/consumer (fused, chained) layer kernel on this handle so far."""
+        return int(_lib.load().eg_graph_ps_launches(self._h))
+
     def deg_inv_sqrt(self) -> torch.Tensor:
         out = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
         _lib.check(_lib.load().eg_graph_deg_inv_sqrt(self._h, _ptr(out), _stream()), "eg_graph_deg_inv_sqrt")
@@ -126,11 +131,13 @@ def gcn_layer_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tenso
                   scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
                   residual: Optional[torch.Tensor] = None, relu: bool = False, transpose_w: bool = False,
                   out: Optional[torch.Tensor] = None, kidsum_in: Optional[torch.Tensor] = None,
-                  kidsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  kidsum_out: Optional[torch.Tensor] = None, jk_in: Optional[torch.Tensor] = None,
+                  jk_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act((A_hat x) W^T * scale + shift) + residual in one kernel.
 
     kidsum_in / kidsum_out: child-sum side buffers of a chained stack of layers (see `new_kidsum`,
-    include/echoglad_hip.h eg_gcn_layer_fwd_chain)."""
+    include/echoglad_hip.h eg_gcn_layer_fwd_chain).  jk_in / jk_out: running JumpingKnowledge('max') maximum,
+    jk_out = max(jk_in, result) (eg_gcn_layer_fwd_jk; the first layer passes x as jk_in)."""
     rows = graph.num_nodes * batch
     _check_rows(x, "x", rows)
     if weight.shape != (C, C) or not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous():
@@ -143,6 +150,18 @@ def gcn_layer_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tenso
         out = torch.empty_like(x)
     else:
         _check_rows(out, "out", rows)
+    if jk_in is not None or jk_out is not None:
+        if jk_in is None or jk_out is None or transpose_w:
+            raise RuntimeError("jk_in and jk_out go together (and not with transpose_w)")
+        _check_rows(jk_in, "jk_in", rows)
+        _check_rows(jk_out, "jk_out", rows)
+        for name, t in (("kidsum_in", kidsum_in), ("kidsum_out", kidsum_out)):
+            if t is not None:
+                _check_rows(t, name, graph.kidsum_rows * batch)
+        _lib.check(_lib.load().eg_gcn_layer_fwd_jk(graph._h, batch, _ptr(x), _ptr(weight), _ptr(scale), _ptr(shift), _ptr(residual),
+                                                   int(relu), _ptr(out), _ptr(kidsum_in), _ptr(kidsum_out), _ptr(jk_in), _ptr(jk_out),
+                                                   _stream()), "eg_gcn_layer_fwd_jk")
+        return out
     if kidsum_in is not None or kidsum_out is not None:
         krows = graph.kidsum_rows * batch
         for name, t in (("kidsum_in", kidsum_in), ("kidsum_out", kidsum_out)):
@@ -162,8 +181,10 @@ def gcn_layer_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tenso
 
 
 def gcn_layer_cls_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tensor, scale, shift, residual, relu: bool,
-                      packed: dict, sigmoid: bool = False, kidsum_in: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Last layer + node-type filter + 4 classifier heads in one kernel -> logits [batch * num_nodes, 4]."""
+                      packed: dict, sigmoid: bool = False, kidsum_in: Optional[torch.Tensor] = None,
+                      jk_in: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Last layer + node-type filter + 4 classifier heads in one kernel -> logits [batch * num_nodes, 4].
+    jk_in: running JumpingKnowledge('max') maximum of the earlier embeddings: the heads then see max(jk_in, layer output)."""
     rows = graph.num_nodes * batch
     _check_rows(x, "x", rows)
     if weight.shape != (C, C) or not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous():
@@ -174,10 +195,12 @@ def gcn_layer_cls_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.T
         _check_rows(residual, "residual", rows)
     if kidsum_in is not None:
         _check_rows(kidsum_in, "kidsum_in", graph.kidsum_rows * batch)
+    if jk_in is not None:
+        _check_rows(jk_in, "jk_in", rows)
     out = torch.empty(rows, 4, dtype=torch.float32, device=x.device)
     p = packed
     _lib.check(_lib.load().eg_gcn_layer_cls_fwd(graph._h, batch, _ptr(x), _ptr(weight), _ptr(scale), _ptr(shift), _ptr(residual),
-                                                int(relu), _ptr(kidsum_in), _ptr(p["w1"]), _ptr(p["s1"]), _ptr(p["t1"]),
+                                                int(relu), _ptr(kidsum_in), _ptr(jk_in), _ptr(p["w1"]), _ptr(p["s1"]), _ptr(p["t1"]),
                                                 _ptr(p["w2"]), _ptr(p["s2"]), _ptr(p["t2"]), _ptr(p["w3"]), _ptr(p["b3"]),
                                                 int(sigmoid), _ptr(out), _stream()), "eg_gcn_layer_cls_fwd")
     return out
@@ -691,3 +714,80 @@ def pack_levels(maps, batch: int, n_rows: int, row_offset: int = 0) -> torch.Ten
     """NCHW level maps [batch,128,p,p] (coarse to fine) -> node-major [batch * n_rows, 128]; level l lands at rows
     row_offset + sum_{k<l} p_k^2 of every frame.  Differentiable w.r.t. the maps."""
     return _PackLevelsFn.apply(int(batch), int(n_rows), int(row_offset), *maps)
+
+
+def _conv_pack_call(feats, weights, biases, nodes, batch, n_rows, row_offset):
+    n = len(feats)
+    if not 1 <= n <= 16 or len(weights) != n or len(biases) != n:
+        raise RuntimeError("1..16 levels, one weight and one bias (or None) per level")
+    sides, chans = [], []
+    for f, w, b in zip(feats, weights, biases):
+        if not f.is_cuda or f.dtype != torch.float32 or f.dim() != 4 or f.shape[0] != batch or f.shape[2] != f.shape[3] or \
+                not f.is_contiguous():
+            raise RuntimeError(f"level features must be contiguous CUDA float32 [batch, C_l, side, side], got {tuple(f.shape)}")
+        cin = int(f.shape[1])
+        if not w.is_cuda or w.dtype != torch.float32 or not w.is_contiguous() or w.numel() != C * cin or w.shape[0] != C:
+            raise RuntimeError(f"level weight must be a contiguous CUDA float32 [{C}, {cin}(, 1, 1)] tensor, got {tuple(w.shape)}")
+        if b is not None:
+            _check_vec(b, "level bias", C)
+        sides.append(int(f.shape[2]))
+        chans.append(cin)
+    fp = (ct.c_void_p * n)(*[f.data_ptr() for f in feats])
+    wp = (ct.c_void_p * n)(*[w.data_ptr() for w in weights])
+    bp = (ct.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in biases])
+    _lib.check(_lib.load().eg_conv1x1_relu_pack_levels(fp, wp, bp, (ct.c_int * n)(*chans), (ct.c_int * n)(*sides), n, batch, n_rows,
+                                                       row_offset, _ptr(nodes), _stream()), "eg_conv1x1_relu_pack_levels")
+
+
+class _ConvReluPackFn(torch.autograd.Function):
+    """relu(conv1x1(features[l])) of every level, packed node-major, in one launch.  The backward unpacks the node gradient to
+    NCHW (eg_unpack_levels) and lets torch differentiate the recomputed relu(conv2d) of each level (the small levels carry the
+    wide channel counts; the frame-sized one has 4 input channels)."""
+
+    @staticmethod
+    def forward(ctx, batch, n_rows, row_offset, n_levels, *tensors):
+        feats = [t.contiguous() for t in tensors[:n_levels]]
+        weights = [t.contiguous() for t in tensors[n_levels:2 * n_levels]]
+        biases = list(tensors[2 * n_levels:3 * n_levels])
+        used = sum(int(f.shape[2]) ** 2 for f in feats)
+        alloc = torch.empty if (row_offset == 0 and used == n_rows) else torch.zeros
+        nodes = alloc(batch * n_rows, C, dtype=torch.float32, device=feats[0].device)
+        _conv_pack_call(feats, weights, [b.contiguous() if b is not None else None for b in biases], nodes, batch, n_rows, row_offset)
+        ctx.meta = (batch, n_rows, row_offset, n_levels)
+        ctx.has_bias = [b is not None for b in biases]
+        ctx.save_for_backward(*feats, *weights, *[b for b in biases if b is not None])
+        return nodes
+
+    @staticmethod
+    def backward(ctx, d_nodes):
+        batch, n_rows, row_offset, n = ctx.meta
+        saved = ctx.saved_tensors
+        feats, weights = saved[:n], saved[n:2 * n]
+        bl = list(saved[2 * n:])
+        biases = [bl.pop(0) if hb else None for hb in ctx.has_bias]
+        g_maps = [torch.empty(batch, C, f.shape[2], f.shape[3], dtype=torch.float32, device=d_nodes.device) for f in feats]
+        _pack_call("eg_unpack_levels", g_maps, d_nodes.contiguous(), batch, n_rows, row_offset)
+        gf, gw, gb = [], [], []
+        for l in range(n):
+            need = (ctx.needs_input_grad[4 + l], ctx.needs_input_grad[4 + n + l], biases[l] is not None and ctx.needs_input_grad[4 + 2 * n + l])
+            if not any(need):
+                gf.append(None); gw.append(None); gb.append(None)
+                continue
+            with torch.enable_grad():
+                f = feats[l].detach().requires_grad_(need[0])
+                w = weights[l].detach().requires_grad_(need[1])
+                b = biases[l].detach().requires_grad_(need[2]) if biases[l] is not None else None
+                y = torch.relu(torch.nn.functional.conv2d(f, w.view(C, -1, 1, 1), b))
+                ins = [t for t, k in ((f, need[0]), (w, need[1]), (b, need[2])) if k]
+                outs = list(torch.autograd.grad(y, ins, g_maps[l]))
+            gf.append(outs.pop(0) if need[0] else None)
+            gw.append(outs.pop(0).view_as(weights[l]) if need[1] else None)
+            gb.append(outs.pop(0) if need[2] else None)
+        return (None, None, None, None, *gf, *gw, *gb)
+
+
+def conv1x1_relu_pack_levels(feats, weights, biases, batch: int, n_rows: int, row_offset: int = 0) -> torch.Tensor:
+    """relu(Conv2d(C_l, 128, 1)(feats[l])) for every level (coarse to fine), written node-major [batch * n_rows, 128] like
+    `pack_levels` (models.py:707-710 + :726-756 in one launch).  Differentiable w.r.t. features, weights and biases."""
+    n = len(feats)
+    return _ConvReluPackFn.apply(int(batch), int(n_rows), int(row_offset), n, *feats, *weights, *biases)

@@ -139,14 +139,26 @@ int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const f
 
 /* Last layer of a stack + node-type filter + the 4 classifier heads in ONE kernel (models.py:431-435 last iteration,
  * :485-490): the layer's output tile never leaves the chip, logits [batch * num_nodes, 4] are the only output.
- * Layer arguments as eg_gcn_layer_fwd (W^T form), kidsum_in as eg_gcn_layer_fwd_chain (or NULL); classifier
+ * Layer arguments as eg_gcn_layer_fwd (W^T form), kidsum_in as eg_gcn_layer_fwd_chain (or NULL), jk_in: NULL or the running
+ * JumpingKnowledge maximum (below); classifier
  * arguments as eg_classifier_fwd.  Needs a topology handle with eg_graph_kidsum_rows(g) > 0 whose rows are all
  * valid nodes (no coordinate / connection nodes) and residual in {NULL, x}; EG_ERR_UNSUPPORTED otherwise (run
  * eg_gcn_layer_fwd + eg_classifier_fwd instead). */
 int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
-                         const float* shift, const float* residual, int relu, const float* kidsum_in, const float* w1,
-                         const float* s1, const float* t1, const float* w2, const float* s2, const float* t2,
+                         const float* shift, const float* residual, int relu, const float* kidsum_in, const float* jk_in,
+                         const float* w1, const float* s1, const float* t1, const float* w2, const float* s2, const float* t2,
                          const float* w3, const float* b3, int sigmoid, float* logits, eg_stream_t stream);
+
+/* JumpingKnowledge('max') of the reference (torch_geometric JumpingKnowledge as used at src/core/models.py:380-382,
+ * :479-482: element-wise maximum over [node features, h_1, .., h_L]) carried through the fused stack as a running maximum:
+ * eg_gcn_layer_fwd_jk is eg_gcn_layer_fwd_chain that also writes jk_out = max(jk_in, out) (the first layer passes its
+ * input x as jk_in; kidsum_in / kidsum_out may be NULL); eg_gcn_layer_cls_fwd with jk_in != NULL runs the heads on
+ * max(jk_in, layer output).  EG_ERR_UNSUPPORTED where the producer/consumer kernel does not cover the handle.
+ * eg_graph_ps_launches: launches of that kernel on the handle so far (tests assert that a model stayed on the fused path). */
+int eg_gcn_layer_fwd_jk(const eg_graph* g, int batch, const float* x, const float* W, const float* scale, const float* shift,
+                        const float* residual, int relu, float* out, const float* kidsum_in, float* kidsum_out,
+                        const float* jk_in, float* jk_out, eg_stream_t stream);
+unsigned eg_graph_ps_launches(const eg_graph* g);
 
 /* out = A_hat x  (aggregation only; training / backward building block) */
 int eg_gcn_aggregate(const eg_graph* g, int batch, const float* x, float* out, eg_stream_t stream);
@@ -320,6 +332,14 @@ int eg_pack_levels(const float* const* level_maps, const int* level_side, int n_
                    int64_t row_offset, float* nodes, eg_stream_t stream);
 int eg_unpack_levels(const float* nodes, float* const* level_maps, const int* level_side, int n_levels, int batch,
                      int64_t n_rows, int64_t row_offset, eg_stream_t stream);
+/* The UNet variant's `F.relu(self.linears[i](features[i]))` (Conv2d(C_l, 128, kernel_size=1) + ReLU per level,
+ * src/core/models.py:707-710) fused into the packing: level_feats[l] [batch, level_channels[l], side_l, side_l] (NCHW),
+ * level_weights[l] [128, level_channels[l]] (the Conv2d weight), level_biases[l] [128] (array or entries may be NULL);
+ * nodes as eg_pack_levels.  The 128-channel NCHW maps are never formed. */
+int eg_conv1x1_relu_pack_levels(const float* const* level_feats, const float* const* level_weights,
+                                const float* const* level_biases, const int* level_channels, const int* level_side,
+                                int n_levels, int batch, int64_t n_rows, int64_t row_offset, float* nodes, eg_stream_t stream);
+
 
 #ifdef __cplusplus
 }

@@ -56,3 +56,45 @@ def test_create_node_pixels_matches_oracle(frame, naux, coord, main_only):
         got = hip.create_node_pixels(frames.to(DEV), B, None if coords is None else coords.to(DEV)).cpu()
     assert got.shape == want.shape
     assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("sides,chans,batch,extra_front,extra_back", [
+    ([2, 4, 8, 16, 32, 64, 128, 224], [512, 256, 128, 64, 32, 16, 8, 4], 2, 0, 0),      # the UNet variant's decoder (models.py:678-683)
+    ([2, 4, 30], [40, 7, 3], 2, 4, 4), ([17], [1], 2, 0, 0), ([1, 3, 65], [33, 64, 5], 1, 2, 0)])
+def test_conv1x1_relu_fused_into_the_packing(sides, chans, batch, extra_front, extra_back):
+    """eg_conv1x1_relu_pack_levels == F.relu(Conv2d(C_l, 128, 1)(features[l])) + the reference's permute / cat
+    (models.py:707-710, :726-756), values and gradients (features, weights, biases)."""
+    rs = np.random.RandomState(sum(sides) + sum(chans))
+    mk = lambda *shape, s=1.0: torch.from_numpy((rs.standard_normal(shape) * s).astype(np.float32)).to(DEV).requires_grad_(True)
+    feats = [mk(batch, c, sd, sd) for sd, c in zip(sides, chans)]
+    convs = [torch.nn.Conv2d(c, 128, kernel_size=1).to(DEV) for c in chans]
+    n_rows = extra_front + sum(s * s for s in sides) + extra_back
+    got = ops.conv1x1_relu_pack_levels(feats, [m.weight for m in convs], [m.bias for m in convs], batch, n_rows, extra_front)
+    maps = [torch.relu(m(f)) for m, f in zip(convs, feats)]
+    want = _reference_pack(maps, batch, n_rows, extra_front)
+    assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert torch.equal((got == 0), (want == 0)) or float(((got == 0) != (want == 0)).float().mean()) < 1e-5      # same ReLU pattern
+    g = torch.from_numpy(rs.standard_normal(tuple(got.shape)).astype(np.float32)).to(DEV)
+    params = feats + [m.weight for m in convs] + [m.bias for m in convs]
+    got_g = torch.autograd.grad(got, params, g)
+    want_g = torch.autograd.grad(want, params, g)
+    for a, b in zip(got_g, want_g):
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
+    # the model-level tail: the same through HierarchicalPatchModel.pack_node_features_linear on the default shape
+    if sides[-1] == 224:
+        hip, _ = model_pair(224, 7, 1)
+        with torch.no_grad():
+            a = hip.pack_node_features_linear([f.detach() for f in feats], convs, batch)
+            b = hip.pack_node_features([m.detach() for m in maps], batch)
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_conv_pack_rejects_bad_arguments():
+    f = torch.zeros(1, 8, 4, 4, device=DEV)
+    w = torch.zeros(128, 8, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.conv1x1_relu_pack_levels([f.cpu()], [w], [None], 1, 16)                 # CPU features
+    with pytest.raises(RuntimeError):
+        ops.conv1x1_relu_pack_levels([f], [torch.zeros(64, 8, device=DEV)], [None], 1, 16)     # not 128 output channels
+    with pytest.raises(RuntimeError):
+        ops.conv1x1_relu_pack_levels([torch.zeros(1, 8, 8, 8, device=DEV)], [w], [None], 1, 16)     # does not fit the frame's rows

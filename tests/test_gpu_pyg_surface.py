@@ -1,6 +1,8 @@
 """-m gpu: the torch_geometric-shaped operator surface — the call shapes the reference's unmodified model code uses
 (src/core/models.py:5, :329-335 construction, :431 ``layer(x, edge_index)``, :434-435 residual, :479-482 JumpingKnowledge)
 — forward AND backward through the HIP kernels against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -113,8 +115,50 @@ def test_model_jumping_knowledge_max(frame, naux, batch):
         got, _ = hip(x=frames.to(DEV), edge_index=ei.to(DEV), node_type=nt.to(DEV), batch_idx=bi.to(DEV))
     assert (got.cpu() - want).abs().max() < 1e-4
     assert torch.equal(O.landmark_argmax(got.cpu(), batch, frame), O.landmark_argmax(want, batch, frame))
+    # the maximum is carried through the FUSED stack (eg_gcn_layer_fwd_jk / eg_gcn_layer_cls_fwd with jk_in): the chained
+    # producer/consumer kernel ran once per layer, and the unfused route (layers one by one + torch.stack().max()) agrees
+    feats = hip.create_node_pixels(frames.to(DEV), batch)
+    graph, gb = hip._resolver.resolve(ei.to(DEV), feats.shape[0])
+    assert graph.fused_classifier_ok
+    before = graph.ps_launches
+    with torch.no_grad():
+        fused, _ = hip.forward_nodes(feats, ei.to(DEV), batch)
+    assert graph.ps_launches - before == 3
+    os.environ["EG_JK_FUSED"] = "0"
+    try:
+        before = graph.ps_launches
+        with torch.no_grad():
+            unfused, _ = hip.forward_nodes(feats, ei.to(DEV), batch)
+        assert graph.ps_launches == before
+    finally:
+        del os.environ["EG_JK_FUSED"]
+    assert (fused - unfused).abs().max() < 2e-5
     with pytest.raises(NotImplementedError):
         model_pair(frame, naux, 3, gnn_jk_mode="cat")
+
+
+def test_jumping_knowledge_max_stays_within_1p3x_of_the_last_path_at_full_size():
+    """configs[1] shape (224 / 7, batch 8): gnn_jk_mode='max' on the fused path against gnn_jk_mode='last', HIP-graph replays."""
+    frame, naux, B = 224, 7, 8
+    topo, ei, nt, bi = graph_tensors(frame, naux, B)
+    x = synthetic_node_feats(B * topo.num_nodes, 128, seed=3).to(DEV)
+    eid = ei.to(DEV)
+    times = {}
+    for mode in ("last", "max"):
+        hip, _ = model_pair(frame, naux, 3, seed=5, gnn_jk_mode=mode)
+        hip.enable_hip_graph(True)
+        with torch.no_grad():
+            for _ in range(5):
+                hip.forward_nodes(x, eid, B)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(30):
+                hip.forward_nodes(x, eid, B)
+            e1.record()
+            torch.cuda.synchronize()
+        times[mode] = e0.elapsed_time(e1) / 30
+    assert times["max"] <= 1.3 * times["last"], times
 
 
 @pytest.mark.parametrize("coord", [False, True])

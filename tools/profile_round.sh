@@ -20,7 +20,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(lambda:[0.0,0]))
 for f in glob.glob("/tmp/prof_$TAG/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k=row["Kernel_Name"]
-        # "k_gcn_layer": the layer kernel proper (k_gcn_layer_ps<false, 0> in the chained step, k_gcn_layer<AGG> otherwise);
+        # "k_gcn_layer": the layer kernel proper (k_gcn_layer_ps<false> in the chained step, k_gcn_layer<AGG> otherwise);
         # the last layer with the fused classifier heads is reported on its own
         name = "k_gcn_layer_ps_cls" if "k_gcn_layer_ps<true" in k else "k_gcn_layer" if "k_gcn_layer" in k else "k_classifier" if "k_classifier" in k else None
         if not name: continue

@@ -38,7 +38,7 @@ for it in range(3):
         ops.gcn_layer_fwd(g, B, x, w, None, None, x, relu=True, out=out, **kw)
     lib.eg_debug_phase_cycles(g._h, buf, 1)
     v = list(buf)
-names = ["c_chain0", "c_chain1", "c_barrier", "c_unused", "p_issue", "p_main(wait+fma)", "p_kids+store", "p_claim+barrier"] if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else ["next_tile", "phase1", "barrier1", "mfma", "barrier2", "dwrite", "barrier3", "phase3"]
+names = ["c_mfma", "c_epilogue", "c_barrier", "c_loop", "p_issue", "p_main(wait+fma)", "p_kids+store", "p_claim+barrier"] if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else ["next_tile", "phase1", "barrier1", "mfma", "barrier2", "dwrite", "barrier3", "phase3"]
 tot = sum(v[:8]); waves = max(v[8], 1)
 tiles = 1128 * B
 print(f"waves(counted)={waves} tiles={tiles}")
