@@ -38,7 +38,7 @@ _pp = ct.POINTER(ClsTrainParams)
 SIGNATURES: Dict[str, tuple] = {
     "eg_version": (_i, []),
     "eg_last_error": (ct.c_char_p, []),
-    "eg_topo_create": (_i, [_i, _i, _i, _i, ct.POINTER(_p)]),
+    "eg_topo_create": (_i, [_i, _i, _i, _i, _i, _i, _i, ct.POINTER(_p)]),
     "eg_csr_create": (_i, [_p, _i64, _i64, _p, ct.POINTER(_p)]),
     "eg_graph_is_symmetric": (_i, [_p]),
     "eg_csr_create_transposed": (_i, [_p, _p, _i64, _p, ct.POINTER(_p)]),

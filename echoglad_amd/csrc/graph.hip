@@ -174,9 +174,13 @@ int eg_version(void) { return 120; }
 
 const char* eg_last_error(void) { return g_last_error.c_str(); }
 
-int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph** out) {
+int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn_nodes, int diag_main, int diag_aux,
+                   eg_graph** out) {
     if (!out) return set_error(EG_ERR_ARG, "out is NULL");
     *out = nullptr;
+    if (conn_nodes || diag_main || diag_aux)
+        return set_error(EG_ERR_UNSUPPORTED, "connection nodes and 'grid-diagonal' levels have no implicit-stencil tables: build the "
+                                             "graph with eg_csr_create");
     Topo T;
     int rc = build_topo(frame, naux, main_only, coord_nodes, T);
     if (rc != EG_OK) return rc;

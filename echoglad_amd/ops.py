@@ -63,13 +63,17 @@ class Graph:
 
     @classmethod
     def topo(cls, frame_size: int, num_aux_graphs: int, use_main_graph_only: bool = False,
-             use_coordinate_graph: bool = False, device=None) -> "Graph":
+             use_coordinate_graph: bool = False, device=None, use_connection_nodes: bool = False, diag_main: bool = False,
+             diag_aux: bool = False) -> "Graph":
+        """Implicit-stencil handle of the closed-form topology.  Connection nodes / 'grid-diagonal' levels raise
+        (EG_ERR_UNSUPPORTED): those graphs run on a CSR handle (``Graph.csr``)."""
         lib = _lib.load()
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         h = ct.c_void_p()
         with torch.cuda.device(device):
             _lib.check(lib.eg_topo_create(frame_size, num_aux_graphs, int(use_main_graph_only),
-                                          int(use_coordinate_graph), ct.byref(h)), "eg_topo_create")
+                                          int(use_coordinate_graph), int(use_connection_nodes), int(diag_main), int(diag_aux),
+                                          ct.byref(h)), "eg_topo_create")
         return cls(h, True, int(lib.eg_graph_num_nodes(h)), device)
 
     @classmethod

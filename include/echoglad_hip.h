@@ -63,9 +63,12 @@ const char* eg_last_error(void);
  * Closed form of DummyDataset.create_graphs (src/core/datasets.py:1441-1584):
  * aux levels 2^k x 2^k (k = 1..naux), main grid frame x frame, 4-neighbour
  * edges, parent<->child edges, centre-crop link with Python slice semantics,
- * optional isolated K4 of coordinate nodes.  Connection nodes and
- * 'grid-diagonal' are not covered (EG_ERR_UNSUPPORTED -> use eg_csr_create). */
-int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, eg_graph** out);
+ * optional isolated K4 of coordinate nodes.  The signature is SURVEY 8(b)'s: every flag of the reference's builder is an
+ * argument.  conn_nodes (datasets.py:1452-1456, :1512-1515) and diag_main / diag_aux ('grid-diagonal', :1469-1475,
+ * :1494-1500) have no implicit-stencil tables yet: != 0 returns EG_ERR_UNSUPPORTED, the caller's cue to build the same
+ * graph with eg_csr_create (what nn.GraphResolver does). */
+int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn_nodes, int diag_main, int diag_aux,
+                   eg_graph** out);
 
 /* Generic CSR (by target node) from a device edge_index [2, n_edges] int64 in
  * PyG layout (row 0 = source, row 1 = target).  Deterministic: neighbours keep

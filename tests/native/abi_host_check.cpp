@@ -17,10 +17,13 @@ int main() {
     EXPECT(eg_version() > 0, "eg_version");
     // ---- argument validation: NULL / out-of-range arguments must come back as EG_ERR_ARG, never crash
     eg_graph* g = nullptr;
-    EXPECT(eg_topo_create(224, 7, 0, 0, nullptr) == EG_ERR_ARG, "eg_topo_create(out = NULL)");
-    EXPECT(eg_topo_create(0, 7, 0, 0, &g) != EG_OK && g == nullptr, "eg_topo_create(frame = 0)");
-    EXPECT(eg_topo_create(224, 99, 0, 0, &g) != EG_OK && g == nullptr, "eg_topo_create(naux = 99)");
-    EXPECT(eg_topo_create(-5, 3, 0, 0, &g) != EG_OK && g == nullptr, "eg_topo_create(frame < 0)");
+    EXPECT(eg_topo_create(224, 7, 0, 0, 0, 0, 0, nullptr) == EG_ERR_ARG, "eg_topo_create(out = NULL)");
+    EXPECT(eg_topo_create(0, 7, 0, 0, 0, 0, 0, &g) != EG_OK && g == nullptr, "eg_topo_create(frame = 0)");
+    EXPECT(eg_topo_create(224, 99, 0, 0, 0, 0, 0, &g) != EG_OK && g == nullptr, "eg_topo_create(naux = 99)");
+    EXPECT(eg_topo_create(-5, 3, 0, 0, 0, 0, 0, &g) != EG_OK && g == nullptr, "eg_topo_create(frame < 0)");
+    EXPECT(eg_topo_create(224, 7, 0, 0, 1, 0, 0, &g) == EG_ERR_UNSUPPORTED && g == nullptr, "eg_topo_create(connection nodes): caller builds a CSR handle");
+    EXPECT(eg_topo_create(224, 7, 0, 0, 0, 1, 0, &g) == EG_ERR_UNSUPPORTED && g == nullptr, "eg_topo_create(grid-diagonal main level)");
+    EXPECT(eg_topo_create(224, 7, 0, 0, 0, 0, 1, &g) == EG_ERR_UNSUPPORTED && g == nullptr, "eg_topo_create(grid-diagonal aux levels)");
     EXPECT(eg_graph_destroy(nullptr) == EG_OK, "eg_graph_destroy(NULL)");
     EXPECT(eg_graph_num_nodes(nullptr) == -1, "eg_graph_num_nodes(NULL)");
     EXPECT(eg_graph_kidsum_rows(nullptr) == 0, "eg_graph_kidsum_rows(NULL)");
@@ -51,7 +54,7 @@ int main() {
     int created = 0;
     for (const auto& c : cfgs) {
         g = nullptr;
-        const int rc = eg_topo_create(c[0], c[1], c[2], c[3], &g);
+        const int rc = eg_topo_create(c[0], c[1], c[2], c[3], 0, 0, 0, &g);
         if (rc == EG_OK) {
             ++created;
             EXPECT(g != nullptr && eg_graph_num_nodes(g) > 0 && eg_graph_num_tiles(g) > 0, "eg_topo_create handle");

@@ -41,8 +41,12 @@ def test_code_object_targets_gfx950(built_lib):
 def test_bad_arguments_return_error_codes(built_lib):
     lib = _lib.load()
     h = ctypes.c_void_p()
-    assert lib.eg_topo_create(1, 7, 0, 0, ctypes.byref(h)) == _lib.EG_ERR_ARG          # frame < 2
+    assert lib.eg_topo_create(1, 7, 0, 0, 0, 0, 0, ctypes.byref(h)) == _lib.EG_ERR_ARG          # frame < 2
     assert "frame" in _lib.last_error()
-    assert lib.eg_topo_create(224, 40, 0, 0, ctypes.byref(h)) == _lib.EG_ERR_ARG        # naux too large
+    assert lib.eg_topo_create(224, 40, 0, 0, 0, 0, 0, ctypes.byref(h)) == _lib.EG_ERR_ARG        # naux too large
+    # connection nodes / 'grid-diagonal' levels are arguments of the builder; no stencil tables -> -2, caller uses CSR
+    for flags in ((1, 0, 0), (0, 1, 0), (0, 0, 1)):
+        assert lib.eg_topo_create(224, 7, 0, 0, *flags, ctypes.byref(h)) == _lib.EG_ERR_UNSUPPORTED and not h.value
+    assert "eg_csr_create" in _lib.last_error()
     assert lib.eg_gcn_layer_fwd(None, 1, None, None, None, None, None, 0, 0, None, None) == _lib.EG_ERR_ARG
     assert lib.eg_graph_destroy(None) == _lib.EG_OK
