@@ -7,6 +7,8 @@
 //   eg_bn_act_bwd     dz, dgamma, dbeta from dy (two passes: reduce, apply); dropout mask regenerated from the seed
 // All reductions are two-stage (per-workgroup partials in a caller-provided workspace, then one fixed-order
 // pass), so results are bitwise reproducible run to run: no float atomics anywhere.
+#include <stdlib.h>
+
 #include "train_common.h"
 
 namespace eg {
@@ -526,7 +528,7 @@ int eg_bn_act_fwd(const float* z, int64_t rows, const float* scale, const float*
     if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
     const ActArgs a = make_act(rows, relu, dropout_p, seed);
     long long blocks = (rows * (C / 4) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 65536) blocks = 65536;        // (measured at batch 32: 4.6 - 4.9 TB/s with 1k - 16k blocks, 5.2 TB/s with 64k)
     hipLaunchKernelGGL(k_bn_act_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, scale, shift, residual, out, a);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
