@@ -439,7 +439,12 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 // ---- usual case: both segments on the fast path, vertically adjacent, same parents ----
                 SegPair A;
                 const bool use_kin = sd0.aux && kin;                // uniform: children already summed by the previous layer
-                segp_issue(sd0, sd1, xf, lane, A);
+                const RowSrc xs = row_src(xf, a.n_per_frame * (C * 4), lane);
+                segp_issue(sd0, sd1, xs, A);
+#ifdef EG_KIN_EARLY
+                SegKidsum KS;
+                if (use_kin) segp_kidsum_issue(sd0, sd1, row_src(kin + (size_t)frame * a.kid_rows * C, a.kid_rows * (C * 4), lane), KS);
+#endif
 #ifdef EG_ABL_NO_LOADS        // timing-only ablation: producers do nothing (results wrong)
                 return;
 #endif
@@ -447,26 +452,29 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 PSTAMP(PS_ISSUE);
                 const float* wqa = s_pat + sd0.pat * PATQ + 32 * (lane >> 5);      // this lane's weights (LDS, quad layout)
                 const float* wqb = s_pat + sd1.pat * PATQ + 32 * (lane >> 5);
-                segw_rows(lane, wqa, A.Sa, A.LRa, A.LRa, A.U, A.Sb, A.P, acc0, s_x, 16 * p);
-                segw_rows(lane, wqb, A.Sb, A.LRb, A.LRb, A.Sa, A.D, A.P, acc1, s_x, 16 * p + 8);
+                float* s_t = s_x ? s_x : s_a;                       // where the segments' own rows pass through LDS
+                segw_rows(lane, wqa, A.Sa, A.LRa, A.U, A.Sb, A.P, acc0, s_t, 16 * p);
+                segw_rows(lane, wqb, A.Sb, A.LRb, A.Sa, A.D, A.P, acc1, s_t, 16 * p + 8);
                 pin_acc4(acc0);
                 pin_acc4(acc1);                                     // the 40 main-stage registers are dead from here on
                 __builtin_amdgcn_sched_barrier(0);
                 PSTAMP(PS_MAIN);
                 if (use_kin) {                                      // (issued here, not with the first batch: registers)
+#ifndef EG_KIN_EARLY
                     SegKidsum KS;
-                    segp_kidsum_issue(sd0, sd1, kin + (size_t)frame * a.kid_rows * C, lane, KS);
+                    segp_kidsum_issue(sd0, sd1, row_src(kin + (size_t)frame * a.kid_rows * C, a.kid_rows * (C * 4), lane), KS);
+#endif
                     segp_kidsum_add(KS, wqa, wqb, acc0, acc1);
                 } else if (sd0.aux) {                               // uniform: aux level, children pulled as rows
                     {
                         SegKids K;
-                        segw_kids_issue(sd0, pats, xf, lane, K);
+                        segw_kids_issue(sd0, pats, xs, lane, K);
                         segw_kids_add(lane, K, acc0);
                     }
                     pin_acc4(acc0);                                 // one segment's 16 child loads in flight at a time (registers)
                     {
                         SegKids K;
-                        segw_kids_issue(sd1, pats, xf, lane, K);
+                        segw_kids_issue(sd1, pats, xs, lane, K);
                         segw_kids_add(lane, K, acc1);
                     }
                 }

@@ -348,14 +348,18 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
     g->n_nodes = T.n_nodes;
     g->n_pats = (int)(pats.size() / 128);
     // The same patterns in "quad" layout for the producer/consumer kernel, which keeps them in LDS: [pattern][row parity
-    // h][slot 0..7][k 0..3] = weight of (node 2k + h, slot); slot 6 = 1.0 when the node has children, slot 7 unused.
+    // h][slot 0..7][k 0..3] = weight of (node 2k + h, slot); slot 6 = 1.0 when the node has children.  The outer
+    // neighbours of a segment's first and last node travel apart from the inner ones (seg_wide.h, segw_rows): node 0's
+    // left weight and node 7's right weight sit in slot 7 (k = 0 of h = 0, k = 3 of h = 1) and are zero in slots 3 / 4.
     std::vector<float> patsq((size_t)g->n_pats * 64, 0.0f);
     for (int pi = 0; pi < g->n_pats; ++pi)
         for (int h = 0; h < 2; ++h)
             for (int sl = 0; sl < 7; ++sl)
                 for (int k = 0; k < 4; ++k) {
                     const float w = pats[(size_t)pi * 128 + (2 * k + h) * 8 + sl];
-                    patsq[(size_t)pi * 64 + h * 32 + sl * 4 + k] = sl < 6 ? w : (w != 0.0f ? 1.0f : 0.0f);
+                    const bool outer = (sl == 3 && h == 0 && k == 0) || (sl == 4 && h == 1 && k == 3);
+                    patsq[(size_t)pi * 64 + h * 32 + sl * 4 + k] = outer ? 0.0f : (sl < 6 ? w : (w != 0.0f ? 1.0f : 0.0f));
+                    if (outer) patsq[(size_t)pi * 64 + h * 32 + 7 * 4 + k] = w;
                 }
     // chained layers run the producer/consumer kernel, which keeps the pattern table in LDS beside its tile buffers
     const size_t ps_lds = (size_t)(4 * TILE * LDA + 16 + 64 + 2 * TILE + (pats.size() / 128) * 64 + 4 * C) * sizeof(float);   // incl. the fused-classifier tables

@@ -11,33 +11,64 @@
 namespace eg {
 
 constexpr int PATQ = 64;       // floats per pattern in quad layout
-enum { SLOT_SELF = 0, SLOT_UP = 1, SLOT_DOWN = 2, SLOT_LEFT = 3, SLOT_RIGHT = 4, SLOT_PARENT = 5, SLOT_HASKIDS = 6 };
+enum { SLOT_SELF = 0, SLOT_UP = 1, SLOT_DOWN = 2, SLOT_LEFT = 3, SLOT_RIGHT = 4, SLOT_PARENT = 5, SLOT_HASKIDS = 6, SLOT_EDGE = 7 };
+
+// Row loads of the producers: buffer loads off a frame descriptor in SGPRs.  The lane's part of the address is one VGPR
+// for the whole kernel, the run's first row goes into the scalar offset and the pair index into the immediate, so a load
+// costs no VALU instruction (a flat 64-bit address costs three per load, and fp32 VALU work takes MFMA issue slots).
+// Rows past the frame read as zero.
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+struct RowSrc {
+    __amdgpu_buffer_rsrc_t r;
+    int pair;        // byte offset of this lane inside a row pair: h * 512 + 16 q
+    int q16;         // 16 q
+    int h;
+};
+__device__ inline RowSrc row_src(const float* base, int bytes, int lane) {
+    return RowSrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000),
+                  (lane >> 5) * (C * 4) + (lane & 31) * 16, (lane & 31) * 16, lane >> 5};
+}
+// rows row0 + 2k + h (row0 wave-uniform)
+__device__ inline f32x4 ldp(const RowSrc& s, int row0, int k) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r, s.pair + k * (2 * C * 4), row0 * (C * 4), 0));
+}
+// row `lower` in the lower half of the wave, row `upper` in the upper half (both wave-uniform)
+__device__ inline f32x4 ld_two_rows(const RowSrc& s, int lower, int upper) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r, s.q16 + s.h * ((upper - lower) * (C * 4)), lower * (C * 4), 0));
+}
 
 __device__ inline f32x4 quad_w(const float* wq, int slot) { return *reinterpret_cast<const f32x4*>(wq + 4 * slot); }
 
 // acc = sum over self / left / right / above / below / parent rows of one segment (children are added afterwards).
 // wq: this lane's quad weights (LDS): pattern base + 32 * (lane >> 5).
-__device__ inline void segw_rows(int lane, const float* wq, const f32x4 (&S)[4], const f32x4& Le, const f32x4& Re,
+// The segment's own rows go to LDS first (s_t: the residual stash of the tile, or the wave's rows of the A tile, which
+// segw_store overwrites afterwards) and the left / right neighbours come back as the rows one above / below, shifted by
+// the LDS address: no cross-lane VALU work (fp32 VALU and the MFMA share one issue slot per SIMD).  The
+// segment's first / last node take their outer neighbour from LR (lower half: the row left of the segment, upper half:
+// the row right of it) with the weights of SLOT_EDGE; SLOT_LEFT / SLOT_RIGHT are zero there (graph.hip).
+__device__ inline void segw_rows(int lane, const float* wq, const f32x4 (&S)[4], const f32x4& LR,
                                  const f32x4 (&U)[4], const f32x4 (&D)[4], const f32x4 (&P)[2], f32x4 (&acc)[4],
-                                 float* s_x, int rl) {
+                                 float* s_t, int rl) {
     const PairLane pl{lane >> 5, lane & 31};
-    const bool up_half = pl.h != 0;
     {
-        const f32x4 w0 = quad_w(wq, SLOT_SELF), w3 = quad_w(wq, SLOT_LEFT), w4 = quad_w(wq, SLOT_RIGHT);
-        f32x4 Mk = seam(Le, S[0], up_half);
+        float* row0 = s_t + rl * LDA + 4 * pl.q;           // row 0 of the segment, this lane's channels
+        float* rowh = row0 + pl.h * LDA;                   // row h
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(rowh + 2 * k * LDA) = S[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // LDS operations of one wave complete in order
+        const f32x4 w0 = quad_w(wq, SLOT_SELF), w3 = quad_w(wq, SLOT_LEFT), w4 = quad_w(wq, SLOT_RIGHT), we = quad_w(wq, SLOT_EDGE);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const f32x4 Mn = seam(S[k], k < 3 ? S[k < 3 ? k + 1 : 3] : Re, up_half);
-            f32x4 a = w4[k] * Mn;
-            a += w3[k] * Mk;
+            // node 2k + h: left neighbour = row 2k + h - 1, right neighbour = row 2k + h + 1, clamped into the segment
+            const f32x4 L = *reinterpret_cast<const f32x4*>(k == 0 ? row0 : rowh + (2 * k - 1) * LDA);
+            const f32x4 R = *reinterpret_cast<const f32x4*>(k == 3 ? row0 + 7 * LDA : rowh + (2 * k + 1) * LDA);
+            f32x4 a = w4[k] * R;
+            a += w3[k] * L;
             a += w0[k] * S[k];
             acc[k] = a;
-            Mk = Mn;
         }
-        if (s_x) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(&s_x[(rl + 2 * k + pl.h) * LDA + 4 * pl.q]) = S[k];
-        }
+        acc[0] += we[0] * LR;
+        acc[3] += we[3] * LR;
     }
     {
         const f32x4 w1 = quad_w(wq, SLOT_UP);
@@ -64,27 +95,23 @@ __device__ inline void segw_rows(int lane, const float* wq, const f32x4 (&S)[4],
 // rows of a segment come in one load: 20 wave loads instead of 32.  SegDesc::pad0 of the upper segment says when this
 // holds (host, graph.hip).
 struct SegPair {
-    f32x4 Sa[4], Sb[4], LRa, LRb, U[4], D[4], P[2];   // LR: upper half = row left of the segment, lower half = row right of it
+    f32x4 Sa[4], Sb[4], LRa, LRb, U[4], D[4], P[2];   // LR: lower half = row left of the segment, upper half = row right of it
 };
 
-__device__ inline void segp_issue(const SegDesc& sa, const SegDesc& sb, const float* __restrict__ xf, int lane, SegPair& A) {
-    const PairLane pl{lane >> 5, lane & 31};
-    const unsigned osa = pair_off(sa.n_first, pl), osb = pair_off(sb.n_first, pl);
-    const unsigned ou = pair_off(sa.up0, pl), od = pair_off(sb.down0, pl), op = pair_off(sa.par0, pl);
+__device__ inline void segp_issue(const SegDesc& sa, const SegDesc& sb, const RowSrc& xs, SegPair& A) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) A.Sa[k] = ld4(xf, osa, k);
+    for (int k = 0; k < 4; ++k) A.Sa[k] = ldp(xs, sa.n_first, k);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) A.Sb[k] = ld4(xf, osb, k);
-    // seam() takes the left edge from the UPPER half of its first operand and the right edge from the LOWER half of
-    // its second one: one 1-KB wave load fetches both edge rows of a segment.
-    A.LRa = *reinterpret_cast<const f32x4*>(xf + bcast_off(pl.h ? sa.left : sa.right, pl));
-    A.LRb = *reinterpret_cast<const f32x4*>(xf + bcast_off(pl.h ? sb.left : sb.right, pl));
+    for (int k = 0; k < 4; ++k) A.Sb[k] = ldp(xs, sb.n_first, k);
+    // one 1-KB wave load fetches both edge rows of a segment, each in the half whose lanes use it (segw_rows)
+    A.LRa = ld_two_rows(xs, sa.left, sa.right);
+    A.LRb = ld_two_rows(xs, sb.left, sb.right);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) A.U[k] = ld4(xf, ou, k);
+    for (int k = 0; k < 4; ++k) A.U[k] = ldp(xs, sa.up0, k);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) A.D[k] = ld4(xf, od, k);
-    A.P[0] = ld4(xf, op, 0);
-    A.P[1] = ld4(xf, op, 1);
+    for (int k = 0; k < 4; ++k) A.D[k] = ldp(xs, sb.down0, k);
+    A.P[0] = ldp(xs, sa.par0, 0);
+    A.P[1] = ldp(xs, sa.par0, 1);
 }
 
 // Aux levels, chained layers: the children's contribution of node n is ONE row of the side buffer (row n; the previous
@@ -92,11 +119,9 @@ __device__ inline void segp_issue(const SegDesc& sa, const SegDesc& sb, const fl
 // segment, loaded once the main stage has freed its registers.
 struct SegKidsum { f32x4 Ka[4], Kb[4]; };
 
-__device__ inline void segp_kidsum_issue(const SegDesc& sa, const SegDesc& sb, const float* __restrict__ kf, int lane, SegKidsum& K) {
-    const PairLane pl{lane >> 5, lane & 31};
-    const unsigned oa = pair_off(sa.n_first, pl), ob = pair_off(sb.n_first, pl);
+__device__ inline void segp_kidsum_issue(const SegDesc& sa, const SegDesc& sb, const RowSrc& ks, SegKidsum& K) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { K.Ka[k] = ld4(kf, oa, k); K.Kb[k] = ld4(kf, ob, k); }
+    for (int k = 0; k < 4; ++k) { K.Ka[k] = ldp(ks, sa.n_first, k); K.Kb[k] = ldp(ks, sb.n_first, k); }
 }
 
 __device__ inline void segp_kidsum_add(const SegKidsum& K, const float* wqa, const float* wqb, f32x4 (&acc0)[4], f32x4 (&acc1)[4]) {
@@ -112,20 +137,15 @@ __device__ inline void segp_kidsum_add(const SegKidsum& K, const float* wqa, con
 struct SegKids { f32x4 Ca[8], Cb[8]; float wa, wb; };      // child rows 2r (Ca) and 2r+1 (Cb): 8 pairs = 16 node rows each
 
 // pats: the lane-layout pattern table in global memory (lane (u, s): weight of slot s / slot 8 + (s & 1) of node u)
-__device__ inline void segw_kids_issue(const SegDesc& sd, const float* __restrict__ pats, const float* __restrict__ xf,
+__device__ inline void segw_kids_issue(const SegDesc& sd, const float* __restrict__ pats, const RowSrc& xs,
                                        int lane, SegKids& K) {
-    const PairLane pl{lane >> 5, lane & 31};
     const float* pw = pats + (size_t)sd.pat * 128;
     K.wa = pw[lane];
     K.wb = pw[64 + lane];
-    const unsigned oc0 = pair_off(sd.c0, pl);
-    const unsigned oc1 = pair_off(sd.c1, pl);
-    const unsigned oc2 = pair_off(sd.c2, pl);
-    const unsigned oc3 = pair_off(sd.c3, pl);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        K.Ca[k] = ld4(xf, oc0, k); K.Ca[4 + k] = ld4(xf, oc1, k);
-        K.Cb[k] = ld4(xf, oc2, k); K.Cb[4 + k] = ld4(xf, oc3, k);
+        K.Ca[k] = ldp(xs, sd.c0, k); K.Ca[4 + k] = ldp(xs, sd.c1, k);
+        K.Cb[k] = ldp(xs, sd.c2, k); K.Cb[4 + k] = ldp(xs, sd.c3, k);
     }
 }
 
