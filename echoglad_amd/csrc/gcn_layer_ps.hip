@@ -37,6 +37,14 @@ struct PsDims {
 #define PSTAMP_FLUSH(base) do {} while (0)
 #endif
 
+// One v_max_f32.  fmaxf() on a value that comes straight out of an MFMA costs two: the compiler first canonicalises a
+// possible signalling NaN with a v_max_f32 x, x, x of its own.
+__device__ inline float max_raw(float x, float y) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
 // Asynchronous claim: the atomic on the own XCD's queue is issued early (ps_claim_issue), its result is looked at
 // only after the tile's row loads have come back (ps_claim_commit); only an exhausted queue takes the slow walk.
 __device__ inline int ps_claim_issue(int* __restrict__ counters, int group) {
@@ -123,13 +131,21 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         constexpr bool RES_LATE = CLS;                 // (the fused-classifier variant has no registers for the residual prefetch)
         float wreg[64];
         load_w_slice(W, wave, lane_k, a.transpose_w, wreg);
-        f32x4 sc[4], sh[4];
+        // The per-channel scale of the epilogue (eval-mode BatchNorm folded by the caller) goes into the W slice -- lane
+        // (i = l & 31) holds output channel 32 wave + i -- and the shift into the accumulators' initial value: the epilogue
+        // is max + residual add, with no LDS or register operand of its own.
+        if (scale) {
+            const float sv = scale[32 * wave + (lane_k & 31)];
+#pragma unroll
+            for (int t = 0; t < 64; ++t) wreg[t] *= sv;
+        }
+        f32x16 shv;                                    // !CLS: shift of channel (r & 3) + 8 (r >> 2) + 4 h in register r
         if (!CLS) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch0 = 32 * wave + 8 * g + 4 * (lane_k >> 5);
-                sc[g] = scale ? *reinterpret_cast<const f32x4*>(scale + ch0) : f32x4{1.f, 1.f, 1.f, 1.f};
-                sh[g] = shift ? *reinterpret_cast<const f32x4*>(shift + ch0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 q = shift ? *reinterpret_cast<const f32x4*>(shift + ch0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                shv[4 * g] = q.x; shv[4 * g + 1] = q.y; shv[4 * g + 2] = q.z; shv[4 * g + 3] = q.w;
             }
         }
         // CLS: wave = classifier head.  First-layer slice of the stacked [128,128] weight in 64 more VGPRs (the per-channel
@@ -141,6 +157,11 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         float b3v = 0.f;
         if (CLS) {
             load_w_slice(ca.w1, wave, lane_k, 0, wreg2);
+            {
+                const float sv = ca.s1[32 * wave + (lane_k & 31)];      // the first head layer's BatchNorm scale, folded the same way
+#pragma unroll
+                for (int t = 0; t < 64; ++t) wreg2[t] *= sv;
+            }
             const f32x4* pw = reinterpret_cast<const f32x4*>(ca.w2 + (size_t)(wave * 16 + (lane_k & 15)) * 32 + 8 * (lane_k >> 4));
             const f32x4 q0 = pw[0], q1 = pw[1];
             w2a[0] = q0.x; w2a[1] = q0.y; w2a[2] = q0.z; w2a[3] = q0.w; w2a[4] = q1.x; w2a[5] = q1.y; w2a[6] = q1.z; w2a[7] = q1.w;
@@ -189,8 +210,18 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     kout_row[i] = pc < npar ? par0 + pc : -1;
                 }
             }
-            f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            f32x16 acc1 = acc0;
+            f32x16 acc0, acc1;
+            if (CLS) {                                  // (no registers for a persistent copy: the shift comes from LDS each tile)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(s_bn + C + 32 * wave + 4 * (lane >> 5) + 8 * g);
+                    acc0[4 * g] = q.x; acc0[4 * g + 1] = q.y; acc0[4 * g + 2] = q.z; acc0[4 * g + 3] = q.w;
+                }
+                acc1 = acc0;
+            } else {
+                acc0 = shv;
+                acc1 = shv;
+            }
             // Epilogue pieces, all branch-free so that they can sit in one scheduling region with MFMAs.
             // Lane (row j of a 32-row block, half h) holds 16 channels of ONE row: stored from there a wave instruction
             // would touch 32 rows x 32 B.  The finished values go back into this wave's own channel slice of the stash
@@ -202,50 +233,76 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             // residual rows of both 32-row blocks, read BEFORE the MFMA chains: an LDS wait inside a chain stalls the
             // wave's next MFMA as well (in-order issue)
             f32x4 res[2][4];
-            if (!RES_LATE) {                                                  // (the fused-classifier variant has no registers to spare)
+            if (RES_LATE) {                                                   // one register set: rows 0..31 now, rows 32..63 once those are done
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int g = 0; g < 4; ++g) res[0][g] = *reinterpret_cast<const f32x4*>(s_x + j * LDA + 32 * wave + 4 * h + 8 * g);
+            } else {
+                if (has_res) {                                                // a real (uniform) branch: 32 selects per tile otherwise
+                    asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        res[rb][g] = *reinterpret_cast<const f32x4*>(s_x + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g);
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            res[rb][g] = *reinterpret_cast<const f32x4*>(s_x + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g);
+                } else {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) res[rb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
             auto finish_group = [&](const f32x16& acc, int rb, int g) {          // 4 channels of row 32 rb + j -> LDS
                 float* xp = s_x + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g;   // LDS row = 8 * patch row + column
-                f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                if (CLS) {
-                    const float* bp = s_bn + 32 * wave + 4 * h + 8 * g;
-                    v = v * *reinterpret_cast<const f32x4*>(bp) + *reinterpret_cast<const f32x4*>(bp + C);
+                f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};          // scale and shift are in already
+                v.x = max_raw(v.x, relu_floor); v.y = max_raw(v.y, relu_floor); v.z = max_raw(v.z, relu_floor); v.w = max_raw(v.w, relu_floor);
+                if (RES_LATE) {
+                    const f32x4 r = res[0][g];
+                    v.x += has_res ? r.x : 0.f; v.y += has_res ? r.y : 0.f; v.z += has_res ? r.z : 0.f; v.w += has_res ? r.w : 0.f;
                 } else {
-                    v = v * sc[g] + sh[g];
+                    v += res[rb][g];
                 }
-                v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-                const f32x4 r = RES_LATE ? *reinterpret_cast<const f32x4*>(xp) : res[rb][g];
-                v.x += has_res ? r.x : 0.f; v.y += has_res ? r.y : 0.f; v.z += has_res ? r.z : 0.f; v.w += has_res ? r.w : 0.f;
                 *reinterpret_cast<f32x4*>(xp) = v;
             };
             const int u8 = lane >> 3, c4 = 4 * (lane & 7);
-            float* ob = out + (size_t)frame * a.n_per_frame * C + 32 * wave + c4;
+            // output rows leave as buffer stores: frame descriptor + scalar offset of the segment's first row; the lane part
+            // (node inside the segment, channel chunk) is the only vector arithmetic of a store
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                CLS ? nullptr : out + (size_t)frame * a.n_per_frame * C, 0, CLS ? 0 : a.n_per_frame * (C * 4), 0x00020000);
+            const int ocol = (32 * wave + c4) * 4;
             f32x4 o[4], jm[4];
-            int node[4];
+            int node[4], ovoff[4], osoff[4];
             const float* jb = JK ? jk_in + (size_t)frame * a.n_per_frame * C + 32 * wave + c4 : nullptr;
             float* jo = JK ? jk_out + (size_t)frame * a.n_per_frame * C + 32 * wave + c4 : nullptr;
             auto read_segments = [&](int i0) {                                   // patch rows i0 .. i0+3: 8 lanes per row
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    // an absent segment (ragged patch) repeats segment 0, a short one its last node: identical stores
-                    const int i = seg_cnt[i0 + e] > 0 ? i0 + e : 0;
-                    const int cnt = seg_cnt[i0 + e] > 0 ? seg_cnt[i0 + e] : seg_cnt[0];
-                    const int first = seg_cnt[i0 + e] > 0 ? seg_first[i0 + e] : seg_first[0];
-                    const int u = u8 < cnt ? u8 : cnt - 1;
-                    o[e] = *reinterpret_cast<const f32x4*>(s_x + (8 * i + u) * LDA + 32 * wave + c4);
-                    node[e] = first + u;
-                    if (JK) jm[e] = *reinterpret_cast<const f32x4*>(jb + (size_t)node[e] * C);
+                    if (JK) {
+                        // an absent segment (ragged patch) repeats segment 0, a short one its last node: identical stores
+                        const int i = seg_cnt[i0 + e] > 0 ? i0 + e : 0;
+                        const int cnt = seg_cnt[i0 + e] > 0 ? seg_cnt[i0 + e] : seg_cnt[0];
+                        const int first = seg_cnt[i0 + e] > 0 ? seg_first[i0 + e] : seg_first[0];
+                        const int u = u8 < cnt ? u8 : cnt - 1;
+                        o[e] = *reinterpret_cast<const f32x4*>(s_x + (8 * i + u) * LDA + 32 * wave + c4);
+                        node[e] = first + u;
+                        ovoff[e] = u * (C * 4) + ocol;
+                        osoff[e] = first * (C * 4);
+                        jm[e] = *reinterpret_cast<const f32x4*>(jb + (size_t)node[e] * C);
+                    } else {
+                        // a short segment repeats its last node (identical stores); an absent one (ragged patch, cnt = 0) gets
+                        // u = -1: a negative buffer offset is out of range and the hardware drops the store
+                        const int last = seg_cnt[i0 + e] - 1;
+                        const int u = u8 < last ? u8 : last;
+                        o[e] = *reinterpret_cast<const f32x4*>(s_x + 8 * (i0 + e) * LDA + __mul24(u, LDA) + 32 * wave + c4);
+                        ovoff[e] = u * (C * 4) + ocol;
+                        osoff[e] = seg_first[i0 + e] * (C * 4);
+                    }
                 }
             };
             auto store_segments = [&]() {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    *reinterpret_cast<f32x4*>(ob + (size_t)node[e] * C) = o[e];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o[e]), orsrc, ovoff[e], osoff[e], 0);
                     if (JK) {
                         const f32x4 m = {fmaxf(jm[e].x, o[e].x), fmaxf(jm[e].y, o[e].y), fmaxf(jm[e].z, o[e].z), fmaxf(jm[e].w, o[e].w)};
                         *reinterpret_cast<f32x4*>(jo + (size_t)node[e] * C) = m;
@@ -260,11 +317,15 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 if (c < 2) { finish_group(acc0, 0, 2 * c); finish_group(acc0, 0, 2 * c + 1); }
                 else if (!CLS && c == 2) read_segments(0);
                 else if (!CLS) store_segments();
+                else if (c == 2) {                      // CLS: the residual rows of the second block, into the registers the first one has left
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) res[0][g] = *reinterpret_cast<const f32x4*>(s_x + (32 + j) * LDA + 32 * wave + 4 * h + 8 * g);
+                }
             };
             mfma_rowblock(s_a, 0, lane, wreg, acc0);
             mfma_rowblock_with(s_a, 32, lane, wreg, acc1, between);
 #else
-            acc0[0] = wreg[0] + s_a[lane]; acc1[0] = wreg[63];
+            acc0[0] += wreg[0] + s_a[lane]; acc1[0] += wreg[63];
 #pragma unroll
             for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
             if (!CLS) { read_segments(0); store_segments(); }
@@ -330,12 +391,14 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 f32x16& hc0 = acc0;
                 f32x16& hc1 = acc1;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { hc0[i] = 0.f; hc1[i] = 0.f; }
+                for (int g = 0; g < 4; ++g) {                      // start from the BatchNorm shift t1 (the scale s1 is in wreg2)
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(s_bn + 3 * C + 32 * wave + 4 * h + 8 * g);
+                    hc0[4 * g] = q.x; hc0[4 * g + 1] = q.y; hc0[4 * g + 2] = q.z; hc0[4 * g + 3] = q.w;
+                }
+                hc1 = hc0;
                 auto hidden_group = [&](const f32x16& hc, int rb, int g) {
-                    const float* bp = s_bn + 2 * C + 32 * wave + 4 * h + 8 * g;
                     f32x4 v = f32x4{hc[4 * g], hc[4 * g + 1], hc[4 * g + 2], hc[4 * g + 3]};
-                    v = v * *reinterpret_cast<const f32x4*>(bp) + *reinterpret_cast<const f32x4*>(bp + C);
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    v.x = max_raw(v.x, 0.f); v.y = max_raw(v.y, 0.f); v.z = max_raw(v.z, 0.f); v.w = max_raw(v.w, 0.f);
                     *reinterpret_cast<f32x4*>(s_a + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g) = v;
                 };
                 mfma_rowblock(s_x, 0, lane, wreg2, hc0);

@@ -47,7 +47,7 @@ __device__ inline f32x4 quad_w(const float* wq, int slot) { return *reinterpret_
 // segment's first / last node take their outer neighbour from LR (lower half: the row left of the segment, upper half:
 // the row right of it) with the weights of SLOT_EDGE; SLOT_LEFT / SLOT_RIGHT are zero there (graph.hip).
 __device__ inline void segw_rows(int lane, const float* wq, const f32x4 (&S)[4], const f32x4& LR,
-                                 const f32x4 (&U)[4], const f32x4 (&D)[4], const f32x4 (&P)[2], f32x4 (&acc)[4],
+                                 const f32x4 (&U)[4], const f32x4 (&D)[4], const f32x4 (&P)[4], f32x4 (&acc)[4],
                                  float* s_t, int rl) {
     const PairLane pl{lane >> 5, lane & 31};
     {
@@ -80,22 +80,19 @@ __device__ inline void segw_rows(int lane, const float* wq, const f32x4 (&S)[4],
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] += w2[k] * D[k];
     }
-    {   // parents: nodes 2k and 2k+1 share parent k = half (k & 1) of parent pair (k >> 1)
+    {   // parents: nodes 2k and 2k+1 share parent k, whose row both halves of P[k] hold
         const f32x4 w5 = quad_w(wq, SLOT_PARENT);
-        f32x4 plo[2], pup[2];
-        halves(P[0], plo[0], pup[0]);
-        halves(P[1], plo[1], pup[1]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] += w5[k] * ((k & 1) ? pup[k >> 1] : plo[k >> 1]);
+        for (int k = 0; k < 4; ++k) acc[k] += w5[k] * P[k];
     }
 }
 
 // ---- two vertically adjacent segments (patch rows 2p, 2p+1) handled by one wave ----------------------------------
 // The rows below segment a ARE segment b and the rows above b are a; both share their 4 parents, and the two edge
-// rows of a segment come in one load: 20 wave loads instead of 32.  SegDesc::pad0 of the upper segment says when this
+// rows of a segment come in one load: 22 wave loads instead of 32.  SegDesc::pad0 of the upper segment says when this
 // holds (host, graph.hip).
 struct SegPair {
-    f32x4 Sa[4], Sb[4], LRa, LRb, U[4], D[4], P[2];   // LR: lower half = row left of the segment, upper half = row right of it
+    f32x4 Sa[4], Sb[4], LRa, LRb, U[4], D[4], P[4];   // LR: lower half = row left of the segment, upper half = row right of it
 };
 
 __device__ inline void segp_issue(const SegDesc& sa, const SegDesc& sb, const RowSrc& xs, SegPair& A) {
@@ -110,8 +107,8 @@ __device__ inline void segp_issue(const SegDesc& sa, const SegDesc& sb, const Ro
     for (int k = 0; k < 4; ++k) A.U[k] = ldp(xs, sa.up0, k);
 #pragma unroll
     for (int k = 0; k < 4; ++k) A.D[k] = ldp(xs, sb.down0, k);
-    A.P[0] = ldp(xs, sa.par0, 0);
-    A.P[1] = ldp(xs, sa.par0, 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A.P[k] = ld_two_rows(xs, sa.par0 + k, sa.par0 + k);     // the same row in both halves
 }
 
 // Aux levels, chained layers: the children's contribution of node n is ONE row of the side buffer (row n; the previous
