@@ -16,7 +16,7 @@
 namespace eg {
 
 constexpr int PS_THREADS = 512;
-constexpr int PS_LDS_DIS = 4 * TILE * LDA + 16 + 64 + 16;  // float offsets inside the dynamic LDS block (tile-id ring, CLS counter, descriptor ring)
+constexpr int PS_LDS_DIS = 4 * TILE * LDA + 16 + 64;  // float offsets inside the dynamic LDS block (tile-id ring, CLS counter, descriptor ring)
 constexpr int PS_LDS_PAT = PS_LDS_DIS + 2 * TILE;
 
 struct PsDims {
@@ -45,25 +45,15 @@ __device__ inline float max_raw(float x, float y) {
     return r;
 }
 
-// Hand-over of the tile buffers between the two roles without a workgroup barrier (EG_DECOUPLE): per buffer and 32-row
-// half a `full` count (the two producer waves of the half add 1 each when their rows are in LDS) and an `empty` count (the
-// four consumer waves add 1 each when they are done with the half).  Tile number t uses buffer t & 1 as occupant t >> 1.
-// LDS operations of a wave execute in order and the counters live in LDS too, so a waiter that sees the count sees the
-// data; the fences are for the compiler only (a workgroup-scope release would also drain the wave's global stores).
-#ifdef EG_DECOUPLE
-constexpr bool PS_DECOUPLED = true;
-#else
-constexpr bool PS_DECOUPLED = false;
-#endif
-constexpr int PS_CLAIM_AHEAD = PS_DECOUPLED ? 5 : 3;   // tiles the ring is filled ahead of the producers (see the ring notes in the kernel)
-__device__ inline void flag_wait(const int* f, int target) {
-    while (*reinterpret_cast<const volatile int*>(f) < target) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ inline void flag_signal(int* f, int lane) {
+// Meeting of the four consumer waves on an LDS counter (fused heads).  LDS operations of a wave execute in order and the
+// counter lives in LDS too: a wave that sees the count sees the rows written before it.  The fences bind the compiler only
+// -- a workgroup-scope release would also wait for the wave's global stores (the logits of the tile before).
+__device__ inline void consumers_meet(int* counter, int target, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's LDS reads and writes are complete
-    if (lane == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's LDS writes have landed
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (*reinterpret_cast<const volatile int*>(counter) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Asynchronous claim: the atomic on the own XCD's queue is issued early (ps_claim_issue), its result is looked at
@@ -116,8 +106,6 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
     int* s_tile = reinterpret_cast<int*>(smem + 4 * TILE * LDA);                  // [8] ring of tile ids
     int* s_sync = s_tile + 8;                         // consumer-only tile counter (CLS)
     int* s_cd = s_tile + 16;                          // [2][8 segments][4] descriptor words of the consumers' epilogue (below)
-    int* s_full = s_tile + 80;                        // [2 buffers][2 halves]  (EG_DECOUPLE)
-    int* s_empty = s_tile + 84;                       // [2 buffers][2 halves]
     float* s_dis0 = smem + PS_LDS_DIS;                // [2][TILE] (deg+1)^-1/2 of the tile's rows (child sums of the output)
     float* s_pat = smem + PS_LDS_PAT;                 // [n_pats][64] weight patterns, quad layout (seg_wide.h)
     float* s_bn = s_pat + a.n_pats * PATQ;            // CLS only: [4][128] layer scale, shift, classifier s1, t1
@@ -129,11 +117,12 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
     const int n_tiles = a.tiles_per_frame * a.batch;
     const int group = xcc_id();
 
-    // ---- prologue: the first PS_CLAIM_AHEAD tiles claimed (before anyone reads the ring) -------------------------------------
+    // ---- prologue: tiles 0, 1 and 2 claimed (before anyone reads the ring) -------------------------------------
     if (tid == 256) {
-        for (int i = 0; i < PS_CLAIM_AHEAD; ++i) ps_claim(counters, group, n_tiles, &s_tile[i]);
+        ps_claim(counters, group, n_tiles, &s_tile[0]);
+        ps_claim(counters, group, n_tiles, &s_tile[1]);
+        ps_claim(counters, group, n_tiles, &s_tile[2]);
     }
-    if (tid < 8) s_full[tid] = 0;                      // (s_full and s_empty are adjacent)
     for (int i = tid; i < a.n_pats * PATQ; i += PS_THREADS) s_pat[i] = patsq[i];
     if (CLS) {
         if (tid < C) {
@@ -208,38 +197,30 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             if (t_cur < 0) break;
             int lane = lane_k;
             asm volatile("" : "+v"(lane));
-            if (PS_DECOUPLED) flag_wait(&s_full[(k & 1) * 2], 2 * ((k >> 1) + 1));          // rows 0..31 are in LDS
-            int cd = 0;
-            if (!PS_DECOUPLED) cd = s_cd[(k & 1) * 32 + (lane & 31)];
-#ifdef EG_CONS_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
+            const int cd = s_cd[(k & 1) * 32 + (lane & 31)];
             PSTAMP(3);
             float* s_a = s_a0 + (k & 1) * TILE * LDA;
             float* s_x = s_x0 + (k & 1) * TILE * LDA;
             const int frame = t_cur / a.tiles_per_frame;
             int seg_first[8], seg_cnt[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                seg_first[i] = __builtin_amdgcn_readlane(cd, 4 * i);
+                seg_cnt[i] = __builtin_amdgcn_readlane(cd, 4 * i + 1);
+            }
             // Child sums of the OUTPUT for the next layer (kout): lane -> (parent q = (lane >> 3) + 8 i, 16-B chunk lane & 7);
             // the parent's four children are rows 2 pr, 2 pr + 1, columns 2 pc, 2 pc + 1 of this patch.
             int kout_row[2];
-            auto decode_descriptors = [&]() {            // (decoupled: once the producers of rows 32..63 have signalled as well)
+            if (kout) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    seg_first[i] = __builtin_amdgcn_readlane(cd, 4 * i);
-                    seg_cnt[i] = __builtin_amdgcn_readlane(cd, 4 * i + 1);
+                for (int i = 0; i < 2; ++i) {
+                    const bool odd = (lane >> 5) != 0;                  // pr = 2 i + odd: segments 4 i (even pr) / 4 i + 2
+                    const int pc = (lane >> 3) & 3;
+                    const int npar = odd ? __builtin_amdgcn_readlane(cd, 4 * (4 * i + 2) + 3) : __builtin_amdgcn_readlane(cd, 4 * (4 * i) + 3);
+                    const int par0 = odd ? __builtin_amdgcn_readlane(cd, 4 * (4 * i + 2) + 2) : __builtin_amdgcn_readlane(cd, 4 * (4 * i) + 2);
+                    kout_row[i] = pc < npar ? par0 + pc : -1;
                 }
-                if (kout) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const bool odd = (lane >> 5) != 0;                  // pr = 2 i + odd: segments 4 i (even pr) / 4 i + 2
-                        const int pc = (lane >> 3) & 3;
-                        const int npar = odd ? __builtin_amdgcn_readlane(cd, 4 * (4 * i + 2) + 3) : __builtin_amdgcn_readlane(cd, 4 * (4 * i) + 3);
-                        const int par0 = odd ? __builtin_amdgcn_readlane(cd, 4 * (4 * i + 2) + 2) : __builtin_amdgcn_readlane(cd, 4 * (4 * i) + 2);
-                        kout_row[i] = pc < npar ? par0 + pc : -1;
-                    }
-                }
-            };
-            if (!PS_DECOUPLED) decode_descriptors();
+            }
             f32x16 acc0, acc1;
             if (CLS) {                                  // (no registers for a persistent copy: the shift comes from LDS each tile)
 #pragma unroll
@@ -270,7 +251,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 if (has_res) {                                                // a real (uniform) branch: 32 selects per tile otherwise
                     asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int rb = 0; rb < (PS_DECOUPLED ? 1 : 2); ++rb)
+                    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
                             res[rb][g] = *reinterpret_cast<const f32x4*>(s_x + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g);
@@ -353,17 +334,6 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 }
             };
             mfma_rowblock(s_a, 0, lane, wreg, acc0);
-            if (PS_DECOUPLED) {
-                flag_wait(&s_full[(k & 1) * 2 + 1], 2 * ((k >> 1) + 1));                      // rows 32..63 and all descriptor words are in LDS
-                cd = s_cd[(k & 1) * 32 + (lane & 31)];
-                decode_descriptors();
-                if (!RES_LATE && has_res) {
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        res[1][g] = *reinterpret_cast<const f32x4*>(s_x + (32 + j) * LDA + 32 * wave + 4 * h + 8 * g);
-                }
-            }
             mfma_rowblock_with(s_a, 32, lane, wreg, acc1, between);
 #else
             acc0[0] += wreg[0] + s_a[lane]; acc1[0] += wreg[63];
@@ -372,12 +342,9 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             if (!CLS) { read_segments(0); store_segments(); }
 #endif
             PSTAMP(0);
-#ifdef EG_CONS_PRIO
-            __builtin_amdgcn_s_setprio(3);                 // the exposed part of the epilogue competes with the producers' FMA bursts
-#endif
-#pragma unroll
-            for (int g = 0; g < 4; ++g) finish_group(acc1, 1, g);
             if (!CLS) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) finish_group(acc1, 1, g);
                 read_segments(4);
                 store_segments();
                 if (kout) {
@@ -396,63 +363,59 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     }
                 }
             } else {
-                // ---- classifier heads on the finished tile (all 128 channels of it are needed: the four consumer waves
-                // meet on an LDS counter; the producers are not involved and keep filling the other buffer) -------------
-                PSTAMP(1);
-                if (JK) {
-                    // this wave's 32 channels of all 64 rows, 8 lanes per row: output tile <- max(jk_in, output tile)
+                // ---- classifier heads on the finished tile.  All 128 channels of a row are needed, so the four consumer waves
+                // meet on an LDS counter (the producers are not involved and keep filling the other buffer) -- twice per tile:
+                // rows 0..31 are complete when the first GEMM's second chain ends (their epilogue ran inside it), so the heads'
+                // first layer starts on them while the epilogue of rows 32..63 runs between ITS MFMAs; rows 32..63 follow
+                // after the second meeting.  No epilogue of the tile is left outside an MFMA chain.
+                auto jk_patch = [&](int i0) {
+                    // this wave's 32 channels of patch rows i0 .. i0+3, 8 lanes per row: output tile <- max(jk_in, output tile)
                     const float* jb = jk_in + (size_t)frame * a.n_per_frame * C + 32 * wave + c4;
+                    f32x4 jm[4];
+                    int row[4];
 #pragma unroll
-                    for (int i0 = 0; i0 < 8; i0 += 4) {
-                        f32x4 jm[4];
-                        int row[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            // an absent segment repeats segment 0, a short one its last node (rows without a node are never used)
-                            const int i = seg_cnt[i0 + e] > 0 ? i0 + e : 0;
-                            const int cnt = seg_cnt[i0 + e] > 0 ? seg_cnt[i0 + e] : seg_cnt[0];
-                            const int first = seg_cnt[i0 + e] > 0 ? seg_first[i0 + e] : seg_first[0];
-                            const int u = u8 < cnt ? u8 : cnt - 1;
-                            row[e] = 8 * i + u;
-                            jm[e] = *reinterpret_cast<const f32x4*>(jb + (size_t)(first + u) * C);
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float* xp = s_x + row[e] * LDA + 32 * wave + c4;
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
-                            *reinterpret_cast<f32x4*>(xp) = f32x4{fmaxf(jm[e].x, v.x), fmaxf(jm[e].y, v.y), fmaxf(jm[e].z, v.z), fmaxf(jm[e].w, v.w)};
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        // an absent segment repeats segment 0, a short one its last node (rows without a node are never used)
+                        const int i = seg_cnt[i0 + e] > 0 ? i0 + e : 0;
+                        const int cnt = seg_cnt[i0 + e] > 0 ? seg_cnt[i0 + e] : seg_cnt[0];
+                        const int first = seg_cnt[i0 + e] > 0 ? seg_first[i0 + e] : seg_first[0];
+                        const int u = u8 < cnt ? u8 : cnt - 1;
+                        row[e] = 8 * i + u;
+                        jm[e] = *reinterpret_cast<const f32x4*>(jb + (size_t)(first + u) * C);
                     }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_fetch_add(s_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int target = 4 * (k + 1);
-                while (__hip_atomic_load(s_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                PSTAMP(2);                                 // (stamp builds: the consumers' wait for each other counts as barrier time)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float* xp = s_x + row[e] * LDA + 32 * wave + c4;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
+                        *reinterpret_cast<f32x4*>(xp) = f32x4{fmaxf(jm[e].x, v.x), fmaxf(jm[e].y, v.y), fmaxf(jm[e].z, v.z), fmaxf(jm[e].w, v.w)};
+                    }
+                };
                 // first layers: hidden[row][32 wave + c] = relu(bn(h3[row][:] . W1[32 wave + c][:])), into this wave's column
-                // slice of the A tile (dead now: every wave is past its MFMAs on it)
+                // slice of the A tile (dead once every wave is past its MFMAs on it: the first meeting)
                 f32x16& hc0 = acc0;
                 f32x16& hc1 = acc1;
+                auto shift_init = [&](f32x16& hc) {                   // start from the BatchNorm shift t1 (the scale s1 is in wreg2)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {                      // start from the BatchNorm shift t1 (the scale s1 is in wreg2)
-                    const f32x4 q = *reinterpret_cast<const f32x4*>(s_bn + 3 * C + 32 * wave + 4 * h + 8 * g);
-                    hc0[4 * g] = q.x; hc0[4 * g + 1] = q.y; hc0[4 * g + 2] = q.z; hc0[4 * g + 3] = q.w;
-                }
-                hc1 = hc0;
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 q = *reinterpret_cast<const f32x4*>(s_bn + 3 * C + 32 * wave + 4 * h + 8 * g);
+                        hc[4 * g] = q.x; hc[4 * g + 1] = q.y; hc[4 * g + 2] = q.z; hc[4 * g + 3] = q.w;
+                    }
+                };
                 auto hidden_group = [&](const f32x16& hc, int rb, int g) {
                     f32x4 v = f32x4{hc[4 * g], hc[4 * g + 1], hc[4 * g + 2], hc[4 * g + 3]};
                     v.x = max_raw(v.x, 0.f); v.y = max_raw(v.y, 0.f); v.z = max_raw(v.z, 0.f); v.w = max_raw(v.w, 0.f);
                     *reinterpret_cast<f32x4*>(s_a + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g) = v;
                 };
-#ifdef EG_CONS_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-                mfma_rowblock(s_x, 0, lane, wreg2, hc0);
+                if (JK) jk_patch(0);
+                shift_init(hc0);
+                consumers_meet(s_sync, 8 * k + 4, lane);               // rows 0..31: every wave's channel slice is in the stash
+                PSTAMP(1);
+                mfma_rowblock_with(s_x, 0, lane, wreg2, hc0, [&](int c) { finish_group(acc1, 1, c); });
+                if (JK) jk_patch(4);
+                consumers_meet(s_sync, 8 * k + 8, lane);               // rows 32..63
+                PSTAMP(2);                                 // (stamp builds: the consumers' wait for each other counts as barrier time)
+                shift_init(hc1);
                 mfma_rowblock_with(s_x, 32, lane, wreg2, hc1, [&](int c) { hidden_group(hc0, 0, c); });
-#ifdef EG_CONS_PRIO
-                __builtin_amdgcn_s_setprio(3);
-#endif
                 PSTAMP(3);                                 // (stamp builds: the second GEMM counts as "loop")
 #pragma unroll
                 for (int g = 0; g < 4; ++g) hidden_group(hc1, 1, g);
@@ -489,12 +452,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 }
             }
             PSTAMP(1);
-            if (PS_DECOUPLED) {                            // this wave is done with both halves of buffer k & 1
-                flag_signal(&s_empty[(k & 1) * 2], lane);
-                flag_signal(&s_empty[(k & 1) * 2 + 1], lane);
-            } else {
-                __syncthreads();                           // barrier k+1: buffer (k+1)&1 is full, buffer k&1 is free
-            }
+            __syncthreads();                               // barrier k+1: buffer (k+1)&1 is full, buffer k&1 is free
             PSTAMP(2);
         }
         PSTAMP_FLUSH(0);
@@ -532,18 +490,16 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             d.pad0 = __builtin_amdgcn_readlane(dv, o + 14);    d.pad1 = __builtin_amdgcn_readlane(dv, o + 15);
             return d;
         };
-        auto produce = [&](int tile_i, int buf, int lane, int dv, int ord) {
+        auto produce = [&](int tile_i, int buf, int lane, int dv) {
             const int frame = tile_i / a.tiles_per_frame;
             const float* __restrict__ xf = x + (size_t)frame * a.n_per_frame * C;
             const SegDesc sd0 = desc_of(dv, 0);
             const SegDesc sd1 = desc_of(dv, 16);
-            auto buffer_free = [&]() {                  // before this wave's first LDS write of the tile
-                if (PS_DECOUPLED) flag_wait(&s_empty[buf * 2 + (p >> 1)], 4 * (ord >> 1));
-                // the consumers' descriptor words of this tile (segments 2p, 2p+1: words 0, 1, 6, 15 -> ring slot [seg][0..3])
+            {   // the consumers' descriptor words of this tile (segments 2p, 2p+1: words 0, 1, 6, 15 -> ring slot [seg][0..3])
                 const int w = lane & 15;
                 const int f = w == 0 ? 0 : (w == 1 ? 1 : (w == 6 ? 2 : (w == 15 ? 3 : -1)));
                 if (lane < 32 && f >= 0) s_cd[buf * 32 + (2 * p + (lane >> 4)) * 4 + f] = dv;
-            };
+            }
             float* s_a = s_a0 + buf * TILE * LDA;
             float* s_x = a.has_res ? s_x0 + buf * TILE * LDA : nullptr;
             f32x4 acc0[4], acc1[4];
@@ -561,15 +517,10 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 const bool use_kin = sd0.aux && kin;                // uniform: children already summed by the previous layer
                 const RowSrc xs = row_src(xf, a.n_per_frame * (C * 4), lane);
                 segp_issue(sd0, sd1, xs, A);
-#ifdef EG_KIN_EARLY
-                SegKidsum KS;
-                if (use_kin) segp_kidsum_issue(sd0, sd1, row_src(kin + (size_t)frame * a.kid_rows * C, a.kid_rows * (C * 4), lane), KS);
-#endif
 #ifdef EG_ABL_NO_LOADS        // timing-only ablation: producers do nothing (results wrong)
                 return;
 #endif
                 __builtin_amdgcn_sched_barrier(0);                  // every load of both segments is issued above this line
-                buffer_free();
                 PSTAMP(PS_ISSUE);
                 const float* wqa = s_pat + sd0.pat * PATQ + 32 * (lane >> 5);      // this lane's weights (LDS, quad layout)
                 const float* wqb = s_pat + sd1.pat * PATQ + 32 * (lane >> 5);
@@ -581,10 +532,8 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 __builtin_amdgcn_sched_barrier(0);
                 PSTAMP(PS_MAIN);
                 if (use_kin) {                                      // (issued here, not with the first batch: registers)
-#ifndef EG_KIN_EARLY
                     SegKidsum KS;
                     segp_kidsum_issue(sd0, sd1, row_src(kin + (size_t)frame * a.kid_rows * C, a.kid_rows * (C * 4), lane), KS);
-#endif
                     segp_kidsum_add(KS, wqa, wqb, acc0, acc1);
                 } else if (sd0.aux) {                               // uniform: aux level, children pulled as rows
                     {
@@ -611,7 +560,6 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 }
             } else {
                 // ---- ragged patches, coordinate nodes, frame end (rare): node by node, scalar neighbour decode ----
-                buffer_free();
 #pragma unroll 1
                 for (int e = 0; e < 2; ++e) {
                     const int n0 = e ? sd1.n_first : sd0.n_first, cnt = e ? sd1.cnt : sd0.cnt;
@@ -623,14 +571,13 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     }
                 }
             }
-            if (PS_DECOUPLED) flag_signal(&s_full[buf * 2 + (p >> 1)], lane);
             PSTAMP(2);
         };
         int dv_next = 0;
         {
             const int t0 = __builtin_amdgcn_readfirstlane(s_tile[0]);
             const int t1 = __builtin_amdgcn_readfirstlane(s_tile[1]);
-            if (t0 >= 0) produce(t0, 0, lane_k, load_desc(t0, lane_k), 0);
+            if (t0 >= 0) produce(t0, 0, lane_k, load_desc(t0, lane_k));
             if (t1 >= 0) dv_next = load_desc(t1, lane_k);
         }
         __syncthreads();                                   // tile 0 is in buffer 0
@@ -644,11 +591,11 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             const int dv_cur = dv_next;
             if (t_nn >= 0) dv_next = load_desc(t_nn, lane);                                 // used by the NEXT iteration
             int got = 0;
-            if (tid == 256) got = ps_claim_issue(counters, group);                          // PS_CLAIM_AHEAD tiles ahead, asynchronous
+            if (tid == 256) got = ps_claim_issue(counters, group);                          // three tiles ahead, asynchronous
             PSTAMP(3);
-            if (t_next >= 0) produce(t_next, (k + 1) & 1, lane, dv_cur, k + 1);
-            if (tid == 256) ps_claim_commit(counters, group, n_tiles, got, &s_tile[(k + PS_CLAIM_AHEAD) & 7]);
-            if (!PS_DECOUPLED) __syncthreads();            // barrier k+1
+            if (t_next >= 0) produce(t_next, (k + 1) & 1, lane, dv_cur);
+            if (tid == 256) ps_claim_commit(counters, group, n_tiles, got, &s_tile[(k + 3) & 7]);
+            __syncthreads();                               // barrier k+1
             PSTAMP(3);
         }
         PSTAMP_FLUSH(4);

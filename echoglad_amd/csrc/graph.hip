@@ -362,7 +362,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                     if (outer) patsq[(size_t)pi * 64 + h * 32 + 7 * 4 + k] = w;
                 }
     // chained layers run the producer/consumer kernel, which keeps the pattern table in LDS beside its tile buffers
-    const size_t ps_lds = (size_t)(4 * TILE * LDA + 16 + 64 + 16 + 2 * TILE + (pats.size() / 128) * 64 + 4 * C) * sizeof(float);   // incl. the fused-classifier tables
+    const size_t ps_lds = (size_t)(4 * TILE * LDA + 16 + 64 + 2 * TILE + (pats.size() / 128) * 64 + 4 * C) * sizeof(float);   // incl. the fused-classifier tables
     g->kid_rows = (kidsum_ok && ps_lds <= 160 * 1024) ? kid_rows : 0;
     g->flat = (T.n_levels == 1 && T.n_desc == 1 && ps_lds <= 160 * 1024) ? 1 : 0;
     g->topo = T;

@@ -103,15 +103,10 @@ __device__ inline void segp_issue(const SegDesc& sa, const SegDesc& sb, const Ro
     // one 1-KB wave load fetches both edge rows of a segment, each in the half whose lanes use it (segw_rows)
     A.LRa = ld_two_rows(xs, sa.left, sa.right);
     A.LRb = ld_two_rows(xs, sb.left, sb.right);
-#ifdef EG_ABL_NO_UD            // timing-only ablation: the rows above / below the pair are not loaded (results wrong)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { A.U[k] = A.Sb[k]; A.D[k] = A.Sa[k]; }
-#else
 #pragma unroll
     for (int k = 0; k < 4; ++k) A.U[k] = ldp(xs, sa.up0, k);
 #pragma unroll
     for (int k = 0; k < 4; ++k) A.D[k] = ldp(xs, sb.down0, k);
-#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) A.P[k] = ld_two_rows(xs, sa.par0 + k, sa.par0 + k);     // the same row in both halves
 }
