@@ -45,17 +45,6 @@ __device__ inline float max_raw(float x, float y) {
     return r;
 }
 
-// Meeting of the four consumer waves on an LDS counter (fused heads).  LDS operations of a wave execute in order and the
-// counter lives in LDS too: a wave that sees the count sees the rows written before it.  The fences bind the compiler only
-// -- a workgroup-scope release would also wait for the wave's global stores (the logits of the tile before).
-__device__ inline void consumers_meet(int* counter, int target, int lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's LDS writes have landed
-    if (lane == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (*reinterpret_cast<const volatile int*>(counter) < target) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // Asynchronous claim: the atomic on the own XCD's queue is issued early (ps_claim_issue), its result is looked at
 // only after the tile's row loads have come back (ps_claim_commit); only an exhausted queue takes the slow walk.
 __device__ inline int ps_claim_issue(int* __restrict__ counters, int group) {
@@ -342,9 +331,9 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             if (!CLS) { read_segments(0); store_segments(); }
 #endif
             PSTAMP(0);
-            if (!CLS) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) finish_group(acc1, 1, g);
+            for (int g = 0; g < 4; ++g) finish_group(acc1, 1, g);
+            if (!CLS) {
                 read_segments(4);
                 store_segments();
                 if (kout) {
@@ -363,58 +352,56 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     }
                 }
             } else {
-                // ---- classifier heads on the finished tile.  All 128 channels of a row are needed, so the four consumer waves
-                // meet on an LDS counter (the producers are not involved and keep filling the other buffer) -- twice per tile:
-                // rows 0..31 are complete when the first GEMM's second chain ends (their epilogue ran inside it), so the heads'
-                // first layer starts on them while the epilogue of rows 32..63 runs between ITS MFMAs; rows 32..63 follow
-                // after the second meeting.  No epilogue of the tile is left outside an MFMA chain.
-                auto jk_patch = [&](int i0) {
-                    // this wave's 32 channels of patch rows i0 .. i0+3, 8 lanes per row: output tile <- max(jk_in, output tile)
+                // ---- classifier heads on the finished tile (all 128 channels of it are needed: the four consumer waves
+                // meet on an LDS counter; the producers are not involved and keep filling the other buffer) -------------
+                PSTAMP(1);
+                if (JK) {
+                    // this wave's 32 channels of all 64 rows, 8 lanes per row: output tile <- max(jk_in, output tile)
                     const float* jb = jk_in + (size_t)frame * a.n_per_frame * C + 32 * wave + c4;
-                    f32x4 jm[4];
-                    int row[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        // an absent segment repeats segment 0, a short one its last node (rows without a node are never used)
-                        const int i = seg_cnt[i0 + e] > 0 ? i0 + e : 0;
-                        const int cnt = seg_cnt[i0 + e] > 0 ? seg_cnt[i0 + e] : seg_cnt[0];
-                        const int first = seg_cnt[i0 + e] > 0 ? seg_first[i0 + e] : seg_first[0];
-                        const int u = u8 < cnt ? u8 : cnt - 1;
-                        row[e] = 8 * i + u;
-                        jm[e] = *reinterpret_cast<const f32x4*>(jb + (size_t)(first + u) * C);
-                    }
+                    for (int i0 = 0; i0 < 8; i0 += 4) {
+                        f32x4 jm[4];
+                        int row[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float* xp = s_x + row[e] * LDA + 32 * wave + c4;
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
-                        *reinterpret_cast<f32x4*>(xp) = f32x4{fmaxf(jm[e].x, v.x), fmaxf(jm[e].y, v.y), fmaxf(jm[e].z, v.z), fmaxf(jm[e].w, v.w)};
+                        for (int e = 0; e < 4; ++e) {
+                            // an absent segment repeats segment 0, a short one its last node (rows without a node are never used)
+                            const int i = seg_cnt[i0 + e] > 0 ? i0 + e : 0;
+                            const int cnt = seg_cnt[i0 + e] > 0 ? seg_cnt[i0 + e] : seg_cnt[0];
+                            const int first = seg_cnt[i0 + e] > 0 ? seg_first[i0 + e] : seg_first[0];
+                            const int u = u8 < cnt ? u8 : cnt - 1;
+                            row[e] = 8 * i + u;
+                            jm[e] = *reinterpret_cast<const f32x4*>(jb + (size_t)(first + u) * C);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float* xp = s_x + row[e] * LDA + 32 * wave + c4;
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
+                            *reinterpret_cast<f32x4*>(xp) = f32x4{fmaxf(jm[e].x, v.x), fmaxf(jm[e].y, v.y), fmaxf(jm[e].z, v.z), fmaxf(jm[e].w, v.w)};
+                        }
                     }
-                };
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(s_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int target = 4 * (k + 1);
+                while (__hip_atomic_load(s_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                PSTAMP(2);                                 // (stamp builds: the consumers' wait for each other counts as barrier time)
                 // first layers: hidden[row][32 wave + c] = relu(bn(h3[row][:] . W1[32 wave + c][:])), into this wave's column
-                // slice of the A tile (dead once every wave is past its MFMAs on it: the first meeting)
+                // slice of the A tile (dead now: every wave is past its MFMAs on it)
                 f32x16& hc0 = acc0;
                 f32x16& hc1 = acc1;
-                auto shift_init = [&](f32x16& hc) {                   // start from the BatchNorm shift t1 (the scale s1 is in wreg2)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 q = *reinterpret_cast<const f32x4*>(s_bn + 3 * C + 32 * wave + 4 * h + 8 * g);
-                        hc[4 * g] = q.x; hc[4 * g + 1] = q.y; hc[4 * g + 2] = q.z; hc[4 * g + 3] = q.w;
-                    }
-                };
+                for (int g = 0; g < 4; ++g) {                      // start from the BatchNorm shift t1 (the scale s1 is in wreg2)
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(s_bn + 3 * C + 32 * wave + 4 * h + 8 * g);
+                    hc0[4 * g] = q.x; hc0[4 * g + 1] = q.y; hc0[4 * g + 2] = q.z; hc0[4 * g + 3] = q.w;
+                }
+                hc1 = hc0;
                 auto hidden_group = [&](const f32x16& hc, int rb, int g) {
                     f32x4 v = f32x4{hc[4 * g], hc[4 * g + 1], hc[4 * g + 2], hc[4 * g + 3]};
                     v.x = max_raw(v.x, 0.f); v.y = max_raw(v.y, 0.f); v.z = max_raw(v.z, 0.f); v.w = max_raw(v.w, 0.f);
                     *reinterpret_cast<f32x4*>(s_a + (32 * rb + j) * LDA + 32 * wave + 4 * h + 8 * g) = v;
                 };
-                if (JK) jk_patch(0);
-                shift_init(hc0);
-                consumers_meet(s_sync, 8 * k + 4, lane);               // rows 0..31: every wave's channel slice is in the stash
-                PSTAMP(1);
-                mfma_rowblock_with(s_x, 0, lane, wreg2, hc0, [&](int c) { finish_group(acc1, 1, c); });
-                if (JK) jk_patch(4);
-                consumers_meet(s_sync, 8 * k + 8, lane);               // rows 32..63
-                PSTAMP(2);                                 // (stamp builds: the consumers' wait for each other counts as barrier time)
-                shift_init(hc1);
+                mfma_rowblock(s_x, 0, lane, wreg2, hc0);
                 mfma_rowblock_with(s_x, 32, lane, wreg2, hc1, [&](int c) { hidden_group(hc0, 0, c); });
                 PSTAMP(3);                                 // (stamp builds: the second GEMM counts as "loop")
 #pragma unroll
