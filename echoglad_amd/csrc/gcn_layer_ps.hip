@@ -504,6 +504,15 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 const bool use_kin = sd0.aux && kin;                // uniform: children already summed by the previous layer
                 const RowSrc xs = row_src(xf, a.n_per_frame * (C * 4), lane);
                 segp_issue(sd0, sd1, xs, A);
+                // the child-sum rows travel with the first batch: issued after the main stage they cost the aux tiles a second,
+                // fully exposed memory round trip (the producers do most of their work after the consumers' MFMA chain has ended,
+                // DESIGN 5.22)
+                SegKidsum KS;
+                if (use_kin) segp_kidsum_issue(sd0, sd1, row_src(kin + (size_t)frame * a.kid_rows * C, a.kid_rows * (C * 4), lane), KS);
+                // unchained calls (a stack's first layer): the first segment's 16 child rows as well; the second segment's
+                // follow once the main stage has freed its registers
+                SegKids K0;
+                if (sd0.aux && !use_kin) segw_kids_issue(sd0, pats, xs, lane, K0);
 #ifdef EG_ABL_NO_LOADS        // timing-only ablation: producers do nothing (results wrong)
                 return;
 #endif
@@ -518,17 +527,11 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 pin_acc4(acc1);                                     // the 40 main-stage registers are dead from here on
                 __builtin_amdgcn_sched_barrier(0);
                 PSTAMP(PS_MAIN);
-                if (use_kin) {                                      // (issued here, not with the first batch: registers)
-                    SegKidsum KS;
-                    segp_kidsum_issue(sd0, sd1, row_src(kin + (size_t)frame * a.kid_rows * C, a.kid_rows * (C * 4), lane), KS);
+                if (use_kin) {
                     segp_kidsum_add(KS, wqa, wqb, acc0, acc1);
                 } else if (sd0.aux) {                               // uniform: aux level, children pulled as rows
-                    {
-                        SegKids K;
-                        segw_kids_issue(sd0, pats, xs, lane, K);
-                        segw_kids_add(lane, K, acc0);
-                    }
-                    pin_acc4(acc0);                                 // one segment's 16 child loads in flight at a time (registers)
+                    segw_kids_add(lane, K0, acc0);
+                    pin_acc4(acc0);                                 // (issuing the second segment's loads ahead of this add measured slower)
                     {
                         SegKids K;
                         segw_kids_issue(sd1, pats, xs, lane, K);

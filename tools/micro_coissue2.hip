@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* src, unsign
                         else if (PK == P_DSREAD) { q[i] = *reinterpret_cast<volatile f32x4*>(mine); }
                         else if (PK == P_DSWRITE) { *reinterpret_cast<volatile f32x4*>(mine) = q[i]; }
                         else if (PK == P_GLOAD) { q[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + 256 * i)); asm volatile("" :: "v"(q[i])); }
-                        else if (PK == P_SALU) { asm volatile("s_add_u32 %0, %0, 3" : "+s"(r)); }
+                        else if (PK == P_SALU) { asm volatile("s_add_u32 %0, %0, 3\n s_add_u32 %0, %0, 5\n s_add_u32 %0, %0, 7\n s_add_u32 %0, %0, 9" : "+s"(r)); }
                         else { r += __builtin_amdgcn_readlane(lane + r, i); asm volatile("" : "+s"(r)); }
                     }
             }
@@ -104,16 +104,9 @@ void run(const char* name, int mode) {
 }
 #define ROW(MF, PK, label) run<MF, PK>(label " alone", 2); run<MF, PK>("32x32x2 chain + " label, 3);
 int main() {
-    run<0, P_FMA>("one 32x32x2 chain alone", 1);
-    run<2, P_FMA>("two independent 32x32x2 chains alone", 1);
-    run<3, P_FMA>("four independent 32x32x2 chains alone", 1);
-    run<0, P_FMA>("v_fma_f32 alone", 2);
-    run<0, P_FMA>("one chain + v_fma_f32", 3);   run<2, P_FMA>("two chains + v_fma_f32", 3);   run<3, P_FMA>("four chains + v_fma_f32", 3);
-    run<0, P_SALU>("s_add_u32 alone", 2);
-    run<0, P_SALU>("one chain + s_add_u32", 3);  run<3, P_SALU>("four chains + s_add_u32", 3);
-    run<0, P_DSREAD>("ds_read_b128 alone", 2);
-    run<0, P_DSREAD>("one chain + ds_read_b128", 3); run<3, P_DSREAD>("four chains + ds_read_b128", 3);
-    run<0, P_GLOAD>("global_load_dwordx4 alone", 2);
-    run<0, P_GLOAD>("one chain + global_load_dwordx4", 3); run<3, P_GLOAD>("four chains + global_load_dwordx4", 3);
+    run<0, P_SALU>("4 x s_add_u32 alone (per group of 4)", 2);
+    run<0, P_SALU>("one chain + 4 x s_add_u32 (per group of 4)", 3);
+    run<0, P_READLANE>("v_readlane alone", 2);
+    run<0, P_READLANE>("one chain + v_readlane", 3);
     return 0;
 }
