@@ -153,7 +153,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         // MFMA 16x16x4 A operand lane (o = l & 15, kq = l >> 4) holds W2[head][o][8 kq + s].
         float wreg2[64];
         float w2a[8];
-        f32x4 s2v, t2v, w3v;
+        f32x4 t2v, w3v;
         float b3v = 0.f;
         if (CLS) {
             load_w_slice(ca.w1, wave, lane_k, 0, wreg2);
@@ -165,8 +165,12 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             const f32x4* pw = reinterpret_cast<const f32x4*>(ca.w2 + (size_t)(wave * 16 + (lane_k & 15)) * 32 + 8 * (lane_k >> 4));
             const f32x4 q0 = pw[0], q1 = pw[1];
             w2a[0] = q0.x; w2a[1] = q0.y; w2a[2] = q0.z; w2a[3] = q0.w; w2a[4] = q1.x; w2a[5] = q1.y; w2a[6] = q1.z; w2a[7] = q1.w;
+            {
+                const float sv = ca.s2[wave * 16 + (lane_k & 15)];         // second BatchNorm's scale into its rows of W2, the shift t2
+#pragma unroll
+                for (int t = 0; t < 8; ++t) w2a[t] *= sv;                  // into the accumulators' initial value (below)
+            }
             const int o4 = wave * 16 + 4 * (lane_k >> 4);
-            s2v = *reinterpret_cast<const f32x4*>(ca.s2 + o4);
             t2v = *reinterpret_cast<const f32x4*>(ca.t2 + o4);
             w3v = *reinterpret_cast<const f32x4*>(ca.w3 + o4);
             b3v = ca.b3[wave];
@@ -331,8 +335,16 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             if (!CLS) { read_segments(0); store_segments(); }
 #endif
             PSTAMP(0);
+#ifdef EG_STAMP3                  // finer consumer stamp: the first EG_STAMP3 groups of the exposed epilogue count as "loop"
+#pragma unroll
+            for (int g = 0; g < EG_STAMP3; ++g) finish_group(acc1, 1, g);
+            PSTAMP(3);
+#pragma unroll
+            for (int g = EG_STAMP3; g < 4; ++g) finish_group(acc1, 1, g);
+#else
 #pragma unroll
             for (int g = 0; g < 4; ++g) finish_group(acc1, 1, g);
+#endif
             if (!CLS) {
                 read_segments(4);
                 store_segments();
@@ -409,34 +421,51 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 // second / third layers per 16-row block: K = 32 on the MFMA (8 x 16x16x4), BN + ReLU + the 16-wide dot
                 // on the accumulator (4 outputs per lane, two cross-lane adds), as in classifier.hip
                 const int j16 = lane & 15, kq = lane >> 4;
-                float* lg = ca.logits + ((size_t)frame * a.n_per_frame) * 4 + wave;
                 f32x4 hb[4][2];
 #pragma unroll
                 for (int b4 = 0; b4 < 4; ++b4) {
                     const f32x4* hp = reinterpret_cast<const f32x4*>(s_a + (16 * b4 + j16) * LDA + 32 * wave + 8 * kq);
                     hb[b4][0] = hp[0]; hb[b4][1] = hp[1];
                 }
+                // logits leave as buffer stores off a frame descriptor: lane (kq = 0, j16) owns node (patch row 2 b4 + (j16 >> 3),
+                // column j16 & 7); every other lane, and columns past the segment's count, get offset -1 (out of range: dropped)
+                const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    ca.logits + (size_t)frame * a.n_per_frame * 4, 0, a.n_per_frame * 16, 0x00020000);
+                int lvoff[4];
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    const bool hi = (j16 >> 3) != 0;
+                    const int first = hi ? seg_first[2 * b4 + 1] : seg_first[2 * b4];
+                    const int cnt = hi ? seg_cnt[2 * b4 + 1] : seg_cnt[2 * b4];
+                    lvoff[b4] = (kq == 0 && (j16 & 7) < cnt) ? (first + (j16 & 7)) * 16 + wave * 4 : -1;
+                }
                 f32x4v z[4];
 #pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4) z[b4] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                for (int b4 = 0; b4 < 4; ++b4) z[b4] = f32x4v{t2v.x, t2v.y, t2v.z, t2v.w};
 #pragma unroll
                 for (int t = 0; t < 8; ++t)                       // the four 16-row blocks interleaved: independent chains
 #pragma unroll
                     for (int b4 = 0; b4 < 4; ++b4)
                         z[b4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[t], hb[b4][t >> 2][t & 3], z[b4], 0, 0, 0);
+                float y[4];
 #pragma unroll
                 for (int b4 = 0; b4 < 4; ++b4) {
-                    float y = w3v.x * fmaxf(z[b4].x * s2v.x + t2v.x, 0.f) + w3v.y * fmaxf(z[b4].y * s2v.y + t2v.y, 0.f) +
-                              w3v.z * fmaxf(z[b4].z * s2v.z + t2v.z, 0.f) + w3v.w * fmaxf(z[b4].w * s2v.w + t2v.w, 0.f);
-                    y += __shfl_xor(y, 16);
-                    y += __shfl_xor(y, 32);
-                    y += b3v;
-                    if (ca.sigmoid) y = 1.0f / (1.0f + __expf(-y));
-                    const bool hi = (j16 >> 3) != 0;                     // patch row 2 b4 + hi, column j16 & 7
-                    const int first = hi ? seg_first[2 * b4 + 1] : seg_first[2 * b4];
-                    const int cnt = hi ? seg_cnt[2 * b4 + 1] : seg_cnt[2 * b4];
-                    if (kq == 0 && (j16 & 7) < cnt) lg[(size_t)(first + (j16 & 7)) * 4] = y;
+                    float v = w3v.x * max_raw(z[b4].x, 0.f);
+                    v += w3v.y * max_raw(z[b4].y, 0.f);
+                    v += w3v.z * max_raw(z[b4].z, 0.f);
+                    v += w3v.w * max_raw(z[b4].w, 0.f);
+                    // sum over the four lane quarters (kq): two register swaps, no LDS round trip
+                    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                    v = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+                    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                    y[b4] = __uint_as_float(r32[0]) + __uint_as_float(r32[1]) + b3v;
                 }
+                if (ca.sigmoid) {
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4) y[b4] = 1.0f / (1.0f + __expf(-y[b4]));
+                }
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[b4]), lrsrc, lvoff[b4], 0, 0);
             }
             PSTAMP(1);
             __syncthreads();                               // barrier k+1: buffer (k+1)&1 is full, buffer k&1 is free
