@@ -416,17 +416,18 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 mfma_rowblock(s_x, 0, lane, wreg2, hc0);
                 mfma_rowblock_with(s_x, 32, lane, wreg2, hc1, [&](int c) { hidden_group(hc0, 0, c); });
                 PSTAMP(3);                                 // (stamp builds: the second GEMM counts as "loop")
-#pragma unroll
-                for (int g = 0; g < 4; ++g) hidden_group(hc1, 1, g);
-                // second / third layers per 16-row block: K = 32 on the MFMA (8 x 16x16x4), BN + ReLU + the 16-wide dot
-                // on the accumulator (4 outputs per lane, two cross-lane adds), as in classifier.hip
                 const int j16 = lane & 15, kq = lane >> 4;
                 f32x4 hb[4][2];
-#pragma unroll
-                for (int b4 = 0; b4 < 4; ++b4) {
+                auto load_hidden = [&](int b4) {
                     const f32x4* hp = reinterpret_cast<const f32x4*>(s_a + (16 * b4 + j16) * LDA + 32 * wave + 8 * kq);
                     hb[b4][0] = hp[0]; hb[b4][1] = hp[1];
-                }
+                };
+                load_hidden(0); load_hidden(1);                       // rows 0..31 (ahead of the LDS writes below)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) hidden_group(hc1, 1, g);
+                load_hidden(2); load_hidden(3);
+                // second / third layers per 16-row block: K = 32 on the MFMA (8 x 16x16x4), BN + ReLU + the 16-wide dot
+                // on the accumulator (4 outputs per lane, two cross-lane adds), as in classifier.hip
                 // logits leave as buffer stores off a frame descriptor: lane (kq = 0, j16) owns node (patch row 2 b4 + (j16 >> 3),
                 // column j16 & 7); every other lane, and columns past the segment's count, get offset -1 (out of range: dropped)
                 const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -442,10 +443,17 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 f32x4v z[4];
 #pragma unroll
                 for (int b4 = 0; b4 < 4; ++b4) z[b4] = f32x4v{t2v.x, t2v.y, t2v.z, t2v.w};
+                // rows 0..31 first: their hidden values were written inside the chain above, so these MFMAs run while the
+                // writes of rows 32..63 and the reads behind them are in flight
 #pragma unroll
-                for (int t = 0; t < 8; ++t)                       // the four 16-row blocks interleaved: independent chains
+                for (int t = 0; t < 8; ++t)
 #pragma unroll
-                    for (int b4 = 0; b4 < 4; ++b4)
+                    for (int b4 = 0; b4 < 2; ++b4)
+                        z[b4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[t], hb[b4][t >> 2][t & 3], z[b4], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int b4 = 2; b4 < 4; ++b4)
                         z[b4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[t], hb[b4][t >> 2][t & 3], z[b4], 0, 0, 0);
                 float y[4];
 #pragma unroll
