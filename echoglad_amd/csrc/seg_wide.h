@@ -148,22 +148,24 @@ __device__ inline void segw_kids_issue(const SegDesc& sd, const float* __restric
 
 __device__ inline void segw_kids_add(int lane, const SegKids& K, f32x4 (&acc)[4]) {
     const PairLane pl{lane >> 5, lane & 31};
-    const bool up_half = pl.h != 0;
     const int hs4 = pl.h * 4;                                  // slot 6 -> 7 / 8 -> 9 for the upper half
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        f32x4 red[2];
+        f32x4 t[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int u = 2 * k + e;                            // child pair u holds node u's two children of a child row
             const float w67 = __int_as_float(__builtin_amdgcn_ds_bpermute(hs4 + (u * 8 + 6) * 4, __float_as_int(K.wa)));
             const float w89 = __int_as_float(__builtin_amdgcn_ds_bpermute(hs4 + (u * 8 + 0) * 4, __float_as_int(K.wb)));
-            const f32x4 t = w67 * K.Ca[u] + w89 * K.Cb[u];
-            f32x4 tl, tu;
-            halves(t, tl, tu);
-            red[e] = tl + tu;
+            t[e] = w67 * K.Ca[u] + w89 * K.Cb[u];
         }
-        acc[k] += sel(up_half, red[0], red[1]);
+        // node 2k (lower half of the wave) wants both halves of t[0], node 2k+1 (upper half) both halves of t[1]:
+        // one swap gives [t0.lo | t1.lo] and [t0.up | t1.up], whose sum is exactly that
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[0][i]), __float_as_uint(t[1][i]), false, false);
+            acc[k][i] += __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
     }
 }
 
