@@ -214,6 +214,23 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     kout_row[i] = pc < npar ? par0 + pc : -1;
                 }
             }
+            // child sums leave as buffer stores too: no parent in this lane's slot (or no child-sum output at all) = offset -1
+            const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
+                kout ? kout + (size_t)frame * a.kid_rows * C : nullptr, 0, kout ? a.kid_rows * (C * 4) : 0, 0x00020000);
+            int kvoff[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) kvoff[i] = (kout && kout_row[i] >= 0) ? kout_row[i] * (C * 4) + (32 * wave + 4 * (lane & 7)) * 4 : -1;
+            auto kout_half = [&](int i) {                 // parents of patch rows 4i .. 4i+3 (LDS rows 32i .. 32i+31), branch-free
+                const int q = (lane >> 3) + 8 * i;
+                const int ra = 16 * (q >> 2) + 2 * (q & 3);            // LDS row of child (2 pr, 2 pc)
+                const float* sp = s_x + ra * LDA + 32 * wave + 4 * (lane & 7);
+                const float* dp = s_dis0 + (k & 1) * TILE + ra;
+                f32x4 ks = dp[0] * *reinterpret_cast<const f32x4*>(sp);
+                ks += dp[1] * *reinterpret_cast<const f32x4*>(sp + LDA);
+                ks += dp[8] * *reinterpret_cast<const f32x4*>(sp + 8 * LDA);
+                ks += dp[9] * *reinterpret_cast<const f32x4*>(sp + 9 * LDA);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ks), krsrc, kvoff[i], 0, 0);
+            };
             f32x16 acc0, acc1;
             if (CLS) {                                  // (no registers for a persistent copy: the shift comes from LDS each tile)
 #pragma unroll
@@ -320,7 +337,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             auto between = [&](int c) {
                 if (c < 2) { finish_group(acc0, 0, 2 * c); finish_group(acc0, 0, 2 * c + 1); }
                 else if (!CLS && c == 2) read_segments(0);
-                else if (!CLS) store_segments();
+                else if (!CLS) { store_segments(); kout_half(0); }
                 else if (c == 2) {                      // CLS: the residual rows of the second block, into the registers the first one has left
 #pragma unroll
                     for (int g = 0; g < 4; ++g) res[0][g] = *reinterpret_cast<const f32x4*>(s_x + (32 + j) * LDA + 32 * wave + 4 * h + 8 * g);
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             acc0[0] += wreg[0] + s_a[lane]; acc1[0] += wreg[63];
 #pragma unroll
             for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
-            if (!CLS) { read_segments(0); store_segments(); }
+            if (!CLS) { read_segments(0); store_segments(); kout_half(0); }
 #endif
             PSTAMP(0);
 #ifdef EG_STAMP3                  // finer consumer stamp: the first EG_STAMP3 groups of the exposed epilogue count as "loop"
@@ -348,21 +365,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             if (!CLS) {
                 read_segments(4);
                 store_segments();
-                if (kout) {
-                    float* kb = kout + (size_t)frame * a.kid_rows * C + 32 * wave + c4;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int q = (lane >> 3) + 8 * i;
-                        const int ra = 16 * (q >> 2) + 2 * (q & 3);            // LDS row of child (2 pr, 2 pc)
-                        const float* sp = s_x + ra * LDA + 32 * wave + c4;
-                        const float* dp = s_dis0 + (k & 1) * TILE + ra;
-                        f32x4 ks = dp[0] * *reinterpret_cast<const f32x4*>(sp);
-                        ks += dp[1] * *reinterpret_cast<const f32x4*>(sp + LDA);
-                        ks += dp[8] * *reinterpret_cast<const f32x4*>(sp + 8 * LDA);
-                        ks += dp[9] * *reinterpret_cast<const f32x4*>(sp + 9 * LDA);
-                        if (kout_row[i] >= 0) *reinterpret_cast<f32x4*>(kb + (size_t)kout_row[i] * C) = ks;
-                    }
-                }
+                kout_half(1);
             } else {
                 // ---- classifier heads on the finished tile (all 128 channels of it are needed: the four consumer waves
                 // meet on an LDS counter; the producers are not involved and keep filling the other buffer) -------------
