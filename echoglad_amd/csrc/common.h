@@ -235,4 +235,4 @@ int eg_launch_layer_sym(const eg_graph* g, int batch, const float* x, const floa
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
                        const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream, const float* jk_in = nullptr,
-                       float* jk_out = nullptr);
+                       float* jk_out = nullptr, float* agg_out = nullptr, float* stats_partial = nullptr, int* grid_out = nullptr);

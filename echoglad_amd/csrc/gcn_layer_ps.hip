@@ -23,7 +23,24 @@ struct PsDims {
     int n_per_frame, batch, tiles_per_frame, relu, transpose_w, has_res;
     int kid_rows;      // rows per frame of the child-sum side buffers (kin / kout)
     int n_pats;
+    // train forward (TRAIN = true): the aggregated rows A_hat x are kept (agg_out, nullable), the column sums of the output and
+    // its square -- the BatchNorm batch statistics -- leave per workgroup (stats_partial [grid][2][128]), and tiles are walked
+    // statically (a workgroup's accumulation order must not depend on who wins a queue: bit-reproducible statistics)
+    float* agg_out;
+    float* stats_partial;
+    int static_walk;
 };
+
+// Static walk: blockIdx % 8 labels the chunk of the tile order (round-robin dispatch puts those workgroups on one XCD: a
+// heuristic that only locality depends on), a workgroup takes every `per`-th tile of its chunk.
+__device__ inline int ps_static_tile(int ord, int n_tiles) {
+    const int chunk = (n_tiles + WALK_GROUPS - 1) / WALK_GROUPS;
+    const int g = blockIdx.x % WALK_GROUPS, l = blockIdx.x / WALK_GROUPS;
+    const int per = ((int)gridDim.x + WALK_GROUPS - 1 - g) / WALK_GROUPS;
+    const int end = (g + 1) * chunk < n_tiles ? (g + 1) * chunk : n_tiles;
+    const long long t = (long long)g * chunk + l + (long long)per * ord;
+    return t < end ? (int)t : -1;
+}
 
 #ifdef EG_STAMP
 #define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
@@ -80,7 +97,7 @@ __device__ inline void ps_claim(int* __restrict__ counters, int group, int n_til
 // JK: JumpingKnowledge('max') of the reference (src/core/models.py:380-382, :479-482) carried through the fused stack as a
 // running element-wise maximum: jk_out = max(jk_in, out) is written beside the layer output (the first layer passes its input
 // as jk_in); with the classifier heads fused in, the heads run on max(jk_in, out) instead of out.
-template <bool CLS, bool JK = false>
+template <bool CLS, bool JK = false, bool TRAIN = false>
 __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ out, const float* __restrict__ dis,
@@ -108,11 +125,18 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
 
     // ---- prologue: tiles 0, 1 and 2 claimed (before anyone reads the ring) -------------------------------------
     if (tid == 256) {
-        ps_claim(counters, group, n_tiles, &s_tile[0]);
-        ps_claim(counters, group, n_tiles, &s_tile[1]);
-        ps_claim(counters, group, n_tiles, &s_tile[2]);
+        if (TRAIN && a.static_walk) {
+            for (int i = 0; i < 3; ++i) s_tile[i] = ps_static_tile(i, n_tiles);
+        } else {
+            ps_claim(counters, group, n_tiles, &s_tile[0]);
+            ps_claim(counters, group, n_tiles, &s_tile[1]);
+            ps_claim(counters, group, n_tiles, &s_tile[2]);
+        }
     }
     for (int i = tid; i < a.n_pats * PATQ; i += PS_THREADS) s_pat[i] = patsq[i];
+    if (TRAIN) {    // rows of a tile that hold no node are masked out of the statistics by a factor 0: they must be finite
+        for (int i = tid; i < 4 * TILE * LDA; i += PS_THREADS) smem[i] = 0.f;
+    }
     if (CLS) {
         if (tid < C) {
             s_bn[tid] = scale ? scale[tid] : 1.0f;
@@ -179,6 +203,11 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         // parent row and parent count of the segment pair -- come through an LDS ring the producers fill from the descriptors
         // they hold anyway (slot = buffer parity).  The consumers issue NO vector-memory load: a load whose result is needed
         // at the top of the next tile made the compiler drain vmcnt there, i.e. wait for every output store of the tile before.
+        // TRAIN: column sums of the output and its square, per lane (= per row slot j and 16 channels) across the workgroup's
+        // tiles; reduced over the row slots once, after the last tile
+        f32x16 csum, csq;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { csum[i] = 0.f; csq[i] = 0.f; }
         __syncthreads();                                   // tile 0 is in buffer 0
         PSTAMP_INIT;
 #ifdef EG_STAMP
@@ -214,6 +243,15 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     kout_row[i] = pc < npar ? par0 + pc : -1;
                 }
             }
+            float rowmask[2] = {1.f, 1.f};              // TRAIN: 1 where row slot j of the 32-row block holds a node
+            if (TRAIN) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const int q = (lane >> 3) & 3;         // patch row 4 rb + q, column lane & 7
+                    const int cnt = q == 0 ? seg_cnt[4 * rb] : (q == 1 ? seg_cnt[4 * rb + 1] : (q == 2 ? seg_cnt[4 * rb + 2] : seg_cnt[4 * rb + 3]));
+                    rowmask[rb] = (lane & 7) < cnt ? 1.f : 0.f;
+                }
+            }
             // child sums leave as buffer stores too: no parent in this lane's slot (or no child-sum output at all) = offset -1
             const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(
                 kout ? kout + (size_t)frame * a.kid_rows * C : nullptr, 0, kout ? a.kid_rows * (C * 4) : 0, 0x00020000);
@@ -230,6 +268,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 ks += dp[8] * *reinterpret_cast<const f32x4*>(sp + 8 * LDA);
                 ks += dp[9] * *reinterpret_cast<const f32x4*>(sp + 9 * LDA);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ks), krsrc, kvoff[i], 0, 0);
+                store_data_guard(ks);
             };
             f32x16 acc0, acc1;
             if (CLS) {                                  // (no registers for a persistent copy: the shift comes from LDS each tile)
@@ -283,6 +322,11 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 } else {
                     v += res[rb][g];
                 }
+                if (TRAIN) {                               // rows that hold no node (duplicates of a valid row) do not count
+                    const f32x4 t = v * rowmask[rb];
+                    csum[4 * g] += t.x; csum[4 * g + 1] += t.y; csum[4 * g + 2] += t.z; csum[4 * g + 3] += t.w;
+                    csq[4 * g] += t.x * v.x; csq[4 * g + 1] += t.y * v.y; csq[4 * g + 2] += t.z * v.z; csq[4 * g + 3] += t.w * v.w;
+                }
                 *reinterpret_cast<f32x4*>(xp) = v;
             };
             const int u8 = lane >> 3, c4 = 4 * (lane & 7);
@@ -329,6 +373,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                         *reinterpret_cast<f32x4*>(jo + (size_t)node[e] * C) = m;
                     }
                 }
+                store_data_guard(o);                   // (the stores' data registers: seg_wide.h)
             };
 #ifndef EG_ABL_NO_MFMA
             // rows 32..63: the MFMA chain leaves ~60 issue cycles per instruction free; the epilogue of rows 0..31
@@ -482,6 +527,19 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             __syncthreads();                               // barrier k+1: buffer (k+1)&1 is full, buffer k&1 is free
             PSTAMP(2);
         }
+        if (TRAIN) {
+            __syncthreads();                               // (with the producers) every tile buffer is dead
+            float* st = smem + (wave * 64 + lane_k) * 32;  // [wave][lane][sum 16 | sum of squares 16], 32 KB over the tile buffers
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { st[i] = csum[i]; st[16 + i] = csq[i]; }
+            __syncthreads();
+            // fixed order over the 32 row slots: thread t -> (quantity t >> 7, channel t & 127 = 32 wave + 8 g + 4 h + e)
+            const int t = tid, q = t >> 7, c = t & 127, w = c >> 5, g = (c >> 3) & 3, hh = (c >> 2) & 1, e = c & 3;
+            float sacc = 0.f;
+#pragma unroll 4
+            for (int jj = 0; jj < 32; ++jj) sacc += smem[((w * 64 + hh * 32 + jj) * 32) + q * 16 + 4 * g + e];
+            a.stats_partial[(size_t)blockIdx.x * 2 * C + t] = sacc;
+        }
         PSTAMP_FLUSH(0);
 #ifdef EG_STAMP
         if (wave == 0 && lane_k == 0) {
@@ -580,6 +638,12 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 }
                 segw_store(lane, wqa, acc0, s_a, 16 * p);
                 segw_store(lane, wqb, acc1, s_a, 16 * p + 8);
+                if (TRAIN && a.agg_out) {
+                    const __amdgpu_buffer_rsrc_t agg = __builtin_amdgcn_make_buffer_rsrc(
+                        a.agg_out + (size_t)frame * a.n_per_frame * C, 0, a.n_per_frame * (C * 4), 0x00020000);
+                    segw_store_agg(lane, wqa, acc0, agg, sd0.n_first, sd0.cnt);
+                    segw_store_agg(lane, wqb, acc1, agg, sd1.n_first, sd1.cnt);
+                }
                 if (kout && (lane & 31) == 0) {                     // (deg+1)^-1/2 of the 16 nodes, for the consumers' child sums
                     const f32x4 da = quad_w(wqa, SLOT_SELF), db = quad_w(wqb, SLOT_SELF);
 #pragma unroll
@@ -596,7 +660,9 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     const int rl = 16 * p + 8 * e;
 #pragma unroll 1
                     for (int u = 0; u < cnt; ++u) {
-                        *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = agg_stencil(T, xf, dis, n0 + u, lane);
+                        const f32x2 av = agg_stencil(T, xf, dis, n0 + u, lane);
+                        *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = av;
+                        if (TRAIN && a.agg_out) *reinterpret_cast<f32x2*>(a.agg_out + ((size_t)frame * a.n_per_frame + n0 + u) * C + 2 * lane) = av;
                         if (s_x) *reinterpret_cast<f32x2*>(&s_x[(rl + u) * LDA + 2 * lane]) = load_row2(xf, n0 + u, lane);
                     }
                 }
@@ -621,12 +687,20 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             const int dv_cur = dv_next;
             if (t_nn >= 0) dv_next = load_desc(t_nn, lane);                                 // used by the NEXT iteration
             int got = 0;
-            if (tid == 256) got = ps_claim_issue(counters, group);                          // three tiles ahead, asynchronous
+            const bool walk_static = TRAIN && a.static_walk;
+            if (tid == 256 && !walk_static) got = ps_claim_issue(counters, group);          // three tiles ahead, asynchronous
             PSTAMP(3);
             if (t_next >= 0) produce(t_next, (k + 1) & 1, lane, dv_cur);
-            if (tid == 256) ps_claim_commit(counters, group, n_tiles, got, &s_tile[(k + 3) & 7]);
+            if (tid == 256) {
+                if (walk_static) s_tile[(k + 3) & 7] = ps_static_tile(k + 3, n_tiles);
+                else ps_claim_commit(counters, group, n_tiles, got, &s_tile[(k + 3) & 7]);
+            }
             __syncthreads();                               // barrier k+1
             PSTAMP(3);
+        }
+        if (TRAIN) {                                       // the consumers' hand-over of the statistics (two barriers)
+            __syncthreads();
+            __syncthreads();
         }
         PSTAMP_FLUSH(4);
     }
@@ -640,8 +714,12 @@ using namespace eg;
 // Returns EG_ERR_UNSUPPORTED when the caller should fall back to the symmetric kernel.
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
-                       const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream, const float* jk_in, float* jk_out) {
+                       const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream, const float* jk_in, float* jk_out,
+                       float* agg_out, float* stats_partial, int* grid_out) {
     if (!g || g->kind != GRAPH_TOPO || (residual != nullptr && residual != x)) return EG_ERR_UNSUPPORTED;
+    const bool train = stats_partial != nullptr;
+    if (agg_out && !train) return set_error(EG_ERR_ARG, "agg_out goes with stats_partial (train forward)");
+    if (train && (kin || kout || cls || jk_in || jk_out)) return set_error(EG_ERR_ARG, "the train forward takes no child sums, heads or running maximum");
     const bool jk = jk_in != nullptr;
     if ((jk_out != nullptr) != (jk && !cls)) return set_error(EG_ERR_ARG, "jk_out goes with jk_in on a plain layer, the fused heads take jk_in alone");
     const bool chained = kin || kout || jk;
@@ -650,11 +728,12 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     if (cls && g->kid_rows == 0 && !g->flat) return EG_ERR_UNSUPPORTED;
     // plain calls: this kernel by default on single-level topologies (no tiles that pull child rows), the symmetric
     // kernel otherwise; EG_LAYER_IMPL = 0 / 1 forces one of them
-    if (!chained && !cls && (g->knobs.layer_impl < 0 ? g->flat : g->knobs.layer_impl) == 0) return EG_ERR_UNSUPPORTED;
+    if (!chained && !cls && !train && (g->knobs.layer_impl < 0 ? g->flat : g->knobs.layer_impl) == 0) return EG_ERR_UNSUPPORTED;
     PsDims a{};
     a.n_per_frame = (int)g->n_nodes; a.batch = batch; a.tiles_per_frame = g->n_tiles;
     a.relu = relu; a.transpose_w = transpose_w; a.has_res = residual != nullptr;
     a.kid_rows = g->kid_rows; a.n_pats = g->n_pats;
+    a.agg_out = agg_out; a.stats_partial = stats_partial; a.static_walk = train ? 1 : 0;
     const long long n_tiles = (long long)a.tiles_per_frame * batch;
     if (n_tiles <= 0) return EG_OK;
     const size_t lds = (size_t)(PS_LDS_PAT + g->n_pats * PATQ + (cls ? 4 * C : 0)) * sizeof(float);      // (graph.hip checks the same sum)
@@ -665,7 +744,8 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         EG_HIP_TRY(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
             const void* kernels[] = {(const void*)k_gcn_layer_ps<false, false>, (const void*)k_gcn_layer_ps<true, false>,
-                                     (const void*)k_gcn_layer_ps<false, true>, (const void*)k_gcn_layer_ps<true, true>};
+                                     (const void*)k_gcn_layer_ps<false, true>, (const void*)k_gcn_layer_ps<true, true>,
+                                     (const void*)k_gcn_layer_ps<false, false, true>};
             for (const void* f : kernels) EG_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
@@ -678,7 +758,9 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out, g->dis, g->topo_dev,
                            g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, jk_in, jk_out, queue, a, cls ? *cls : none);
     };
-    if (cls) { if (jk) launch(k_gcn_layer_ps<true, true>); else launch(k_gcn_layer_ps<true, false>); }
+    if (grid_out) *grid_out = (int)grid;
+    if (train) launch(k_gcn_layer_ps<false, false, true>);
+    else if (cls) { if (jk) launch(k_gcn_layer_ps<true, true>); else launch(k_gcn_layer_ps<true, false>); }
     else { if (jk) launch(k_gcn_layer_ps<false, true>); else launch(k_gcn_layer_ps<false, false>); }
     g->ps_launches.fetch_add(1u, std::memory_order_relaxed);
     EG_HIP_TRY(hipGetLastError());

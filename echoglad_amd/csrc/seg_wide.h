@@ -37,6 +37,16 @@ __device__ inline f32x4 ld_two_rows(const RowSrc& s, int lower, int upper) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r, s.q16 + s.h * ((upper - lower) * (C * 4)), lower * (C * 4), 0));
 }
 
+// Two wait states behind 16-byte buffer stores whose scalar offset is a register, with the stores' data registers as inputs: the
+// registers stay allocated (nothing can write them) until the wait states have passed (see segw_store_agg).
+__device__ inline void store_data_guard(const f32x4& a) {
+    asm volatile("s_nop 1" :: "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w) : "memory");
+}
+__device__ inline void store_data_guard(const f32x4 (&o)[4]) {
+    asm volatile("s_nop 1" :: "v"(o[0].x), "v"(o[0].y), "v"(o[0].z), "v"(o[0].w), "v"(o[1].x), "v"(o[1].y), "v"(o[1].z), "v"(o[1].w),
+                 "v"(o[2].x), "v"(o[2].y), "v"(o[2].z), "v"(o[2].w), "v"(o[3].x), "v"(o[3].y), "v"(o[3].z), "v"(o[3].w) : "memory");
+}
+
 __device__ inline f32x4 quad_w(const float* wq, int slot) { return *reinterpret_cast<const f32x4*>(wq + 4 * slot); }
 
 // acc = sum over self / left / right / above / below / parent rows of one segment (children are added afterwards).
@@ -178,6 +188,28 @@ __device__ inline void segw_store(int lane, const float* wq, const f32x4 (&acc)[
         const f32x4 o = acc[k] * w0[k];
         *reinterpret_cast<f32x4*>(&s_a[(rl + 2 * k + pl.h) * LDA + 4 * pl.q]) = o;       // rows >= cnt are padding rows
     }
+}
+
+// TRAIN: the same rows to global memory as well (A_hat x, kept for the weight gradient): two rows per store, rows that hold
+// no node get offset -1 (out of range: dropped)
+__device__ inline void segw_store_agg(int lane, const float* wq, const f32x4 (&acc)[4], __amdgpu_buffer_rsrc_t agg, int n_first, int cnt) {
+    const PairLane pl{lane >> 5, lane & 31};
+    const f32x4 w0 = quad_w(wq, SLOT_SELF);
+    const int pair = pl.h * (C * 4) + pl.q * 16;
+    f32x4 o[4];
+    int voff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[k] = acc[k] * w0[k];
+        voff[k] = (2 * k + pl.h) < cnt ? pair + k * (2 * C * 4) : -1;
+    }
+    // All four values exist before the first store and nothing writes their registers until two wait states after the last
+    // one: a 16-byte buffer store with a REGISTER scalar offset still reads its data when the next instruction issues -- a
+    // VALU write of those registers right behind it corrupted the stored rows (LLVM's hazard table only covers the
+    // immediate-offset form; measured on gfx950).
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o[k]), agg, voff[k], n_first * (C * 4), 0);
+    store_data_guard(o);
 }
 
 }  // namespace eg

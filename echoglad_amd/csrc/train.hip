@@ -560,7 +560,14 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
     float* partial = (float*)workspace;
     double* totals = (double*)workspace + (size_t)RED_BLOCKS * 2 * C;
     int grid = 0;
-    int rc = eg_launch_layer_sym(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, agg, partial, &grid, stream);
+    // implicit topologies: the producer / consumer kernel in its train form (static tile walk: bit-reproducible partial sums);
+    // anything else, or EG_TRAIN_PS=0: the symmetric kernel
+    static const bool train_ps = !(getenv("EG_TRAIN_PS") && atoi(getenv("EG_TRAIN_PS")) == 0);
+    int rc = EG_ERR_UNSUPPORTED;
+    if (train_ps && out != z)
+        rc = eg_launch_layer_ps(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, nullptr, nullptr, nullptr, stream, nullptr, nullptr,
+                                agg, partial, &grid);
+    if (rc == EG_ERR_UNSUPPORTED) rc = eg_launch_layer_sym(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, agg, partial, &grid, stream);
     if (rc != EG_OK) return rc;
     const long long rows = (long long)g->n_nodes * batch;
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * C / 32), dim3(256), 0, stream, partial, grid, 2 * C, totals);

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 from echoglad_amd import ops
 from echoglad_amd.synthetic import synthetic_node_feats
-B = 8
+B = int(os.environ.get("EG_B", "8"))
 g = ops.Graph.topo(224, 7)
 x = synthetic_node_feats(B * g.num_nodes, 128, 1).cuda()
 w = (synthetic_node_feats(128, 128, 2) * 0.1).cuda()
