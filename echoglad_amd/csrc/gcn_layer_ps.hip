@@ -29,6 +29,7 @@ struct PsDims {
     float* agg_out;
     float* stats_partial;
     int static_walk;
+    const float* res;  // MODE 2: residual rows (has_res is set; the stash holds THESE rows, not the input's)
 };
 
 // Static walk: blockIdx % 8 labels the chunk of the tile order (round-robin dispatch puts those workgroups on one XCD: a
@@ -97,7 +98,7 @@ __device__ inline void ps_claim(int* __restrict__ counters, int group, int n_til
 // JK: JumpingKnowledge('max') of the reference (src/core/models.py:380-382, :479-482) carried through the fused stack as a
 // running element-wise maximum: jk_out = max(jk_in, out) is written beside the layer output (the first layer passes its input
 // as jk_in); with the classifier heads fused in, the heads run on max(jk_in, out) instead of out.
-template <bool CLS, bool JK = false, bool TRAIN = false>
+template <bool CLS, bool JK = false, int MODE = 0>
 __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ out, const float* __restrict__ dis,
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                                                                 const float* __restrict__ patsq, const float* __restrict__ kin, float* __restrict__ kout,
                                                                 const float* __restrict__ jk_in, float* __restrict__ jk_out,
                                                                 int* __restrict__ counters, const PsDims a, const ClsArgs ca) {
+    constexpr bool TRAIN = MODE == 1;                 // train forward: aggregated rows kept, BatchNorm sums, static walk
+    constexpr bool RSEP = MODE == 2;                  // the residual is a tensor of its own (a.res: the backward's dX = (A_hat dz) W + dy)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_a0 = smem;                               // [2][TILE * LDA]  aggregated tiles
     float* s_x0 = smem + 2 * TILE * LDA;              // [2][TILE * LDA]  raw self rows (residual); then the output tile
@@ -601,6 +604,12 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 SegPair A;
                 const bool use_kin = sd0.aux && kin;                // uniform: children already summed by the previous layer
                 const RowSrc xs = row_src(xf, a.n_per_frame * (C * 4), lane);
+                f32x4 Ra[4], Rb[4];                                  // RSEP: the residual's own rows of both segments
+                if (RSEP) {
+                    const RowSrc rs = row_src(a.res + (size_t)frame * a.n_per_frame * C, a.n_per_frame * (C * 4), lane);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { Ra[k] = ldp(rs, sd0.n_first, k); Rb[k] = ldp(rs, sd1.n_first, k); }
+                }
                 segp_issue(sd0, sd1, xs, A);
                 // the child-sum rows travel with the first batch: issued after the main stage they cost the aux tiles a second,
                 // fully exposed memory round trip (the producers do most of their work after the consumers' MFMA chain has ended,
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 // unchained calls (a stack's first layer): the first segment's 16 child rows as well; the second segment's
                 // follow once the main stage has freed its registers
                 SegKids K0;
-                if (sd0.aux && !use_kin) segw_kids_issue(sd0, pats, xs, lane, K0);
+                if (!RSEP && sd0.aux && !use_kin) segw_kids_issue(sd0, pats, xs, lane, K0);      // (RSEP: no registers left for them here)
 #ifdef EG_ABL_NO_LOADS        // timing-only ablation: producers do nothing (results wrong)
                 return;
 #endif
@@ -618,7 +627,15 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 PSTAMP(PS_ISSUE);
                 const float* wqa = s_pat + sd0.pat * PATQ + 32 * (lane >> 5);      // this lane's weights (LDS, quad layout)
                 const float* wqb = s_pat + sd1.pat * PATQ + 32 * (lane >> 5);
-                float* s_t = s_x ? s_x : s_a;                       // where the segments' own rows pass through LDS
+                float* s_t = (s_x && !RSEP) ? s_x : s_a;            // where the segments' own rows pass through LDS
+                if (RSEP) {                                         // first back (first issued): hand the residual rows to the consumers
+                    const PairLane pl{lane >> 5, lane & 31};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        *reinterpret_cast<f32x4*>(&s_x[(16 * p + 2 * k + pl.h) * LDA + 4 * pl.q]) = Ra[k];
+                        *reinterpret_cast<f32x4*>(&s_x[(16 * p + 8 + 2 * k + pl.h) * LDA + 4 * pl.q]) = Rb[k];
+                    }
+                }
                 segw_rows(lane, wqa, A.Sa, A.LRa, A.U, A.Sb, A.P, acc0, s_t, 16 * p);
                 segw_rows(lane, wqb, A.Sb, A.LRb, A.Sa, A.D, A.P, acc1, s_t, 16 * p + 8);
                 pin_acc4(acc0);
@@ -628,6 +645,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 if (use_kin) {
                     segp_kidsum_add(KS, wqa, wqb, acc0, acc1);
                 } else if (sd0.aux) {                               // uniform: aux level, children pulled as rows
+                    if (RSEP) segw_kids_issue(sd0, pats, xs, lane, K0);
                     segw_kids_add(lane, K0, acc0);
                     pin_acc4(acc0);                                 // (issuing the second segment's loads ahead of this add measured slower)
                     {
@@ -663,7 +681,8 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                         const f32x2 av = agg_stencil(T, xf, dis, n0 + u, lane);
                         *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = av;
                         if (TRAIN && a.agg_out) *reinterpret_cast<f32x2*>(a.agg_out + ((size_t)frame * a.n_per_frame + n0 + u) * C + 2 * lane) = av;
-                        if (s_x) *reinterpret_cast<f32x2*>(&s_x[(rl + u) * LDA + 2 * lane]) = load_row2(xf, n0 + u, lane);
+                        if (s_x) *reinterpret_cast<f32x2*>(&s_x[(rl + u) * LDA + 2 * lane]) =
+                            load_row2(RSEP ? a.res + (size_t)frame * a.n_per_frame * C : xf, n0 + u, lane);
                     }
                 }
             }
@@ -716,8 +735,10 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
                        const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream, const float* jk_in, float* jk_out,
                        float* agg_out, float* stats_partial, int* grid_out) {
-    if (!g || g->kind != GRAPH_TOPO || (residual != nullptr && residual != x)) return EG_ERR_UNSUPPORTED;
+    if (!g || g->kind != GRAPH_TOPO) return EG_ERR_UNSUPPORTED;
     const bool train = stats_partial != nullptr;
+    const bool rsep = residual != nullptr && residual != x;       // a residual tensor of its own: MODE 2, plain calls only
+    if (rsep && (train || kin || kout || cls || jk_in || jk_out)) return EG_ERR_UNSUPPORTED;
     if (agg_out && !train) return set_error(EG_ERR_ARG, "agg_out goes with stats_partial (train forward)");
     if (train && (kin || kout || cls || jk_in || jk_out)) return set_error(EG_ERR_ARG, "the train forward takes no child sums, heads or running maximum");
     const bool jk = jk_in != nullptr;
@@ -728,12 +749,13 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     if (cls && g->kid_rows == 0 && !g->flat) return EG_ERR_UNSUPPORTED;
     // plain calls: this kernel by default on single-level topologies (no tiles that pull child rows), the symmetric
     // kernel otherwise; EG_LAYER_IMPL = 0 / 1 forces one of them
-    if (!chained && !cls && !train && (g->knobs.layer_impl < 0 ? g->flat : g->knobs.layer_impl) == 0) return EG_ERR_UNSUPPORTED;
+    if (!chained && !cls && !train && !rsep && (g->knobs.layer_impl < 0 ? g->flat : g->knobs.layer_impl) == 0) return EG_ERR_UNSUPPORTED;
     PsDims a{};
     a.n_per_frame = (int)g->n_nodes; a.batch = batch; a.tiles_per_frame = g->n_tiles;
     a.relu = relu; a.transpose_w = transpose_w; a.has_res = residual != nullptr;
     a.kid_rows = g->kid_rows; a.n_pats = g->n_pats;
     a.agg_out = agg_out; a.stats_partial = stats_partial; a.static_walk = train ? 1 : 0;
+    a.res = rsep ? residual : nullptr;
     const long long n_tiles = (long long)a.tiles_per_frame * batch;
     if (n_tiles <= 0) return EG_OK;
     const size_t lds = (size_t)(PS_LDS_PAT + g->n_pats * PATQ + (cls ? 4 * C : 0)) * sizeof(float);      // (graph.hip checks the same sum)
@@ -745,7 +767,7 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
             const void* kernels[] = {(const void*)k_gcn_layer_ps<false, false>, (const void*)k_gcn_layer_ps<true, false>,
                                      (const void*)k_gcn_layer_ps<false, true>, (const void*)k_gcn_layer_ps<true, true>,
-                                     (const void*)k_gcn_layer_ps<false, false, true>};
+                                     (const void*)k_gcn_layer_ps<false, false, 1>, (const void*)k_gcn_layer_ps<false, false, 2>};
             for (const void* f : kernels) EG_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
@@ -759,7 +781,8 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
                            g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, jk_in, jk_out, queue, a, cls ? *cls : none);
     };
     if (grid_out) *grid_out = (int)grid;
-    if (train) launch(k_gcn_layer_ps<false, false, true>);
+    if (train) launch(k_gcn_layer_ps<false, false, 1>);
+    else if (rsep) launch(k_gcn_layer_ps<false, false, 2>);
     else if (cls) { if (jk) launch(k_gcn_layer_ps<true, true>); else launch(k_gcn_layer_ps<true, false>); }
     else { if (jk) launch(k_gcn_layer_ps<false, true>); else launch(k_gcn_layer_ps<false, false>); }
     g->ps_launches.fetch_add(1u, std::memory_order_relaxed);

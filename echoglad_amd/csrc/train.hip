@@ -591,8 +591,14 @@ int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const fl
                               dw ? agg : nullptr, nullptr, dw, stream);
     if (rc != EG_OK) return rc;
     if (dx) {
-        rc = eg_launch_layer_sym(g_bwd, batch, dz_scratch, W, nullptr, nullptr, residual ? dy : nullptr, 0, 1, dx, nullptr, nullptr,
-                                 nullptr, stream);
+        // dX = (A_hat dz) W + dy: the producer / consumer kernel with the residual as a tensor of its own (implicit topologies)
+        static const bool train_ps = !(getenv("EG_TRAIN_PS") && atoi(getenv("EG_TRAIN_PS")) == 0);
+        rc = EG_ERR_UNSUPPORTED;
+        if (train_ps && residual)
+            rc = eg_launch_layer_ps(g_bwd, batch, dz_scratch, W, nullptr, nullptr, dy, 0, 1, dx, nullptr, nullptr, nullptr, stream);
+        if (rc == EG_ERR_UNSUPPORTED)
+            rc = eg_launch_layer_sym(g_bwd, batch, dz_scratch, W, nullptr, nullptr, residual ? dy : nullptr, 0, 1, dx, nullptr, nullptr,
+                                     nullptr, stream);
         if (rc != EG_OK) return rc;
     }
     if (db) EG_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * C, stream));     // a bias in front of a train-mode BatchNorm
