@@ -387,7 +387,11 @@ def test_coordinate_mlp_kernel_eval_mode_and_fallbacks():
 
 
 @pytest.mark.parametrize("frame,naux,coord,relu,residual,p", [(16, 3, False, True, True, 0.0), (32, 4, True, False, True, 0.5),
-                                                             (30, 3, False, True, False, 0.3)])
+                                                             (30, 3, False, True, False, 0.3),
+                                                             # ragged patches, a one-level pyramid, a deep one: the train form of the
+                                                             # producer / consumer kernel (static walk, masked statistics, row stores)
+                                                             (17, 3, False, True, True, 0.0), (8, 1, False, False, True, 0.2),
+                                                             (64, 6, False, True, True, 0.0)])
 def test_layer_train_composites_vs_torch_autograd(frame, naux, coord, relu, residual, p):
     """eg_gcn_layer_train_fwd / eg_gcn_layer_bwd: one whole train-mode layer (GCNConv, batch-stat BN, dropout with the
     kernel's own mask, ReLU, residual) against dense-A_hat torch autograd; also on a directed (asymmetric) CSR graph."""
