@@ -161,7 +161,8 @@ def test_fused_layer_vs_oracle(frame, naux, main_only, coord, relu):
         assert (got - want).abs().max() < 3e-5, (graph.structured, float((got - want).abs().max()))
 
 
-CHAIN_CASES = TOPO_CASES + [(224, 7, False, False), (128, 5, False, False)]
+CHAIN_CASES = TOPO_CASES + [(224, 7, False, False), (128, 5, False, False), (100, 5, False, False), (200, 6, False, False),
+                            (112, 6, False, True)]
 
 
 @pytest.mark.parametrize("frame,naux,main_only,coord", CHAIN_CASES)
