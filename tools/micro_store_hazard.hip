@@ -35,6 +35,41 @@ __global__ __launch_bounds__(512) void k(unsigned* out, int tiles) {
     }
 }
 
+// the same for a global (flat-address) store: `global_store_dwordx4 v[addr], v[10:13], off`
+template <int GAP>
+__global__ __launch_bounds__(512) void kg(unsigned* out, int tiles) {
+    const unsigned good = 0x600D0000u, bad = 0xBAD0BAD0u;
+    for (int t = 0; t < tiles; ++t) {
+        const unsigned row = (unsigned)((blockIdx.x * tiles + t) * 512 + threadIdx.x);
+        unsigned* p = out + (size_t)row * 4;
+        const unsigned g = good | (row & 0xFFFFu);
+        asm volatile(
+            "v_mov_b32 v10, %0\n v_mov_b32 v11, %0\n v_mov_b32 v12, %0\n v_mov_b32 v13, %0\n s_nop 4\n"
+            "global_store_dwordx4 %1, v[10:13], off\n"
+            ".if %3 > 0\n s_nop %3 - 1\n .endif\n"
+            "v_mov_b32 v10, %2\n v_mov_b32 v11, %2\n v_mov_b32 v12, %2\n v_mov_b32 v13, %2\n"
+            :: "v"(g), "v"(p), "v"(bad), "n"(GAP) : "v10", "v11", "v12", "v13", "memory");
+    }
+}
+template <int GAP>
+void run_global() {
+    const int tiles = 64, blocks = 256;
+    const size_t n = (size_t)blocks * tiles * 512 * 4;
+    unsigned* out;
+    (void)hipMalloc(&out, n * 4);
+    long bad = 0;
+    for (int rep = 0; rep < 5; ++rep) {
+        (void)hipMemset(out, 0, n * 4);
+        hipLaunchKernelGGL((kg<GAP>), dim3(blocks), dim3(512), 0, 0, out, tiles);
+        (void)hipDeviceSynchronize();
+        std::vector<unsigned> h(n);
+        (void)hipMemcpy(h.data(), out, n * 4, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < n; ++i) bad += h[i] == 0xBAD0BAD0u;
+    }
+    printf("global_store_dwordx4      %d wait state(s) between the store and the overwrite: %ld of %zu dwords poisoned\n", GAP, bad, 5 * n);
+    (void)hipFree(out);
+}
+
 template <int GAP, bool SREG>
 void run() {
     const int tiles = 64, blocks = 256;
@@ -57,5 +92,6 @@ void run() {
 int main() {
     run<0, true>(); run<1, true>(); run<2, true>(); run<3, true>(); run<4, true>();
     run<0, false>(); run<1, false>(); run<2, false>();
+    run_global<0>(); run_global<1>(); run_global<2>(); run_global<3>();
     return 0;
 }
