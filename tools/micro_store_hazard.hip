@@ -70,6 +70,42 @@ void run_global() {
     (void)hipFree(out);
 }
 
+// and for an LDS store: `ds_write_b128 v_addr, v[10:13]`, read back by the same thread after the write has completed
+template <int GAP>
+__global__ __launch_bounds__(512) void kd(unsigned* out, int tiles) {
+    __shared__ unsigned lds[512 * 4];
+    const unsigned good = 0x600D0000u, bad = 0xBAD0BAD0u;
+    unsigned poisoned = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const unsigned g = good | (unsigned)(t & 0xFFFF);
+        const unsigned addr = threadIdx.x * 16;
+        asm volatile(
+            "v_mov_b32 v10, %0\n v_mov_b32 v11, %0\n v_mov_b32 v12, %0\n v_mov_b32 v13, %0\n s_nop 4\n"
+            "ds_write_b128 %1, v[10:13]\n"
+            ".if %3 > 0\n s_nop %3 - 1\n .endif\n"
+            "v_mov_b32 v10, %2\n v_mov_b32 v11, %2\n v_mov_b32 v12, %2\n v_mov_b32 v13, %2\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            :: "v"(g), "v"(addr), "v"(bad), "n"(GAP) : "v10", "v11", "v12", "v13", "memory");
+        for (int i = 0; i < 4; ++i) poisoned += ((volatile unsigned*)lds)[threadIdx.x * 4 + i] == bad;
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = poisoned;
+}
+template <int GAP>
+void run_lds() {
+    const int tiles = 2048, blocks = 256;
+    unsigned* out;
+    (void)hipMalloc(&out, blocks * 512 * 4);
+    hipLaunchKernelGGL((kd<GAP>), dim3(blocks), dim3(512), 0, 0, out, tiles);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned> h(blocks * 512);
+    (void)hipMemcpy(h.data(), out, blocks * 512 * 4, hipMemcpyDeviceToHost);
+    long bad = 0;
+    for (unsigned v : h) bad += v;
+    printf("ds_write_b128             %d wait state(s) between the store and the overwrite: %ld of %ld dwords poisoned\n", GAP, bad,
+           (long)blocks * 512 * 4 * tiles);
+    (void)hipFree(out);
+}
+
 template <int GAP, bool SREG>
 void run() {
     const int tiles = 64, blocks = 256;
@@ -93,5 +129,6 @@ int main() {
     run<0, true>(); run<1, true>(); run<2, true>(); run<3, true>(); run<4, true>();
     run<0, false>(); run<1, false>(); run<2, false>();
     run_global<0>(); run_global<1>(); run_global<2>(); run_global<3>();
+    run_lds<0>(); run_lds<1>(); run_lds<2>();
     return 0;
 }
