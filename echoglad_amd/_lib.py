@@ -15,6 +15,7 @@ LIB_PATH = Path(os.environ.get("ECHOGLAD_LIB", _PKG / "lib" / "libechoglad_hip.s
 HEADER_PATH = _PKG.parent / "include" / "echoglad_hip.h"
 
 EG_OK, EG_ERR_ARG, EG_ERR_UNSUPPORTED, EG_ERR_HIP = 0, -1, -2, -3
+ABI_VERSION = 130          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
 
 _lib: Optional[ct.CDLL] = None
 
@@ -105,6 +106,16 @@ def load() -> ct.CDLL:
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -m echoglad_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
     lib = ct.CDLL(str(LIB_PATH), mode=ct.RTLD_GLOBAL if hasattr(ct, "RTLD_GLOBAL") else 0)
+    # a library built from other sources than this binding would take the calls below with shifted arguments: refuse it
+    try:
+        lib.eg_version.restype = _i
+        lib.eg_version.argtypes = []
+        got = int(lib.eg_version())
+    except AttributeError:
+        got = None
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports eg_version() = {got}, this binding is written for ABI {ABI_VERSION}: rebuild the "
+                           "library (python -m echoglad_amd.build --force) or point ECHOGLAD_LIB at a matching build")
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)

@@ -181,6 +181,10 @@ constexpr int QUEUE_SLOTS = 1;          // stamp builds keep their cycle sums ri
 constexpr int QUEUE_SLOTS = 64;
 #endif
 constexpr int QUEUE_TAIL_INTS = 64;     // stamp statistics (diagnostic builds)
+// internal return code of the launchers: the queue ring refused the launch (the message is set; the public entry points turn it
+// into EG_ERR_UNSUPPORTED).  Distinct from EG_ERR_UNSUPPORTED, which between launchers means "use the other kernel".
+constexpr int EG_ERR_RING = -100;
+inline int public_rc(int rc) { return rc == EG_ERR_RING ? EG_ERR_UNSUPPORTED : rc; }
 
 }  // namespace eg
 
@@ -209,11 +213,17 @@ struct eg_graph {
     mutable std::atomic<unsigned> ps_launches;  // launches of the producer/consumer kernel on this handle (eg_graph_ps_launches)
     eg::Knobs knobs;          // environment knobs, read once at creation
 
-    // the slice of the queue ring for one launch
-    int* next_queue_slice() const {
-        const unsigned s = launch_seq.fetch_add(1u, std::memory_order_relaxed) % (unsigned)eg::QUEUE_SLOTS;
-        return walk_counters + (size_t)s * eg::QUEUE_SLICE_INTS;
-    }
+    // Guard of the ring: an event per slice, recorded behind the launch that used it, and the stream it was recorded on.
+    // A launch that would reuse a slice whose previous user (on ANOTHER stream) has not finished is refused
+    // (EG_ERR_UNSUPPORTED) instead of sharing live counters with it.
+    hipEvent_t slot_event[eg::QUEUE_SLOTS];
+    mutable std::atomic<void*> slot_stream[eg::QUEUE_SLOTS];     // nullptr-with-flag encoding: see graph.hip
+    mutable std::atomic<unsigned char> slot_used[eg::QUEUE_SLOTS];
+
+    // the slice of the queue ring for one launch on `stream` (graph.hip); EG_OK / EG_ERR_UNSUPPORTED / EG_ERR_HIP
+    int acquire_queue_slice(hipStream_t stream, int** slice, int* slot) const;
+    // to be called right after the launch that uses the slice
+    void commit_queue_slice(int slot, hipStream_t stream) const;
 };
 
 // producer/consumer layer kernel (gcn_layer_ps.hip); EG_ERR_UNSUPPORTED -> caller uses the symmetric kernel

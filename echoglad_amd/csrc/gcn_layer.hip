@@ -42,6 +42,7 @@ struct LayerArgs {         // host-side bundle only
     GraphPtrs gp;
     LayerDims d;
     int* walk_counters;    // this launch's slice of the handle's queue ring (NULL: static walk)
+    const eg_graph* graph; // the handle whose ring the slice comes from (NULL: handle-less entry points)
     Knobs knobs;
 };
 
@@ -352,6 +353,11 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out
     const dim3 grid(grid_for_tiles(n_tiles, a.knobs)), block(LAYER_THREADS);
     if (grid_out) *grid_out = (int)grid.x;
     const bool train = a.agg_out || a.stats_partial;
+    int slot = -1;
+    if (a.graph) {
+        const int rc = a.graph->acquire_queue_slice(stream, &a.walk_counters, &slot);
+        if (rc != EG_OK) return rc == EG_ERR_UNSUPPORTED ? EG_ERR_RING : rc;
+    }
     a.d.walk_mode = a.walk_counters ? a.knobs.walk_mode : WALK_MOD8;
     // Batch statistics are summed per WORKGROUP over the tiles it walks: with the dynamic queue the set of tiles behind each
     // partial sum, hence the rounding of the totals, would change from launch to launch.  A static walk keeps a training step
@@ -373,6 +379,7 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out
             else hipLaunchKernelGGL((k_gcn_layer<AGG_STENCIL, true>), grid, block, 0, stream, LAYER_KARGS);
             break;
     }
+    if (a.graph) a.graph->commit_queue_slice(slot, stream);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }
@@ -385,7 +392,8 @@ static int fill_graph_args(const eg_graph* g, int batch, LayerArgs& a, int& agg)
     a.gp.rowptr = g->rowptr;
     a.gp.colidx = g->colidx;
     a.gp.topo = g->topo_dev;
-    a.walk_counters = g->next_queue_slice();
+    a.walk_counters = nullptr;                   // taken per launch (launch_layer): the slice is tied to the launch's stream
+    a.graph = g;
     a.knobs = g->knobs;
     a.d.n_per_frame = (int)g->n_nodes;
     a.d.batch = batch;
@@ -436,10 +444,10 @@ int eg_gcn_layer_fwd(const eg_graph* g, int batch, const float* x, const float* 
     if (rc != EG_OK) return rc;
     // implicit topology with the residual in {none, x}: producer/consumer kernel
     rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, transpose_w, out, nullptr, nullptr, nullptr, (hipStream_t)stream);
-    if (rc != EG_ERR_UNSUPPORTED) return rc;
+    if (rc != EG_ERR_UNSUPPORTED) return public_rc(rc);
     a.x = x; a.W = W; a.scale = scale; a.shift = shift; a.residual = residual; a.out = out;
     a.d.relu = relu; a.d.transpose_w = transpose_w;
-    return launch_layer(agg, a, (hipStream_t)stream);
+    return public_rc(launch_layer(agg, a, (hipStream_t)stream));
 }
 
 int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
@@ -454,7 +462,7 @@ int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const f
                                       nullptr, (hipStream_t)stream);
     if (rc == EG_ERR_UNSUPPORTED)
         return set_error(EG_ERR_UNSUPPORTED, "chained layers need a topology handle with eg_graph_kidsum_rows() > 0 and residual in {NULL, x}");
-    return rc;
+    return public_rc(rc);
 }
 
 int eg_graph_fused_classifier_ok(const eg_graph* g) {
@@ -465,8 +473,12 @@ int eg_gcn_layer_fwd_jk(const eg_graph* g, int batch, const float* x, const floa
                         const float* residual, int relu, float* out, const float* kidsum_in, float* kidsum_out, const float* jk_in,
                         float* jk_out, eg_stream_t stream) {
     if (!x || !W || !out || !jk_in || !jk_out) return set_error(EG_ERR_ARG, "x, W, out, jk_in and jk_out must not be NULL");
-    if (out == x || out == residual || jk_out == x || jk_out == out || jk_out == jk_in)
+    if (out == x || out == residual || out == jk_in || jk_out == x || jk_out == out || jk_out == jk_in || jk_out == residual)
         return set_error(EG_ERR_ARG, "out / jk_out must not alias the inputs or each other");
+    // the child-sum side buffers are [kidsum_rows, 128] arrays of their own: an overlap with any row array is a race
+    for (const float* k : {kidsum_in, (const float*)kidsum_out})
+        if (k && (k == x || k == out || k == jk_in || k == jk_out || k == residual))
+            return set_error(EG_ERR_ARG, "kidsum_in / kidsum_out must not alias x, out, residual, jk_in or jk_out");
     if (kidsum_in && kidsum_in == kidsum_out) return set_error(EG_ERR_ARG, "kidsum_out must not alias kidsum_in");
     if (!g || batch <= 0) return set_error(EG_ERR_ARG, "bad graph handle or batch");
     const int rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, 0, out, kidsum_in, kidsum_out, nullptr,
@@ -474,7 +486,7 @@ int eg_gcn_layer_fwd_jk(const eg_graph* g, int batch, const float* x, const floa
     if (rc == EG_ERR_UNSUPPORTED)
         return set_error(EG_ERR_UNSUPPORTED, "the running JumpingKnowledge maximum needs a topology handle on the producer/consumer kernel "
                                              "(child sums available, or a single-level grid) and residual in {NULL, x}");
-    return rc;
+    return public_rc(rc);
 }
 
 int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
@@ -490,7 +502,7 @@ int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const flo
                                       (hipStream_t)stream, jk_in, nullptr);
     if (rc == EG_ERR_UNSUPPORTED)
         return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs eg_graph_fused_classifier_ok() and residual in {NULL, x}");
-    return rc;
+    return public_rc(rc);
 }
 
 unsigned eg_graph_ps_launches(const eg_graph* g) { return g ? g->ps_launches.load(std::memory_order_relaxed) : 0u; }

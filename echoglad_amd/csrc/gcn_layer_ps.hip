@@ -772,7 +772,12 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
     }
-    int* const queue = g->next_queue_slice();
+    int* queue = nullptr;
+    int slot = -1;
+    {
+        const int rc = g->acquire_queue_slice(stream, &queue, &slot);
+        if (rc != EG_OK) return rc == EG_ERR_UNSUPPORTED ? EG_ERR_RING : rc;
+    }
     EG_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
     long long grid = n_tiles < 256 ? n_tiles : g->knobs.ps_grid;      // one persistent workgroup per CU
     const ClsArgs none{};
@@ -785,6 +790,7 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     else if (rsep) launch(k_gcn_layer_ps<false, false, 2>);
     else if (cls) { if (jk) launch(k_gcn_layer_ps<true, true>); else launch(k_gcn_layer_ps<true, false>); }
     else { if (jk) launch(k_gcn_layer_ps<false, true>); else launch(k_gcn_layer_ps<false, false>); }
+    g->commit_queue_slice(slot, stream);
     g->ps_launches.fetch_add(1u, std::memory_order_relaxed);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;

@@ -29,6 +29,12 @@ Knobs read_knobs() {
     k.grid_cap = env_int("EG_GRID", 512);
     k.layer_impl = env_int("EG_LAYER_IMPL", -1);
     k.ps_grid = env_int("EG_PS_GRID", 256);
+    // the static tile walk of the train forward labels chunks with blockIdx % 8 (a grid below 8 would leave chunks without
+    // an owner) and its statistics partials fill at most 2048 slabs of the workspace
+    if (k.ps_grid < 8) k.ps_grid = 8;
+    if (k.ps_grid > 2048) k.ps_grid = 2048;
+    if (k.grid_cap < 8) k.grid_cap = 8;
+    if (k.grid_cap > 2048) k.grid_cap = 2048;
     return k;
 }
 
@@ -38,6 +44,48 @@ const Knobs& process_knobs() {
 }
 
 constexpr size_t QUEUE_RING_BYTES = sizeof(int) * ((size_t)QUEUE_SLOTS * QUEUE_SLICE_INTS + QUEUE_TAIL_INTS);
+
+}  // namespace eg
+
+// ---- the tile-queue ring of a handle (common.h) ---------------------------------------------------------------------------
+// Every launch takes the next slice.  Slice s was last used by launch k - 64; if that launch ran on the same stream it is
+// ordered in front of this one, and if it ran on another stream its event tells whether it has finished.  A slice whose last
+// user is still in flight on another stream is NOT handed out: the call fails with EG_ERR_UNSUPPORTED (the caller serialises,
+// or uses a handle per stream).  Launches recorded into a HIP graph (stream capture) carry no event: a captured launch keeps its
+// slice for every replay, which is ordered with later eager launches only on the replaying stream itself (header note).
+int eg_graph::acquire_queue_slice(hipStream_t stream, int** slice, int* slot) const {
+    const unsigned s = launch_seq.fetch_add(1u, std::memory_order_relaxed) % (unsigned)eg::QUEUE_SLOTS;
+    if (slot_used[s].load(std::memory_order_acquire) && slot_stream[s].load(std::memory_order_acquire) != (void*)stream) {
+        const hipError_t q = hipEventQuery(slot_event[s]);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return eg::set_error(EG_ERR_UNSUPPORTED, "more than 64 launches of this graph handle are in flight on different streams: "
+                                                     "the tile-queue slice of the launch 64 calls ago is still in use");
+        }
+        if (q != hipSuccess) { (void)hipGetLastError(); }      // (e.g. an event that was never recorded outside a capture: free)
+    }
+    *slice = walk_counters + (size_t)s * eg::QUEUE_SLICE_INTS;
+    *slot = (int)s;
+    return EG_OK;
+}
+
+void eg_graph::commit_queue_slice(int slot, hipStream_t stream) const {
+    if (slot < 0 || slot >= eg::QUEUE_SLOTS) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs != hipStreamCaptureStatusNone) { slot_used[slot].store(0, std::memory_order_release); return; }
+    if (hipEventRecord(slot_event[slot], stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    slot_stream[slot].store((void*)stream, std::memory_order_release);
+    slot_used[slot].store(1, std::memory_order_release);
+}
+
+namespace eg {
+
+static int create_slot_events(eg_graph* g) {
+    for (int i = 0; i < QUEUE_SLOTS; ++i)
+        if (hipEventCreateWithFlags(&g->slot_event[i], hipEventDisableTiming) != hipSuccess) return EG_ERR_HIP;
+    return EG_OK;
+}
 
 // Python floor division
 static inline int floordiv(int a, int b) {
@@ -170,7 +218,7 @@ using namespace eg;
 
 extern "C" {
 
-int eg_version(void) { return 120; }
+int eg_version(void) { return EG_ABI_VERSION; }
 
 const char* eg_last_error(void) { return g_last_error.c_str(); }
 
@@ -371,6 +419,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
     if (e == hipSuccess) e = hipMemcpy(g->dis, dis.data(), sizeof(float) * T.n_nodes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&g->walk_counters, QUEUE_RING_BYTES);
     if (e == hipSuccess) e = hipMemset(g->walk_counters, 0, QUEUE_RING_BYTES);
+    if (e == hipSuccess && create_slot_events(g) != EG_OK) e = hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMalloc((void**)&g->topo_dev, sizeof(Topo));
     if (e == hipSuccess) e = hipMemcpy(g->topo_dev, &T, sizeof(Topo), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&g->tiles_dev, sizeof(TileDesc) * tiles.size());
@@ -460,6 +509,7 @@ static int eg::csr_build(const int64_t* ei, int64_t n_nodes, int64_t n_edges, hi
     CSR_TRY(hipMalloc((void**)&g->dis, sizeof(float) * (size_t)n));
     CSR_TRY(hipMalloc((void**)&g->walk_counters, QUEUE_RING_BYTES));
     CSR_TRY(hipMemsetAsync(g->walk_counters, 0, QUEUE_RING_BYTES, stream));
+    if (create_slot_events(g) != EG_OK) CSR_TRY(hipErrorOutOfMemory);
     CSR_TRY(hipMemsetAsync(counts, 0, sizeof(int) * ((size_t)n + 1), stream));
     if (m > 0) {
         hipLaunchKernelGGL(k_edge_keys, dim3((m + 255) / 256), dim3(256), 0, stream, ei, n_edges, n, base ? 1 : 0, keys, vals, counts);
@@ -519,6 +569,8 @@ int eg_graph_destroy(eg_graph* g) {
     if (g->patsq_dev) (void)hipFree(g->patsq_dev);
     if (g->tiles_dev) (void)hipFree(g->tiles_dev);
     if (g->walk_counters) (void)hipFree(g->walk_counters);
+    for (int i = 0; i < eg::QUEUE_SLOTS; ++i)
+        if (g->slot_event[i]) (void)hipEventDestroy(g->slot_event[i]);
     if (g->rowptr) (void)hipFree(g->rowptr);
     if (g->colidx) (void)hipFree(g->colidx);
     delete g;

@@ -615,7 +615,7 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
         rc = eg_launch_layer_ps(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, nullptr, nullptr, nullptr, stream, nullptr, nullptr,
                                 agg, partial, &grid);
     if (rc == EG_ERR_UNSUPPORTED) rc = eg_launch_layer_sym(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, agg, partial, &grid, stream);
-    if (rc != EG_OK) return rc;
+    if (rc != EG_OK) return public_rc(rc);
     const long long rows = (long long)g->n_nodes * batch;
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * C / 32), dim3(256), 0, stream, partial, grid, 2 * C, totals);
     BnFinalize f{totals, rows, C, gamma, beta, eps, momentum, running_mean, running_var, bn, bn + C, bn + 2 * C, bn + 3 * C};
@@ -646,7 +646,7 @@ int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const fl
         if (rc == EG_ERR_UNSUPPORTED)
             rc = eg_launch_layer_sym(g_bwd, batch, dz_scratch, W, nullptr, nullptr, residual ? dy : nullptr, 0, 1, dx, nullptr, nullptr,
                                      nullptr, stream);
-        if (rc != EG_OK) return rc;
+        if (rc != EG_OK) return public_rc(rc);
     }
     if (db) EG_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * C, stream));     // a bias in front of a train-mode BatchNorm
     return EG_OK;

@@ -27,8 +27,14 @@
  *     only host state a launch touches is one atomic counter in the handle
  *     that picks the launch's own slice of the handle's tile-queue ring
  *     (64 slices; a slice is zeroed on the launch's stream right before its
- *     kernel, so more than 64 launches of one handle must not be IN FLIGHT on
- *     different streams at the same time).  Process-wide state: the
+ *     kernel).  The ring is guarded: every slice carries an event recorded
+ *     behind its last launch, and a launch that would reuse a slice whose last
+ *     user is still in flight on ANOTHER stream returns EG_ERR_UNSUPPORTED
+ *     instead of sharing live counters with it (use one handle per stream, or
+ *     synchronise).  Launches recorded into a HIP graph carry no event: a
+ *     captured launch keeps its slice for every replay, so replays of such a
+ *     graph and more than 64 eager launches of the same handle on other
+ *     streams must not overlap.  Process-wide state: the
  *     thread-local error string, and an idempotent per-device "kernel
  *     attribute set" flag.  Environment knobs (EG_*) are read once, when a
  *     handle is created, never on a launch path.
@@ -47,6 +53,13 @@ extern "C" {
 #define EG_ERR_ARG (-1)
 #define EG_ERR_UNSUPPORTED (-2)
 #define EG_ERR_HIP (-3)
+
+/* ABI version: bumped whenever an entry point changes its argument list.  eg_version() of a loaded library must equal the
+ * EG_ABI_VERSION the binding was written for (echoglad_amd/_lib.py refuses to load anything else: a stale .so would accept
+ * the new calls with shifted arguments).  130: eg_topo_create with the reference builder's full flag set, jk_in inside
+ * eg_gcn_layer_cls_fwd, eg_graph_set_precision removed (round 3); train-forward child sums, fused heads backward, the
+ * 64-slice queue ring refuses instead of corrupting (round 4). */
+#define EG_ABI_VERSION 130
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
 

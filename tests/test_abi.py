@@ -10,7 +10,9 @@ from echoglad_amd import _lib
 def test_library_builds_and_loads(built_lib):
     assert os.path.exists(built_lib)
     lib = _lib.load()
-    assert lib.eg_version() >= 100
+    assert lib.eg_version() == _lib.ABI_VERSION           # _lib.load() refuses any other library
+    hdr = open(_lib.HEADER_PATH).read()
+    assert f"#define EG_ABI_VERSION {_lib.ABI_VERSION}" in hdr
     assert _lib.last_error() == "" or isinstance(_lib.last_error(), str)
 
 
@@ -31,6 +33,31 @@ def test_header_signatures_and_exports_agree_in_both_directions(built_lib):
                 and ln.split()[-2] in ("T", "t", "W")}
     # C++-mangled internals do not start with eg_; what remains must be exactly the public ABI
     assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+
+
+def test_documents_name_only_entry_points_that_exist():
+    """Every eg_* name in INTEGRATION.md, README.md and DESIGN.md's coverage / boundary sections is a declared entry point
+    (a maintainer who follows the documents must not meet an undefined symbol)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set(_lib.header_symbols())
+    internal = {"eg_graph", "eg_stream_t", "eg_cls_train_params", "eg_last_error", "eg_launch_layer_ps", "eg_launch_layer_sym",
+                "eg_launch_bn_bwd", "eg_launch_dweight", "eg_allreduce_"}        # types, and internal launchers DESIGN.md names as such
+    for doc in ("INTEGRATION.md", "README.md", "DESIGN.md"):
+        text = open(os.path.join(root, doc)).read()
+        names = set(re.findall(r"\b(eg_[a-z0-9_]+)", text))
+        # wildcard mentions like eg_bce_logits_* / eg_heatmap_expect_*: a declared name must start with the stem
+        bad = []
+        for n in sorted(names):
+            if n in declared or n in internal:
+                continue
+            if n.endswith("_") and any(d.startswith(n) for d in declared):
+                continue
+            if doc == "DESIGN.md" and n == "eg_graph_set_precision":      # named there as REMOVED (the history of an experiment)
+                assert re.search(r"REMOVED[^.]*eg_graph_set_precision|eg_graph_set_precision[^.]*(removed|gone)", text)
+                continue
+            bad.append(n)
+        assert not bad, f"{doc} names entry points that do not exist: {bad}"
 
 
 def test_code_object_targets_gfx950(built_lib):

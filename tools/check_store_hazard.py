@@ -3,7 +3,8 @@ ALU instruction with fewer than two wait states in between.  `tools/micro_store_
 state (what LLVM's hazard recogniser inserts for flat / global stores and for buffer stores with a literal scalar offset; it
 inserts none for buffer stores with a register scalar offset) still lets the new value reach memory now and then; two are safe
 (DESIGN 5.26).  Usage: python tools/check_store_hazard.py [library.so]; exit code 1 if anything is found.
-Linear scan per kernel (fall-through order); a label or branch between the store and the write ends the window."""
+The scan follows the control-flow graph: both successors of a conditional branch, the target of an unconditional one (loop
+back edges included); only indirect jumps end a path."""
 import os
 import re
 import subprocess
@@ -66,40 +67,77 @@ def device_code(lib):
     return outs
 
 
-def scan(lib):
-    text = "\n".join(subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
-                     for co in device_code(lib))
-    findings, kernel, window = [], "?", []          # window: [data regs, wait states so far, store text]
-    n_stores = 0
+def parse(text):
+    """-> {kernel: [(address, mnemonic, operands, branch target address | None, text)]} from llvm-objdump -d output."""
+    kernels, cur, base = {}, None, {}
     for line in text.splitlines():
         s = line.strip()
         if not s:
             continue
-        m = re.match(r"^[0-9a-f]+ <(.+)>:$", s)
+        m = re.match(r"^([0-9a-f]+) <(.+)>:$", s)
         if m:
-            name = m.group(1)
-            if not name.startswith("L"):        # a function symbol (local labels look like <L12>)
-                kernel = name
-            window = []
+            name = m.group(2)
+            if not re.fullmatch(r"L\d+", name):        # a function symbol (local labels look like <L12>)
+                cur = kernels.setdefault(name, [])
+                base[name] = int(m.group(1), 16)
             continue
-        s = s.split("//")[0].strip()
-        if not s:
+        if cur is None:
             continue
-        parts = s.split(None, 1)
+        code, _, comment = s.partition("//")
+        code = code.strip()
+        if not code:
+            continue
+        am = re.match(r"\s*([0-9A-Fa-f]+):", comment)
+        addr = int(am.group(1), 16) if am else None
+        parts = code.split(None, 1)
         mn = parts[0]
         ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
-        if mn.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc", "s_swappc")):
-            window = []
-            continue
-        w = written(mn, ops)
-        for data, ws, what in window:
-            if ws < NEED and (w & data):
-                findings.append((kernel, what, s, ws))
-        passed = (int(ops[0], 0) + 1) if mn == "s_nop" and ops else 1
-        window = [[d, ws + passed, what] for d, ws, what in window if ws + passed < NEED]
-        if WIDE_STORE.match(mn):
+        target = None
+        if mn.startswith(("s_branch", "s_cbranch")):
+            tm = re.search(r"<(.+?)\+0x([0-9a-fA-F]+)>", comment)
+            if tm and tm.group(1) in base:
+                target = base[tm.group(1)] + int(tm.group(2), 16)
+            elif re.search(r"<(.+?)>", comment) and re.search(r"<(.+?)>", comment).group(1) in base:
+                target = base[re.search(r"<(.+?)>", comment).group(1)]
+        cur.append((addr, mn, ops, target, code))
+    return kernels
+
+
+def scan(lib):
+    """Every path of the control-flow graph behind a wide store is followed until NEED wait states have passed: the fall-through
+    AND the target of a conditional branch, the target of an unconditional one (so a store at the end of a loop body is checked
+    against the first instructions of the next iteration).  A branch itself counts as one wait state.  Indirect jumps
+    (s_setpc / s_swappc) and s_endpgm end a path."""
+    text = "\n".join(subprocess.run([OBJDUMP, "-d", co], check=True, capture_output=True, text=True).stdout
+                     for co in device_code(lib))
+    findings, n_stores = [], 0
+    for kernel, ins in parse(text).items():
+        index = {a: i for i, (a, *_r) in enumerate(ins) if a is not None}
+        for i, (_a, mn, ops, _t, code) in enumerate(ins):
+            if not WIDE_STORE.match(mn):
+                continue
             n_stores += 1
-            window.append([store_data(mn, ops), 0, s])
+            data = store_data(mn, ops)
+            seen = set()
+            stack = [(i + 1, 0)]
+            while stack:
+                j, ws = stack.pop()
+                if ws >= NEED or j >= len(ins) or (j, ws) in seen:
+                    continue
+                seen.add((j, ws))
+                _aj, mj, oj, tj, cj = ins[j]
+                if written(mj, oj) & data:
+                    findings.append((kernel, code, cj, ws))
+                if mj.startswith(("s_endpgm", "s_setpc", "s_swappc")):
+                    continue
+                passed = (int(oj[0], 0) + 1) if mj == "s_nop" and oj else 1
+                if mj.startswith("s_branch"):
+                    if tj in index:
+                        stack.append((index[tj], ws + passed))
+                    continue
+                if mj.startswith("s_cbranch") and tj in index:
+                    stack.append((index[tj], ws + passed))
+                stack.append((j + 1, ws + passed))
     return findings, n_stores
 
 
