@@ -740,7 +740,7 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     const bool rsep = residual != nullptr && residual != x;       // a residual tensor of its own: MODE 2, plain calls only
     if (rsep && (train || kin || kout || cls || jk_in || jk_out)) return EG_ERR_UNSUPPORTED;
     if (agg_out && !train) return set_error(EG_ERR_ARG, "agg_out goes with stats_partial (train forward)");
-    if (train && (kin || kout || cls || jk_in || jk_out)) return set_error(EG_ERR_ARG, "the train forward takes no child sums, heads or running maximum");
+    if (train && (kout || cls || jk_in || jk_out)) return set_error(EG_ERR_ARG, "the train forward writes no child sums (its activation pass does) and takes no heads or running maximum");
     const bool jk = jk_in != nullptr;
     if ((jk_out != nullptr) != (jk && !cls)) return set_error(EG_ERR_ARG, "jk_out goes with jk_in on a plain layer, the fused heads take jk_in alone");
     const bool chained = kin || kout || jk;

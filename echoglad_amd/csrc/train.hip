@@ -481,6 +481,9 @@ static int red_blocks(long long rows) {
 
 using namespace eg;
 
+int eg_launch_bn_act_tiles(const eg_graph* g, int batch, const float* z, const float* scale, const float* shift, const float* residual,
+                           int relu, float dropout_p, unsigned long long seed, float* out, float* kout, hipStream_t stream);
+
 int eg_launch_dweight(const float* g, const float* x, long long rows, const eg::RowMap* xmap, void* workspace, float* dw, hipStream_t stream) {
     if (!g || !x || !workspace || !dw || rows < 1) return set_error(EG_ERR_ARG, "bad argument");
     long long nt = (rows + DW_ROWS - 1) / DW_ROWS;
@@ -599,9 +602,16 @@ int eg_dweight128(const float* g, const float* x, int64_t rows, void* workspace,
 int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* bias, const float* gamma,
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
                            float dropout_p, uint64_t seed, int residual, void* workspace, float* z, float* agg, float* bn,
-                           float* out, eg_stream_t stream_) {
+                           float* out, const float* kidsum_in, float* kidsum_out, eg_stream_t stream_) {
     if (!g || !x || !W || !gamma || !beta || !workspace || !z || !bn || !out) return set_error(EG_ERR_ARG, "NULL argument");
     if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    if (batch < 1) return set_error(EG_ERR_ARG, "batch must be >= 1");
+    if ((kidsum_in || kidsum_out) && (g->kind != GRAPH_TOPO || g->kid_rows == 0))
+        return set_error(EG_ERR_UNSUPPORTED, "child sums need a topology handle with eg_graph_kidsum_rows() > 0");
+    if (kidsum_in && (kidsum_in == kidsum_out || kidsum_in == x || kidsum_in == z || kidsum_in == agg || kidsum_in == out))
+        return set_error(EG_ERR_ARG, "kidsum_in must not alias kidsum_out or a row array");
+    if (kidsum_out && (kidsum_out == x || kidsum_out == z || kidsum_out == agg || kidsum_out == out))
+        return set_error(EG_ERR_ARG, "kidsum_out must not alias a row array");
     hipStream_t stream = (hipStream_t)stream_;
     // the layer kernel's epilogue leaves the column sums of z and z^2 per workgroup: no separate statistics pass
     float* partial = (float*)workspace;
@@ -612,8 +622,9 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
     static const bool train_ps = !(getenv("EG_TRAIN_PS") && atoi(getenv("EG_TRAIN_PS")) == 0);
     int rc = EG_ERR_UNSUPPORTED;
     if (train_ps && out != z)
-        rc = eg_launch_layer_ps(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, nullptr, nullptr, nullptr, stream, nullptr, nullptr,
+        rc = eg_launch_layer_ps(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, kidsum_in, nullptr, nullptr, stream, nullptr, nullptr,
                                 agg, partial, &grid);
+    // (the symmetric kernel pulls the children as rows: it needs no child sums, kidsum_in is simply not used)
     if (rc == EG_ERR_UNSUPPORTED) rc = eg_launch_layer_sym(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, agg, partial, &grid, stream);
     if (rc != EG_OK) return public_rc(rc);
     const long long rows = (long long)g->n_nodes * batch;
@@ -621,6 +632,13 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
     BnFinalize f{totals, rows, C, gamma, beta, eps, momentum, running_mean, running_var, bn, bn + C, bn + 2 * C, bn + 3 * C};
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(128), 0, stream, f);
     EG_HIP_TRY(hipGetLastError());
+    // the activation pass in tile order leaves the child sums of `out` behind for the next layer's train forward
+    static const bool act_tiles = getenv("EG_ACT_TILES") && atoi(getenv("EG_ACT_TILES")) != 0;      // (experiment: tile order without child sums too)
+    if (kidsum_out || act_tiles) {
+        rc = eg_launch_bn_act_tiles(g, batch, z, bn + 2 * C, bn + 3 * C, residual ? x : nullptr, relu, dropout_p, seed, out, kidsum_out, stream);
+        if (rc != EG_ERR_UNSUPPORTED) return rc;
+        if (kidsum_out) return set_error(EG_ERR_UNSUPPORTED, "child sums of the output: frames of 2 GB and more are not covered");
+    }
     return eg_bn_act_fwd(z, rows, bn + 2 * C, bn + 3 * C, residual ? x : nullptr, relu, dropout_p, seed, out, stream_);
 }
 

@@ -154,63 +154,6 @@ class _GCNConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-# ---- who owns an incoming gradient buffer? -------------------------------------------------------------------------------
-# _LayerTrainFn.backward and _CoordScatterFn.backward work IN PLACE on the gradient they receive (4 coordinate rows per frame
-# are patched; nothing of [B*N,128] size is cloned, filled or added).  Autograd does not promise that the buffer is theirs
-# alone: Add hands ONE tensor to both inputs (as an expanded view), a tensor hook may keep the very object, a later consumer
-# may read it.  The exclusive case has a fixed signature in a given torch build -- (python references, TensorImpl use count,
-# storage use count, no view base) -- which is measured once on a toy function of the same arity; anything else is cloned.
-def _grad_signature(t: torch.Tensor) -> tuple:
-    return (sys.getrefcount(t), t._use_count(), torch._C._storage_Use_Count(t.untyped_storage()._cdata))
-
-
-_OWN_SIG: Dict[int, Optional[tuple]] = {}
-
-
-def _probe_entry(dy: torch.Tensor, n_out: int, seen: list) -> None:
-    seen.append(_grad_signature(dy))
-
-
-def _calibrate_ownership(n_out: int) -> Optional[tuple]:
-    seen = []
-
-    class _Probe(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x):
-            return tuple(x * float(k + 2) for k in range(n_out)) if n_out > 1 else x * 2.0
-
-        @staticmethod
-        def backward(ctx, dy, *rest):
-            _probe_entry(dy, n_out, seen)              # same call depth as _own_or_clone below (the frames hold references too)
-            return dy
-
-    try:
-        with torch.enable_grad():
-            x = torch.zeros(2, 2, requires_grad=True)
-            y = _Probe.apply(x)
-            first = y[0] if n_out > 1 else y
-            loss = (first * 3.0).sum()                # a fresh, exclusively owned gradient reaches the probe
-            for other in (y[1:] if n_out > 1 else ()):
-                loss = loss + (other * 5.0).sum()
-            loss.backward()
-        return seen[0]
-    except Exception:                               # an unknown torch build: never assume ownership
-        return None
-
-
-def _own_or_clone(dy: torch.Tensor, n_out: int) -> torch.Tensor:
-    """``dy`` itself when this backward provably holds the only references to it, else a contiguous copy."""
-    if n_out not in _OWN_SIG:
-        _OWN_SIG[n_out] = _calibrate_ownership(n_out)
-    base = _OWN_SIG[n_out]
-    if base is None or dy._base is not None or not dy.is_contiguous():
-        return dy.contiguous() if (dy._base is None and not dy.is_contiguous()) else dy.clone(memory_format=torch.contiguous_format)
-    sig = _grad_signature(dy)
-    if sig[0] > base[0] or sig[1] > base[1] or sig[2] > base[2]:
-        return dy.clone(memory_format=torch.contiguous_format)
-    return dy
-
-
 def _bn_step(bn: nn.BatchNorm1d):
     """What nn.BatchNorm1d.forward decides before calling F.batch_norm: (use batch statistics?, update factor | None).
     Counts the batch in ``num_batches_tracked``; ``momentum=None`` is the cumulative moving average."""
@@ -228,71 +171,116 @@ class _LayerTrainFn(torch.autograd.Function):
     (eg_gcn_layer_train_fwd / eg_gcn_layer_bwd; models.py:328-335, :431-435):
         z = A_hat x W^T + b;  out = relu|id(dropout(BN_batch(z))) + x.
     Kept for the backward: z, the aggregated input A_hat x (so that dW = dz^T (A_hat x) needs no second aggregation) and the
-    batch statistics — not x.  Returns (out, lm): lm = out's coordinate-node rows [4B,128] (``coord_rows`` = (B, n, first
-    row), else an empty tensor), i.e. the gather of models.py:447 done here so that its gradient comes back into THIS node
-    and is added into 4 rows per frame, instead of autograd summing two dense [B*N,128] gradients."""
+    batch statistics -- not x.  ``kid`` = (kidsum_in | None, kidsum_out | None): child-sum side buffers of a chained train
+    forward (the layer that produces x leaves the child sums of x behind, eg_gcn_layer_train_fwd)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, graph, batch, relu, p, momentum, eps, seed,
-                residual, coord_rows):
+                residual, kid=(None, None)):
         x = x.contiguous()
         need_w = weight.requires_grad
         out, z, agg, bn = ops.gcn_layer_train_fwd(graph, batch, x, weight.contiguous(), bias.contiguous(), gamma.contiguous(),
                                                   beta.contiguous(), running_mean, running_var, momentum, eps, relu, p, seed,
-                                                  residual, want_agg=need_w)
+                                                  residual, want_agg=need_w, kidsum_in=kid[0], kidsum_out=kid[1])
         ctx.save_for_backward(z, agg if agg is not None else z.new_zeros(0), weight.detach().contiguous(),
                               gamma.detach().contiguous(), beta.detach().contiguous(), bn)
-        ctx.cfg = (graph, batch, relu, p, seed, residual, coord_rows, need_w)
-        if coord_rows is not None:
-            B, n, lo = coord_rows
-            lm = out.view(B, n, C)[:, lo:lo + 4, :].reshape(B * 4, C).clone()     # a copy: out is overwritten in place later
-        else:
-            lm = out.new_zeros(0)
-        return out, lm
+        ctx.cfg = (graph, batch, relu, p, seed, residual, need_w)
+        return out
 
     @staticmethod
-    def backward(ctx, dy, dlm):
+    def backward(ctx, dy):
         z, agg, weight, gamma, beta, bn = ctx.saved_tensors
-        graph, batch, relu, p, seed, residual, coord_rows, had_agg = ctx.cfg
-        if coord_rows is not None and dlm is not None:
-            dy = _own_or_clone(dy, 2)                                     # in place only on a buffer that is provably ours
-            B, n, lo = coord_rows
-            dy.view(B, n, C)[:, lo:lo + 4, :] += dlm.view(B, 4, C)
-        else:
-            dy = dy.contiguous()
+        graph, batch, relu, p, seed, residual, had_agg = ctx.cfg
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and had_agg, ctx.needs_input_grad[2]
-        dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dy, z, agg if had_agg else None, weight, gamma, beta, bn,
-                                                      relu, p, seed, residual, need_x, need_w)
+        dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dy.contiguous(), z, agg if had_agg else None, weight, gamma,
+                                                      beta, bn, relu, p, seed, residual, need_x, need_w)
         return (dx, dw, db if need_b else None, dgamma, dbeta) + (None,) * 11
 
 
-class _CoordScatterFn(torch.autograd.Function):
-    """models.py:455-473 in place: sample the layer output's main grid at the updated landmark coordinates
-    (bilinear_interpolation as a 4-tap gather) and overwrite the frame's 4 coordinate-node rows with the samples.
-    Backward works in place on the incoming gradient buffer as well: the coordinate rows' gradient becomes the samples'
-    gradient, those rows are zeroed (their old values were overwritten) and the 16 taps per frame are accumulated into the
-    main-grid rows; d/d coords comes from the same kernel."""
+# ---- the coordinate-graph update (models.py:438-473) as part of the node that CONSUMES the layer output -------------------------
+# The update of layer i reads the layer's output h (its 4 coordinate rows per frame -> node_coordinate_mlp -> new landmark
+# positions), samples h's main grid at the new positions and overwrites the coordinate rows with the samples.  Under autograd
+# that is a scatter into a [B*N,128] tensor and, backwards, a patch of 4 + up to 16 rows per frame of a [B*N,128] gradient.  Done
+# as nodes of their own those patches either cost dense copies / adds per layer (autograd sums two [B*N,128] gradients), or have
+# to happen in place on a gradient buffer that autograd may have handed to somebody else as well.  Neither: the update is
+# folded into the NEXT node (layer i + 1, or the classifier heads after the last layer), whose backward allocates the gradient
+# it returns -- every in-place row patch happens on a buffer that node created itself, and the forward overwrites rows of a
+# tensor that is the fresh output of the node before it (nothing else holds it; forward_nodes takes this route only when no
+# hook could have seen it).
+_MLP_NAMES = ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3", "b3")
+
+
+def _coord_update_fwd(h, coords_prev, dims, mlp_cfg, mlp_params, want_backward=True):
+    """h [B*N,128] (coordinate rows overwritten IN PLACE) -> (new coords [4B,2], state for _coord_update_bwd)."""
+    B, n, main_base, frame, coord_base = dims
+    lm = h.view(B, n, C)[:, coord_base:coord_base + 4, :].reshape(B * 4, C).contiguous()        # (a copy: the rows change below)
+    P = dict(mlp_cfg)
+    P.update({k: p.detach().contiguous() for k, p in zip(_MLP_NAMES, mlp_params)})
+    flat = coords_prev.reshape(B * 4, 2).contiguous()
+    new, saved = ops.coord_mlp_fwd(lm, flat, B, P, True, frame, want_backward)
+    rows = ops.bilinear4_fwd(h, new, B, n, main_base, frame)
+    h.view(B, n, C)[:, coord_base:coord_base + 4, :] = rows.view(B, 4, C)
+    return new, (lm, flat, saved, {k: v for k, v in P.items() if not k.startswith("running")})
+
+
+def _coord_update_bwd(dx, dcoords_new, h, new, lm, flat, saved, P, dims, need_dprev, sampled_rows_used=True):
+    """dx: gradient w.r.t. the tensor AFTER the overwrite, a buffer the caller has just allocated; turned IN PLACE into the
+    gradient w.r.t. the tensor BEFORE it.  -> (dcoords_prev [4B,2] | None, packed MLP gradients)."""
+    B, n, main_base, frame, coord_base = dims
+    rows = dx.view(B, n, C)[:, coord_base:coord_base + 4, :]
+    total = dcoords_new
+    if sampled_rows_used:
+        dnew = rows.reshape(B * 4, C).contiguous()               # gradient of the sampled rows
+        rows.zero_()                                             # (their old values were overwritten)
+        dbil = ops.bilinear4_bwd(dnew, h, new, B, n, main_base, frame, dh=dx, want_dcoords=True)      # 16 taps per frame into dx
+        total = dbil if total is None else total + dbil
+    if total is None:
+        total = torch.zeros(B * 4, 2, dtype=torch.float32, device=dx.device)
+    dlm, dprev, g = ops.coord_mlp_bwd(total.contiguous().view(B * 4, 2), lm, flat, B, P, frame, saved, True, need_dprev)
+    if sampled_rows_used:
+        rows.copy_(dlm.view(B, 4, C))                            # the coordinate rows fed the MLP, nothing else
+    else:
+        rows.add_(dlm.view(B, 4, C))
+    return dprev, g
+
+
+def _mlp_grads(g):
+    sizes = (32 * 136, 32, 32, 32, 16 * 32, 16, 16, 16, 2 * 16, 2)
+    parts = torch.split(g, sizes)
+    return (parts[0].view(32, 136), parts[1], parts[2], parts[3], parts[4].view(16, 32), parts[5], parts[6], parts[7],
+            parts[8].view(2, 16), parts[9])
+
+
+class _CoordLayerTrainFn(torch.autograd.Function):
+    """Coordinate update of layer i - 1 (on this node's input) + train-mode layer i:
+        (h_prev [B*N,128], coords_prev [B,4,2]) -> (out, coords [B,4,2]).
+    ``cfg`` = (graph, batch, relu, p, momentum, eps, seed, residual, dims, mlp_cfg, kid); params = the 10 tensors of
+    node_coordinate_mlp[i - 1] in _HEAD_PARAM_IDX order."""
 
     @staticmethod
-    def forward(ctx, h, coords, batch, n, main_base, frame, coord_base):
-        coords = coords.reshape(batch * 4, 2).contiguous()
-        new = ops.bilinear4_fwd(h, coords, batch, n, main_base, frame)
-        h.view(batch, n, C)[:, coord_base:coord_base + 4, :] = new.view(batch, 4, C)
-        ctx.mark_dirty(h)
-        ctx.save_for_backward(h, coords)
-        ctx.dims = (batch, n, main_base, frame, coord_base)
-        return h
+    def forward(ctx, h_prev, coords_prev, weight, bias, gamma, beta, running_mean, running_var, cfg, *mlp_params):
+        graph, batch, relu, p, momentum, eps, seed, residual, dims, mlp_cfg, kid = cfg
+        new, (lm, flat, saved, P) = _coord_update_fwd(h_prev, coords_prev, dims, mlp_cfg, mlp_params)
+        need_w = weight.requires_grad
+        out, z, agg, bn = ops.gcn_layer_train_fwd(graph, batch, h_prev, weight.contiguous(), bias.contiguous(), gamma.contiguous(),
+                                                  beta.contiguous(), running_mean, running_var, momentum, eps, relu, p, seed,
+                                                  residual, want_agg=need_w, kidsum_in=kid[0], kidsum_out=kid[1])
+        ctx.save_for_backward(z, agg if agg is not None else z.new_zeros(0), weight.detach().contiguous(),
+                              gamma.detach().contiguous(), beta.detach().contiguous(), bn, h_prev, new, lm, flat, *saved)
+        ctx.cfg = (graph, batch, relu, p, seed, residual, need_w, dims, P)
+        return out, new.view(batch, 4, 2)
 
     @staticmethod
-    def backward(ctx, dh):
-        h, coords = ctx.saved_tensors
-        batch, n, main_base, frame, coord_base = ctx.dims
-        dh = _own_or_clone(dh, 1)                                          # in place only on a buffer that is provably ours
-        rows = dh.view(batch, n, C)[:, coord_base:coord_base + 4, :]
-        dnew = rows.reshape(batch * 4, C).clone()
-        rows.zero_()
-        dcoords = ops.bilinear4_bwd(dnew, h, coords, batch, n, main_base, frame, dh=dh, want_dcoords=ctx.needs_input_grad[1])
-        return dh, (dcoords.view(batch, 4, 2) if dcoords is not None else None), None, None, None, None, None
+    def backward(ctx, dy, dcoords):
+        z, agg, weight, gamma, beta, bn, h_prev, new, lm, flat, *saved = ctx.saved_tensors
+        graph, batch, relu, p, seed, residual, had_agg, dims, P = ctx.cfg
+        need_w, need_b = ctx.needs_input_grad[2] and had_agg, ctx.needs_input_grad[3]
+        dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dy.contiguous(), z, agg if had_agg else None, weight, gamma,
+                                                      beta, bn, relu, p, seed, residual, True, need_w)
+        dprev, g = _coord_update_bwd(dx, None if dcoords is None else dcoords.reshape(batch * 4, 2), h_prev, new, lm, flat,
+                                     tuple(saved), P, dims, ctx.needs_input_grad[1])
+        return (dx, None if dprev is None else dprev.view(batch, 4, 2), dw, db if need_b else None, dgamma, dbeta, None, None,
+                None) + _mlp_grads(g)
 
 
 _HEAD_PARAM_IDX = ((0, "weight"), (0, "bias"), (1, "weight"), (1, "bias"), (4, "weight"), (4, "bias"), (5, "weight"),
@@ -307,11 +295,7 @@ class _ClassifierTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, batch, n, row_lo, n_valid, sigmoid, cfg, *params):
-        heads = [params[10 * k:10 * k + 10] for k in range(4)]
-        cat = lambda j: torch.cat([hd[j].reshape(-1) if hd[j].dim() == 1 else hd[j] for hd in heads], dim=0).contiguous()
-        P = dict(cfg)
-        P.update(w1=cat(0), b1=cat(1), gamma1=cat(2), beta1=cat(3), w2=torch.stack([hd[4] for hd in heads]).contiguous(),
-                 b2=cat(5), gamma2=cat(6), beta2=cat(7), w3=cat(8), b3=cat(9))
+        P = _stack_head_params(params, cfg)
         h = h.contiguous()
         logits, z1, z2, bn = ops.classifier_train_fwd(h, batch, n, row_lo, n_valid, P, sigmoid)
         ctx.P = {k: v for k, v in P.items() if not k.startswith("running")}
@@ -327,19 +311,62 @@ class _ClassifierTrainFn(torch.autograd.Function):
         if sigmoid:
             dl = dl * y * (1.0 - y)
         dh, g = ops.classifier_bwd(dl, h, batch, n, row_lo, n_valid, ctx.P, z1, z2, bn, ctx.needs_input_grad[0])
-        dw1, db1, dg1, dbe1 = g[:16384].view(4, 32, C), g[16384:16512].view(4, 32), g[16512:16640].view(4, 32), g[16640:16768].view(4, 32)
-        o = 16768
-        dw2 = g[o:o + 2048].view(4, 16, 32)
-        db2, dg2, dbe2 = (g[o + 2048 + 64 * k:o + 2048 + 64 * (k + 1)].view(4, 16) for k in range(3))
-        dw3 = g[o + 2240:o + 2304].view(4, 1, 16)
-        db3 = g[o + 2304:o + 2308].view(4, 1)
-        grads = []
-        for k in range(4):
-            grads += [dw1[k], db1[k], dg1[k], dbe1[k], dw2[k], db2[k], dg2[k], dbe2[k], dw3[k], db3[k]]
-        return (dh, None, None, None, None, None, None) + tuple(grads)
+        return (dh, None, None, None, None, None, None) + _unstack_head_grads(g)
 
 
-_MLP_NAMES = ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3", "b3")
+def _stack_head_params(params, cfg):
+    heads = [params[10 * k:10 * k + 10] for k in range(4)]
+    cat = lambda j: torch.cat([hd[j].reshape(-1) if hd[j].dim() == 1 else hd[j] for hd in heads], dim=0).contiguous()
+    P = dict(cfg)
+    P.update(w1=cat(0), b1=cat(1), gamma1=cat(2), beta1=cat(3), w2=torch.stack([hd[4] for hd in heads]).contiguous(),
+             b2=cat(5), gamma2=cat(6), beta2=cat(7), w3=cat(8), b3=cat(9))
+    return P
+
+
+def _unstack_head_grads(g):
+    dw1, db1, dg1, dbe1 = g[:16384].view(4, 32, C), g[16384:16512].view(4, 32), g[16512:16640].view(4, 32), g[16640:16768].view(4, 32)
+    o = 16768
+    dw2 = g[o:o + 2048].view(4, 16, 32)
+    db2, dg2, dbe2 = (g[o + 2048 + 64 * k:o + 2048 + 64 * (k + 1)].view(4, 16) for k in range(3))
+    dw3 = g[o + 2240:o + 2304].view(4, 1, 16)
+    db3 = g[o + 2304:o + 2308].view(4, 1)
+    grads = []
+    for k in range(4):
+        grads += [dw1[k], db1[k], dg1[k], dbe1[k], dw2[k], db2[k], dg2[k], dbe2[k], dw3[k], db3[k]]
+    return tuple(grads)
+
+
+class _CoordClassifierTrainFn(torch.autograd.Function):
+    """Coordinate update of the LAST layer (on this node's input) + node-type filter + the four heads in train mode:
+        (h [B*N,128], coords_prev [B,4,2]) -> (logits, coords [B,4,2]).
+    The heads drop the coordinate rows (models.py:485), so the rows the update samples into h feed nothing: backwards only the
+    MLP's gradient enters the coordinate rows (no bilinear backward).  params = 10 MLP tensors + 4 x 10 head tensors."""
+
+    @staticmethod
+    def forward(ctx, h, coords_prev, dims5, sigmoid, cls_cfg, coord_dims, mlp_cfg, *params):
+        batch, n, row_lo, n_valid = dims5
+        new, (lm, flat, saved, Pm) = _coord_update_fwd(h, coords_prev, coord_dims, mlp_cfg, params[:10])
+        P = _stack_head_params(params[10:], cls_cfg)
+        logits, z1, z2, bn = ops.classifier_train_fwd(h, batch, n, row_lo, n_valid, P, sigmoid)
+        ctx.P = {k: v for k, v in P.items() if not k.startswith("running")}
+        ctx.cfg = (batch, n, row_lo, n_valid, sigmoid, coord_dims, Pm)
+        ctx.save_for_backward(h, z1, z2, bn, logits if sigmoid else logits.new_zeros(0), new, lm, flat, *saved)
+        return logits, new.view(batch, 4, 2)
+
+    @staticmethod
+    def backward(ctx, dy, dcoords):
+        h, z1, z2, bn, y, new, lm, flat, *saved = ctx.saved_tensors
+        batch, n, row_lo, n_valid, sigmoid, coord_dims, Pm = ctx.cfg
+        if dy is None:
+            dy = torch.zeros(batch * n_valid, 4, dtype=torch.float32, device=h.device)
+        dl = dy.contiguous()
+        if sigmoid:
+            dl = dl * y * (1.0 - y)
+        dh, g = ops.classifier_bwd(dl, h, batch, n, row_lo, n_valid, ctx.P, z1, z2, bn, True)
+        dprev, gm = _coord_update_bwd(dh, None if dcoords is None else dcoords.reshape(batch * 4, 2), h, new, lm, flat, tuple(saved),
+                                      Pm, coord_dims, ctx.needs_input_grad[1], sampled_rows_used=False)
+        return (dh, None if dprev is None else dprev.view(batch, 4, 2), None, None, None, None, None) + _mlp_grads(gm) + \
+            _unstack_head_grads(g)
 
 
 class _CoordMlpFn(torch.autograd.Function):
@@ -365,11 +392,7 @@ class _CoordMlpFn(torch.autograd.Function):
         batch, frame = ctx.dims
         dlm, dc, g = ops.coord_mlp_bwd(dnew.contiguous().view(batch * 4, 2), lm, flat, batch, ctx.P, frame, (z1, z2, bn, pre),
                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        sizes = (32 * 136, 32, 32, 32, 16 * 32, 16, 16, 16, 2 * 16, 2)
-        parts = torch.split(g, sizes)
-        grads = (parts[0].view(32, 136), parts[1], parts[2], parts[3], parts[4].view(16, 32), parts[5], parts[6], parts[7],
-                 parts[8].view(2, 16), parts[9])
-        return (dlm, dc.view(batch, 4, 2) if dc is not None else None, None, None, None) + grads
+        return (dlm, dc.view(batch, 4, 2) if dc is not None else None, None, None, None) + _mlp_grads(g)
 
 
 # ---------------------------------------------------------------------------
@@ -600,33 +623,36 @@ class HierarchicalPatchModel(nn.Module):
         return hit[1]
 
     # ---- one GNN layer in train mode: one autograd node over eg_gcn_layer_train_fwd / eg_gcn_layer_bwd ------------------
-    def _layer_train(self, i: int, x_in: torch.Tensor, graph: ops.Graph, gb: int, coord_rows=None):
-        """-> (h, lm): lm = the coordinate-node rows of h (models.py:447) when ``coord_rows`` is given, else None."""
+    def _layer_cfg(self, i: int):
+        """(conv, bn, relu?, dropout p, seed) of layer i, or None when its BatchNorm / Dropout are frozen inside a training model."""
         layer = self.gnn_layers[i]
         conv, bn, drop = layer.module_0, layer.module_1, layer.module_2
+        if not (bn.training and bn.affine and drop.training):
+            return None
         p = float(drop.p)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0      # host RNG: reproducible under torch.manual_seed
-        relu = i < self.num_gnn_layers - 1
-        if not (bn.training and bn.affine and drop.training):
-            # a frozen (eval-mode) BatchNorm / Dropout inside a training model: GCNConv kernel + the torch modules
-            h = layer.forward_graph(x_in, graph, gb)
-            return (h + x_in if self.residual else h), None
-        _, momentum = _bn_step(bn)
-        h, lm = _LayerTrainFn.apply(x_in, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                    graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), coord_rows)
-        return h, (lm if coord_rows is not None else None)
+        return conv, bn, i < self.num_gnn_layers - 1, p, seed
 
-    # ---- coordinate-graph update (models.py:438-473) ---------------------------------------
-    def _coordinate_update(self, i: int, h: torch.Tensor, node_coords: torch.Tensor, batch: int, lm=None):
+    def _layer_train(self, i: int, x_in: torch.Tensor, graph: ops.Graph, gb: int, kid=(None, None)):
+        cfg = self._layer_cfg(i)
+        if cfg is None:
+            # a frozen (eval-mode) BatchNorm / Dropout inside a training model: GCNConv kernel + the torch modules
+            h = self.gnn_layers[i].forward_graph(x_in, graph, gb)
+            return h + x_in if self.residual else h
+        conv, bn, relu, p, seed = cfg
+        _, momentum = _bn_step(bn)
+        return _LayerTrainFn.apply(x_in, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid)
+
+    # ---- coordinate-graph update (models.py:438-473), explicit form ------------------------------------------------------
+    def _coordinate_update(self, i: int, h: torch.Tensor, node_coords: torch.Tensor, batch: int):
+        """The update as autograd nodes of its own (eval mode; train mode with hooks, JumpingKnowledge or frozen sub-modules):
+        nothing is modified in place under autograd -- the overwrite of the coordinate rows copies h.  The training step's
+        route folds the update into the node that consumes h instead (_CoordLayerTrainFn, _CoordClassifierTrainFn)."""
         n, _, _, main_base, coord_base = self._row_ranges()
         fs = self.frame_size
-        # lm given: h is the fresh output of _LayerTrainFn, which nothing else has saved for its backward -- only then may
-        # the resampled rows overwrite it in place (the output of a torch module, e.g. the ReLU of the frozen-BatchNorm
-        # fallback, is saved by that module and must not be written to)
-        fresh_layer_output = lm is not None
         # pairwise (other - self) offsets per frame, flattened to 8 numbers per landmark (:441-444)
-        if lm is None:
-            lm = h.view(batch, n, C)[:, coord_base:, :].reshape(batch * 4, C).clone()
+        lm = h.view(batch, n, C)[:, coord_base:, :].reshape(batch * 4, C).clone()
         new_coords = self._coord_mlp_kernel(self.node_coordinate_mlp[i], lm, node_coords, batch, fs)
         if new_coords is None:
             # a mix of frozen and training sub-modules, or eval mode with gradients: the torch modules, op by op
@@ -634,13 +660,31 @@ class HierarchicalPatchModel(nn.Module):
             delta = self.node_coordinate_mlp[i](torch.cat((lm, shape_feats), dim=1))
             new_coords = torch.clamp(node_coords + delta.view(batch, 4, 2), min=0, max=fs - 1)
         node_coords = new_coords
-        if fresh_layer_output and torch.is_grad_enabled() and (h.requires_grad or node_coords.requires_grad) and h.grad_fn is not None:
-            # train step: in place on the layer output, in place on its gradient (no [B*N,128] copies, fills or adds)
-            h = _CoordScatterFn.apply(h, node_coords, batch, n, main_base, fs, coord_base)
-        else:
-            new_feats = ops.bilinear4(h, node_coords, batch, n, main_base, fs)            # [4B, 128]
-            h = ops.scatter_coord_rows(h, new_feats, batch, n, coord_base)
+        new_feats = ops.bilinear4(h, node_coords, batch, n, main_base, fs)            # [4B, 128]
+        h = ops.scatter_coord_rows(h, new_feats, batch, n, coord_base)
         return h, node_coords
+
+    def _coord_mlp_cfg(self, mlp: nn.Sequential):
+        """(cfg, params) of node_coordinate_mlp[i] for the kernels when every sub-module is in plain train state, else None."""
+        if self.classifier_hidden_dim != 32 or self.node_embedding_dim != C or os.environ.get("EG_COORD_MLP_KERNEL", "1") == "0":
+            return None
+        bn1, bn2, d1, d2 = mlp[1], mlp[5], mlp[3], mlp[7]
+        if not (bn1.affine and bn2.affine and bn1.training and bn2.training and d1.training and d2.training):
+            return None
+        params = [getattr(mlp[j], name) for j, name in _HEAD_PARAM_IDX]
+        cfg = dict(eps1=bn1.eps, eps2=bn2.eps, p1=float(d1.p), p2=float(d2.p), seed1=0, seed2=0,
+                   running_mean1=bn1.running_mean, running_var1=bn1.running_var, running_mean2=bn2.running_mean,
+                   running_var2=bn2.running_var)
+        return cfg, params
+
+    def _coord_mlp_train_cfg(self, mlp: nn.Sequential):
+        """The same with this step's dropout seeds drawn and the BatchNorm batches counted (call once per forward)."""
+        cfg, params = self._coord_mlp_cfg(mlp)
+        if cfg["p1"] > 0 or cfg["p2"] > 0:
+            cfg["seed1"], cfg["seed2"] = torch.randint(0, 2 ** 62, (2,)).tolist()     # host RNG, like the layers
+        _, cfg["momentum1"] = _bn_step(mlp[1])
+        _, cfg["momentum2"] = _bn_step(mlp[5])
+        return cfg, params
 
     def _coord_mlp_kernel(self, mlp: nn.Sequential, lm: torch.Tensor, node_coords: torch.Tensor, batch: int, frame: int):
         """models.py:441-453 on eg_coord_mlp_fwd / _bwd (one launch each way) -> new coords [B,4,2], or None when the
@@ -651,16 +695,13 @@ class HierarchicalPatchModel(nn.Module):
         bn1, bn2, d1, d2 = mlp[1], mlp[5], mlp[3], mlp[7]
         if not (bn1.affine and bn2.affine):
             return None
+        if self._coord_mlp_cfg(mlp) is not None:
+            cfg, params = self._coord_mlp_train_cfg(mlp)
+            return _CoordMlpFn.apply(lm, node_coords, batch, frame, cfg, *params)
         params = [getattr(mlp[j], name) for j, name in _HEAD_PARAM_IDX]
         cfg = dict(eps1=bn1.eps, eps2=bn2.eps, p1=float(d1.p), p2=float(d2.p), seed1=0, seed2=0,
                    running_mean1=bn1.running_mean, running_var1=bn1.running_var, running_mean2=bn2.running_mean,
                    running_var2=bn2.running_var)
-        if bn1.training and bn2.training and d1.training and d2.training:
-            if cfg["p1"] > 0 or cfg["p2"] > 0:
-                cfg["seed1"], cfg["seed2"] = torch.randint(0, 2 ** 62, (2,)).tolist()     # host RNG, like the layers
-            _, cfg["momentum1"] = _bn_step(bn1)
-            _, cfg["momentum2"] = _bn_step(bn2)
-            return _CoordMlpFn.apply(lm, node_coords, batch, frame, cfg, *params)
         frozen = not (bn1.training or bn2.training or d1.training or d2.training)
         needs_grad = torch.is_grad_enabled() and (lm.requires_grad or node_coords.requires_grad or
                                                   any(p.requires_grad for p in params))
@@ -671,6 +712,51 @@ class HierarchicalPatchModel(nn.Module):
                                        False)
             return new.view(batch, 4, 2)
         return None
+
+    # ---- the training step's route with the coordinate graph on: every update folded into the consuming node -----------------
+    def _train_coord_fused_ok(self, node_coords) -> bool:
+        if not (self.training and self.use_coordinate_graph and self.layer_output_hook is None and self.jk is None):
+            return False
+        if node_coords is None or node_coords.shape[-1] != 2 or node_coords.dtype != torch.float32:
+            return False
+        if os.environ.get("EG_COORD_FUSED", "1") == "0" or not self._stacked_heads_ok():
+            return False
+        for l in self.gnn_layers:
+            if not (l.module_1.training and l.module_1.affine and l.module_2.training):
+                return False
+        return all(self._coord_mlp_cfg(m) is not None for m in self.node_coordinate_mlp)
+
+    def _forward_train_coord_fused(self, x0: torch.Tensor, graph: ops.Graph, gb: int, B: int, node_coords: torch.Tensor):
+        n, n_conn, n_valid, main_base, coord_base = self._row_ranges()
+        dims = (B, n, main_base, self.frame_size, coord_base)
+        kids = self._train_kidsums(graph, gb)
+        h, coords = x0.contiguous(), node_coords
+        for i in range(self.num_gnn_layers):
+            conv, bn, relu, p, seed = self._layer_cfg(i)
+            _, momentum = _bn_step(bn)
+            kid = (kids[(i + 1) & 1] if i > 0 else None, kids[i & 1] if i < self.num_gnn_layers - 1 else None)
+            if i == 0:
+                h = _LayerTrainFn.apply(h, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                        graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid)
+            else:
+                mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i - 1])
+                cfg = (graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), dims, mlp_cfg, kid)
+                h, coords = _CoordLayerTrainFn.apply(h, coords, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                                     bn.running_var, cfg, *mlp_params)
+        mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[self.num_gnn_layers - 1])
+        cls_cfg, head_params, finish = self._classifier_train_cfg()
+        logits, coords = _CoordClassifierTrainFn.apply(h, coords, (B, n, n_conn, n_valid), self.output_activation == "sigmoid",
+                                                       cls_cfg, dims, mlp_cfg, *mlp_params, *head_params)
+        finish()
+        return logits.squeeze(1), coords.reshape(B * 4, -1)
+
+    def _train_kidsums(self, graph: ops.Graph, gb: int):
+        """Child-sum side buffers of the chained train forward (layer i leaves the child sums of its output for layer i + 1:
+        eg_gcn_layer_train_fwd), or (None, None)."""
+        if graph.kidsum_rows == 0 or self.num_gnn_layers < 2 or os.environ.get("EG_TRAIN_CHAIN", "1") == "0" or \
+                not ops.train_chain_supported():
+            return None, None
+        return self._kidsum_buffers(graph, gb)
 
     # ---- the hot path ------------------------------------------------------------------------
     def forward_nodes(self, node_feats: torch.Tensor, edge_index: torch.Tensor, batch: Optional[int] = None,
@@ -696,6 +782,8 @@ class HierarchicalPatchModel(nn.Module):
         jk_fused = (fused and self.jk is not None and graph.fused_classifier_ok and not self.use_coordinate_graph
                     and os.environ.get("EG_JK_FUSED", "1") != "0")
         fused = fused and (self.jk is None or jk_fused)
+        if not fused and self._train_coord_fused_ok(node_coords):
+            return self._forward_train_coord_fused(node_feats, graph, gb, B, node_coords)
         if fused and self.use_hip_graph and not self.use_coordinate_graph and not torch.cuda.is_current_stream_capturing():
             return self._forward_nodes_graphed(node_feats, edge_index, B), None
         hidden = [node_feats.contiguous()]
@@ -709,6 +797,9 @@ class HierarchicalPatchModel(nn.Module):
                     and (kid[0] is not None or graph.kidsum_rows == 0) and n_conn == 0 and n_valid == n
                     and self.num_output_channels == 4 and self.classifier_hidden_dim == 32)
         jkb = self._jk_buffers(graph, gb, node_feats) if jk_fused else None
+        train_kids = (None, None)
+        if self.training and not fused and all(self._layer_cfg_static_ok(i) for i in range(self.num_gnn_layers)):
+            train_kids = self._train_kidsums(graph, gb)
         for i in range(self.num_gnn_layers):
             x_in = hidden[i]
             if fused:
@@ -726,14 +817,15 @@ class HierarchicalPatchModel(nn.Module):
                                       kidsum_out=None if last else kid[i & 1], jk_in=jk_prev,
                                       jk_out=jkb[i & 1] if jk_fused else None)
             elif self.training:
-                _, _, _, _, coord_base = self._row_ranges()
-                h, lm = self._layer_train(i, x_in, graph, gb, (B, n, coord_base) if self.use_coordinate_graph else None)
+                tk = train_kids if not self.use_coordinate_graph else (None, None)      # (the explicit coordinate update rewrites rows)
+                h = self._layer_train(i, x_in, graph, gb, (tk[(i + 1) & 1] if i > 0 else None,
+                                                           tk[i & 1] if i < self.num_gnn_layers - 1 else None))
             else:
                 h = self.gnn_layers[i].forward_graph(x_in, graph, gb)
                 if self.residual and h.shape[1] == x_in.shape[1]:
                     h = h + x_in
             if self.use_coordinate_graph:
-                h, node_coords = self._coordinate_update(i, h, node_coords, B, lm if (self.training and not fused) else None)
+                h, node_coords = self._coordinate_update(i, h, node_coords, B)
             if self.layer_output_hook is not None:
                 self.layer_output_hook(i, h)              # e.g. h.retain_grad() / h.register_hook(...) in a test
             hidden.append(h)
@@ -763,10 +855,9 @@ class HierarchicalPatchModel(nn.Module):
         return (self.num_output_channels == 4 and self.classifier_hidden_dim == 32 and self.node_embedding_dim == C
                 and plain_bn and drops_on and os.environ.get("EG_STACKED_HEADS", "1") != "0")
 
-    def _classifier_train(self, h: torch.Tensor, B: int, n: int, row_lo: int, n_valid: int) -> torch.Tensor:
-        """models.py:363-377, :485-490 in train mode on the HIP kernels (_ClassifierTrainFn): the node-type filter is a row
-        range, the four heads run as one stacked network.  Running statistics: the kernels update stacked copies, which are
-        written back to the 8 BatchNorm modules with two multi-tensor copies."""
+    def _classifier_train_cfg(self):
+        """(cfg, the 40 head parameters, finish()) for _ClassifierTrainFn / _CoordClassifierTrainFn.  Running statistics: the
+        kernels update stacked copies, which finish() writes back to the 8 BatchNorm modules with two multi-tensor copies."""
         heads = list(self.node_classifiers)
         bn1, bn2 = [hd[1] for hd in heads], [hd[5] for hd in heads]
         p1, p2 = float(heads[0][3].p), float(heads[0][7].p)
@@ -777,13 +868,26 @@ class HierarchicalPatchModel(nn.Module):
         cfg = dict(running_mean1=rm1, running_var1=rv1, running_mean2=rm2, running_var2=rv2, eps1=bn1[0].eps, eps2=bn2[0].eps,
                    momentum1=bn1[0].momentum, momentum2=bn2[0].momentum, p1=p1, p2=p2, seed1=seeds[0], seed2=seeds[1])
         params = [getattr(hd[j], name) for hd in heads for j, name in _HEAD_PARAM_IDX]
+
+        def finish():
+            with torch.no_grad():
+                torch._foreach_copy_([b.running_mean for b in bn1] + [b.running_var for b in bn1] +
+                                     [b.running_mean for b in bn2] + [b.running_var for b in bn2],
+                                     list(rm1.split(32)) + list(rv1.split(32)) + list(rm2.split(16)) + list(rv2.split(16)))
+                torch._foreach_add_([b.num_batches_tracked for b in bn1 + bn2], 1)
+        return cfg, params, finish
+
+    def _classifier_train(self, h: torch.Tensor, B: int, n: int, row_lo: int, n_valid: int) -> torch.Tensor:
+        """models.py:363-377, :485-490 in train mode on the HIP kernels (_ClassifierTrainFn): the node-type filter is a row
+        range, the four heads run as one stacked network."""
+        cfg, params, finish = self._classifier_train_cfg()
         out = _ClassifierTrainFn.apply(h, B, n, row_lo, n_valid, self.output_activation == "sigmoid", cfg, *params)
-        with torch.no_grad():
-            torch._foreach_copy_([b.running_mean for b in bn1] + [b.running_var for b in bn1] +
-                                 [b.running_mean for b in bn2] + [b.running_var for b in bn2],
-                                 list(rm1.split(32)) + list(rv1.split(32)) + list(rm2.split(16)) + list(rv2.split(16)))
-            torch._foreach_add_([b.num_batches_tracked for b in bn1 + bn2], 1)
+        finish()
         return out
+
+    def _layer_cfg_static_ok(self, i: int) -> bool:
+        l = self.gnn_layers[i]
+        return bool(l.module_1.training and l.module_1.affine and l.module_2.training)
 
     def _kidsum_buffers(self, graph, gb):
         key = (id(graph), gb)

@@ -331,12 +331,23 @@ def bn_act_bwd(dy, z, mean, invstd, gamma, beta, relu=False, dropout_p=0.0, seed
 # ---------------------------------------------------------------------------
 # whole train-mode layers (eg_gcn_layer_train_fwd / _bwd, eg_classifier_train_fwd / _bwd)
 # ---------------------------------------------------------------------------
+def train_chain_supported() -> bool:
+    """The train forward hands child sums from layer to layer (kidsum_in / kidsum_out of eg_gcn_layer_train_fwd)."""
+    return True
+
+
 def gcn_layer_train_fwd(graph: Graph, batch: int, x, weight, bias, gamma, beta, running_mean, running_var, momentum,
-                        eps: float, relu: bool, dropout_p: float, seed: int, residual: bool, want_agg: bool = True):
+                        eps: float, relu: bool, dropout_p: float, seed: int, residual: bool, want_agg: bool = True,
+                        kidsum_in: Optional[torch.Tensor] = None, kidsum_out: Optional[torch.Tensor] = None):
     """-> (out, z, agg | None, bn [4,128] = mean, invstd, scale, shift).  running_* are updated in place
-    (momentum None: no update)."""
+    (momentum None: no update).  kidsum_in / kidsum_out: child-sum side buffers of a chained train forward (`new_kidsum`)."""
     rows = graph.num_nodes * batch
     _check_rows(x, "x", rows)
+    for name, t in (("kidsum_in", kidsum_in), ("kidsum_out", kidsum_out)):
+        if t is not None:
+            if graph.kidsum_rows == 0:
+                raise RuntimeError("this graph handle has no child-sum side buffer (kidsum_rows == 0)")
+            _check_rows(t, name, graph.kidsum_rows * batch)
     for t, n in ((bias, "bias"), (gamma, "gamma"), (beta, "beta")):
         _check_vec(t, n, C)
     z = torch.empty_like(x)
@@ -348,7 +359,7 @@ def gcn_layer_train_fwd(graph: Graph, batch: int, x, weight, bias, gamma, beta, 
         graph._h, batch, _ptr(x), _ptr(weight), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(running_mean) if upd else None,
         _ptr(running_var) if upd else None, float(momentum) if upd else -1.0, float(eps), int(relu), float(dropout_p),
         int(seed) & 0xFFFFFFFFFFFFFFFF, int(residual), _ptr(_workspace(x.device)), _ptr(z), _ptr(agg), _ptr(bn), _ptr(out),
-        _stream()), "eg_gcn_layer_train_fwd")
+        _ptr(kidsum_in), _ptr(kidsum_out), _stream()), "eg_gcn_layer_train_fwd")
     return out, z, agg, bn
 
 

@@ -231,6 +231,11 @@ int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* me
  *     bn  = { batch mean, 1/sqrt(var + eps), gamma * invstd, beta - mean * scale }   [4,128]
  *     running_mean / running_var <- nn.BatchNorm1d update with `momentum` (unbiased variance); momentum < 0 or NULL: none
  *     out = relu?(dropout(z * scale + shift)) + (residual ? x : 0)    dropout mask = pure function of (seed, element)
+ *     kidsum_in / kidsum_out (both nullable; [batch * eg_graph_kidsum_rows(g), 128], see eg_gcn_layer_fwd_chain): chained train
+ *     forward.  kidsum_out receives the child sums of `out` (written by the activation pass, which then runs in tile order);
+ *     kidsum_in = the child sums of x left by the layer that produced x: aux nodes read one row instead of four child rows.
+ *     (The coordinate-graph update that the reference runs between two layers rewrites only coordinate rows, which are nobody's
+ *     children: the sums stay valid.)
  * eg_gcn_layer_bwd, given dy = d loss / d out and the tensors kept by the forward:
  *     dz (scratch [rows,128]; may be NULL when dx is NULL and dw is not: the first layer of a stack whose input needs no
  *         gradient never writes it) = BatchNorm'(dy * dropout / ReLU mask);  dgamma, dbeta [128]
@@ -241,7 +246,7 @@ int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* me
 int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* bias, const float* gamma,
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
                            float dropout_p, uint64_t seed, int residual, void* workspace, float* z, float* agg, float* bn,
-                           float* out, eg_stream_t stream);
+                           float* out, const float* kidsum_in, float* kidsum_out, eg_stream_t stream);
 int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
                      const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
                      int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,

@@ -277,3 +277,37 @@ def test_shared_handle_on_two_streams():
                 outs.append(ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True))
         torch.cuda.synchronize()
         assert torch.equal(outs[0], serial[0]) and torch.equal(outs[1], serial[1])
+
+
+def test_queue_ring_refuses_a_slice_still_in_flight_on_another_stream():
+    """include/echoglad_hip.h: a launch takes the next of 64 tile-queue slices of its handle; the slice of the launch 64 calls
+    ago must be free.  If that launch is still in flight on ANOTHER stream the call is refused (unsupported) instead of sharing
+    live counters -- and it works again once that stream has drained.  Same-stream reuse is ordered and always fine."""
+    B = 2
+    g = ops.Graph.topo(32, 4)
+    x = synthetic_node_feats(B * g.num_nodes, 128, seed=1).to(DEV)
+    w = torch.eye(128, device=DEV)
+    want = ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True)
+    torch.cuda.synchronize()
+    for _ in range(200):                                             # one stream: the ring wraps three times, no refusal
+        ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        torch.cuda._sleep(int(4e9))                                  # ~2 s of GPU time in front of the launch that takes a slice
+        held = ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True)
+    refused = None
+    with torch.cuda.stream(s2):
+        for k in range(70):
+            try:
+                ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True)
+            except RuntimeError as ex:
+                refused = (k, str(ex))
+                break
+    assert refused is not None and refused[0] == 63 and "unsupported" in refused[1] and "in flight" in refused[1], refused
+    torch.cuda.synchronize()
+    assert torch.equal(held, want)
+    with torch.cuda.stream(s2):
+        got = ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True)   # the held slice is free again
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

@@ -431,6 +431,90 @@ def test_layer_train_composites_vs_torch_autograd(frame, naux, coord, relu, resi
     assert db.abs().max() == 0 and br.grad.abs().max() < 1e-3 * dw.abs().max()      # the bias gradient is analytically zero
 
 
+@pytest.mark.parametrize("frame,naux,coord,p", [(32, 4, True, 0.0), (64, 6, False, 0.5), (224, 7, True, 0.5), (16, 3, False, 0.3)])
+def test_train_forward_chain_child_sums(frame, naux, coord, p):
+    """eg_gcn_layer_train_fwd with kidsum_out / kidsum_in: the activation pass in tile order writes the same `out` as the
+    flat pass (bit for bit: same expression per element) and the child sums of it (against an fp64 gather over the
+    edge list); a layer that reads them gives the z / agg / statistics of the layer that pulls the four child rows."""
+    B = 2
+    g = ops.Graph.topo(frame, naux, False, coord)
+    if g.kidsum_rows == 0:
+        with pytest.raises(RuntimeError):
+            ops.gcn_layer_train_fwd(g, B, rand_rows(B * g.num_nodes, 1).to(DEV), torch.eye(128, device=DEV), torch.zeros(128, device=DEV),
+                                    torch.ones(128, device=DEV), torch.zeros(128, device=DEV), None, None, None, 1e-5, True, 0.0, 0,
+                                    True, kidsum_out=torch.zeros(8, 128, device=DEV))
+        return
+    n = g.num_nodes
+    topo = graph_tensors(frame, naux, 1, coord=coord)[0]
+    rs = np.random.RandomState(frame + 1)
+    W = torch.from_numpy(rs.uniform(-0.15, 0.15, (128, 128)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.standard_normal(128).astype(np.float32) * 0.1).to(DEV)
+    gamma = torch.from_numpy(1 + 0.3 * rs.standard_normal(128).astype(np.float32)).to(DEV)
+    beta = torch.from_numpy(0.1 * rs.standard_normal(128).astype(np.float32)).to(DEV)
+    x = rand_rows(B * n, seed=3).to(DEV)
+    args = (W, bias, gamma, beta, None, None, None, 1e-5, True, p, 1234, True)
+    out0, z0, agg0, bn0 = ops.gcn_layer_train_fwd(g, B, x, *args)
+    ka = ops.new_kidsum(g, B)
+    out1, z1, agg1, bn1 = ops.gcn_layer_train_fwd(g, B, x, *args, kidsum_out=ka)
+    assert torch.equal(z0, z1) and torch.equal(agg0, agg1) and torch.equal(bn0, bn1)
+    assert torch.equal(out0, out1)
+    # child sums of out1 (same construction as test_chained_layers_match_unchained)
+    dis = g.deg_inv_sqrt().double()
+    ei = torch.from_numpy(topo.edge_index()).to(DEV)
+    bases = torch.from_numpy(topo.level_table()[:, 0].astype(np.int64)).to(DEV)
+    lvl = torch.bucketize(torch.arange(n, device=DEV), bases, right=True)
+    src, dst = ei[0], ei[1]
+    child_edges = (lvl[src] == lvl[dst] + 1) & (src < topo.coord_base)
+    want_k = torch.zeros(B, n, 128, dtype=torch.float64, device=DEV)
+    ov = out1.view(B, n, 128).double()
+    want_k.index_add_(1, dst[child_edges], ov[:, src[child_edges], :] * dis[src[child_edges]][None, :, None])
+    got_k = ka.view(B, g.kidsum_rows, 128).double()
+    assert float((got_k - want_k[:, :g.kidsum_rows]).abs().max()) < 1e-5 * max(1.0, float(want_k.abs().max()))
+    # the next layer on the child sums == the next layer pulling child rows
+    out2a, z2a, agg2a, bn2a = ops.gcn_layer_train_fwd(g, B, out1, *args)
+    out2b, z2b, agg2b, bn2b = ops.gcn_layer_train_fwd(g, B, out1, *args, kidsum_in=ka)
+    scale = float(agg2a.abs().max())
+    assert float((agg2a - agg2b).abs().max()) < 2e-6 * scale and float((z2a - z2b).abs().max()) < 1e-5 * float(z2a.abs().max())
+    assert torch.allclose(bn2a, bn2b, rtol=1e-4, atol=1e-6)
+    assert torch.equal(out2b, ops.gcn_layer_train_fwd(g, B, out1, *args, kidsum_in=ka)[0])            # deterministic
+
+
+def test_chained_train_step_equals_unchained(monkeypatch):
+    """The whole training step with child sums handed from layer to layer (default) against EG_TRAIN_CHAIN=0 (every layer
+    pulls its child rows): same logits, coordinates and parameter gradients up to summation order."""
+    frame, naux, B, L = 64, 6, 2, 3
+    for coord in (False, True):
+        hip, _ = model_pair(frame, naux, L, coord=coord, seed=41)
+        for m in hip.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0                                # (ReLU masks recomputed at the kink aside, nothing depends on the route)
+        hip.train()
+        topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=coord)
+        x = synthetic_node_feats(B * topo.num_nodes, 128, seed=3).to(DEV)
+        coords0 = initial_coords(B, frame).to(DEV) if coord else None
+        state = {k: v.clone() for k, v in hip.state_dict().items()}
+        res = {}
+        for chain in ("1", "0"):
+            monkeypatch.setenv("EG_TRAIN_CHAIN", chain)
+            hip.load_state_dict(state)
+            for q in hip.parameters():
+                q.grad = None
+            g = hip._resolver.resolve(ei.to(DEV), x.shape[0])[0]
+            before = g.ps_launches
+            got, gc = hip.forward_nodes(x, ei.to(DEV), B, None if coords0 is None else coords0.clone())
+            ((got ** 2).mean() + (0 if gc is None else (gc ** 2).mean() * 1e-3)).backward()
+            res[chain] = (got.detach().clone(), None if gc is None else gc.detach().clone(),
+                          {k: q.grad.clone() for k, q in hip.named_parameters()})
+            assert g.ps_launches > before
+        assert hip._train_kidsums(hip._resolver.resolve(ei.to(DEV), x.shape[0])[0], B)[0] is None       # knob off now
+        a, b = res["1"], res["0"]
+        assert float((a[0] - b[0]).abs().max()) < 2e-5 * max(1.0, float(b[0].abs().max()))
+        if coord:
+            assert float((a[1] - b[1]).abs().max()) < 1e-4
+        for k in a[2]:
+            assert float((a[2][k] - b[2][k]).abs().max()) < 2e-4 * float(b[2][k].abs().max()) + 1e-7, k
+
+
 def test_layer_train_composites_on_a_directed_graph():
     """A_hat of a directed edge_index is not symmetric: forward aggregates over in-edges, backward over out-edges
     (eg_csr_create_transposed)."""
@@ -528,10 +612,13 @@ def test_cfg4_train_full_batch_32_properties():
 
 
 def test_in_place_backward_leaves_retained_and_hooked_gradients_intact():
-    """_LayerTrainFn / _CoordScatterFn patch the gradient they receive IN PLACE, but only when the buffer is provably theirs
-    (nn._own_or_clone).  A middle layer's output with retain_grad() and with a hook that KEEPS the gradient object -- the case
-    where the in-place patch would corrupt somebody else's tensor -- must give the oracle's dL/dh, and must not change the
-    parameter gradients."""
+    """The training step folds every coordinate update into the node that consumes the layer output, whose backward patches
+    rows IN PLACE only on the gradient buffer it has allocated itself (nn._CoordLayerTrainFn).  No incoming gradient is ever
+    written to: there is no ownership heuristic to get wrong.  With a layer_output_hook the model takes the explicit route
+    (separate nodes, copies).  A middle layer's output with retain_grad() and with a hook that KEEPS the gradient object must
+    give the oracle's dL/dh, and the two routes must agree on every parameter gradient."""
+    from echoglad_amd import nn as egnn
+    assert not hasattr(egnn, "_own_or_clone") and not hasattr(egnn, "_calibrate_ownership") and not hasattr(egnn, "_CoordScatterFn")
     frame, naux, B, L = 32, 4, 2, 3
     hip, ref = model_pair(frame, naux, L, coord=True, seed=37)
     for m in list(hip.modules()) + list(ref.modules()):
