@@ -66,12 +66,13 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_dweight128": (_i, [_p, _p, _i64, _p, _p, _p]),
     "eg_bn_stats": (_i, [_p, _i64, _p, _p, _p, _p]),
     "eg_bn_act_fwd": (_i, [_p, _i64, _p, _p, _p, _i, ct.c_float, ct.c_uint64, _p, _p]),
+    "eg_bn_act_fwd_tiles": (_i, [_p, _i, _p, _p, _p, _p, _i, ct.c_float, ct.c_uint64, _p, _p, _p]),
     "eg_bn_act_bwd": (_i, [_p, _p, _i64, _p, _p, _p, _p, _i, ct.c_float, ct.c_uint64, _p, _p, _p, _p, _p]),
     "eg_gcn_layer_train_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _f, _u64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "eg_gcn_layer_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _f, _u64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "eg_classifier_train_workspace_bytes": (ct.c_size_t, []),
     "eg_classifier_train_fwd": (_i, [_p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _i, _p, _p]),
-    "eg_classifier_bwd": (_i, [_p, _p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "eg_classifier_bwd": (_i, [_p, _p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _p, _p, _p, _p]),
     "eg_coord_mlp_fwd": (_i, [_p, _p, _i, _pp, _i, _i, _p, _p, _p, _p, _p, _p]),
     "eg_coord_mlp_bwd": (_i, [_p, _p, _p, _i, _pp, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "eg_bilinear4_fwd": (_i, [_p, _p, _i, _i, _i64, _i64, _i, _p, _p]),

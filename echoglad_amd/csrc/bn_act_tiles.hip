@@ -28,17 +28,19 @@ __device__ inline f32x4 act4(const f32x4& z, const f32x4& sc, const f32x4& sh, c
     return v;
 }
 
+#ifndef EG_ACT_AUX
+#define EG_ACT_AUX 0            // aux bits of the row loads (2 = nt)
+#endif
+__device__ inline f32x4 ldp_s(const RowSrc& s, int row0, int k) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.r, s.pair + k * (2 * C * 4), row0 * (C * 4), EG_ACT_AUX));
+}
+#define ldp ldp_s
+
 template <bool KOUT>
-__global__ __launch_bounds__(256) void k_bn_act_fwd_tiles(const float* __restrict__ z, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, const float* __restrict__ residual,
-                                                          float* __restrict__ out, float* __restrict__ kout,
-                                                          const SegDesc* __restrict__ segs, const float* __restrict__ patsq,
-                                                          const ActTileArgs a) {
-    const int lane = threadIdx.x & 63, p = wave_id();
-    const int tile = blockIdx.x;
-    const int frame = tile / a.tiles_per_frame, t_in = tile - frame * a.tiles_per_frame;
-    const SegDesc sd0 = segs[t_in * 8 + 2 * p];
-    const SegDesc sd1 = segs[t_in * 8 + 2 * p + 1];
+__device__ inline void act_pair(const float* __restrict__ z, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const float* __restrict__ residual,
+                                float* __restrict__ out, float* __restrict__ kout, const float* __restrict__ patsq,
+                                const ActTileArgs& a, int frame, const SegDesc& sd0, const SegDesc& sd1, int lane) {
     if (sd0.cnt == 0 && sd1.cnt == 0) return;
     const size_t fbase = (size_t)frame * a.n_per_frame * C;
     const int fbytes = a.n_per_frame * (C * 4);
@@ -123,6 +125,55 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd_tiles(const float* __restric
         }
     }
 }
+#undef ldp
+
+// One workgroup per tile (wave = segment pair).
+template <bool KOUT>
+__global__ __launch_bounds__(256) void k_bn_act_fwd_tiles(const float* __restrict__ z, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ residual,
+                                                          float* __restrict__ out, float* __restrict__ kout,
+                                                          const SegDesc* __restrict__ segs, const float* __restrict__ patsq,
+                                                          const ActTileArgs a) {
+    const int lane = threadIdx.x & 63, p = wave_id();
+    const int tile = blockIdx.x;
+    const int frame = tile / a.tiles_per_frame, t_in = tile - frame * a.tiles_per_frame;
+    const SegDesc sd0 = segs[t_in * 8 + 2 * p];
+    const SegDesc sd1 = segs[t_in * 8 + 2 * p + 1];
+    act_pair<KOUT>(z, scale, shift, residual, out, kout, patsq, a, frame, sd0, sd1, lane);
+}
+
+// Persistent form: a wave walks segment pairs (unit = 4 tile + p) with a grid stride; the descriptors of its NEXT pair are
+// fetched (scalar loads) while the rows of the current one are in flight, so no row load waits behind a descriptor round trip.
+template <bool KOUT>
+__global__ __launch_bounds__(256) void k_bn_act_fwd_tiles_p(const float* __restrict__ z, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ residual,
+                                                            float* __restrict__ out, float* __restrict__ kout,
+                                                            const SegDesc* __restrict__ segs, const float* __restrict__ patsq,
+                                                            const ActTileArgs a) {
+    const int lane_k = threadIdx.x & 63;
+    const long long units = (long long)a.tiles_per_frame * a.batch * 4;
+    const long long stride = (long long)gridDim.x * 4;
+    long long u = (long long)blockIdx.x * 4 + wave_id();
+    if (u >= units) return;
+    auto seg_index = [&](long long unit) -> int {
+        const int tile = (int)(unit >> 2), p = (int)(unit & 3);
+        const int frame = tile / a.tiles_per_frame;
+        return (tile - frame * a.tiles_per_frame) * 8 + 2 * p;
+    };
+    int si = seg_index(u);
+    SegDesc n0 = segs[si], n1 = segs[si + 1];
+    for (; u < units; u += stride) {
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
+        const SegDesc sd0 = n0, sd1 = n1;
+        const int frame = (int)(u >> 2) / a.tiles_per_frame;
+        if (u + stride < units) {
+            si = seg_index(u + stride);
+            n0 = segs[si]; n1 = segs[si + 1];
+        }
+        act_pair<KOUT>(z, scale, shift, residual, out, kout, patsq, a, frame, sd0, sd1, lane);
+    }
+}
 
 }  // namespace eg
 
@@ -140,10 +191,30 @@ int eg_launch_bn_act_tiles(const eg_graph* g, int batch, const float* z, const f
     const long long n_tiles = (long long)g->n_tiles * batch;
     if (n_tiles <= 0) return EG_OK;
     if (n_tiles >= (1ll << 31)) return eg::set_error(EG_ERR_ARG, "too many tiles");
-    if (kout) hipLaunchKernelGGL(k_bn_act_fwd_tiles<true>, dim3((unsigned)n_tiles), dim3(256), 0, stream, z, scale, shift, residual, out,
+    static const int persist = getenv("EG_ACT_PERSIST") ? atoi(getenv("EG_ACT_PERSIST")) : 0;      // workgroups per CU; 0: one per tile
+    if (persist > 0) {
+        long long grid = 256ll * persist;
+        if (grid > n_tiles) grid = n_tiles;
+        if (kout) hipLaunchKernelGGL(k_bn_act_fwd_tiles_p<true>, dim3((unsigned)grid), dim3(256), 0, stream, z, scale, shift, residual, out,
+                                     kout, g->segs_dev, g->patsq_dev, a);
+        else hipLaunchKernelGGL(k_bn_act_fwd_tiles_p<false>, dim3((unsigned)grid), dim3(256), 0, stream, z, scale, shift, residual, out,
+                                kout, g->segs_dev, g->patsq_dev, a);
+    } else if (kout) hipLaunchKernelGGL(k_bn_act_fwd_tiles<true>, dim3((unsigned)n_tiles), dim3(256), 0, stream, z, scale, shift, residual, out,
                                  kout, g->segs_dev, g->patsq_dev, a);
     else hipLaunchKernelGGL(k_bn_act_fwd_tiles<false>, dim3((unsigned)n_tiles), dim3(256), 0, stream, z, scale, shift, residual, out,
                             kout, g->segs_dev, g->patsq_dev, a);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
+}
+
+extern "C" int eg_bn_act_fwd_tiles(const eg_graph* g, int batch, const float* z, const float* scale, const float* shift,
+                                   const float* residual, int relu, float dropout_p, uint64_t seed, float* out, float* kidsum_out,
+                                   eg_stream_t stream) {
+    if (!g || !z || !scale || !shift || !out || batch < 1) return set_error(EG_ERR_ARG, "bad argument");
+    if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    if (out == z || out == residual || kidsum_out == out) return set_error(EG_ERR_ARG, "out must not alias an input, kidsum_out must not alias out");
+    const int rc = eg_launch_bn_act_tiles(g, batch, z, scale, shift, residual, relu, dropout_p, seed, out, kidsum_out, (hipStream_t)stream);
+    if (rc == EG_ERR_UNSUPPORTED)
+        return set_error(EG_ERR_UNSUPPORTED, "the tile-order activation pass needs a topology handle (with eg_graph_kidsum_rows() > 0 for child sums)");
+    return rc;
 }

@@ -19,6 +19,8 @@
 //             k_dweight_partial     dW1 = dz1^T h[valid rows]                                               (train.hip)
 // Biases in front of a train-mode BatchNorm (b1, b2) have an identically zero gradient (the batch mean absorbs them).
 // Every reduction is two-stage with a fixed order: bitwise reproducible, no float atomics.
+#include <stdlib.h>
+
 #include "train_common.h"
 
 namespace eg {
@@ -316,7 +318,8 @@ __global__ __launch_bounds__(CT_THREADS, 3) void k_cls_mid_bwd(const float* __re
                                                             const float* __restrict__ z1, long long rows, const ClsBn bn1, const ClsDrop d1,
                                                             const ClsBn bn2, const ClsDrop d2, const float* __restrict__ w2,
                                                             const float* __restrict__ w3, const double* __restrict__ tot,
-                                                            float* __restrict__ dh1, float* __restrict__ partial_dw2) {
+                                                            float* __restrict__ dh1, float* __restrict__ partial_dw2,
+                                                            float* __restrict__ partial_bn1) {
     __shared__ __attribute__((aligned(16))) float s_h[TILE * LDA];      // h1 tile, then the dh1 tile
     __shared__ __attribute__((aligned(16))) float s_dz[TILE * LDZ];
     __shared__ float s_c[3][H2];                                          // a2 = gamma2 invstd2, mean g2, mean g2 xhat2
@@ -334,6 +337,10 @@ __global__ __launch_bounds__(CT_THREADS, 3) void k_cls_mid_bwd(const float* __re
 #pragma unroll
         for (int t = 0; t < 4; ++t) wt[ib][t] = w2[(size_t)(head * 16 + 4 * t + (lane >> 4)) * 32 + 16 * ib + (lane & 15)];
     f32x4v dw[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};      // dW2[head][4 q + e][16 ib + i]
+    // Sums of the FIRST layers' BatchNorm backward, taken here where dh1 is produced (g1 = dh1 * mask1: sum g1, sum g1 xhat1 --
+    // what a separate pass over dh1 and z1 computed before): a thread always owns the same 4 channels, c4 = 4 (tid & 31)
+    f32x4 sg1 = {0.f, 0.f, 0.f, 0.f}, sx1 = sg1;
+    const int c4s = (tid & 31) * 4;
     __syncthreads();
     const long long n_tiles = (rows + TILE - 1) / TILE;
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -394,13 +401,42 @@ __global__ __launch_bounds__(CT_THREADS, 3) void k_cls_mid_bwd(const float* __re
             *reinterpret_cast<f32x4v*>(&s_h[(16 * b4 + i16) * LDA + 32 * head + 16 + 4 * kq]) = acc1;
         }
         __syncthreads();
+        // (this thread's per-channel constants, fetched per tile -- L1 hits -- so that they are not live across the products above)
+        int c4o = c4s;
+        asm volatile("" : "+v"(c4o));
+        const f32x4 mn1 = *reinterpret_cast<const f32x4*>(bn1.mean + c4o), is1 = *reinterpret_cast<const f32x4*>(bn1.invstd + c4o);
+        const f32x4 sc1 = *reinterpret_cast<const f32x4*>(bn1.scale + c4o), sh1 = *reinterpret_cast<const f32x4*>(bn1.shift + c4o);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int e = tid + CT_THREADS * it, r = e >> 5, c4 = (e & 31) * 4;
-            if (r < rows_here)
-                *reinterpret_cast<f32x4*>(dh1 + (size_t)(row0 + r) * H1 + c4) = *reinterpret_cast<const f32x4*>(&s_h[r * LDA + c4]);
+            if (r < rows_here) {
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(&s_h[r * LDA + c4]);
+                *reinterpret_cast<f32x4*>(dh1 + (size_t)(row0 + r) * H1 + c4) = dv;
+                // z1 of this element again (the tile was read a moment ago: an L2 hit) for the mask and xhat
+                const size_t off = (size_t)(row0 + r) * H1 + c4;
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(z1 + off);
+                const f32x4 kk = d1.p > 0.f ? keep_scale4(d1.seed, (unsigned long long)off, d1.p, d1.inv_keep) : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = zz[u] * sc1[u] + sh1[u];                      // (hidden_act4's expression: the same mask)
+                    const float g = v > 0.f ? dv[u] * kk[u] : 0.f;
+                    sg1[u] += g;
+                    sx1[u] += g * ((zz[u] - mn1[u]) * is1[u]);
+                }
+            }
         }
         __syncthreads();
+    }
+    {   // per-block partial [2][128]: the 8 threads that share a channel group are added in a fixed order
+        float* red = s_h;                                                     // [8][2][128]
+        const int rg = tid >> 5;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { red[(rg * 2 + 0) * H1 + c4s + u] = sg1[u]; red[(rg * 2 + 1) * H1 + c4s + u] = sx1[u]; }
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 2 * H1 + tid];
+        partial_bn1[(size_t)blockIdx.x * 2 * H1 + tid] = t;                    // tid < 256 = 2 * 128
     }
     // per-block dW2 partial [4][16][32]: lane (i = l & 15, q), reg e -> [head][4 q + e][16 ib + i]
     float* p = partial_dw2 + (size_t)blockIdx.x * (4 * 16 * 32) + head * 512;
@@ -408,6 +444,152 @@ __global__ __launch_bounds__(CT_THREADS, 3) void k_cls_mid_bwd(const float* __re
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
         for (int e = 0; e < 4; ++e) p[(4 * (lane >> 4) + e) * 32 + 16 * ib + (lane & 15)] = dw[ib][e];
+}
+
+// ---- backward of the FIRST layers, one kernel: dz1 = bn1'(dh1 mask1) formed on load, never written; both products on it:
+//          dW1 += dz1^T h[valid rows]      (K = rows)          waves 0..3: 32 output channels x 128 inputs each
+//          dh[valid rows] = dz1 W1         (K = 128)           waves 4..7: 32 columns of dh each, two 32-row blocks
+// (before: an apply + dW pass that wrote dz1, and a plain-rows product that read it back: 2.4 GB of traffic and one launch more
+//  at batch 32).  64-row tiles, 512 threads, one workgroup per CU; the 12 row loads per thread of the next tile are issued
+// before the products of the current one.  tot = sum g1, sum g1 xhat1 (double [2][128]) from k_cls_mid_bwd's partials.
+constexpr int FB_BLOCKS = 256;
+struct FirstBwdArgs {
+    const float *dh1, *z1, *h, *W1;
+    const double* tot;
+    long long rows;
+    RowMap xm;
+    ClsDrop d1;
+    float* dh;
+    float* partial_dw1;
+};
+
+// The two roles run separate instantiations of the tile loop (so that neither carries the other's persistent registers: the
+// [32 x 128] accumulators of the weight gradient / the W1 slice); both execute the same two workgroup barriers per tile.
+template <bool GEMM2>
+__device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* s_x, float* s_o, const float* s_c, int wave) {
+    const int tid = threadIdx.x, lane_k = tid & 63;
+    const int c4 = (tid & 31) * 4;
+    float wreg[GEMM2 ? 64 : 1];                   // waves 4..7: W1[64 kh + s][32 (wave - 4) + i] (the transposed slice)
+    f32x16 acc[GEMM2 ? 1 : 4];                    // waves 0..3: dW1[32 wave + m][32 jb + n]
+    if constexpr (GEMM2) load_w_slice(a.W1, wave - 4, lane_k, 1, wreg);
+    else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+    }
+    const long long rows = a.rows;
+    const long long n_tiles = (rows + TILE - 1) / TILE;
+    f32x4 pd[4], pz[4], px[4];
+    auto issue = [&](long long t) {
+        const long long r0 = t * TILE + (tid >> 5);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long r = r0 + 16 * q;
+            pd[q] = pz[q] = px[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < rows) {
+                const size_t off = (size_t)r * C + c4;
+                pd[q] = *reinterpret_cast<const f32x4*>(a.dh1 + off);
+                pz[q] = *reinterpret_cast<const f32x4*>(a.z1 + off);
+                px[q] = *reinterpret_cast<const f32x4*>(a.h + (size_t)map_row(a.xm, r) * C + c4);
+            }
+        }
+    };
+    if ((long long)blockIdx.x < n_tiles) issue(blockIdx.x);
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
+        const long long r0 = t * TILE;
+        {
+            const f32x4 mn = *reinterpret_cast<const f32x4*>(s_c + 0 * H1 + c4), is = *reinterpret_cast<const f32x4*>(s_c + 1 * H1 + c4);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(s_c + 2 * H1 + c4), be = *reinterpret_cast<const f32x4*>(s_c + 3 * H1 + c4);
+            const f32x4 mg = *reinterpret_cast<const f32x4*>(s_c + 4 * H1 + c4), mgx = *reinterpret_cast<const f32x4*>(s_c + 5 * H1 + c4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rl = (tid >> 5) + 16 * q;
+                const long long r = r0 + rl;
+                f32x4 vg = {0.f, 0.f, 0.f, 0.f};
+                if (r < rows) {
+                    f32x4 d = pd[q];
+                    if (a.d1.p > 0.f) d *= keep_scale4(a.d1.seed, (unsigned long long)r * C + c4, a.d1.p, a.d1.inv_keep);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float xh = (pz[q][u] - mn[u]) * is[u];
+                        const float v = xh * ga[u] + be[u];
+                        const float g = v > 0.f ? d[u] : 0.f;
+                        vg[u] = ga[u] * is[u] * (g - mg[u] - xh * mgx[u]);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(&s_g[rl * LDA + c4]) = vg;
+                *reinterpret_cast<f32x4*>(&s_x[rl * LDA + c4]) = px[q];
+            }
+        }
+        __syncthreads();                          // tile in LDS; s_o of the tile before has been stored
+        if (t + gridDim.x < n_tiles) issue(t + gridDim.x);
+        if constexpr (!GEMM2) {
+            const int i = lane & 31, kh = lane >> 5;
+#pragma unroll 4
+            for (int s = 0; s < TILE / 2; ++s) {
+                const int r = 2 * s + kh;
+                const float av = s_g[r * LDA + 32 * wave + i];
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb)
+                    acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_x[r * LDA + 32 * jb + i], acc[jb], 0, 0, 0);
+            }
+        } else {
+            const int j = lane & 31, hh = lane >> 5, w = wave - 4;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x16 o;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] = 0.f;
+                mfma_rowblock(s_g, 32 * rb, lane, wreg, o);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(&s_o[(32 * rb + j) * LDA + 32 * w + 4 * hh + 8 * g]) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+            }
+        }
+        __syncthreads();                          // products done: s_g / s_x may be refilled, s_o is complete
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rl = (tid >> 5) + 16 * q;
+            const long long r = r0 + rl;
+            if (r < rows)
+                *reinterpret_cast<f32x4*>(a.dh + (size_t)map_row(a.xm, r) * C + c4) = *reinterpret_cast<const f32x4*>(&s_o[rl * LDA + c4]);
+        }
+    }
+    if constexpr (!GEMM2) {
+        const int i = lane_k & 31, kh = lane_k >> 5;
+        float* p = a.partial_dw1 + (size_t)blockIdx.x * C * C;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                p[(size_t)(32 * wave + m) * C + 32 * jb + i] = acc[jb][e];
+            }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_cls_first_bwd(const FirstBwdArgs a, const ClsBn bn1, const float* __restrict__ beta1) {
+    extern __shared__ __attribute__((aligned(16))) float fb_smem[];
+    float* s_g = fb_smem;                         // [64][LDA]  dz1 tile
+    float* s_x = fb_smem + TILE * LDA;            // [64][LDA]  h tile (valid rows)
+    float* s_o = fb_smem + 2 * TILE * LDA;        // [64][LDA]  dh tile on its way out
+    float* s_c = fb_smem + 3 * TILE * LDA;        // [6][128]   mean, invstd, gamma, beta, mean g, mean g xhat
+    const int tid = threadIdx.x, wave = wave_id();
+    if (tid < H1) {
+        const double inv_n = 1.0 / (double)a.rows;
+        s_c[0 * H1 + tid] = bn1.mean[tid];
+        s_c[1 * H1 + tid] = bn1.invstd[tid];
+        s_c[2 * H1 + tid] = bn1.gamma[tid];
+        s_c[3 * H1 + tid] = beta1[tid];
+        s_c[4 * H1 + tid] = (float)(a.tot[tid] * inv_n);
+        s_c[5 * H1 + tid] = (float)(a.tot[H1 + tid] * inv_n);
+    }
+    __syncthreads();
+    if (wave < 4) first_bwd_role<false>(a, s_g, s_x, s_o, s_c, wave);
+    else first_bwd_role<true>(a, s_g, s_x, s_o, s_c, wave);
 }
 
 __global__ void k_zero_rows(float* __restrict__ x, int batch, int stride, int lo, int n_valid) {
@@ -422,7 +604,8 @@ __global__ void k_zero_rows(float* __restrict__ x, int batch, int stride, int lo
     }
 }
 
-__global__ void k_cls_grads_final(const double* __restrict__ tot_out, const double* __restrict__ tot_dw2, float* __restrict__ grads) {
+__global__ void k_cls_grads_final(const double* __restrict__ tot_out, const double* __restrict__ tot_dw2, const double* __restrict__ tot_bn1,
+                                  float* __restrict__ grads) {
     // grads layout: eg_classifier_bwd in the header
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     float* dw2 = grads + 128 * 128 + 3 * 128;
@@ -435,7 +618,11 @@ __global__ void k_cls_grads_final(const double* __restrict__ tot_out, const doub
         tail[3 * H2 + t] = (float)tot_out[2 * H2 + t];      // dw3
     }
     if (t < 4) tail[4 * H2 + t] = (float)tot_out[3 * H2 + t];
-    if (t < 128) grads[128 * 128 + t] = 0.f;                // db1
+    if (t < 128) {
+        grads[128 * 128 + t] = 0.f;                         // db1
+        grads[128 * 128 + 128 + t] = (float)tot_bn1[H1 + t];      // dgamma1 = sum g1 xhat1
+        grads[128 * 128 + 256 + t] = (float)tot_bn1[t];           // dbeta1 = sum g1
+    }
 }
 
 static int grid_for(long long work_items, int per_block, int cap) {
@@ -507,8 +694,8 @@ int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int6
 
 int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                       const eg_cls_train_params* P, const float* z1, const float* z2, const float* bn, void* workspace,
-                      float* dh1_scratch, float* dz1_scratch, float* dh, float* grads, eg_stream_t stream_) {
-    if (!dlogits || !h || !P || !z1 || !z2 || !bn || !workspace || !dh1_scratch || !dz1_scratch || !grads)
+                      float* dh1_scratch, float* dh, float* grads, eg_stream_t stream_) {
+    if (!dlogits || !h || !P || !z1 || !z2 || !bn || !workspace || !dh1_scratch || !grads)
         return set_error(EG_ERR_ARG, "NULL argument");
     if (batch < 1 || n_per_frame < 1 || row_lo < 0 || n_valid < 1 || row_lo + n_valid > n_per_frame)
         return set_error(EG_ERR_ARG, "bad row range");
@@ -526,34 +713,50 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
     const int ga = grid_for(rows * 4, CT_THREADS * 8, CT_MAX_BLOCKS);
     hipLaunchKernelGGL(k_cls_out_bwd_sums, dim3(ga), dim3(CT_THREADS), 0, stream, dlogits, z2, rows, bn2, d2, P->w3, partial);
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3((OUT_SUMS + 31) / 32), dim3(256), 0, stream, partial, ga, OUT_SUMS, totals);
-    // ---- second layers: dz2, dW2, dh1
+    // ---- second layers: dz2, dW2, dh1 -- and the sums of the first layers' BatchNorm backward over g1 = dh1 * mask1
     const int gb = grid_for(rows, TILE, 768);
     float* partial2 = partial + (size_t)CT_MAX_BLOCKS * OUT_SUMS;
+    float* partial_bn1 = partial2 + (size_t)768 * (4 * 16 * 32);               // [gb][2][128]
+    double* tot_bn1 = totals + 256 + 4 * 16 * 32;
     hipLaunchKernelGGL(k_cls_mid_bwd, dim3(gb), dim3(CT_THREADS), 0, stream, dlogits, z2, z1, rows, bn1, d1, bn2, d2, P->w2, P->w3,
-                       totals, dh1_scratch, partial2);
+                       totals, dh1_scratch, partial2, partial_bn1);
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4 * 16 * 32 / 32), dim3(256), 0, stream, partial2, gb, 4 * 16 * 32, totals + 256);
-    hipLaunchKernelGGL(k_cls_grads_final, dim3(8), dim3(256), 0, stream, totals, totals + 256, grads);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(256), 0, stream, partial_bn1, gb, 2 * H1, tot_bn1);
+    hipLaunchKernelGGL(k_cls_grads_final, dim3(8), dim3(256), 0, stream, totals, totals + 256, tot_bn1, grads);
     EG_HIP_TRY(hipGetLastError());
-    // ---- first layers: dz1 (+ dgamma1, dbeta1), dh, dW1
-    float* dgamma1 = grads + 128 * 128 + 128;
-    float* dbeta1 = dgamma1 + 128;
-    // dz1 (+ dgamma1, dbeta1) fused with dW1 = dz1^T h[valid rows]
+    // ---- first layers: dz1 formed on the fly, dW1 = dz1^T h[valid rows] and dh[valid rows] = dz1 W1 in ONE kernel
     const RowMap xm{(int)n_valid, (int)n_per_frame, (int)row_lo};
-    int rc = eg_launch_bn_bwd(dh1_scratch, z1, rows, bn + 0 * H1, bn + 1 * H1, P->gamma1, P->beta1, 1, P->p1, P->seed1, shared,
-                              dz1_scratch, dgamma1, dbeta1, h, &xm, grads, stream);
-    if (rc != EG_OK) return rc;
-    if (dh) {
+    static const bool fused_first = !(getenv("EG_CLS_FUSED_BWD") && atoi(getenv("EG_CLS_FUSED_BWD")) == 0);
+    if (dh && fused_first) {
         if (n_valid < n_per_frame)
             hipLaunchKernelGGL(k_zero_rows, dim3(64), dim3(256), 0, stream, dh, batch, (int)n_per_frame, (int)row_lo, (int)n_valid);
-        LinMapDims d{};
-        d.n_valid = (int)n_valid; d.tiles_per_frame = (int)((n_valid + TILE - 1) / TILE); d.batch = batch; d.transpose_w = 1;
-        d.in_stride = (int)n_valid; d.in_lo = 0; d.out_stride = (int)n_per_frame; d.out_lo = (int)row_lo;
-        const long long n_tiles = (long long)d.tiles_per_frame * batch;
-        hipLaunchKernelGGL(k_lin128_map<false>, dim3((unsigned)(n_tiles < LIN_GRID ? n_tiles : LIN_GRID)), dim3(512), 0, stream, dz1_scratch,
-                           P->w1, (const float*)nullptr, dh, (float*)nullptr, d);
+        {
+            static std::atomic<bool> attr_set[64];
+            int dev = 0;
+            EG_HIP_TRY(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+                EG_HIP_TRY(hipFuncSetAttribute((const void*)k_cls_first_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
+            }
+        }
+        const long long nt = (rows + TILE - 1) / TILE;
+        const int nf = (int)(nt < FB_BLOCKS ? nt : FB_BLOCKS);
+        float* slabs = (float*)((char*)shared + eg_workspace_bytes() - (size_t)FB_BLOCKS * C * C * sizeof(float));
+        const size_t lds = (size_t)(3 * TILE * LDA + 6 * H1) * sizeof(float);
+        const FirstBwdArgs fa{dh1_scratch, z1, h, P->w1, (const double*)tot_bn1, rows, xm, d1, dh, slabs};
+        hipLaunchKernelGGL(k_cls_first_bwd, dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
+        hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(256), 0, stream, (const float*)slabs, nf, grads);
         EG_HIP_TRY(hipGetLastError());
+        return EG_OK;
     }
-    return EG_OK;
+    // dh not wanted (or EG_CLS_FUSED_BWD=0, which needs one more [rows,128] scratch array: not provided any more): dW1 alone out of
+    // the apply + dW pass, which then writes no dz1
+    float* dgamma1 = grads + 128 * 128 + 128;
+    float* dbeta1 = dgamma1 + 128;
+    if (dh) return set_error(EG_ERR_UNSUPPORTED, "EG_CLS_FUSED_BWD=0 is a diagnostic of the round-3 route and no longer has its scratch array");
+    int rc = eg_launch_bn_bwd(dh1_scratch, z1, rows, bn + 0 * H1, bn + 1 * H1, P->gamma1, P->beta1, 1, P->p1, P->seed1, shared,
+                              nullptr, dgamma1, dbeta1, h, &xm, grads, stream);
+    return rc;
 }
 
 }  // extern "C"

@@ -52,6 +52,9 @@ __device__ inline long long map_row(const RowMap& m, long long r) {
 // stage 2 of every column reduction: partial float [nblocks][n] -> totals double [n], fixed order (bitwise reproducible)
 __global__ void k_reduce_f32_partials(const float* __restrict__ partial, int nblocks, int n, double* __restrict__ totals);
 
+// fixed-order sum of per-workgroup [128,128] float slabs -> dw (launch with 128 * 128 / 32 workgroups of 256 threads; train.hip)
+__global__ void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw);
+
 // Train-mode BatchNorm1d from column totals: totals[0..cc) = sum, totals[cc..2cc) = sum of squares over `rows` rows.
 //   mean, invstd = 1/sqrt(var_biased + eps), scale = gamma * invstd, shift = beta - mean * scale,
 //   running <- (1 - momentum) running + momentum * {mean, var_unbiased}   (momentum < 0 or NULL pointers: no update)

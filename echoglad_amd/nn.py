@@ -213,7 +213,7 @@ _MLP_NAMES = ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3"
 def _coord_update_fwd(h, coords_prev, dims, mlp_cfg, mlp_params, want_backward=True):
     """h [B*N,128] (coordinate rows overwritten IN PLACE) -> (new coords [4B,2], state for _coord_update_bwd)."""
     B, n, main_base, frame, coord_base = dims
-    lm = h.view(B, n, C)[:, coord_base:coord_base + 4, :].reshape(B * 4, C).contiguous()        # (a copy: the rows change below)
+    lm = h.view(B, n, C)[:, coord_base:coord_base + 4, :].reshape(B * 4, C).clone()     # (a COPY also at B = 1, where the slice is contiguous: the rows change below)
     P = dict(mlp_cfg)
     P.update({k: p.detach().contiguous() for k, p in zip(_MLP_NAMES, mlp_params)})
     flat = coords_prev.reshape(B * 4, 2).contiguous()
@@ -230,7 +230,7 @@ def _coord_update_bwd(dx, dcoords_new, h, new, lm, flat, saved, P, dims, need_dp
     rows = dx.view(B, n, C)[:, coord_base:coord_base + 4, :]
     total = dcoords_new
     if sampled_rows_used:
-        dnew = rows.reshape(B * 4, C).contiguous()               # gradient of the sampled rows
+        dnew = rows.reshape(B * 4, C).clone()                    # gradient of the sampled rows (a copy also at B = 1)
         rows.zero_()                                             # (their old values were overwritten)
         dbil = ops.bilinear4_bwd(dnew, h, new, B, n, main_base, frame, dh=dx, want_dcoords=True)      # 16 taps per frame into dx
         total = dbil if total is None else total + dbil
@@ -268,7 +268,7 @@ class _CoordLayerTrainFn(torch.autograd.Function):
         ctx.save_for_backward(z, agg if agg is not None else z.new_zeros(0), weight.detach().contiguous(),
                               gamma.detach().contiguous(), beta.detach().contiguous(), bn, h_prev, new, lm, flat, *saved)
         ctx.cfg = (graph, batch, relu, p, seed, residual, need_w, dims, P)
-        return out, new.view(batch, 4, 2)
+        return out, new.view(dims[0], 4, 2).clone()      # (a tensor of its own: `new` is saved for the backward; dims[0] = frames; `batch` = copies of the handle's graph: 1 for a CSR of the whole batch)
 
     @staticmethod
     def backward(ctx, dy, dcoords):
@@ -277,9 +277,10 @@ class _CoordLayerTrainFn(torch.autograd.Function):
         need_w, need_b = ctx.needs_input_grad[2] and had_agg, ctx.needs_input_grad[3]
         dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dy.contiguous(), z, agg if had_agg else None, weight, gamma,
                                                       beta, bn, relu, p, seed, residual, True, need_w)
-        dprev, g = _coord_update_bwd(dx, None if dcoords is None else dcoords.reshape(batch * 4, 2), h_prev, new, lm, flat,
+        B = dims[0]
+        dprev, g = _coord_update_bwd(dx, None if dcoords is None else dcoords.reshape(B * 4, 2), h_prev, new, lm, flat,
                                      tuple(saved), P, dims, ctx.needs_input_grad[1])
-        return (dx, None if dprev is None else dprev.view(batch, 4, 2), dw, db if need_b else None, dgamma, dbeta, None, None,
+        return (dx, None if dprev is None else dprev.view(B, 4, 2), dw, db if need_b else None, dgamma, dbeta, None, None,
                 None) + _mlp_grads(g)
 
 
@@ -351,7 +352,7 @@ class _CoordClassifierTrainFn(torch.autograd.Function):
         ctx.P = {k: v for k, v in P.items() if not k.startswith("running")}
         ctx.cfg = (batch, n, row_lo, n_valid, sigmoid, coord_dims, Pm)
         ctx.save_for_backward(h, z1, z2, bn, logits if sigmoid else logits.new_zeros(0), new, lm, flat, *saved)
-        return logits, new.view(batch, 4, 2)
+        return logits, new.view(batch, 4, 2).clone()
 
     @staticmethod
     def backward(ctx, dy, dcoords):

@@ -312,6 +312,23 @@ def bn_act_fwd(z, scale, shift, residual=None, relu=False, dropout_p=0.0, seed=0
     return out
 
 
+def bn_act_fwd_tiles(graph: Graph, batch: int, z, scale, shift, residual=None, relu=False, dropout_p=0.0, seed=0,
+                     kidsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bn_act_fwd in the layer kernels' tile order; kidsum_out (optional) receives the child sums of the result."""
+    _check_rows(z, "z", graph.num_nodes * batch)
+    _check_vec(scale, "scale", C)
+    _check_vec(shift, "shift", C)
+    if residual is not None:
+        _check_rows(residual, "residual", z.shape[0])
+    if kidsum_out is not None:
+        _check_rows(kidsum_out, "kidsum_out", graph.kidsum_rows * batch)
+    out = torch.empty_like(z)
+    _lib.check(_lib.load().eg_bn_act_fwd_tiles(graph._h, batch, _ptr(z), _ptr(scale), _ptr(shift), _ptr(residual), int(relu),
+                                               float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(out), _ptr(kidsum_out),
+                                               _stream()), "eg_bn_act_fwd_tiles")
+    return out
+
+
 def bn_act_bwd(dy, z, mean, invstd, gamma, beta, relu=False, dropout_p=0.0, seed=0):
     """-> (dz, dgamma, dbeta)"""
     _check_rows(dy, "dy")
@@ -430,12 +447,11 @@ def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_vali
     dev = h.device
     _check_logits(dlogits, "dlogits", rows)
     dh1 = torch.empty(rows, C, dtype=torch.float32, device=dev)
-    dz1 = torch.empty(rows, C, dtype=torch.float32, device=dev)
     dh = torch.empty_like(h) if need_dh else None
     grads = torch.empty(CLS_GRADS_FLOATS, dtype=torch.float32, device=dev)
     s = _cls_params(P)
     _lib.check(_lib.load().eg_classifier_bwd(_ptr(dlogits), _ptr(h), batch, n_per_frame, row_lo, n_valid, ct.byref(s), _ptr(z1),
-                                             _ptr(z2), _ptr(bn), _ptr(_cls_workspace(dev)), _ptr(dh1), _ptr(dz1), _ptr(dh),
+                                             _ptr(z2), _ptr(bn), _ptr(_cls_workspace(dev)), _ptr(dh1), _ptr(dh),
                                              _ptr(grads), _stream()), "eg_classifier_bwd")
     return dh, grads
 

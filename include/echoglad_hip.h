@@ -218,6 +218,14 @@ int eg_bn_stats(const float* x, int64_t rows, void* workspace, float* mean, floa
 int eg_bn_act_fwd(const float* z, int64_t rows, const float* scale, const float* shift, const float* residual,
                   int relu, float dropout_p, uint64_t seed, float* out, eg_stream_t stream);
 
+/* The same pass walked in the layer kernels' tile order over a topology handle (rows = batch * eg_graph_num_nodes(g)), which lets
+ * it leave the child sums of `out` behind: kidsum_out (nullable) [batch * eg_graph_kidsum_rows(g), 128], row p of a frame =
+ * sum over the 4 children c of aux node p of (deg_c + 1)^-1/2 out[c] -- what eg_gcn_layer_train_fwd / eg_gcn_layer_fwd_chain take
+ * as kidsum_in.  Same values as eg_bn_act_fwd (same expression per element, same dropout mask). */
+int eg_bn_act_fwd_tiles(const eg_graph* g, int batch, const float* z, const float* scale, const float* shift,
+                        const float* residual, int relu, float dropout_p, uint64_t seed, float* out, float* kidsum_out,
+                        eg_stream_t stream);
+
 /* backward of  y = relu?(dropout(BN_train(z)))  given dy: dz[rows,128], dgamma[128], dbeta[128].
  * mean / invstd are the batch statistics used in the forward (invstd = 1/sqrt(var + eps)). */
 int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* mean, const float* invstd,
@@ -263,7 +271,8 @@ int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const fl
  *   dh [batch*n_per_frame,128] (NULL: skipped): gradient w.r.t. h; the rows the filter drops are written as zeros
  *   grads [19076] = dw1 [128*128], db1 [128] (= 0), dgamma1 [128], dbeta1 [128], dw2 [4*16*32], db2 [64] (= 0), dgamma2 [64],
  *                   dbeta2 [64], dw3 [64], db3 [4]
- *   dh1_scratch, dz1_scratch: [batch*n_valid,128] each.
+ *   dh1_scratch: [batch*n_valid,128] (the gradient of the first hidden layer on its way from the second layers' kernel to the
+ *   first layers' one; dz1 = BatchNorm'(dh1 * mask) is formed on load there and never written).
  * workspace: eg_classifier_train_workspace_bytes() bytes. */
 typedef struct eg_cls_train_params {
     const float *w1, *b1, *gamma1, *beta1;
@@ -281,7 +290,7 @@ int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int6
                             float* logits, eg_stream_t stream);
 int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                       const eg_cls_train_params* params, const float* z1, const float* z2, const float* bn, void* workspace,
-                      float* dh1_scratch, float* dz1_scratch, float* dh, float* grads, eg_stream_t stream);
+                      float* dh1_scratch, float* dh, float* grads, eg_stream_t stream);
 
 /* ---- coordinate-graph landmark update (src/core/models.py:438-453) -----------------------------------
  * For the 4 landmark rows of every frame (R = 4 * batch rows):
