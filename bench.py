@@ -58,6 +58,9 @@ def parse():
     p.add_argument("--force-collective", action="store_true",
                    help="train mode: initialise torch.distributed (nccl = RCCL) and run the gradient reducer's collectives even "
                         "at world size 1 -- the single-GPU way through the code path the multi-GPU step takes")
+    p.add_argument("--bucket-kb", type=int, default=0,
+                   help="train mode: size of a gradient all-reduce bucket in KiB (0: the reducer's default, max(total / 2, 64 KiB) "
+                        "capped at 8 MiB); the first multi-GPU run can sweep it")
     p.add_argument("--mode", choices=["infer", "train"], default="infer",
                    help="infer (default): BASELINE configs[1], the metric's configuration.  train: one full training "
                         "step of the GNN stack on configs[3] (coordinate graph; SURVEY 8d), reported under its own metric name")
@@ -145,7 +148,7 @@ def infer_workload(frame, naux, layers, main_only, B, device, rank, hip_graph=Tr
     return model, kw, topo, feats, edge_index, step
 
 
-def train_workload(frame, naux, layers, B, device, world, rank, force_collective=False):
+def train_workload(frame, naux, layers, B, device, world, rank, force_collective=False, bucket_kb=0):
     """forward + losses + backward + gradient all-reduce + Adam on the stack's parameters,
     node features [B*N,128] resident in HBM, B frames per GPU (32 in BASELINE's cfg4), coordinate graph on."""
     import numpy as np
@@ -173,8 +176,10 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
     reducer = None
     if world > 1 or force_collective:
         broadcast_parameters(model)
-        reducer = GradientAllReducer(params, force_collective=force_collective)
+        reducer = GradientAllReducer(params, force_collective=force_collective,
+                                     bucket_bytes=(bucket_kb << 10) if bucket_kb > 0 else None)
         reducer.attach_hooks()
+        reducer.profile = True
 
     def step():
         preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0.clone())
@@ -189,6 +194,11 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
 
     step.reducer = reducer
     return step, topo
+
+
+def logits_digest(t):
+    """Bit-exact fingerprint of a logits tensor (sha256 of its bytes)."""
+    return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
 
 
 def timed_loop(step, steps, world, device):
@@ -213,16 +223,77 @@ def timed_loop(step, steps, world, device):
     return elapsed, out
 
 
+def train_layer_roofline(B, topo, device, layers):
+    """The dominant kernel of the training step -- the train-forward layer kernel (k_gcn_layer_ps<false, false, 1>: aggregation,
+    128x128 node update, BatchNorm partial sums; 3 launches per step) -- timed live with HIP events on the launch stream.
+    eg_gcn_layer_train_fwd with out = NULL runs that kernel and the two tiny launches that reduce its statistics, not the
+    activation pass.  Algorithmic bytes per launch: read x, write z, write A_hat x (kept for dW) = 3 * B * N * 512 B; the
+    chained form (layers 2, 3 of a step) also reads the child sums of x."""
+    import torch
+    from echoglad_amd import ops
+    g = ops.Graph.topo(topo.spec.frame_size, topo.spec.num_aux_graphs, False, True, device=device)
+    rows = B * topo.num_nodes
+    x = torch.randn(rows, C, device=device)
+    W = torch.randn(C, C, device=device) * 0.08
+    one, zero = torch.ones(C, device=device), torch.zeros(C, device=device)
+    kin = ops.new_kidsum(g, B)
+    forms = [dict()] + ([dict(kidsum_in=kin)] * (layers - 1) if kin is not None else [dict()] * (layers - 1))
+
+    def launches():
+        for f in forms:
+            ops.gcn_layer_train_fwd(g, B, x, W, zero, one, zero, None, None, None, 1e-5, True, 0.0, 0, True, want_out=False, **f)
+
+    ms = time_steps(launches, iters=10, warm=2) / len(forms)
+    n, e_dir = topo.num_nodes, 2 * topo.num_undirected_edges
+    bytes_alg = 3 * rows * C * 4
+    flops = B * (n * 2 * C * C + (e_dir + n) * 2 * C)
+    tf, gbs = flops / (ms * 1e-3) / 1e12, bytes_alg / (ms * 1e-3) / 1e9
+    rf = {"bound": "hbm", "kernel": "k_gcn_layer_ps<false, false, 1> (train-forward layer kernel, 3 launches per step)",
+          "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+          "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_alg,
+          "note": "avg over the step's 3 forms (first layer pulls child rows, layers 2-3 read child sums); the timed call also "
+                  "runs the 2 launches that reduce the kernel's BatchNorm partial sums (~25 us)",
+          "mfma": {"achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TF, 4),
+                   "frac_mfma_only": round(B * n * 2 * C * C / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4)}}
+    pm, src = _pmc_summary(r"r\d+_train_pmc\.json", TRAIN_KERNEL_SOURCES)
+    rf["traffic"], rf["mfma_busy_frac"], rf["traffic_source"] = None, None, src
+    if pm is not None:
+        for k, v in pm.items():
+            if isinstance(v, dict) and k.startswith("k_gcn_layer_ps<false, false, 1>"):
+                rf["traffic"] = int(v.get("hbm_bytes_per_launch", 0)) or None
+                rf["mfma_busy_frac"] = round(v["mfma_busy_frac"], 4) if "mfma_busy_frac" in v else None
+    return rf
+
+
 def main_train(args, world, rank, device, dist_info):
+    import torch
     B = args.batch
-    step, topo = train_workload(args.frame, args.naux, args.layers, B, device, world, rank, args.force_collective)
+    step, topo = train_workload(args.frame, args.naux, args.layers, B, device, world, rank, args.force_collective, args.bucket_kb)
     for _ in range(max(args.warmup, 2)):
         loss = step()
+    if step.reducer is not None:
+        step.reducer.collective_wait_ms()                    # drop the warm-up steps' events
     elapsed, loss = timed_loop(step, args.steps, world, device)
+    # per rank: its own clock over the same K steps (the reported time is the maximum), and how long its compute stream sat in
+    # finish() behind the gradient collectives -- what to look at first when the scaling curve bends
+    t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    own = []
+    for _ in range(min(args.steps, 5)):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        own.append(1e3 * (time.perf_counter() - t0))
+    wait_ms = step.reducer.collective_wait_ms() if step.reducer is not None else None
+    per_rank = [{"rank": rank, "ms_per_step_alone": round(min(own), 3), "ms_in_finish_behind_collectives": None if wait_ms is None else round(wait_ms, 4)}]
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
     if rank == 0:
         fps = world * B * args.steps / elapsed
         sb, sf = stack_work(topo, args.layers)
-        print(json.dumps({
+        out = {
             "metric": "echo frames/sec, one full training step of the GNN stack (fwd + losses + bwd + all-reduce + Adam)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2),
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -236,7 +307,18 @@ def main_train(args, world, rank, device, dist_info):
             "stack_hbm_frac": round(fps / world * 3 * sb / 1e9 / PEAK_HBM_GBS, 4),
             "stack_mfma_frac": round(fps / world * 3 * sf / 1e12 / PEAK_F32_MFMA_TF, 4), "final_loss": float(loss.detach()),
             "distributed": dict(dist_info, gradient_collectives_issued=(step.reducer.collectives_issued if step.reducer else 0),
-                                gradient_buckets=(len(step.reducer._buckets) if step.reducer else 0))}), flush=True)
+                                gradient_buckets=(len(step.reducer._buckets) if step.reducer else 0),
+                                gradient_collectives=(step.reducer.describe() if step.reducer else None),
+                                per_rank=per_rank,
+                                note="ms_in_finish_behind_collectives = mean time per step the compute stream waited in "
+                                     "GradientAllReducer.finish() for the bucket all-reduces (issued from inside backward on a "
+                                     "side stream); ms_per_step_alone = this rank's own synchronised step time")}
+        if world == 1 and not args.no_other_configs:
+            try:
+                out["roofline"] = train_layer_roofline(B, topo, device, args.layers)
+            except Exception as ex:
+                out["roofline"] = {"error": repr(ex)}
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(args, kw, state_dict):
@@ -436,6 +518,9 @@ def other_configs(args, device):
         out["cfg4_train"].update({"traffic_bytes_per_step": tb, "traffic_source": tsrc,
                                   "algorithmic_bytes_per_step": 3 * sb * B})
         del step
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["cfg4_train"]["roofline"] = train_layer_roofline(B, topo, device, args.layers)
     except Exception as ex:
         out["cfg4_train"] = {"workload": what, "error": repr(ex)}
     gc.collect()
@@ -514,6 +599,26 @@ def main_infer(args, world, rank, device, dist_info):
     frames_per_s = world * B * args.steps / elapsed
     rep = [1e3 * timed_loop(step, args.steps, world, device)[0] / args.steps for _ in range(max(args.repeats, 0))]
 
+    # ---- every rank's logits for ITS shard must be what one GPU alone computes for the same frames (frames are seeded by global
+    # rank index; the kernels are bitwise deterministic): rank 0 recomputes every other shard and compares digests
+    if world > 1:
+        digest = logits_digest(out)
+        digests = [None] * world
+        torch.distributed.all_gather_object(digests, digest)
+        if rank == 0:
+            from echoglad_amd.synthetic import synthetic_node_feats
+            bad = []
+            for r in range(1, world):
+                fr = synthetic_node_feats(B * N, C, seed=200 + r).to(device)
+                with torch.no_grad():
+                    lone = model.forward_nodes(fr, edge_index, B)[0]
+                if logits_digest(lone) != digests[r]:
+                    bad.append(r)
+                del fr
+            dist_info = dict(dist_info, shard_digests_equal_single_rank=not bad, shards_checked=world - 1,
+                             shard_digest_mismatch_ranks=bad)
+            if bad:
+                print(f"warning: ranks {bad} computed other logits for their shard than rank 0 does for the same frames", file=sys.stderr)
     if rank != 0:
         return
     # ---- dominant kernel: the fused GCN layer, timed with HIP events on the launch stream
@@ -551,7 +656,11 @@ def main_infer(args, world, rank, device, dist_info):
         traffic, traffic_src = pmc_traffic("k_gcn_layer")
     roofline = {"bound": "mfma", "kernel": kname,
                 "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(tf / PEAK_F32_MFMA_TF, 4),
+                # `frac` books SURVEY 8(d)'s per-layer FLOPs, which include the aggregation's FMAs (vector ALU work); the 128x128
+                # node update alone -- what the MFMA pipe executes -- against the same roof:
+                "frac_mfma_only": round(B * N * 2 * C * C / (layer_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(layer_ms, 4),
                 "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": bytes_alg}}

@@ -314,7 +314,10 @@ __global__ __launch_bounds__(CT_THREADS) void k_cls_out_bwd_sums(const float* __
 // dh1 = dz2 W2 (MFMA), written as whole rows.  tot = the reduced sums of k_cls_out_bwd_sums (double).
 // (3 waves per SIMD = the 3 workgroups per CU the 768-block grid counts on: 150 VGPRs, no spills; left to itself the
 //  compiler took 182 and the third of the grid that was not resident ran as a tail: 1.06 -> 0.71 ms at B = 32)
-__global__ __launch_bounds__(CT_THREADS, 3) void k_cls_mid_bwd(const float* __restrict__ dlogits, const float* __restrict__ z2,
+#ifndef MID_BWD_WGS
+#define MID_BWD_WGS 2               // workgroups per CU (register budget 256 / 168 VGPRs for 2 / 3)
+#endif
+__global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const float* __restrict__ dlogits, const float* __restrict__ z2,
                                                             const float* __restrict__ z1, long long rows, const ClsBn bn1, const ClsDrop d1,
                                                             const ClsBn bn2, const ClsDrop d2, const float* __restrict__ w2,
                                                             const float* __restrict__ w3, const double* __restrict__ tot,
@@ -341,20 +344,52 @@ __global__ __launch_bounds__(CT_THREADS, 3) void k_cls_mid_bwd(const float* __re
     // what a separate pass over dh1 and z1 computed before): a thread always owns the same 4 channels, c4 = 4 (tid & 31)
     f32x4 sg1 = {0.f, 0.f, 0.f, 0.f}, sx1 = sg1;
     const int c4s = (tid & 31) * 4;
-    __syncthreads();
     const long long n_tiles = (rows + TILE - 1) / TILE;
+    // The row loads of a tile (z1: 8, z2: 4 float4 per thread, 4 dlogits) are issued one tile ahead, right behind the first
+    // barrier of the tile before: their round trip runs under that tile's products instead of in front of this one's.
+    f32x4 pz1[8], pz2[4];
+    float pdl[4];
+    auto issue = [&](long long tile) {
+        const long long row0 = tile * TILE;
+        const int rows_here = (int)((rows - row0) < TILE ? (rows - row0) : TILE);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = tid + CT_THREADS * it, r = e >> 5, c4 = (e & 31) * 4;
+            pz1[it] = r < rows_here ? *reinterpret_cast<const f32x4*>(z1 + (size_t)(row0 + r) * H1 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = tid + CT_THREADS * it, r = e >> 4, c4 = (e & 15) * 4;
+            const bool ok = r < rows_here;
+            pz2[it] = ok ? *reinterpret_cast<const f32x4*>(z2 + (size_t)(row0 + r) * H2 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            pdl[it] = ok ? dlogits[(row0 + r) * 4 + (c4 >> 4)] : 0.f;
+        }
+    };
+    if ((long long)blockIdx.x < n_tiles) issue(blockIdx.x);
+    __syncthreads();
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long row0 = tile * TILE;
         const int rows_here = (int)((rows - row0) < TILE ? (rows - row0) : TILE);
-        load_h1_tile(z1, row0, rows_here, bn1.scale, bn1.shift, d1, s_h, tid);
+        {   // h1 tile from the prefetched z1 (rows >= rows_here are zero)
+            int c4o = c4s;
+            asm volatile("" : "+v"(c4o));
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(bn1.scale + c4o), sh = *reinterpret_cast<const f32x4*>(bn1.shift + c4o);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int e = tid + CT_THREADS * it, r = e >> 5, c4 = (e & 31) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < rows_here) v = hidden_act4(pz1[it], sc, sh, d1, (unsigned long long)(row0 + r) * H1 + c4);
+                *reinterpret_cast<f32x4*>(&s_h[r * LDA + c4]) = v;
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {                                 // dz2 tile: rows >= rows_here are zero
             const int e = tid + CT_THREADS * it, r = e >> 4, c4 = (e & 15) * 4;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
             if (r < rows_here) {
                 const long long row = row0 + r;
-                const float dl = dlogits[row * 4 + (c4 >> 4)];
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(z2 + (size_t)row * H2 + c4);
+                const float dl = pdl[it];
+                const f32x4 zz = pz2[it];
                 const f32x4 mn = *reinterpret_cast<const f32x4*>(bn2.mean + c4), is = *reinterpret_cast<const f32x4*>(bn2.invstd + c4);
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(bn2.scale + c4), sh = *reinterpret_cast<const f32x4*>(bn2.shift + c4);
                 const f32x4 ww = *reinterpret_cast<const f32x4*>(w3 + c4);
@@ -375,6 +410,7 @@ __global__ __launch_bounds__(CT_THREADS, 3) void k_cls_mid_bwd(const float* __re
             *reinterpret_cast<f32x4*>(&s_dz[r * LDZ + c4]) = o;
         }
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) issue(tile + gridDim.x);
         const int i16 = lane & 15, kq = lane >> 4;
         // dW2[head] += dz2[:, head]^T h1[:, head]:  A[o][k] = dz2[4 s + k][16 head + o],  B[k][i] = h1[4 s + k][32 head + 16 ib + i]
 #pragma unroll 4
@@ -481,17 +517,32 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
     const long long rows = a.rows;
     const long long n_tiles = (rows + TILE - 1) / TILE;
     f32x4 pd[4], pz[4], px[4];
+    // Row of the unfiltered array behind compact row r of tile t: the tile's first row is decoded once (a 32-bit division on the
+    // scalar unit), a row of the tile lies in that frame or the next one (n_valid >= 64 is checked on the host).  A 64-bit
+    // division per row -- map_row -- cost more instructions than the rest of the tile's address arithmetic together.
+    auto tile_map = [&](long long t, int& f0, int& in0) {
+        const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(t * TILE));
+        f0 = (int)(r0 / (unsigned)a.xm.n_valid);
+        in0 = (int)(r0 - (unsigned)f0 * (unsigned)a.xm.n_valid);
+    };
+    auto mapped = [&](int f0, int in0, int rl) -> unsigned {
+        const int in = in0 + rl;
+        const bool next = in >= a.xm.n_valid;
+        return (unsigned)((f0 + (next ? 1 : 0)) * a.xm.stride + a.xm.lo + (next ? in - a.xm.n_valid : in));
+    };
     auto issue = [&](long long t) {
+        int f0, in0;
+        tile_map(t, f0, in0);
         const long long r0 = t * TILE + (tid >> 5);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long long r = r0 + 16 * q;
             pd[q] = pz[q] = px[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (r < rows) {
-                const size_t off = (size_t)r * C + c4;
+                const unsigned off = (unsigned)r * (unsigned)C + (unsigned)c4;
                 pd[q] = *reinterpret_cast<const f32x4*>(a.dh1 + off);
                 pz[q] = *reinterpret_cast<const f32x4*>(a.z1 + off);
-                px[q] = *reinterpret_cast<const f32x4*>(a.h + (size_t)map_row(a.xm, r) * C + c4);
+                px[q] = *reinterpret_cast<const f32x4*>(a.h + (mapped(f0, in0, (tid >> 5) + 16 * q) * (unsigned)C + (unsigned)c4));
             }
         }
     };
@@ -550,12 +601,16 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
             }
         }
         __syncthreads();                          // products done: s_g / s_x may be refilled, s_o is complete
+        {
+            int f0, in0;
+            tile_map(t, f0, in0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rl = (tid >> 5) + 16 * q;
-            const long long r = r0 + rl;
-            if (r < rows)
-                *reinterpret_cast<f32x4*>(a.dh + (size_t)map_row(a.xm, r) * C + c4) = *reinterpret_cast<const f32x4*>(&s_o[rl * LDA + c4]);
+            for (int q = 0; q < 4; ++q) {
+                const int rl = (tid >> 5) + 16 * q;
+                const long long r = r0 + rl;
+                if (r < rows)
+                    *reinterpret_cast<f32x4*>(a.dh + (mapped(f0, in0, rl) * (unsigned)C + (unsigned)c4)) = *reinterpret_cast<const f32x4*>(&s_o[rl * LDA + c4]);
+            }
         }
     }
     if constexpr (!GEMM2) {
@@ -714,7 +769,7 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
     hipLaunchKernelGGL(k_cls_out_bwd_sums, dim3(ga), dim3(CT_THREADS), 0, stream, dlogits, z2, rows, bn2, d2, P->w3, partial);
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3((OUT_SUMS + 31) / 32), dim3(256), 0, stream, partial, ga, OUT_SUMS, totals);
     // ---- second layers: dz2, dW2, dh1 -- and the sums of the first layers' BatchNorm backward over g1 = dh1 * mask1
-    const int gb = grid_for(rows, TILE, 768);
+    const int gb = grid_for(rows, TILE, 256 * MID_BWD_WGS);
     float* partial2 = partial + (size_t)CT_MAX_BLOCKS * OUT_SUMS;
     float* partial_bn1 = partial2 + (size_t)768 * (4 * 16 * 32);               // [gb][2][128]
     double* tot_bn1 = totals + 256 + 4 * 16 * 32;
@@ -727,7 +782,7 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
     // ---- first layers: dz1 formed on the fly, dW1 = dz1^T h[valid rows] and dh[valid rows] = dz1 W1 in ONE kernel
     const RowMap xm{(int)n_valid, (int)n_per_frame, (int)row_lo};
     static const bool fused_first = !(getenv("EG_CLS_FUSED_BWD") && atoi(getenv("EG_CLS_FUSED_BWD")) == 0);
-    if (dh && fused_first) {
+    if (dh && fused_first && n_valid >= TILE && (long long)batch * n_per_frame * C < (1ll << 32) && rows * C < (1ll << 32)) {
         if (n_valid < n_per_frame)
             hipLaunchKernelGGL(k_zero_rows, dim3(64), dim3(256), 0, stream, dh, batch, (int)n_per_frame, (int)row_lo, (int)n_valid);
         {
@@ -753,10 +808,22 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
     // the apply + dW pass, which then writes no dz1
     float* dgamma1 = grads + 128 * 128 + 128;
     float* dbeta1 = dgamma1 + 128;
-    if (dh) return set_error(EG_ERR_UNSUPPORTED, "EG_CLS_FUSED_BWD=0 is a diagnostic of the round-3 route and no longer has its scratch array");
+    // dh wanted but the fused kernel does not cover the shape (fewer than 64 valid rows per frame, or 2^32 elements and more):
+    // dz1 goes through dh's own rows -- dh [batch * n_per_frame, 128] has room for the [rows, 128] array -- and the plain-rows
+    // product then runs from a copy of it in dh1_scratch (dh1 is dead once dz1 exists)
     int rc = eg_launch_bn_bwd(dh1_scratch, z1, rows, bn + 0 * H1, bn + 1 * H1, P->gamma1, P->beta1, 1, P->p1, P->seed1, shared,
-                              nullptr, dgamma1, dbeta1, h, &xm, grads, stream);
-    return rc;
+                              dh, dgamma1, dbeta1, h, &xm, grads, stream);
+    if (rc != EG_OK || !dh) return rc;
+    EG_HIP_TRY(hipMemcpyAsync(dh1_scratch, dh, sizeof(float) * (size_t)rows * C, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(k_zero_rows, dim3(64), dim3(256), 0, stream, dh, batch, (int)n_per_frame, (int)row_lo, (int)n_valid);
+    LinMapDims d{};
+    d.n_valid = (int)n_valid; d.tiles_per_frame = (int)((n_valid + TILE - 1) / TILE); d.batch = batch; d.transpose_w = 1;
+    d.in_stride = (int)n_valid; d.in_lo = 0; d.out_stride = (int)n_per_frame; d.out_lo = (int)row_lo;
+    const long long n_tiles = (long long)d.tiles_per_frame * batch;
+    hipLaunchKernelGGL(k_lin128_map<false>, dim3((unsigned)(n_tiles < LIN_GRID ? n_tiles : LIN_GRID)), dim3(512), 0, stream, dh1_scratch,
+                       P->w1, (const float*)nullptr, dh, (float*)nullptr, d);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
 }
 
 }  // extern "C"

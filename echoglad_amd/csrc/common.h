@@ -167,6 +167,7 @@ struct Knobs {
     int grid_cap;       // EG_GRID        persistent grid of the symmetric kernel (default 512 = 2 workgroups per CU)
     int layer_impl;     // EG_LAYER_IMPL  -1 auto, 0 symmetric kernel, 1 producer/consumer kernel for plain calls
     int ps_grid;        // EG_PS_GRID     persistent grid of the producer/consumer kernel (default 256 = 1 per CU)
+    int ring_guard;     // EG_RING_GUARD  0: no event behind a launch (diagnostic: the queue ring is then unguarded, as before round 4)
 };
 Knobs read_knobs();
 const Knobs& process_knobs();
@@ -218,7 +219,10 @@ struct eg_graph {
     // (EG_ERR_UNSUPPORTED) instead of sharing live counters with it.
     hipEvent_t slot_event[eg::QUEUE_SLOTS];
     mutable std::atomic<void*> slot_stream[eg::QUEUE_SLOTS];     // nullptr-with-flag encoding: see graph.hip
-    mutable std::atomic<unsigned char> slot_used[eg::QUEUE_SLOTS];
+    mutable std::atomic<unsigned char> slot_used[eg::QUEUE_SLOTS];   // 0 free / captured, 1 event recorded, 2 used without an event
+    mutable std::atomic<void*> only_stream;      // the one stream this handle has launched on so far ...
+    mutable std::atomic<unsigned char> multi_stream;   // ... until a second one shows up: from then on every launch records its event
+    mutable std::atomic<unsigned char> any_launch;
 
     // the slice of the queue ring for one launch on `stream` (graph.hip); EG_OK / EG_ERR_UNSUPPORTED / EG_ERR_HIP
     int acquire_queue_slice(hipStream_t stream, int** slice, int* slot) const;

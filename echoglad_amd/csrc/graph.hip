@@ -29,6 +29,7 @@ Knobs read_knobs() {
     k.grid_cap = env_int("EG_GRID", 512);
     k.layer_impl = env_int("EG_LAYER_IMPL", -1);
     k.ps_grid = env_int("EG_PS_GRID", 256);
+    k.ring_guard = env_int("EG_RING_GUARD", 1);
     // the static tile walk of the train forward labels chunks with blockIdx % 8 (a grid below 8 would leave chunks without
     // an owner) and its statistics partials fill at most 2048 slabs of the workspace
     if (k.ps_grid < 8) k.ps_grid = 8;
@@ -49,20 +50,27 @@ constexpr size_t QUEUE_RING_BYTES = sizeof(int) * ((size_t)QUEUE_SLOTS * QUEUE_S
 
 // ---- the tile-queue ring of a handle (common.h) ---------------------------------------------------------------------------
 // Every launch takes the next slice.  Slice s was last used by launch k - 64; if that launch ran on the same stream it is
-// ordered in front of this one, and if it ran on another stream its event tells whether it has finished.  A slice whose last
+// ordered in front of this one, and if it ran on another stream its event (or, for launches from the time when the handle had
+// seen a single stream and recorded none, a query of that whole stream) tells whether it has finished.  A slice whose last
 // user is still in flight on another stream is NOT handed out: the call fails with EG_ERR_UNSUPPORTED (the caller serialises,
 // or uses a handle per stream).  Launches recorded into a HIP graph (stream capture) carry no event: a captured launch keeps its
 // slice for every replay, which is ordered with later eager launches only on the replaying stream itself (header note).
 int eg_graph::acquire_queue_slice(hipStream_t stream, int** slice, int* slot) const {
     const unsigned s = launch_seq.fetch_add(1u, std::memory_order_relaxed) % (unsigned)eg::QUEUE_SLOTS;
-    if (slot_used[s].load(std::memory_order_acquire) && slot_stream[s].load(std::memory_order_acquire) != (void*)stream) {
-        const hipError_t q = hipEventQuery(slot_event[s]);
+    // a handle that has only ever launched on ONE stream needs no events (its launches are ordered); the moment a second stream
+    // shows up every launch records one.  Slices last used before that moment carry none: their stream is queried as a whole.
+    if (!any_launch.exchange(1, std::memory_order_acq_rel)) only_stream.store((void*)stream, std::memory_order_release);
+    else if (!multi_stream.load(std::memory_order_acquire) && only_stream.load(std::memory_order_acquire) != (void*)stream)
+        multi_stream.store(1, std::memory_order_release);
+    const unsigned char used = slot_used[s].load(std::memory_order_acquire);
+    if (used && slot_stream[s].load(std::memory_order_acquire) != (void*)stream) {
+        const hipError_t q = used == 1 ? hipEventQuery(slot_event[s]) : hipStreamQuery((hipStream_t)slot_stream[s].load(std::memory_order_acquire));
         if (q == hipErrorNotReady) {
             (void)hipGetLastError();
             return eg::set_error(EG_ERR_UNSUPPORTED, "more than 64 launches of this graph handle are in flight on different streams: "
                                                      "the tile-queue slice of the launch 64 calls ago is still in use");
         }
-        if (q != hipSuccess) { (void)hipGetLastError(); }      // (e.g. an event that was never recorded outside a capture: free)
+        if (q != hipSuccess) { (void)hipGetLastError(); }      // (a destroyed stream, an event never recorded: nothing in flight)
     }
     *slice = walk_counters + (size_t)s * eg::QUEUE_SLICE_INTS;
     *slot = (int)s;
@@ -71,11 +79,13 @@ int eg_graph::acquire_queue_slice(hipStream_t stream, int** slice, int* slot) co
 
 void eg_graph::commit_queue_slice(int slot, hipStream_t stream) const {
     if (slot < 0 || slot >= eg::QUEUE_SLOTS) return;
+    if (!knobs.ring_guard) return;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
     if (cs != hipStreamCaptureStatusNone) { slot_used[slot].store(0, std::memory_order_release); return; }
-    if (hipEventRecord(slot_event[slot], stream) != hipSuccess) { (void)hipGetLastError(); return; }
     slot_stream[slot].store((void*)stream, std::memory_order_release);
+    if (!multi_stream.load(std::memory_order_acquire)) { slot_used[slot].store(2, std::memory_order_release); return; }
+    if (hipEventRecord(slot_event[slot], stream) != hipSuccess) { (void)hipGetLastError(); slot_used[slot].store(2, std::memory_order_release); return; }
     slot_used[slot].store(1, std::memory_order_release);
 }
 

@@ -603,7 +603,8 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
                            const float* beta, float* running_mean, float* running_var, float momentum, float eps, int relu,
                            float dropout_p, uint64_t seed, int residual, void* workspace, float* z, float* agg, float* bn,
                            float* out, const float* kidsum_in, float* kidsum_out, eg_stream_t stream_) {
-    if (!g || !x || !W || !gamma || !beta || !workspace || !z || !bn || !out) return set_error(EG_ERR_ARG, "NULL argument");
+    if (!g || !x || !W || !gamma || !beta || !workspace || !z || !bn) return set_error(EG_ERR_ARG, "NULL argument");
+    if (!out && kidsum_out) return set_error(EG_ERR_ARG, "kidsum_out are the child sums of out: out must not be NULL");
     if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
     if (batch < 1) return set_error(EG_ERR_ARG, "batch must be >= 1");
     if ((kidsum_in || kidsum_out) && (g->kind != GRAPH_TOPO || g->kid_rows == 0))
@@ -621,7 +622,7 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
     // anything else, or EG_TRAIN_PS=0: the symmetric kernel
     static const bool train_ps = !(getenv("EG_TRAIN_PS") && atoi(getenv("EG_TRAIN_PS")) == 0);
     int rc = EG_ERR_UNSUPPORTED;
-    if (train_ps && out != z)
+    if (train_ps)
         rc = eg_launch_layer_ps(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, kidsum_in, nullptr, nullptr, stream, nullptr, nullptr,
                                 agg, partial, &grid);
     // (the symmetric kernel pulls the children as rows: it needs no child sums, kidsum_in is simply not used)
@@ -632,6 +633,7 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
     BnFinalize f{totals, rows, C, gamma, beta, eps, momentum, running_mean, running_var, bn, bn + C, bn + 2 * C, bn + 3 * C};
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(128), 0, stream, f);
     EG_HIP_TRY(hipGetLastError());
+    if (!out) return EG_OK;                       // z, agg and the batch statistics only
     // the activation pass in tile order leaves the child sums of `out` behind for the next layer's train forward
     static const bool act_tiles = getenv("EG_ACT_TILES") && atoi(getenv("EG_ACT_TILES")) != 0;      // (experiment: tile order without child sums too)
     if (kidsum_out || act_tiles) {

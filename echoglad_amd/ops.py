@@ -355,7 +355,8 @@ def train_chain_supported() -> bool:
 
 def gcn_layer_train_fwd(graph: Graph, batch: int, x, weight, bias, gamma, beta, running_mean, running_var, momentum,
                         eps: float, relu: bool, dropout_p: float, seed: int, residual: bool, want_agg: bool = True,
-                        kidsum_in: Optional[torch.Tensor] = None, kidsum_out: Optional[torch.Tensor] = None):
+                        kidsum_in: Optional[torch.Tensor] = None, kidsum_out: Optional[torch.Tensor] = None,
+                        want_out: bool = True):
     """-> (out, z, agg | None, bn [4,128] = mean, invstd, scale, shift).  running_* are updated in place
     (momentum None: no update).  kidsum_in / kidsum_out: child-sum side buffers of a chained train forward (`new_kidsum`)."""
     rows = graph.num_nodes * batch
@@ -368,7 +369,7 @@ def gcn_layer_train_fwd(graph: Graph, batch: int, x, weight, bias, gamma, beta, 
     for t, n in ((bias, "bias"), (gamma, "gamma"), (beta, "beta")):
         _check_vec(t, n, C)
     z = torch.empty_like(x)
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if want_out else None           # None: z, agg and the statistics only (no activation pass)
     agg = torch.empty_like(x) if want_agg else None
     bn = torch.empty(4, C, dtype=torch.float32, device=x.device)
     upd = momentum is not None and running_mean is not None

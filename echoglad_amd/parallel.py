@@ -112,6 +112,10 @@ class GradientAllReducer:
         self._hooks = []
         self._works = []
         self._side = None
+        # diagnostics (bench.py --mode train at world > 1): how long the compute stream sat in finish() behind the collectives
+        self.profile = False
+        self._wait_events: List[tuple] = []
+        self.finish_calls = 0
 
     # ---- plumbing -----------------------------------------------------------------------------------------------
     def _buffer(self) -> torch.Tensor:
@@ -182,11 +186,19 @@ class GradientAllReducer:
         if not self.params:
             return
         self._flush()
+        flat = self._buffer()
+        self.finish_calls += 1
+        timed = self.profile and flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._works:
             w.wait()
-        flat = self._buffer()
         if flat.is_cuda and self._side is not None:
             torch.cuda.current_stream(flat.device).wait_stream(self._side)
+        if timed:
+            e1.record()
+            self._wait_events.append((e0, e1))
         world = self._world()
         if self.average and world > 1:
             flat.div_(world)
@@ -205,6 +217,21 @@ class GradientAllReducer:
         if have:
             torch._foreach_copy_(have, views)
         self._works, self._next = [], 0
+
+    def describe(self) -> dict:
+        """What one step sends: number of collectives (= buckets), bytes per collective, total bytes."""
+        return {"collectives_per_step": len(self._buckets), "bucket_bytes_target": self.bucket_bytes,
+                "bytes_per_collective": [4 * (b.hi - b.lo) for b in self._buckets], "bytes_per_step": 4 * self._total}
+
+    def collective_wait_ms(self, reset: bool = True) -> Optional[float]:
+        """Mean time per finish() the compute stream spent behind the collectives (``profile = True``; synchronises)."""
+        if not self._wait_events:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._wait_events) / len(self._wait_events)
+        if reset:
+            self._wait_events = []
+        return ms
 
     # ---- hook-less form (kept for callers that reduce after backward has returned) ---------------------------------
     def allreduce(self, async_op: bool = False):

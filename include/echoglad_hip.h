@@ -27,8 +27,9 @@
  *     only host state a launch touches is one atomic counter in the handle
  *     that picks the launch's own slice of the handle's tile-queue ring
  *     (64 slices; a slice is zeroed on the launch's stream right before its
- *     kernel).  The ring is guarded: every slice carries an event recorded
- *     behind its last launch, and a launch that would reuse a slice whose last
+ *     kernel).  The ring is guarded: once a handle has been used on more than
+ *     one stream every slice carries an event recorded behind its last
+ *     launch (none before that: a single stream orders its launches), and a launch that would reuse a slice whose last
  *     user is still in flight on ANOTHER stream returns EG_ERR_UNSUPPORTED
  *     instead of sharing live counters with it (use one handle per stream, or
  *     synchronise).  Launches recorded into a HIP graph carry no event: a
@@ -239,6 +240,7 @@ int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* me
  *     bn  = { batch mean, 1/sqrt(var + eps), gamma * invstd, beta - mean * scale }   [4,128]
  *     running_mean / running_var <- nn.BatchNorm1d update with `momentum` (unbiased variance); momentum < 0 or NULL: none
  *     out = relu?(dropout(z * scale + shift)) + (residual ? x : 0)    dropout mask = pure function of (seed, element)
+ *           (out NULL: z, agg, bn and the running statistics only -- the activation pass is not run)
  *     kidsum_in / kidsum_out (both nullable; [batch * eg_graph_kidsum_rows(g), 128], see eg_gcn_layer_fwd_chain): chained train
  *     forward.  kidsum_out receives the child sums of `out` (written by the activation pass, which then runs in tile order);
  *     kidsum_in = the child sums of x left by the layer that produced x: aux nodes read one row instead of four child rows.

@@ -171,6 +171,12 @@ def _full_size_properties(frame, naux, B, main_only=False, layers=3, seed=5):
     assert torch.equal(d, a) and torch.equal(e, a)
 
 
+def test_cfg2_default_full_batch_8_graph_replay_vs_oracle():
+    """BASELINE configs[1] at the batch the metric is quoted on (8 per GPU), on the path bench.py times: the HIP-graph replay
+    of the chained layers + fused heads gives the eager bits, and frame 6 of the batch equals the CPU oracle on that frame."""
+    _full_size_properties(224, 7, 8)
+
+
 def test_cfg3_main_only_full_batch_32():
     """BASELINE configs[2]: use_main_graph_only, 224x224, batch 32 per GPU."""
     _full_size_properties(224, 7, 32, main_only=True)

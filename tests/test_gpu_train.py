@@ -209,8 +209,9 @@ def test_cfg4_train_step_vs_reference_fixture(golden_dir):
                   batch_idx=bi.to(DEV))
     loss = (got ** 2).mean() + (gc ** 2).mean() * 1e-3
     loss.backward()
-    assert np.abs(got.detach().cpu().numpy()[g["train_rows"]] - g["train_logits_rows"]).max() < 3e-4
-    assert np.abs(gc.detach().cpu().numpy() - g["train_coords"]).max() < 5e-4
+    # distance between two fp32 evaluations <= (4 + 1) x the reference's own distance from the fp64 result (see the fp64 test below)
+    assert np.abs(got.detach().cpu().numpy()[g["train_rows"]] - g["train_logits_rows"]).max() < 5 * float(g["train_logits_ref_err"]) + 1e-6
+    assert np.abs(gc.detach().cpu().numpy() - g["train_coords"]).max() < 5 * float(g["train_coords_ref_err"]) + 1e-5
     assert abs(float(loss.detach()) - float(g["train_loss"])) < 1e-4 * float(g["train_loss"])
     want_norm = dict(zip([str(k) for k in g["grad_keys"]], g["grad_norms"]))
     for name, p in hip.named_parameters():
@@ -229,6 +230,62 @@ def test_cfg4_train_step_vs_reference_fixture(golden_dir):
         rg = ref_grads[name].grad
         err = (p.grad.cpu() - rg).abs().max().item()
         assert err < 5e-3 * rg.abs().max().item() + 1e-6, (name, err, rg.abs().max().item())
+
+
+def test_cfg4_train_step_error_against_fp64_is_the_references_own(golden_dir, capsys):
+    """Tolerances DERIVED, not chosen: the fixture holds the same train step run by the reference's classes in fp64, and
+    |reference fp32 - fp64| per quantity (max over all elements: logits, coordinates, every parameter gradient).  Two fp32
+    evaluations of one step differ from the exact result by rounding noise of the same size but not the same sign: per quantity
+    the ratio |HIP - fp64| / |reference fp32 - fp64| scatters around 1 (observed 0.2 .. 3.0 over the 77 quantities).  Asserted:
+    every quantity within FACTOR = 4 x the reference's own distance (plus 8 ulp of the quantity's scale, for entries where the
+    reference happens to be exact), AND the geometric mean of the ratios <= 1.5 -- on the whole the HIP path is as good an fp32
+    evaluation of the step as the reference's.  The observed maxima are printed (pytest -s / the log of the GPU run)."""
+    FACTOR = float(os.environ.get("EG_PARITY_FACTOR", "4"))
+    g = np.load(os.path.join(golden_dir, "cfg4_f224_a7_coord.npz"))
+    frame, naux, L, B = int(g["frame"]), int(g["naux"]), int(g["layers"]), 1
+    hip, _ = model_pair(frame, naux, L, coord=True, seed=int(g["weight_seed"]))
+    for m in hip.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    hip.train()
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+    frames = synthetic_frames(B, 128, frame, int(g["train_frame_seed"]))
+    got, gc = hip(x=frames.to(DEV), node_coords=initial_coords(B, frame).to(DEV), edge_index=ei.to(DEV), node_type=nt.to(DEV),
+                  batch_idx=bi.to(DEV))
+    ((got ** 2).mean() + (gc ** 2).mean() * 1e-3).backward()
+    ulp = 2.0 ** -23
+    report, worst = [], 0.0
+
+    def check(name, hip_vals, ref64, ref_err, scale):
+        nonlocal worst
+        err = float(np.abs(hip_vals.astype(np.float64) - ref64).max())
+        tol = FACTOR * ref_err + 8 * ulp * scale
+        report.append((name, err, ref_err, err / max(ref_err, 1e-300), tol))
+        worst = max(worst, err / tol)
+        return err <= tol
+
+    ok = check("logits", got.detach().cpu().numpy()[g["train_rows"]], g["train64_logits_rows"], float(g["train_logits_ref_err"]),
+               float(np.abs(g["train64_logits_rows"]).max()))
+    ok &= check("coords", gc.detach().cpu().numpy(), g["train64_coords"], float(g["train_coords_ref_err"]), float(frame))
+    offs, idx = g["grad_sample_offsets"], g["grad_sample_idx"]
+    params = dict(hip.named_parameters())
+    for k, name in enumerate(str(x) for x in g["grad_keys"]):
+        sl = slice(int(offs[k]), int(offs[k + 1]))
+        hv = params[name].grad.detach().reshape(-1).cpu().numpy()[idx[sl]]
+        scale = float(g["grad64_maxabs"][k])
+        if scale < 1e-12:            # a bias in front of a train-mode BatchNorm: analytically zero, both sides hold rounding noise
+            assert float(np.abs(hv).max()) <= 1e-3 * float(g["grad64_maxabs"].max()), name
+            continue
+        ok &= check(name, hv, g["grad64_samples"][sl], float(g["grad_ref_err"][k]), scale)
+    with capsys.disabled():
+        print(f"\n  train step vs fp64 (FACTOR {FACTOR:g}): worst err / tol = {worst:.3f}")
+        for name, err, ref_err, ratio, tol in sorted(report, key=lambda r: -r[1] / r[4])[:12]:
+            print(f"    {name:42s} |hip-fp64| {err:.3e}   |ref32-fp64| {ref_err:.3e}   ratio {ratio:6.2f}   tol {tol:.3e}")
+    assert ok, [(n, e, t) for n, e, _, _, t in report if e > t]
+    gmean = float(np.exp(np.mean([np.log(max(r[3], 1e-3)) for r in report])))
+    with capsys.disabled():
+        print(f"    geometric mean of the {len(report)} ratios: {gmean:.3f}")
+    assert gmean <= 1.5, gmean
 
 
 def _torch_heads(model, hv, mask1=None, mask2=None):

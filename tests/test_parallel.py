@@ -98,6 +98,14 @@ def _worker(rank, world, port, frame, naux, B, out_dir, mode="after"):
         n_in_backward = len(fired)
         red.finish()
         assert n_in_backward >= len(red._buckets) - 1 and len(fired) == len(red._buckets)
+        # the diagnostics bench.py --mode train reports at world > 1 (what one step sends; time behind the collectives)
+        d = red.describe()
+        assert d["collectives_per_step"] == len(red._buckets) == len(d["bytes_per_collective"]) and d["bucket_bytes_target"] == 16 << 10
+        assert sum(d["bytes_per_collective"]) == d["bytes_per_step"] == 4 * sum(p.numel() for p in model.parameters())
+        assert all(bb >= 16 << 10 for bb in d["bytes_per_collective"][:-1])
+        assert red.finish_calls == 1 and red.collectives_issued == len(red._buckets)
+        red.profile = True                              # CPU tensors: nothing to time, and nothing may break
+        assert red.collective_wait_ms() is None
         # the classifier heads' bucket goes out first, the first GNN layer's last
         names = {id(p): k for k, p in model.named_parameters()}
         assert names[id(fired[0].params[0])].startswith("node_classifiers")

@@ -8,7 +8,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { P_FMA = 0, P_DSREAD = 1, P_DSWRITE = 2, P_GLOAD = 3, P_READLANE = 4, P_SALU = 5 };
+enum { P_FMA = 0, P_DSREAD = 1, P_DSWRITE = 2, P_GLOAD = 3, P_READLANE = 4, P_SALU = 5, P_WAITCNT = 6, P_SNOP = 7, P_BRANCH = 8 };
 
 template <int MF, int PK>
 __global__ __launch_bounds__(512, 2) void k(float* out, const float* src, unsigned long long* cyc, int iters, int mode) {
@@ -73,6 +73,9 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* src, unsign
                         else if (PK == P_DSREAD) { q[i] = *reinterpret_cast<volatile f32x4*>(mine); }
                         else if (PK == P_DSWRITE) { *reinterpret_cast<volatile f32x4*>(mine) = q[i]; }
                         else if (PK == P_GLOAD) { q[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + 256 * i)); asm volatile("" :: "v"(q[i])); }
+                        else if (PK == P_WAITCNT) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_waitcnt vmcnt(0) lgkmcnt(0)\n s_waitcnt vmcnt(0) lgkmcnt(0)\n s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+                        else if (PK == P_SNOP) { asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0" ::: "memory"); }
+                        else if (PK == P_BRANCH) { asm volatile("s_cmp_eq_u32 %0, 12345\n s_cbranch_scc1 1f\n s_add_u32 %0, %0, 1\n1:\n s_sub_u32 %0, %0, 1" : "+s"(r) :: "scc"); }
                         else if (PK == P_SALU) { asm volatile("s_add_u32 %0, %0, 3\n s_add_u32 %0, %0, 5\n s_add_u32 %0, %0, 7\n s_add_u32 %0, %0, 9" : "+s"(r)); }
                         else { r += __builtin_amdgcn_readlane(lane + r, i); asm volatile("" : "+s"(r)); }
                     }
@@ -108,5 +111,13 @@ int main() {
     run<0, P_SALU>("one chain + 4 x s_add_u32 (per group of 4)", 3);
     run<0, P_READLANE>("v_readlane alone", 2);
     run<0, P_READLANE>("one chain + v_readlane", 3);
+    run<0, P_WAITCNT>("4 x s_waitcnt (satisfied) alone (per group of 4)", 2);
+    run<0, P_WAITCNT>("one chain + 4 x s_waitcnt (per group of 4)", 3);
+    run<0, P_SNOP>("4 x s_nop 0 alone (per group of 4)", 2);
+    run<0, P_SNOP>("one chain + 4 x s_nop 0 (per group of 4)", 3);
+    run<0, P_BRANCH>("s_cmp + s_cbranch (not taken) + 2 SALU alone (per group of 4)", 2);
+    run<0, P_BRANCH>("one chain + s_cmp + s_cbranch + 2 SALU (per group of 4)", 3);
+    run<0, P_FMA>("v_fma_f32 alone", 2);
+    run<0, P_FMA>("one chain + v_fma_f32", 3);
     return 0;
 }
