@@ -129,14 +129,14 @@ def stack_work(topo, layers):
     return n * (layers * 1024 + 528), n * (layers * 2 * C * C + 36992) + layers * (e_dir + n) * 2 * C
 
 
-def infer_workload(frame, naux, layers, main_only, B, device, rank, hip_graph=True):
+def infer_workload(frame, naux, layers, main_only, B, device, rank, hip_graph=True, graph_type="grid"):
     import torch
     from echoglad_amd.topology import TopologySpec, get_topology
     from echoglad_amd.synthetic import synthetic_node_feats
     kw = model_kwargs(frame, naux, layers, main_only)
     model = build_model(kw, device)
     model.enable_hip_graph(hip_graph)
-    topo = get_topology(TopologySpec(frame, naux, main_only))
+    topo = get_topology(TopologySpec(frame, naux, main_only, False, False, graph_type, graph_type))
     # this rank's shard of the global batch: frames [rank*B, (rank+1)*B) — synthetic N(0,1) node features
     feats = synthetic_node_feats(B * topo.num_nodes, C, seed=200 + rank).to(device)
     edge_index = torch.from_numpy(topo.batched_edge_index(B)).to(device)
@@ -466,6 +466,23 @@ def other_configs(args, device):
             out[key] = {"workload": what, "error": repr(ex)}
         gc.collect()
         torch.cuda.empty_cache()
+    what = ("configs[1]'s shape with 'grid-diagonal' levels (datasets.py:1469-1475, :1494-1500: 8-neighbour grids, E_dir = 858,"
+            "312 per frame), batch 8, eval: the implicit stencil of the producer/consumer kernel (round 3: CSR fallback)")
+    try:
+        model, kw, topo, feats, ei, step = infer_workload(224, 7, args.layers, False, 8, device, 0, graph_type="grid-diagonal")
+        ms = time_steps(step, iters=20, warm=5)
+        graph, _ = model._resolver.resolve(ei, feats.shape[0])
+        sb, sf = stack_work(topo, args.layers)
+        fps = 8 / (ms * 1e-3)
+        out["cfg2_diagonal"] = {"workload": what, "ms_per_step": round(ms, 4), "frames_s": round(fps, 1),
+                                "mfma_frac": round(fps * sf / 1e12 / PEAK_F32_MFMA_TF, 4),
+                                "hbm_frac": round(fps * sb / 1e9 / PEAK_HBM_GBS, 4), "stencil_handle": bool(graph.structured),
+                                "directed_edges_per_frame": 2 * topo.num_undirected_edges}
+        del model, feats, ei, step
+    except Exception as ex:
+        out["cfg2_diagonal"] = {"workload": what, "error": repr(ex)}
+    gc.collect()
+    torch.cuda.empty_cache()
     what = ("configs[1] through the GENERIC path: the same 224x224 / 7-aux-level batch of 8 with its edge_index turned into a CSR "
             "handle (what grid-diagonal graphs, connection nodes or arbitrary edge_index take): 3 x eg_gcn_layer_fwd + eg_classifier_fwd")
     try:

@@ -66,6 +66,7 @@ struct Topo {
     int n_levels;            // aux levels + 1
     int n_aux;               // 0 when use_main_graph_only
     int frame;               // F
+    int diag_main, diag_aux; // 'grid-diagonal' main grid / aux levels (8-neighbour grids, datasets.py:1469-1475, :1494-1500)
     int crop0, ncrop;        // run of rows/cols of the last aux level wired to the main grid
     int coord_base;          // first coordinate node id (== n_nodes when there are none)
     int base[MAX_LEVELS];    // first node id of each level (aux 1..naux, then main)
@@ -201,6 +202,9 @@ struct eg_graph {
     float* patsq_dev;         // device [n_pats * 64] the same patterns in quad layout (graph.hip)
     int n_pats;
     int kid_rows;             // rows per frame of the child-sum side buffer (= aux nodes), 0 when the topology does not qualify
+    int hybrid;               // 1: a closed-form topology whose stencil only the producer/consumer kernel implements ('grid-diagonal'
+                              //    levels): rowptr / colidx then hold the CSR of ONE frame for every other path (symmetric kernel,
+                              //    eg_gcn_aggregate, the node-by-node path of ragged segments)
     int flat;                 // 1: a single grid level (use_main_graph_only): no parents, no children; the producer/consumer
                               //    kernel needs no child sums there and is the default layer kernel when its tables fit LDS
     int n_tiles;

@@ -398,7 +398,8 @@ static int fill_graph_args(const eg_graph* g, int batch, LayerArgs& a, int& agg)
     a.d.n_per_frame = (int)g->n_nodes;
     a.d.batch = batch;
     a.gp.tiles = g->tiles_dev;
-    agg = g->kind == GRAPH_TOPO ? AGG_STENCIL : AGG_CSR;
+    // (a 'grid-diagonal' topology handle carries the CSR of one frame for this kernel: its stencil lives in the producer/consumer kernel)
+    agg = (g->kind == GRAPH_TOPO && !g->hybrid) ? AGG_STENCIL : AGG_CSR;
     // implicit topology: one tile per 8x8 patch of a level; CSR: 64 consecutive rows
     a.d.tiles_per_frame = agg == AGG_STENCIL ? g->n_tiles : (int)((g->n_nodes + TILE - 1) / TILE);
     return EG_OK;

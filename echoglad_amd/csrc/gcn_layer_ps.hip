@@ -112,7 +112,9 @@ __device__ inline void ps_claim(int* __restrict__ counters, int group, int n_til
 // JK: JumpingKnowledge('max') of the reference (src/core/models.py:380-382, :479-482) carried through the fused stack as a
 // running element-wise maximum: jk_out = max(jk_in, out) is written beside the layer output (the first layer passes its input
 // as jk_in); with the classifier heads fused in, the heads run on max(jk_in, out) instead of out.
-template <bool CLS, bool JK = false, int MODE = 0>
+// DIAG: the handle has 'grid-diagonal' levels (8-neighbour grids); their segment pairs aggregate through segp_diag_rows, and
+// the rare node-by-node path reads the handle's per-frame CSR (rowptr / colidx) instead of decoding the plain stencil.
+template <bool CLS, bool JK = false, int MODE = 0, bool DIAG = false>
 __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 float* __restrict__ out, const float* __restrict__ dis,
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                                                                 const SegDesc* __restrict__ segs, const float* __restrict__ pats,
                                                                 const float* __restrict__ patsq, const float* __restrict__ kin, float* __restrict__ kout,
                                                                 const float* __restrict__ jk_in, float* __restrict__ jk_out,
-                                                                int* __restrict__ counters, const PsDims a, const ClsArgs ca) {
+                                                                int* __restrict__ counters, const PsDims a, const ClsArgs ca,
+                                                                const int* __restrict__ rowptr, const int* __restrict__ colidx) {
     constexpr bool TRAIN = MODE == 1;                 // train forward: aggregated rows kept, BatchNorm sums, static walk
     constexpr bool RSEP = MODE == 2;                  // the residual is a tensor of its own (a.res: the backward's dX = (A_hat dz) W + dy)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
 #endif
                 // ---- usual case: both segments on the fast path, vertically adjacent, same parents ----
                 SegPair A;
-                const bool use_kin = sd0.aux && kin;                // uniform: children already summed by the previous layer
+                const bool use_kin = (sd0.aux & 1) && kin;                // uniform: children already summed by the previous layer
                 const RowSrc xs = row_src(xf, a.n_per_frame * (C * 4), lane);
                 f32x4 Ra[4], Rb[4];                                  // RSEP: the residual's own rows of both segments
                 if (RSEP) {
@@ -647,6 +650,9 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     for (int k = 0; k < 4; ++k) { Ra[k] = ldp(rs, sd0.n_first, k); Rb[k] = ldp(rs, sd1.n_first, k); }
                 }
                 segp_issue(sd0, sd1, xs, A);
+                SegPairDiag DE;
+                const bool diag = DIAG && (sd0.aux & SEG_AUX_DIAG);          // uniform
+                if (diag) segp_diag_issue(sd0, sd1, xs, a.n_per_frame - 1, DE);
                 // the child-sum rows travel with the first batch: issued after the main stage they cost the aux tiles a second,
                 // fully exposed memory round trip (the producers do most of their work after the consumers' MFMA chain has ended,
                 // DESIGN 5.22)
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 // unchained calls (a stack's first layer): the first segment's 16 child rows as well; the second segment's
                 // follow once the main stage has freed its registers
                 SegKids K0;
-                if (!RSEP && sd0.aux && !use_kin) segw_kids_issue(sd0, pats, xs, lane, K0);      // (RSEP: no registers left for them here)
+                if (!RSEP && !DIAG && (sd0.aux & 1) && !use_kin) segw_kids_issue(sd0, pats, xs, lane, K0);      // (RSEP, DIAG: no registers left for them here)
 #ifdef EG_ABL_NO_LOADS        // timing-only ablation: producers do nothing (results wrong)
                 return;
 #endif
@@ -672,16 +678,28 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                         *reinterpret_cast<f32x4*>(&s_x[(16 * p + 8 + 2 * k + pl.h) * LDA + 4 * pl.q]) = Rb[k];
                     }
                 }
-                segw_rows(lane, wqa, A.Sa, A.LRa, A.U, A.Sb, A.P, acc0, s_t, 16 * p);
-                segw_rows(lane, wqb, A.Sb, A.LRb, A.Sa, A.D, A.P, acc1, s_t, 16 * p + 8);
+                if (diag) {
+                    if (s_x && !RSEP) {                             // the raw self rows for the consumers' residual
+                        const PairLane pl{lane >> 5, lane & 31};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            *reinterpret_cast<f32x4*>(&s_x[(16 * p + 2 * k + pl.h) * LDA + 4 * pl.q]) = A.Sa[k];
+                            *reinterpret_cast<f32x4*>(&s_x[(16 * p + 8 + 2 * k + pl.h) * LDA + 4 * pl.q]) = A.Sb[k];
+                        }
+                    }
+                    segp_diag_rows(lane, wqa, wqb, A, DE, acc0, acc1, s_a + 16 * p * LDA);
+                } else {
+                    segw_rows(lane, wqa, A.Sa, A.LRa, A.U, A.Sb, A.P, acc0, s_t, 16 * p);
+                    segw_rows(lane, wqb, A.Sb, A.LRb, A.Sa, A.D, A.P, acc1, s_t, 16 * p + 8);
+                }
                 pin_acc4(acc0);
                 pin_acc4(acc1);                                     // the 40 main-stage registers are dead from here on
                 __builtin_amdgcn_sched_barrier(0);
                 PSTAMP(PS_MAIN);
                 if (use_kin) {
                     segp_kidsum_add(KS, wqa, wqb, acc0, acc1);
-                } else if (sd0.aux) {                               // uniform: aux level, children pulled as rows
-                    if (RSEP) segw_kids_issue(sd0, pats, xs, lane, K0);
+                } else if (sd0.aux & 1) {                           // uniform: aux level, children pulled as rows
+                    if (RSEP || DIAG) segw_kids_issue(sd0, pats, xs, lane, K0);
                     segw_kids_add(lane, K0, acc0);
                     pin_acc4(acc0);                                 // (issuing the second segment's loads ahead of this add measured slower)
                     {
@@ -714,7 +732,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     const int rl = 16 * p + 8 * e;
 #pragma unroll 1
                     for (int u = 0; u < cnt; ++u) {
-                        const f32x2 av = agg_stencil(T, xf, dis, n0 + u, lane);
+                        const f32x2 av = DIAG ? agg_csr(xf, dis, rowptr, colidx, n0 + u, lane) : agg_stencil(T, xf, dis, n0 + u, lane);
                         *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = av;
                         if (TRAIN && a.agg_out) *reinterpret_cast<f32x2*>(a.agg_out + ((size_t)frame * a.n_per_frame + n0 + u) * C + 2 * lane) = av;
                         if (s_x) *reinterpret_cast<f32x2*>(&s_x[(rl + u) * LDA + 2 * lane]) =
@@ -785,7 +803,9 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     if (cls && g->kid_rows == 0 && !g->flat) return EG_ERR_UNSUPPORTED;
     // plain calls: this kernel by default on single-level topologies (no tiles that pull child rows), the symmetric
     // kernel otherwise; EG_LAYER_IMPL = 0 / 1 forces one of them
-    if (!chained && !cls && !train && !rsep && (g->knobs.layer_impl < 0 ? g->flat : g->knobs.layer_impl) == 0) return EG_ERR_UNSUPPORTED;
+    const bool diag = g->hybrid != 0;                             // 'grid-diagonal' levels: this kernel is the stencil path of such handles
+    if (diag && jk) return EG_ERR_UNSUPPORTED;                    // (the running maximum has no diagonal instantiation: the caller takes it outside)
+    if (!chained && !cls && !train && !rsep && !diag && (g->knobs.layer_impl < 0 ? g->flat : g->knobs.layer_impl) == 0) return EG_ERR_UNSUPPORTED;
     PsDims a{};
     a.n_per_frame = (int)g->n_nodes; a.batch = batch; a.tiles_per_frame = g->n_tiles;
     a.relu = relu; a.transpose_w = transpose_w; a.has_res = residual != nullptr;
@@ -803,7 +823,9 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
             const void* kernels[] = {(const void*)k_gcn_layer_ps<false, false>, (const void*)k_gcn_layer_ps<true, false>,
                                      (const void*)k_gcn_layer_ps<false, true>, (const void*)k_gcn_layer_ps<true, true>,
-                                     (const void*)k_gcn_layer_ps<false, false, 1>, (const void*)k_gcn_layer_ps<false, false, 2>};
+                                     (const void*)k_gcn_layer_ps<false, false, 1>, (const void*)k_gcn_layer_ps<false, false, 2>,
+                                     (const void*)k_gcn_layer_ps<false, false, 0, true>, (const void*)k_gcn_layer_ps<true, false, 0, true>,
+                                     (const void*)k_gcn_layer_ps<false, false, 1, true>, (const void*)k_gcn_layer_ps<false, false, 2, true>};
             for (const void* f : kernels) EG_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
@@ -819,10 +841,16 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     const ClsArgs none{};
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(PS_THREADS), lds, stream, x, W, scale, shift, out, g->dis, g->topo_dev,
-                           g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, jk_in, jk_out, queue, a, cls ? *cls : none);
+                           g->tiles_dev, g->segs_dev, g->pats_dev, g->patsq_dev, kin, kout, jk_in, jk_out, queue, a, cls ? *cls : none,
+                           (const int*)g->rowptr, (const int*)g->colidx);
     };
     if (grid_out) *grid_out = (int)grid;
-    if (train) launch(k_gcn_layer_ps<false, false, 1>);
+    if (diag) {
+        if (train) launch(k_gcn_layer_ps<false, false, 1, true>);
+        else if (rsep) launch(k_gcn_layer_ps<false, false, 2, true>);
+        else if (cls) launch(k_gcn_layer_ps<true, false, 0, true>);
+        else launch(k_gcn_layer_ps<false, false, 0, true>);
+    } else if (train) launch(k_gcn_layer_ps<false, false, 1>);
     else if (rsep) launch(k_gcn_layer_ps<false, false, 2>);
     else if (cls) { if (jk) launch(k_gcn_layer_ps<true, true>); else launch(k_gcn_layer_ps<true, false>); }
     else { if (jk) launch(k_gcn_layer_ps<false, true>); else launch(k_gcn_layer_ps<false, false>); }

@@ -2,6 +2,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
+#include <algorithm>
 #include <map>
 #include <vector>
 
@@ -111,12 +112,14 @@ static inline void py_slice(int len, int start, int stop, int& lo, int& hi) {
     if (hi < lo) hi = lo;
 }
 
-static int build_topo(int frame, int naux, int main_only, int coord_nodes, Topo& T) {
+static int build_topo(int frame, int naux, int main_only, int coord_nodes, int diag_main, int diag_aux, Topo& T) {
     if (frame < 2 || frame > 4096) return set_error(EG_ERR_ARG, "frame must be in [2, 4096]");
     if (!main_only && (naux < 1 || naux + 1 > MAX_LEVELS)) return set_error(EG_ERR_ARG, "naux out of range");
     T = Topo{};
     int nid = 0;
     T.n_aux = main_only ? 0 : naux;
+    T.diag_main = diag_main ? 1 : 0;
+    T.diag_aux = (!main_only && diag_aux) ? 1 : 0;
     for (int k = 1; k <= T.n_aux; ++k) {
         T.base[k - 1] = nid;
         T.side[k - 1] = 1 << k;
@@ -236,17 +239,50 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                    eg_graph** out) {
     if (!out) return set_error(EG_ERR_ARG, "out is NULL");
     *out = nullptr;
-    if (conn_nodes || diag_main || diag_aux)
-        return set_error(EG_ERR_UNSUPPORTED, "connection nodes and 'grid-diagonal' levels have no implicit-stencil tables: build the "
-                                             "graph with eg_csr_create");
+    if (conn_nodes)
+        return set_error(EG_ERR_UNSUPPORTED, "connection nodes have no implicit-stencil tables: build the graph with eg_csr_create");
     Topo T;
-    int rc = build_topo(frame, naux, main_only, coord_nodes, T);
+    int rc = build_topo(frame, naux, main_only, coord_nodes, diag_main, diag_aux, T);
     if (rc != EG_OK) return rc;
+    const bool any_diag = T.diag_main || T.diag_aux;
+    // level / position of a grid node, and whether its level is 'grid-diagonal'
+    auto level_diag = [&](int l) { return l == T.n_levels - 1 ? T.diag_main != 0 : T.diag_aux != 0; };
+    auto diag_ids = [&](int n, int (&out)[4]) -> int {          // the up-to-4 diagonal neighbours of node n (datasets.py:1469-1475)
+        if (n >= T.coord_base) return 0;
+        const int l = level_of(T, n);
+        if (!level_diag(l)) return 0;
+        const int side = T.side[l], idx = n - T.base[l], r = idx / side, c = idx - r * side;
+        int k = 0;
+        for (int dr = -1; dr <= 1; dr += 2)
+            for (int dc = -1; dc <= 1; dc += 2)
+                if (r + dr >= 0 && r + dr < side && c + dc >= 0 && c + dc < side) out[k++] = n + dr * side + dc;
+        return k;
+    };
     std::vector<float> dis(T.n_nodes);
     Nbrs nb;
     for (int n = 0; n < T.n_nodes; ++n) {
         neighbours(T, n, nb);
-        dis[n] = (float)(1.0 / std::sqrt((double)(nb.degree + 1)));
+        int dg[4];
+        dis[n] = (float)(1.0 / std::sqrt((double)(nb.degree + diag_ids(n, dg) + 1)));
+    }
+    // 'grid-diagonal' handles also carry the CSR of one frame (sorted by target, then source): every path but the
+    // producer/consumer kernel's stencil reads it (common.h eg_graph::hybrid)
+    std::vector<int> h_rowptr, h_colidx;
+    if (any_diag) {
+        h_rowptr.assign((size_t)T.n_nodes + 1, 0);
+        std::vector<int> row;
+        for (int n = 0; n < T.n_nodes; ++n) {
+            neighbours(T, n, nb);
+            row.clear();
+            for (int sl = 1; sl < nb.count; ++sl)
+                if (nb.valid[sl]) row.push_back(nb.id[sl]);
+            int dg[4];
+            const int nd = diag_ids(n, dg);
+            row.insert(row.end(), dg, dg + nd);
+            std::sort(row.begin(), row.end());
+            h_colidx.insert(h_colidx.end(), row.begin(), row.end());
+            h_rowptr[(size_t)n + 1] = (int)h_colidx.size();
+        }
     }
     // 2-D patch table.  Order = depth-first post-order over the pyramid of 8x8 patches: the patches under a
     // coarse patch are emitted (recursively, 2x2 blocks) before it, so vertical neighbours, parents and
@@ -314,6 +350,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
     // Interior segments of a level all share one pattern, so the table stays at a few dozen entries.
     std::vector<SegDesc> segs(tiles.size() * 8);
     std::vector<float> pats;
+    std::vector<float> pat_extra;                     // 5 floats per pattern (see `w` below)
     int kid_rows = 0;
     bool kidsum_ok = false;
     {
@@ -322,7 +359,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
         std::map<std::vector<float>, int> pat_index;
         auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
         const int n_frame = T.n_nodes, hi8 = n_frame - 8, last = n_frame - 1;
-        std::vector<float> w(128);
+        std::vector<float> w(128 + 5);                // lane weights + {diagonal?, edge weights of the row above (l, r) and below (l, r)}
         for (size_t t = 0; t < tiles.size(); ++t) {
             const TileDesc& td = tiles[t];
             const LevelDesc& d = T.desc[td.level];
@@ -339,10 +376,12 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                 // 8 rows (self / below / children) would have to be clamped while some of its rows are real neighbours
                 // (the rows below the LAST grid row are no neighbours: their clamped run carries weight 0)
                 const bool below = d.kind != KIND_COORD && r < d.side - 1;
+                const bool ldiag = d.kind != KIND_COORD && level_diag(td.level);
+                // (a 'grid-diagonal' segment takes the run path only when it is a whole 8-node run: seg_wide.h row_sum3)
                 const bool slow = d.kind == KIND_COORD || sd.n_first + 8 > n_frame || (below && sd.n_first + d.side + 8 > n_frame) ||
-                                  (kids && (cb < 0 || cb + d.cside + 16 > n_frame));
+                                  (kids && (cb < 0 || cb + d.cside + 16 > n_frame)) || (ldiag && sd.cnt != 8);
                 sd.mode = sd.cnt == 0 ? 0 : (slow ? 2 : 1);
-                sd.aux = d.kind == KIND_AUX;
+                sd.aux = (d.kind == KIND_AUX ? 1 : 0) | (ldiag ? 2 : 0);
                 if (sd.mode == 1) {
                     sd.up0 = clampi(sd.n_first - d.side, 0, hi8);
                     sd.down0 = clampi(sd.n_first + d.side, 0, hi8);
@@ -359,12 +398,20 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                         neighbours(T, n, nb);
                         w[lane] = nb.valid[sl] ? dis[nb.id[sl]] : 0.0f;
                         const int sb = 8 + (sl & 1);
-                        w[64 + lane] = (sd.aux && nb.valid[sb]) ? dis[nb.id[sb]] : 0.0f;
+                        w[64 + lane] = ((sd.aux & 1) && nb.valid[sb]) ? dis[nb.id[sb]] : 0.0f;
+                    }
+                    for (int e = 0; e < 5; ++e) w[128 + e] = 0.0f;
+                    if (ldiag) {                                // the nodes left / right of the 8-node runs above and below
+                        auto dnode = [&](int rr, int cc) { return (rr >= 0 && rr < d.side && cc >= 0 && cc < d.side) ? dis[d.base + rr * d.side + cc] : 0.0f; };
+                        w[128] = 1.0f;
+                        w[129] = dnode(r - 1, c0 - 1); w[130] = dnode(r - 1, c0 + 8);
+                        w[131] = dnode(r + 1, c0 - 1); w[132] = dnode(r + 1, c0 + 8);
                     }
                     auto it = pat_index.find(w);
                     if (it == pat_index.end()) {
                         it = pat_index.emplace(w, (int)pat_index.size()).first;
-                        pats.insert(pats.end(), w.begin(), w.end());
+                        pats.insert(pats.end(), w.begin(), w.begin() + 128);
+                        pat_extra.insert(pat_extra.end(), w.begin() + 128, w.end());
                     }
                     sd.pat = it->second;
                 }
@@ -386,18 +433,22 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                         if (cend > c0 && ((cend - c0) & 1)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: odd t=%zu tr=%d\n", t, tr); }
                     }
                     const int par_raw = d.pbase + (d.poff + (r >> 1)) * d.pside + d.poff + (c0 >> 1);
-                    if (npar > 0 && (!sa.pad0 || par_raw != sa.par0 || par_raw + npar > kid_rows)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: parent t=%zu tr=%d level=%d pad0=%d par_raw=%d par0=%d npar=%d kid_rows=%d modes %d %d\n", t, tr, td.level, sa.pad0, par_raw, sa.par0, npar, kid_rows, sa.mode, sb.mode); }
+                    // ('grid-diagonal' levels of fewer than 8 columns run node by node -- rows pulled through the CSR, children
+                    //  included -- and never read the side buffer: child sums that nobody writes for THEIR rows are not missed)
+                    const bool parent_slow = td.level > 0 && level_diag(td.level - 1) && T.side[td.level - 1] < 8 && d.kind == KIND_AUX;
+                    if (npar > 0 && !parent_slow && (!sa.pad0 || par_raw != sa.par0 || par_raw + npar > kid_rows)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: parent t=%zu tr=%d level=%d pad0=%d par_raw=%d par0=%d npar=%d kid_rows=%d modes %d %d\n", t, tr, td.level, sa.pad0, par_raw, sa.par0, npar, kid_rows, sa.mode, sb.mode); }
                     sa.pad1 = npar;
                     const bool kids = d.kind == KIND_AUX && ((r >= d.clo && r < d.chi) || (r + 1 >= d.clo && r + 1 < d.chi)) && c0 < d.chi && c0 + 8 > d.clo;
+                    const bool self_slow = level_diag(td.level) && d.side < 8;
                     // the pair path reads runs of 8 child-sum rows from each segment's first node: they must stay inside the
                     // frame's slice of the side buffer (tiny pyramids only: a 2x2 or 4x4 level right at its end; an over-read
                     // past the LAST frame's slice left the allocation and aborted a test run once)
-                    if (kids && (sa.n_first + 8 > kid_rows || sb.n_first + 8 > kid_rows)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: 8-row run past the side buffer t=%zu tr=%d\n", t, tr); }
-                    if (kids && !sa.pad0) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: kids unpaired t=%zu tr=%d level=%d\n", t, tr, td.level); }      // a segment that would read the side buffer is not on the pair path
+                    if (kids && !self_slow && (sa.n_first + 8 > kid_rows || sb.n_first + 8 > kid_rows)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: 8-row run past the side buffer t=%zu tr=%d\n", t, tr); }
+                    if (kids && !sa.pad0 && !self_slow) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: kids unpaired t=%zu tr=%d level=%d\n", t, tr, td.level); }      // a segment that would read the side buffer is not on the pair path
                 }
             }
         }
-        if (pats.empty()) pats.assign(128, 0.0f);
+        if (pats.empty()) { pats.assign(128, 0.0f); pat_extra.assign(5, 0.0f); }
         if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "topo: %zu tiles, %zu patterns, kidsum %d\n", tiles.size(), pats.size() / 128, (int)kidsum_ok);
     }
     eg_graph* g = new eg_graph{};
@@ -419,6 +470,16 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                     patsq[(size_t)pi * 64 + h * 32 + sl * 4 + k] = outer ? 0.0f : (sl < 6 ? w : (w != 0.0f ? 1.0f : 0.0f));
                     if (outer) patsq[(size_t)pi * 64 + h * 32 + 7 * 4 + k] = w;
                 }
+    for (int pi = 0; pi < g->n_pats && !pat_extra.empty(); ++pi) {
+        const float* ex = &pat_extra[(size_t)pi * 5];
+        if (ex[0] == 0.0f) continue;
+        // diagonal segment: slots 3 / 4 = edge nodes of the row above / below (seg_wide.h SLOT_EDGE_U / SLOT_EDGE_D), laid out like
+        // slot 7: the left edge belongs to node 0 (k = 0 of h = 0), the right edge to node 7 (k = 3 of h = 1)
+        for (int h = 0; h < 2; ++h)
+            for (int k = 0; k < 4; ++k) { patsq[(size_t)pi * 64 + h * 32 + 3 * 4 + k] = 0.0f; patsq[(size_t)pi * 64 + h * 32 + 4 * 4 + k] = 0.0f; }
+        patsq[(size_t)pi * 64 + 0 * 32 + 3 * 4 + 0] = ex[1]; patsq[(size_t)pi * 64 + 1 * 32 + 3 * 4 + 3] = ex[2];
+        patsq[(size_t)pi * 64 + 0 * 32 + 4 * 4 + 0] = ex[3]; patsq[(size_t)pi * 64 + 1 * 32 + 4 * 4 + 3] = ex[4];
+    }
     // chained layers run the producer/consumer kernel, which keeps the pattern table in LDS beside its tile buffers
     const size_t ps_lds = (size_t)(4 * TILE * LDA + 16 + 64 + 2 * TILE + (pats.size() / 128) * 64 + 4 * C) * sizeof(float);   // incl. the fused-classifier tables
     g->kid_rows = (kidsum_ok && ps_lds <= 160 * 1024) ? kid_rows : 0;
@@ -440,6 +501,15 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
     if (e == hipSuccess) e = hipMemcpy(g->pats_dev, pats.data(), sizeof(float) * pats.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&g->patsq_dev, sizeof(float) * patsq.size());
     if (e == hipSuccess) e = hipMemcpy(g->patsq_dev, patsq.data(), sizeof(float) * patsq.size(), hipMemcpyHostToDevice);
+    if (any_diag) {
+        g->hybrid = 1;
+        g->nnz = (int64_t)h_colidx.size();
+        g->symmetric = 1;
+        if (e == hipSuccess) e = hipMalloc((void**)&g->rowptr, sizeof(int) * h_rowptr.size());
+        if (e == hipSuccess) e = hipMemcpy(g->rowptr, h_rowptr.data(), sizeof(int) * h_rowptr.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&g->colidx, sizeof(int) * (h_colidx.empty() ? 1 : h_colidx.size()));
+        if (e == hipSuccess && !h_colidx.empty()) e = hipMemcpy(g->colidx, h_colidx.data(), sizeof(int) * h_colidx.size(), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         if (g->segs_dev) (void)hipFree(g->segs_dev);
         if (g->pats_dev) (void)hipFree(g->pats_dev);
@@ -448,6 +518,8 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
         if (g->topo_dev) (void)hipFree(g->topo_dev);
         if (g->tiles_dev) (void)hipFree(g->tiles_dev);
         if (g->walk_counters) (void)hipFree(g->walk_counters);
+        if (g->rowptr) (void)hipFree(g->rowptr);
+        if (g->colidx) (void)hipFree(g->colidx);
         delete g;
         return set_error(EG_ERR_HIP, std::string("eg_topo_create: ") + hipGetErrorString(e));
     }

@@ -121,6 +121,74 @@ __device__ inline void segp_issue(const SegDesc& sa, const SegDesc& sb, const Ro
     for (int k = 0; k < 4; ++k) A.P[k] = ld_two_rows(xs, sa.par0 + k, sa.par0 + k);     // the same row in both halves
 }
 
+// ---- 'grid-diagonal' levels (8-neighbour grids: reference src/core/datasets.py:1469-1475, :1494-1500) --------------------------
+// A neighbour's weight d_j belongs to the SOURCE node, not to the (target, source) pair: a row scaled once by its own nodes'
+// d_j serves its three targets (the node below / above it and the two diagonal ones) unweighted.  So every row set -- the
+// pair's own two rows, the row above, the row below -- goes through LDS scaled, and a target adds the entries one to the
+// left, at and one to the right of its column ("sum3").  What lies outside the segment comes from the edge rows (one load per
+// row set: left edge in the lower half-wave, right edge in the upper), whose weights are zero where the grid ends.  Pattern
+// slots of a diagonal segment (graph.hip): SELF / UP / DOWN = d of the node itself / above / below, EDGE = own row's edge
+// nodes, slots 3 / 4 (LEFT / RIGHT on plain levels) = the edge nodes of the row above / below.
+constexpr int SLOT_EDGE_U = SLOT_LEFT, SLOT_EDGE_D = SLOT_RIGHT;
+constexpr int SEG_AUX_DIAG = 2;                       // SegDesc::aux bit 1: the segment's level is 'grid-diagonal'
+
+struct SegPairDiag { f32x4 LRu, LRd; };               // edge rows of the row above segment a / below segment b
+
+__device__ inline void segp_diag_issue(const SegDesc& sa, const SegDesc& sb, const RowSrc& xs, int last_row, SegPairDiag& E) {
+    const int ul = sa.up0 > 0 ? sa.up0 - 1 : 0, ur = sa.up0 + 8 < last_row ? sa.up0 + 8 : last_row;
+    const int dl = sb.down0 > 0 ? sb.down0 - 1 : 0, dr = sb.down0 + 8 < last_row ? sb.down0 + 8 : last_row;
+    E.LRu = ld_two_rows(xs, ul, ur);
+    E.LRd = ld_two_rows(xs, dl, dr);
+}
+
+// out[k] (+)= R'[c-1] + R'[c] + R'[c+1] for node c = 2k + h of an 8-node row set R scaled by w (R' = w R); the entries left of
+// node 0 / right of node 7 are the edge rows LR scaled by we (non-zero only in the half that holds that edge's target).
+// s_r: 8 LDS rows this wave may use for the set (LDS operations of one wave complete in order).
+template <bool ADD>
+__device__ inline void row_sum3(int lane, const f32x4 (&R)[4], const f32x4& w, const f32x4& LR, const f32x4& we, float* s_r, f32x4 (&out)[4]) {
+    const PairLane pl{lane >> 5, lane & 31};
+    float* row0 = s_r + 4 * pl.q;
+    float* rowh = row0 + pl.h * LDA;
+    f32x4 Rs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        Rs[k] = w[k] * R[k];
+        *reinterpret_cast<f32x4*>(rowh + 2 * k * LDA) = Rs[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float in_l = (float)pl.h, in_r = (float)(1 - pl.h);      // node 0 has no left, node 7 no right neighbour inside the segment
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x4 L = *reinterpret_cast<const f32x4*>(k == 0 ? row0 : rowh + (2 * k - 1) * LDA);
+        const f32x4 Rr = *reinterpret_cast<const f32x4*>(k == 3 ? row0 + 7 * LDA : rowh + (2 * k + 1) * LDA);
+        f32x4 t = Rs[k];
+        if (k == 0) t += in_l * L; else t += L;
+        if (k == 3) t += in_r * Rr; else t += Rr;
+        if (ADD) out[k] += t; else out[k] = t;
+    }
+    out[0] += we[0] * LR;
+    out[3] += we[3] * LR;
+}
+
+// both segments of a pair on a diagonal level: acc = sum over the 8 grid neighbours + self + parents (children follow)
+__device__ inline void segp_diag_rows(int lane, const float* wqa, const float* wqb, const SegPair& A, const SegPairDiag& E,
+                                      f32x4 (&acc0)[4], f32x4 (&acc1)[4], float* s_rows) {
+    // the pair's own rows serve both segments (own row + the row below for a, above for b): their sum T goes into acc0, the row
+    // below the pair is added to a copy (acc1), the row above to acc0 itself
+    row_sum3<false>(lane, A.Sa, quad_w(wqa, SLOT_SELF), A.LRa, quad_w(wqa, SLOT_EDGE), s_rows, acc0);
+    row_sum3<true>(lane, A.Sb, quad_w(wqb, SLOT_SELF), A.LRb, quad_w(wqb, SLOT_EDGE), s_rows + 8 * LDA, acc0);
+    const f32x4 pa = quad_w(wqa, SLOT_PARENT), pb = quad_w(wqb, SLOT_PARENT);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc1[k] = acc0[k] + pb[k] * A.P[k];
+        acc0[k] += pa[k] * A.P[k];
+    }
+    pin_acc4(acc0);
+    pin_acc4(acc1);
+    row_sum3<true>(lane, A.D, quad_w(wqb, SLOT_DOWN), E.LRd, quad_w(wqb, SLOT_EDGE_D), s_rows + 8 * LDA, acc1);
+    row_sum3<true>(lane, A.U, quad_w(wqa, SLOT_UP), E.LRu, quad_w(wqa, SLOT_EDGE_U), s_rows, acc0);
+}
+
 // Aux levels, chained layers: the children's contribution of node n is ONE row of the side buffer (row n; the previous
 // layer's epilogue summed dis[c] * h[c] over the four children), so the children are one more run of 8 rows per
 // segment, loaded once the main stage has freed its registers.

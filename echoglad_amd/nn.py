@@ -28,7 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .topology import TopologySpec, candidate_specs, commutative_edge_hash, get_topology
+from .topology import TopologySpec, candidate_specs, commutative_edge_hash, get_topology, graph_type_variants
 
 C = ops.C
 
@@ -42,12 +42,14 @@ _EXPECTED_HASH: Dict[tuple, Tuple[int, int]] = {}  # (spec, batch) -> (E_dir, di
 
 def _topo_graph(spec: TopologySpec, device) -> ops.Graph:
     device = torch.device(device)
+    diag_main = spec.main_graph_type == "grid-diagonal"
+    diag_aux = spec.aux_graph_type == "grid-diagonal" and not spec.use_main_graph_only
     key = (spec.frame_size, 0 if spec.use_main_graph_only else spec.num_aux_graphs, spec.use_main_graph_only,
-           spec.use_coordinate_graph and not spec.use_main_graph_only, device)
+           spec.use_coordinate_graph and not spec.use_main_graph_only, diag_main, diag_aux, device)
     g = _TOPO_GRAPHS.get(key)
     if g is None:
         g = ops.Graph.topo(spec.frame_size, spec.num_aux_graphs, spec.use_main_graph_only, spec.use_coordinate_graph,
-                           device=device)
+                           device=device, diag_main=diag_main, diag_aux=diag_aux)
         _TOPO_GRAPHS[key] = g
     return g
 
@@ -86,12 +88,16 @@ class GraphResolver:
 
     def _candidates(self, num_rows: int, n_edges: int):
         if self.spec is not None:
-            topo = get_topology(self.spec)
-            if topo.is_structured() and num_rows % topo.num_nodes == 0:
-                batch = num_rows // topo.num_nodes
-                if n_edges == batch * 2 * topo.num_undirected_edges:
-                    return [(self.spec, batch)]
-            return []
+            # the model's own static topology, with whichever graph types ('grid' / 'grid-diagonal' per level kind: dataset
+            # configuration, not a constructor argument of the model) give this edge count
+            out = []
+            for spec in graph_type_variants(self.spec):
+                topo = get_topology(spec)
+                if topo.is_structured() and num_rows % topo.num_nodes == 0:
+                    batch = num_rows // topo.num_nodes
+                    if n_edges == batch * 2 * topo.num_undirected_edges:
+                        out.append((spec, batch))
+            return out
         return candidate_specs(num_rows, n_edges)
 
     def resolve(self, edge_index: torch.Tensor, num_rows: int) -> Tuple[ops.Graph, int]:
@@ -781,7 +787,7 @@ class HierarchicalPatchModel(nn.Module):
         # (eg_gcn_layer_fwd_jk); where those do not cover the handle (CSR graphs, coordinate / connection nodes) the
         # layers run one by one and torch takes the maximum, as before
         jk_fused = (fused and self.jk is not None and graph.fused_classifier_ok and not self.use_coordinate_graph
-                    and os.environ.get("EG_JK_FUSED", "1") != "0")
+                    and not graph.hybrid and os.environ.get("EG_JK_FUSED", "1") != "0")
         fused = fused and (self.jk is None or jk_fused)
         if not fused and self._train_coord_fused_ok(node_coords):
             return self._forward_train_coord_fused(node_feats, graph, gb, B, node_coords)

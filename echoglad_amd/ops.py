@@ -58,6 +58,8 @@ class Graph:
         self.device = device
         # rows per frame of a child-sum side buffer (chained layers); 0 = not available for this handle
         self.kidsum_rows = int(_lib.load().eg_graph_kidsum_rows(handle)) if structured else 0
+        # a closed-form topology with 'grid-diagonal' levels: stencil in the producer/consumer kernel, per-frame CSR elsewhere
+        self.hybrid = False
         # the handle whose aggregation is A_hat^T (what a backward pass needs): the handle itself unless edge_index is directed
         self.bwd: "Graph" = self
 
@@ -65,7 +67,7 @@ class Graph:
     def topo(cls, frame_size: int, num_aux_graphs: int, use_main_graph_only: bool = False,
              use_coordinate_graph: bool = False, device=None, use_connection_nodes: bool = False, diag_main: bool = False,
              diag_aux: bool = False) -> "Graph":
-        """Implicit-stencil handle of the closed-form topology.  Connection nodes / 'grid-diagonal' levels raise
+        """Implicit-stencil handle of the closed-form topology ('grid' or 'grid-diagonal' levels).  Connection nodes raise
         (EG_ERR_UNSUPPORTED): those graphs run on a CSR handle (``Graph.csr``)."""
         lib = _lib.load()
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -74,7 +76,9 @@ class Graph:
             _lib.check(lib.eg_topo_create(frame_size, num_aux_graphs, int(use_main_graph_only),
                                           int(use_coordinate_graph), int(use_connection_nodes), int(diag_main), int(diag_aux),
                                           ct.byref(h)), "eg_topo_create")
-        return cls(h, True, int(lib.eg_graph_num_nodes(h)), device)
+        g = cls(h, True, int(lib.eg_graph_num_nodes(h)), device)
+        g.hybrid = bool(diag_main or (diag_aux and not use_main_graph_only))
+        return g
 
     @classmethod
     def csr(cls, edge_index: torch.Tensor, num_nodes: int) -> "Graph":

@@ -246,12 +246,9 @@ class HierTopology:
         return np.asarray(rows, dtype=np.int32)
 
     def is_structured(self) -> bool:
-        """True when the implicit-stencil kernels cover this graph: plain 4-neighbour
-        grids, no connection nodes, and a crop that is one contiguous run of the
-        last aux level (always the case with Python slices of a range)."""
-        s = self.spec
-        if s.main_graph_type != "grid" or s.aux_graph_type != "grid":
-            return False
+        """True when the implicit-stencil kernels cover this graph: 4-neighbour or
+        'grid-diagonal' (8-neighbour) grids, no connection nodes, and a crop that is one
+        contiguous run of the last aux level (always the case with Python slices of a range)."""
         if self.n_conn:
             return False
         return True
@@ -276,12 +273,20 @@ def candidate_specs(num_rows: int, num_directed_edges: int, max_frame: int = 409
         aux_nodes = 0 if main_only else sum(4 ** k for k in range(1, naux + 1))
         n = aux_nodes + F * F + n_coord
         for f in F[(n <= num_rows) & (num_rows % n == 0)]:
-            spec = TopologySpec(int(f), naux, main_only, n_coord > 0)
-            topo = HierTopology(spec)
-            batch = num_rows // topo.num_nodes
-            if 2 * batch * topo.count_undirected_edges() == num_directed_edges:
-                out.append((spec, batch))
+            for spec in graph_type_variants(TopologySpec(int(f), naux, main_only, n_coord > 0)):
+                topo = HierTopology(spec)
+                batch = num_rows // topo.num_nodes
+                if 2 * batch * topo.count_undirected_edges() == num_directed_edges:
+                    out.append((spec, batch))
     return out
+
+
+def graph_type_variants(spec: TopologySpec):
+    """The spec with every combination of 'grid' / 'grid-diagonal' levels (the graph TYPE is dataset configuration,
+    datasets.py:1441: a model is constructed without it and meets it only in the edge_index)."""
+    from dataclasses import replace
+    aux_types = ("grid",) if spec.use_main_graph_only else ("grid", "grid-diagonal")
+    return [replace(spec, main_graph_type=m, aux_graph_type=a) for m in ("grid", "grid-diagonal") for a in aux_types]
 
 
 def commutative_edge_hash(edge_index: np.ndarray) -> Tuple[int, int]:

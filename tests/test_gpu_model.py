@@ -81,9 +81,14 @@ def test_stack_vs_oracle_from_node_features(frame, naux, layers, batch, main_onl
 
 
 def test_generic_edge_index_falls_back_to_csr_kernel():
-    """grid-diagonal graphs are not the closed form the model implies -> CSR path, same answer."""
+    """A graph that is no closed form (here: the model's grid with 40 random extra edges) -> CSR path, same answer as the oracle.
+    ('grid-diagonal' graphs, the fallback's customers until round 3, are closed forms now: tests/test_gpu_diag.py.)"""
     hip, ref = model_pair(16, 3, 2, seed=8)
-    topo, ei, nt, bi = graph_tensors(16, 3, 2, main_type="grid-diagonal", aux_type="grid-diagonal")
+    topo, ei, nt, bi = graph_tensors(16, 3, 2)
+    rs = np.random.RandomState(5)
+    extra = torch.from_numpy(rs.randint(0, 2 * topo.num_nodes, (2, 40)).astype(np.int64))
+    extra = extra[:, extra[0] != extra[1]]
+    ei = torch.cat([ei, extra, extra.flip(0)], dim=1)
     feats = synthetic_node_feats(2 * topo.num_nodes, 128, seed=9)
     with torch.no_grad():
         want, _ = ref.forward_nodes(feats, ei, nt, 2)
