@@ -397,6 +397,20 @@ def make_cfg4():
     print("cfg4 train", float(loss), "fp64", float(loss_64), "logits ref err", float(out["train_logits_ref_err"]), flush=True)
 
 
+def make_unet_keys():
+    """state_dict keys and shapes of the reference's UNet variant (models.py:639-756, the class configs/default.yml names): what
+    echoglad_amd.examples.UNetNodeFeatureModel must register to load a reference checkpoint strict=True."""
+    # (encoder_embedding_dims must be truthy: models.py:652-653 overwrites a supplied list with the default and crashes on None)
+    m = RM.UNETHierarchicalPatchModel(encoder_embedding_dims=[1], frame_size=224, gnn_dropout_p=0.5, classifier_dropout_p=0.5, node_embedding_dim=128,
+                                      node_hidden_dim=128, num_output_channels=4, num_gnn_layers=3, num_aux_graphs=7,
+                                      gnn_jk_mode="last", classifier_hidden_dim=32, residual=True, use_coordinate_graph=True,
+                                      output_activation="logit", use_connection_nodes=False, use_main_graph_only=False)
+    keys = {k: list(v.shape) for k, v in m.state_dict().items()}
+    json.dump({"n_parameters": int(sum(p.numel() for p in m.parameters())), "state_dict": keys},
+              open(os.path.join(HERE, "unet_state_keys.json"), "w"), indent=0, sort_keys=True)
+    print("unet keys", len(keys))
+
+
 def make_mainonly():
     frame, naux, L, B = 16, 2, 3, 2
     ei, nt, n = reference_graph(frame, naux, True, False, False, "grid", "grid")
@@ -552,6 +566,8 @@ if __name__ == "__main__":
         make_labels()
     if "cfg4" in which:
         make_cfg4()
+    if "unet" in which or "models" in which:
+        make_unet_keys()
     if "decode" in which or "models" in which:
         make_decode(16, 3, 3, 11, "f16_a3")
         make_decode(30, 3, 2, 12, "f30_a3")

@@ -62,3 +62,25 @@ def test_collate_is_a_disjoint_union(coord):
         assert b1.node_coords.shape == (12, 2) and b1.node_coord_y.shape == (12, 2)
     else:
         assert not hasattr(b1, "node_coords")
+
+
+def test_unet_variant_example_registers_the_references_state_dict(golden_dir):
+    """echoglad_amd.examples.UNetNodeFeatureModel (INTEGRATION.md route A for the class configs/default.yml names) has the
+    state_dict of the reference's UNETHierarchicalPatchModel -- every key, every shape (tests/golden/unet_state_keys.json, dumped
+    from the reference class by make_golden.py) -- so a reference checkpoint loads strict=True (checkpointers.py:94-98)."""
+    import json
+    import os
+    from echoglad_amd.examples import UNetNodeFeatureModel
+    ref = json.load(open(os.path.join(golden_dir, "unet_state_keys.json")))
+    m = UNetNodeFeatureModel(frame_size=224, num_aux_graphs=7, node_embedding_dim=128, node_hidden_dim=128, classifier_hidden_dim=32,
+                             num_gnn_layers=3, output_activation="logit", use_coordinate_graph=True, gnn_dropout_p=0.5,
+                             classifier_dropout_p=0.5)
+    mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert mine == ref["state_dict"]
+    assert sum(p.numel() for p in m.parameters()) == ref["n_parameters"] == 8089074
+    # the decoder's maps are the graph's levels, coarse to fine (CPU: stock torch modules, no HIP involved)
+    import torch
+    with torch.no_grad():
+        maps = m.eval().decoder_maps(torch.zeros(1, 4, 224, 224))
+    assert [tuple(t.shape[1:]) for t in maps] == [(512, 2, 2), (256, 4, 4), (128, 8, 8), (64, 16, 16), (32, 32, 32), (16, 64, 64),
+                                                  (8, 128, 128), (4, 224, 224)]

@@ -98,3 +98,43 @@ def test_conv_pack_rejects_bad_arguments():
         ops.conv1x1_relu_pack_levels([f], [torch.zeros(64, 8, device=DEV)], [None], 1, 16)     # not 128 output channels
     with pytest.raises(RuntimeError):
         ops.conv1x1_relu_pack_levels([torch.zeros(1, 8, 8, 8, device=DEV)], [w], [None], 1, 16)     # does not fit the frame's rows
+
+
+@pytest.mark.parametrize("frame,naux,coord", [(32, 4, False), (64, 5, True), (224, 7, True)])
+def test_unet_variant_example_end_to_end(frame, naux, coord):
+    """INTEGRATION.md route A for the reference's UNet variant (echoglad_amd/examples.py): the subclass's create_node_pixels
+    (stock torch front-end + ONE fused launch for the 1x1 convolutions, ReLU and the node-major packing) gives the reference
+    tail's node features, and forward() runs frame -> logits on the HIP path (eval and one train step)."""
+    from echoglad_amd.examples import UNetNodeFeatureModel, reference_tail
+    from echoglad_amd.topology import HierTopology, TopologySpec
+    from fixtures_util import initial_coords
+    B = 2
+    widths = [2 ** g for g in range(naux, 0, -1)]
+    dims = [8 * 2 ** i for i in range(naux)]
+    torch.manual_seed(3)
+    model = UNetNodeFeatureModel(encoder_embedding_widths=widths, encoder_embedding_dims=dims, frame_size=frame, num_aux_graphs=naux,
+                                 node_embedding_dim=128, node_hidden_dim=128, classifier_hidden_dim=32, num_gnn_layers=3,
+                                 output_activation="logit", use_coordinate_graph=coord, gnn_dropout_p=0.0,
+                                 classifier_dropout_p=0.0).to(DEV).eval()
+    topo = HierTopology(TopologySpec(frame, naux, False, coord))
+    ei = torch.from_numpy(topo.batched_edge_index(B)).to(DEV)
+    frames = torch.randn(B, dims[0] // 2, frame, frame, device=DEV)
+    c0 = initial_coords(B, frame).to(DEV) if coord else None
+    with torch.no_grad():
+        maps = model.decoder_maps(frames)
+        got = model.create_node_pixels(frames, B, None if c0 is None else c0.view(B, 4, 2))
+        want = reference_tail(model, maps, B).view(B, -1, 128)
+        n_grid = want.shape[1]
+        assert float((got.view(B, topo.num_nodes, 128)[:, :n_grid] - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+        logits, coords = model(x=frames, node_coords=c0, edge_index=ei, node_type=None, batch_idx=None)
+        again, _ = model.forward_nodes(got, ei, B, None if c0 is None else c0.clone())
+    assert logits.shape == (B * topo.num_valid_nodes, 4) and torch.isfinite(logits).all()
+    assert torch.equal(logits, again)
+    if frame > 64:
+        return
+    model.train()
+    logits, coords = model(x=frames, node_coords=None if c0 is None else c0.clone(), edge_index=ei, node_type=None, batch_idx=None)
+    ((logits ** 2).mean() + (0 if coords is None else (coords ** 2).mean() * 1e-3)).backward()
+    missing = [k for k, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing
+    assert float(model.linears[0].weight.grad.abs().max()) > 0 and float(model.down_convs[0].conv1.weight.grad.abs().max()) > 0

@@ -33,12 +33,19 @@ def test_reducer_hooks_on_rccl_world_1_leave_the_gradients_bit_identical():
 
 def test_bench_train_step_with_the_reducer_attached_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--batch", "4", "--steps", "3", "--warmup", "2",
-                        "--force-collective"], capture_output=True, text=True, timeout=900, env=_child_env())
+                        "--force-collective", "--bucket-kb", "64"], capture_output=True, text=True, timeout=900, env=_child_env())
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     dist = d["distributed"]
     assert dist["backend"] == "nccl" and dist["world_size"] == 1 and dist["allreduce_check"] is True
-    assert dist["gradient_buckets"] >= 1 and dist["gradient_collectives_issued"] == dist["gradient_buckets"] * 5      # 2 warm-up + 3 timed steps
+    # 2 warm-up + 3 timed steps + 3 steps on this rank's own clock (the per-rank diagnostics)
+    assert dist["gradient_buckets"] >= 1 and dist["gradient_collectives_issued"] == dist["gradient_buckets"] * 8
+    # what the first multi-GPU run will be read by: collectives per step and their bytes, per-rank step time, time behind the collectives
+    gc = dist["gradient_collectives"]
+    assert gc["collectives_per_step"] == dist["gradient_buckets"] == len(gc["bytes_per_collective"]) and sum(gc["bytes_per_collective"]) == gc["bytes_per_step"] > 250_000
+    pr = dist["per_rank"]
+    assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["ms_per_step_alone"] > 0 and pr[0]["ms_in_finish_behind_collectives"] is not None
+    assert 0 <= pr[0]["ms_in_finish_behind_collectives"] < pr[0]["ms_per_step_alone"]
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["final_loss"] == d["final_loss"]                                  # (not NaN)
 
 
