@@ -129,7 +129,8 @@ def test_unet_variant_example_end_to_end(frame, naux, coord):
         logits, coords = model(x=frames, node_coords=c0, edge_index=ei, node_type=None, batch_idx=None)
         again, _ = model.forward_nodes(got, ei, B, None if c0 is None else c0.clone())
     assert logits.shape == (B * topo.num_valid_nodes, 4) and torch.isfinite(logits).all()
-    assert torch.equal(logits, again)
+    # (not bit-equal: the second forward re-runs the torch front-end, and MIOpen may pick another convolution algorithm on a later call)
+    assert float((logits - again).abs().max()) < 1e-4 * max(1.0, float(again.abs().max()))
     if frame > 64:
         return
     model.train()
