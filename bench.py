@@ -106,12 +106,12 @@ def spawn_ranks(n: int) -> int:
 # ---------------------------------------------------------------------------------------------------------------------
 # models / workloads
 # ---------------------------------------------------------------------------------------------------------------------
-def model_kwargs(frame, naux, layers, main_only=False, coord=False):
+def model_kwargs(frame, naux, layers, main_only=False, coord=False, conn=False):
     drop = float(os.environ.get("EG_BENCH_DROPOUT", "0.5"))          # diagnostic knob; the reported workloads use 0.5
     return dict(frame_size=frame, gnn_dropout_p=drop, classifier_dropout_p=drop, node_embedding_dim=C,
                 node_hidden_dim=C, num_output_channels=4, num_gnn_layers=layers, num_aux_graphs=naux,
                 gnn_jk_mode="last", classifier_hidden_dim=32, residual=True, use_coordinate_graph=coord,
-                output_activation="logit", use_main_graph_only=main_only)
+                output_activation="logit", use_main_graph_only=main_only, use_connection_nodes=conn)
 
 
 def build_model(kw, device, train=False):
@@ -129,14 +129,14 @@ def stack_work(topo, layers):
     return n * (layers * 1024 + 528), n * (layers * 2 * C * C + 36992) + layers * (e_dir + n) * 2 * C
 
 
-def infer_workload(frame, naux, layers, main_only, B, device, rank, hip_graph=True, graph_type="grid"):
+def infer_workload(frame, naux, layers, main_only, B, device, rank, hip_graph=True, graph_type="grid", conn=False):
     import torch
     from echoglad_amd.topology import TopologySpec, get_topology
     from echoglad_amd.synthetic import synthetic_node_feats
-    kw = model_kwargs(frame, naux, layers, main_only)
+    kw = model_kwargs(frame, naux, layers, main_only, conn=conn)
     model = build_model(kw, device)
     model.enable_hip_graph(hip_graph)
-    topo = get_topology(TopologySpec(frame, naux, main_only, False, False, graph_type, graph_type))
+    topo = get_topology(TopologySpec(frame, naux, main_only, False, conn, graph_type, graph_type))
     # this rank's shard of the global batch: frames [rank*B, (rank+1)*B) — synthetic N(0,1) node features
     feats = synthetic_node_feats(B * topo.num_nodes, C, seed=200 + rank).to(device)
     edge_index = torch.from_numpy(topo.batched_edge_index(B)).to(device)
@@ -481,6 +481,22 @@ def other_configs(args, device):
         del model, feats, ei, step
     except Exception as ex:
         out["cfg2_diagonal"] = {"workload": what, "error": repr(ex)}
+    gc.collect()
+    torch.cuda.empty_cache()
+    what = ("configs[1]'s shape with use_connection_nodes=True (datasets.py:1450-1456, :1512-1515: 8 connection nodes per frame, each "
+            "wired to a whole aux level), batch 8, eval: level sums by a pre-pass, then the stencil kernel (round 3: CSR fallback)")
+    try:
+        model, kw, topo, feats, ei, step = infer_workload(224, 7, args.layers, False, 8, device, 0, conn=True)
+        ms = time_steps(step, iters=20, warm=5)
+        graph, _ = model._resolver.resolve(ei, feats.shape[0])
+        sb, sf = stack_work(topo, args.layers)
+        fps = 8 / (ms * 1e-3)
+        out["cfg2_connection_nodes"] = {"workload": what, "ms_per_step": round(ms, 4), "frames_s": round(fps, 1),
+                                        "mfma_frac": round(fps * sf / 1e12 / PEAK_F32_MFMA_TF, 4),
+                                        "hbm_frac": round(fps * sb / 1e9 / PEAK_HBM_GBS, 4), "stencil_handle": bool(graph.structured)}
+        del model, feats, ei, step
+    except Exception as ex:
+        out["cfg2_connection_nodes"] = {"workload": what, "error": repr(ex)}
     gc.collect()
     torch.cuda.empty_cache()
     what = ("configs[1] through the GENERIC path: the same 224x224 / 7-aux-level batch of 8 with its edge_index turned into a CSR "

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <mutex>
 #include <string>
 
 #include "../../include/echoglad_hip.h"
@@ -43,17 +44,19 @@ struct TileDesc {
     int level, r0, c0, nrows, ncols, pad0, pad1, pad2;
 };
 
-enum { KIND_AUX = 0, KIND_MAIN = 1, KIND_COORD = 2 };      // LevelDesc::kind
+enum { KIND_AUX = 0, KIND_MAIN = 1, KIND_COORD = 2, KIND_CONN = 3 };      // LevelDesc::kind (CONN: the connection nodes' pseudo-level)
 
 // Precomputed (host, at handle creation) description of one 8-node segment = patch row tr of a patch:
 // everything the aggregation needs that does not depend on the features.  One s_load_dwordx16 per segment.
 struct SegDesc {
-    int n_first, cnt, mode;      // first node id, nodes in the segment, 0 none / 1 fast (runs) / 2 per-node slow path
+    int n_first, cnt, mode;      // first node id, nodes in the segment, 0 none / 1 fast (runs) / 2 per-node slow path /
+                                 // 3 connection nodes: the aggregated rows come precomputed (conn.hip)
     int pat;                     // index into the weight-pattern table (128 floats per pattern: 64 wa + 64 wb)
     int up0, down0, par0;        // first row of the 8 rows above / below, of the 4 parent rows (clamped into the frame)
     int left, right;             // the two edge rows (clamped)
     int c0, c1, c2, c3;          // child runs: rows 2r cols 0-7 / 8-15 of the segment's children, rows 2r+1 likewise (aux)
-    int aux;                     // 1 on aux levels (children exist as slots)
+    int aux;                     // bit 0: aux level (children exist as slots); bit 1: 'grid-diagonal' level; bits 2..: 1 + the
+                                 // connection node wired to every node of this level (0: none)
     int pad0;                    // patch row 2p only: rows 2p and 2p+1 can be aggregated as a pair (shared rows)
     int pad1;                    // patch row 2p only: number of parents whose 4 children are columns 2j, 2j+1 of rows 2p, 2p+1
 };
@@ -66,6 +69,8 @@ struct Topo {
     int n_levels;            // aux levels + 1
     int n_aux;               // 0 when use_main_graph_only
     int frame;               // F
+    int n_conn;              // connection nodes at the head of every frame (naux + 1 with use_connection_nodes, else 0): node g - 1
+                             // is wired to every node of aux level g, g = 1 .. naux - 1, and to the other connection nodes
     int diag_main, diag_aux; // 'grid-diagonal' main grid / aux levels (8-neighbour grids, datasets.py:1469-1475, :1494-1500)
     int crop0, ncrop;        // run of rows/cols of the last aux level wired to the main grid
     int coord_base;          // first coordinate node id (== n_nodes when there are none)
@@ -203,8 +208,18 @@ struct eg_graph {
     int n_pats;
     int kid_rows;             // rows per frame of the child-sum side buffer (= aux nodes), 0 when the topology does not qualify
     int hybrid;               // 1: a closed-form topology whose stencil only the producer/consumer kernel implements ('grid-diagonal'
-                              //    levels): rowptr / colidx then hold the CSR of ONE frame for every other path (symmetric kernel,
-                              //    eg_gcn_aggregate, the node-by-node path of ragged segments)
+                              //    levels, connection nodes): rowptr / colidx then hold the CSR of ONE frame for every other path
+                              //    (symmetric kernel, eg_gcn_aggregate, the node-by-node path of ragged segments)
+    // connection nodes (conn.hip): per-launch scratch, one slice per slot of the queue ring -- level sums in chunks, then per frame
+    // the connection nodes' aggregated rows and their (deg + 1)^-1/2-scaled feature rows
+    int n_conn;               // connection nodes per frame
+    int conn_chunks;          // chunks of <= 256 rows the hub-wired levels are cut into (per frame)
+    int* conn_table;          // device [conn_chunks][4] = {level index, first row, rows, 0}
+    // device [QUEUE_SLOTS][conn_cap][conn_chunks + 2 n_conn][128]; grown (under conn_mutex, after a device synchronisation) the
+    // first time a launch brings more frames than it holds -- the one place a launch may allocate, once per new maximum
+    mutable float* conn_scratch;
+    mutable int conn_cap;
+    mutable std::mutex conn_mutex;
     int flat;                 // 1: a single grid level (use_main_graph_only): no parents, no children; the producer/consumer
                               //    kernel needs no child sums there and is the default layer kernel when its tables fit LDS
     int n_tiles;

@@ -30,6 +30,10 @@ struct PsDims {
     float* stats_partial;
     int static_walk;
     const float* res;  // MODE 2: residual rows (has_res is set; the stash holds THESE rows, not the input's)
+    // connection nodes (DIAG instantiations; conn.hip): this launch's slice of the handle's scratch, floats per frame in it, and the
+    // offsets of the connection nodes' aggregated / scaled rows inside a frame's part
+    const float* conn;
+    int conn_stride, conn_agg, conn_scaled, n_conn;
 };
 
 // Static walk: blockIdx % 8 labels the chunk of the tile order (round-robin dispatch puts those workgroups on one XCD: a
@@ -653,6 +657,10 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 SegPairDiag DE;
                 const bool diag = DIAG && (sd0.aux & SEG_AUX_DIAG);          // uniform
                 if (diag) segp_diag_issue(sd0, sd1, xs, a.n_per_frame - 1, DE);
+                const int hub = DIAG ? (sd0.aux >> 2) - 1 : -1;             // uniform: the connection node of this level, or none
+                f32x4 HS = {0.f, 0.f, 0.f, 0.f};
+                if (DIAG && hub >= 0)                                       // its d-scaled row, the same in both half-waves
+                    HS = ld_two_rows(row_src(a.conn + (size_t)frame * a.conn_stride + a.conn_scaled, a.n_conn * (C * 4), lane), hub, hub);
                 // the child-sum rows travel with the first batch: issued after the main stage they cost the aux tiles a second,
                 // fully exposed memory round trip (the producers do most of their work after the consumers' MFMA chain has ended,
                 // DESIGN 5.22)
@@ -692,6 +700,10 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     segw_rows(lane, wqa, A.Sa, A.LRa, A.U, A.Sb, A.P, acc0, s_t, 16 * p);
                     segw_rows(lane, wqb, A.Sb, A.LRb, A.Sa, A.D, A.P, acc1, s_t, 16 * p + 8);
                 }
+                if (DIAG && hub >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { acc0[k] += HS; acc1[k] += HS; }
+                }
                 pin_acc4(acc0);
                 pin_acc4(acc1);                                     // the 40 main-stage registers are dead from here on
                 __builtin_amdgcn_sched_barrier(0);
@@ -729,10 +741,12 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
 #pragma unroll 1
                 for (int e = 0; e < 2; ++e) {
                     const int n0 = e ? sd1.n_first : sd0.n_first, cnt = e ? sd1.cnt : sd0.cnt;
+                    const bool given = DIAG && (e ? sd1.mode : sd0.mode) == 3;      // connection nodes: rows aggregated by the pre-pass
                     const int rl = 16 * p + 8 * e;
 #pragma unroll 1
                     for (int u = 0; u < cnt; ++u) {
-                        const f32x2 av = DIAG ? agg_csr(xf, dis, rowptr, colidx, n0 + u, lane) : agg_stencil(T, xf, dis, n0 + u, lane);
+                        const f32x2 av = given ? load_row2(a.conn + (size_t)frame * a.conn_stride + a.conn_agg, n0 + u, lane)
+                                               : (DIAG ? agg_csr(xf, dis, rowptr, colidx, n0 + u, lane) : agg_stencil(T, xf, dis, n0 + u, lane));
                         *reinterpret_cast<f32x2*>(&s_a[(rl + u) * LDA + 2 * lane]) = av;
                         if (TRAIN && a.agg_out) *reinterpret_cast<f32x2*>(a.agg_out + ((size_t)frame * a.n_per_frame + n0 + u) * C + 2 * lane) = av;
                         if (s_x) *reinterpret_cast<f32x2*>(&s_x[(rl + u) * LDA + 2 * lane]) =
@@ -782,6 +796,8 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
 }  // namespace eg
 
 using namespace eg;
+
+int eg_launch_conn_prepass(const eg_graph* g, int batch, const float* x, int slot, hipStream_t stream, const float** base);
 
 // Used by eg_gcn_layer_fwd (gcn_layer.hip) for topology handles when the residual is NULL or x itself.
 // Returns EG_ERR_UNSUPPORTED when the caller should fall back to the symmetric kernel.
@@ -837,6 +853,16 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         if (rc != EG_OK) return rc == EG_ERR_UNSUPPORTED ? EG_ERR_RING : rc;
     }
     EG_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
+    if (g->n_conn > 0) {                                          // connection nodes: level sums of THIS launch's input first (conn.hip)
+        const float* slice = nullptr;
+        const int rc = eg_launch_conn_prepass(g, batch, x, slot, stream, &slice);
+        if (rc != EG_OK) return rc;                               // (EG_ERR_UNSUPPORTED: more frames than the scratch holds -> the caller's other kernel)
+        a.conn = slice;
+        a.conn_stride = (g->conn_chunks + 2 * g->n_conn) * C;
+        a.conn_agg = g->conn_chunks * C;
+        a.conn_scaled = (g->conn_chunks + g->n_conn) * C;
+        a.n_conn = g->n_conn;
+    }
     long long grid = n_tiles < 256 ? n_tiles : g->knobs.ps_grid;      // one persistent workgroup per CU
     const ClsArgs none{};
     auto launch = [&](auto kernel) {

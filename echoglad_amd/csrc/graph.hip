@@ -112,12 +112,13 @@ static inline void py_slice(int len, int start, int stop, int& lo, int& hi) {
     if (hi < lo) hi = lo;
 }
 
-static int build_topo(int frame, int naux, int main_only, int coord_nodes, int diag_main, int diag_aux, Topo& T) {
+static int build_topo(int frame, int naux, int main_only, int coord_nodes, int conn_nodes, int diag_main, int diag_aux, Topo& T) {
     if (frame < 2 || frame > 4096) return set_error(EG_ERR_ARG, "frame must be in [2, 4096]");
     if (!main_only && (naux < 1 || naux + 1 > MAX_LEVELS)) return set_error(EG_ERR_ARG, "naux out of range");
     T = Topo{};
-    int nid = 0;
     T.n_aux = main_only ? 0 : naux;
+    T.n_conn = (!main_only && conn_nodes) ? naux + 1 : 0;     // datasets.py:1450-1456: only inside `if not use_main_graph_only`
+    int nid = T.n_conn;
     T.diag_main = diag_main ? 1 : 0;
     T.diag_aux = (!main_only && diag_aux) ? 1 : 0;
     for (int k = 1; k <= T.n_aux; ++k) {
@@ -168,6 +169,13 @@ static int build_topo(int frame, int naux, int main_only, int coord_nodes, int d
         LevelDesc& d = T.desc[T.n_levels];
         d = LevelDesc{};
         d.base = T.coord_base; d.end = T.n_nodes; d.side = 4; d.kind = 2;
+    }
+    if (T.n_conn > 0) {                            // the connection nodes' pseudo-level, 8 nodes per (pseudo) row
+        if (T.n_desc + 1 > MAX_LEVELS + 1) return set_error(EG_ERR_ARG, "too many levels");
+        LevelDesc& d = T.desc[T.n_desc];
+        d = LevelDesc{};
+        d.base = 0; d.end = T.n_conn; d.side = 8; d.kind = KIND_CONN;
+        T.n_desc += 1;
     }
     return EG_OK;
 }
@@ -239,16 +247,16 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                    eg_graph** out) {
     if (!out) return set_error(EG_ERR_ARG, "out is NULL");
     *out = nullptr;
-    if (conn_nodes)
-        return set_error(EG_ERR_UNSUPPORTED, "connection nodes have no implicit-stencil tables: build the graph with eg_csr_create");
     Topo T;
-    int rc = build_topo(frame, naux, main_only, coord_nodes, diag_main, diag_aux, T);
+    int rc = build_topo(frame, naux, main_only, coord_nodes, conn_nodes, diag_main, diag_aux, T);
     if (rc != EG_OK) return rc;
-    const bool any_diag = T.diag_main || T.diag_aux;
+    const bool any_diag = T.diag_main || T.diag_aux || T.n_conn > 0;      // (any topology whose stencil lives in the producer/consumer kernel only)
+    // connection node wired to every node of level l (datasets.py:1512-1515: node g - 1 <-> aux level g, g = 1 .. naux - 1), or -1
+    auto hub_of_level = [&](int l) { return (T.n_conn > 0 && l <= T.n_aux - 2) ? l : -1; };
     // level / position of a grid node, and whether its level is 'grid-diagonal'
     auto level_diag = [&](int l) { return l == T.n_levels - 1 ? T.diag_main != 0 : T.diag_aux != 0; };
     auto diag_ids = [&](int n, int (&out)[4]) -> int {          // the up-to-4 diagonal neighbours of node n (datasets.py:1469-1475)
-        if (n >= T.coord_base) return 0;
+        if (n >= T.coord_base || n < T.n_conn) return 0;
         const int l = level_of(T, n);
         if (!level_diag(l)) return 0;
         const int side = T.side[l], idx = n - T.base[l], r = idx / side, c = idx - r * side;
@@ -258,12 +266,36 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                 if (r + dr >= 0 && r + dr < side && c + dc >= 0 && c + dc < side) out[k++] = n + dr * side + dc;
         return k;
     };
-    std::vector<float> dis(T.n_nodes);
+    // every neighbour of node n (no self loop), sorted: grid stencil + diagonals + the level's connection node; connection nodes:
+    // the other connection nodes + every node of their level
     Nbrs nb;
-    for (int n = 0; n < T.n_nodes; ++n) {
+    auto full_row = [&](int n, std::vector<int>& row) {
+        row.clear();
+        if (n < T.n_conn) {
+            for (int h = 0; h < T.n_conn; ++h) if (h != n) row.push_back(h);
+            if (n <= T.n_aux - 2)
+                for (int j = T.base[n]; j < T.base[n + 1]; ++j) row.push_back(j);
+            return;
+        }
         neighbours(T, n, nb);
+        for (int sl = 1; sl < nb.count; ++sl)
+            if (nb.valid[sl]) row.push_back(nb.id[sl]);
         int dg[4];
-        dis[n] = (float)(1.0 / std::sqrt((double)(nb.degree + diag_ids(n, dg) + 1)));
+        const int nd = diag_ids(n, dg);
+        row.insert(row.end(), dg, dg + nd);
+        if (n < T.coord_base) {
+            const int hub = hub_of_level(level_of(T, n));
+            if (hub >= 0) row.push_back(hub);
+        }
+        std::sort(row.begin(), row.end());
+    };
+    std::vector<float> dis(T.n_nodes);
+    {
+        std::vector<int> row;
+        for (int n = 0; n < T.n_nodes; ++n) {
+            full_row(n, row);
+            dis[n] = (float)(1.0 / std::sqrt((double)(row.size() + 1)));
+        }
     }
     // 'grid-diagonal' handles also carry the CSR of one frame (sorted by target, then source): every path but the
     // producer/consumer kernel's stencil reads it (common.h eg_graph::hybrid)
@@ -272,14 +304,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
         h_rowptr.assign((size_t)T.n_nodes + 1, 0);
         std::vector<int> row;
         for (int n = 0; n < T.n_nodes; ++n) {
-            neighbours(T, n, nb);
-            row.clear();
-            for (int sl = 1; sl < nb.count; ++sl)
-                if (nb.valid[sl]) row.push_back(nb.id[sl]);
-            int dg[4];
-            const int nd = diag_ids(n, dg);
-            row.insert(row.end(), dg, dg + nd);
-            std::sort(row.begin(), row.end());
+            full_row(n, row);
             h_colidx.insert(h_colidx.end(), row.begin(), row.end());
             h_rowptr[(size_t)n + 1] = (int)h_colidx.size();
         }
@@ -340,10 +365,12 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                             if (ty < ts && tx < ts && !seen[l][(size_t)ty * ts + tx]) { seen[l][(size_t)ty * ts + tx] = 1; push(l, ty, tx); }
                         }
         }
-        if (T.n_desc > T.n_levels) {
+        if (T.coord_base < T.n_nodes) {
             const LevelDesc& d = T.desc[T.n_levels];
             tiles.push_back(TileDesc{T.n_levels, 0, 0, 1, d.end - d.base, 0, 0, 0});
         }
+        for (int h0 = 0; h0 < T.n_conn; h0 += 8)           // connection nodes: 8 per pseudo-tile (one segment each)
+            tiles.push_back(TileDesc{T.n_desc - 1, h0 / 8, 0, 1, T.n_conn - h0 < 8 ? T.n_conn - h0 : 8, 0, 0, 0});
     }
     // Per-segment descriptors (8 per patch) and the table of distinct weight patterns.  A pattern is the 64 + 64
     // lane weights of a segment: lane (u, s) -> valid(slot s of node u) ? (deg + 1)^-1/2 of that neighbour : 0.
@@ -368,20 +395,21 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                 sd.n_first = d.base + (td.r0 + tr) * d.side + td.c0;
                 sd.cnt = tr < td.nrows ? td.ncols : 0;
                 const int idx = sd.n_first - d.base;
-                const int r = d.kind == KIND_COORD ? 0 : idx / d.side;
+                const bool grid = d.kind == KIND_AUX || d.kind == KIND_MAIN;       // (not the coordinate / connection pseudo-levels)
+                const int r = grid ? idx / d.side : 0;
                 const int c0 = idx - r * d.side;
                 const int cb = d.cbase + 2 * (r - d.clo) * d.cside + 2 * (c0 - d.clo);
                 const bool kids = d.kind == KIND_AUX && r >= d.clo && r < d.chi && c0 < d.chi && c0 + 8 > d.clo;   // some node of the segment has children
                 // per-node scalar path: coordinate K4, and segments so close to the end of the frame that a run of
                 // 8 rows (self / below / children) would have to be clamped while some of its rows are real neighbours
                 // (the rows below the LAST grid row are no neighbours: their clamped run carries weight 0)
-                const bool below = d.kind != KIND_COORD && r < d.side - 1;
-                const bool ldiag = d.kind != KIND_COORD && level_diag(td.level);
+                const bool below = grid && r < d.side - 1;
+                const bool ldiag = grid && level_diag(td.level);
                 // (a 'grid-diagonal' segment takes the run path only when it is a whole 8-node run: seg_wide.h row_sum3)
-                const bool slow = d.kind == KIND_COORD || sd.n_first + 8 > n_frame || (below && sd.n_first + d.side + 8 > n_frame) ||
+                const bool slow = !grid || sd.n_first + 8 > n_frame || (below && sd.n_first + d.side + 8 > n_frame) ||
                                   (kids && (cb < 0 || cb + d.cside + 16 > n_frame)) || (ldiag && sd.cnt != 8);
-                sd.mode = sd.cnt == 0 ? 0 : (slow ? 2 : 1);
-                sd.aux = (d.kind == KIND_AUX ? 1 : 0) | (ldiag ? 2 : 0);
+                sd.mode = sd.cnt == 0 ? 0 : (d.kind == KIND_CONN ? 3 : (slow ? 2 : 1));
+                sd.aux = (d.kind == KIND_AUX ? 1 : 0) | (ldiag ? 2 : 0) | (d.kind == KIND_AUX ? (hub_of_level(td.level) + 1) << 2 : 0);
                 if (sd.mode == 1) {
                     sd.up0 = clampi(sd.n_first - d.side, 0, hi8);
                     sd.down0 = clampi(sd.n_first + d.side, 0, hi8);
@@ -424,7 +452,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                           sb.up0 == sa.n_first && sa.cnt == sb.cnt;
                 // pad1 = number of parents whose four children are exactly columns 2j, 2j+1 of this pair of rows
                 // (child-sum side buffer, gcn_layer_ps.hip).  Anything irregular switches the side buffer off.
-                if (sa.cnt > 0 && d.kind != KIND_COORD) {
+                if (sa.cnt > 0 && (d.kind == KIND_AUX || d.kind == KIND_MAIN)) {
                     const int idx = sa.n_first - d.base, r = idx / d.side, c0 = idx - r * d.side;
                     int npar = 0;
                     if (r < d.plim) {
@@ -501,6 +529,24 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
     if (e == hipSuccess) e = hipMemcpy(g->pats_dev, pats.data(), sizeof(float) * pats.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&g->patsq_dev, sizeof(float) * patsq.size());
     if (e == hipSuccess) e = hipMemcpy(g->patsq_dev, patsq.data(), sizeof(float) * patsq.size(), hipMemcpyHostToDevice);
+    if (T.n_conn > 0) {
+        // chunks of <= 256 rows over the levels that hang on a connection node (levels 0 .. naux - 2): the pre-pass (conn.hip) sums
+        // (deg + 1)^-1/2 x over a chunk per workgroup, then over a level's chunks in order
+        std::vector<int> table;
+        for (int l = 0; l <= T.n_aux - 2; ++l)
+            for (int r0 = T.base[l]; r0 < T.base[l + 1]; r0 += 256) {
+                const int rows = T.base[l + 1] - r0 < 256 ? T.base[l + 1] - r0 : 256;
+                table.insert(table.end(), {l, r0, rows, 0});
+            }
+        g->n_conn = T.n_conn;
+        g->conn_chunks = (int)(table.size() / 4);
+        g->conn_cap = env_int("EG_CONN_BATCH", 8);        // frames the scratch holds at first (it grows: conn.hip)
+        if (g->conn_cap < 1) g->conn_cap = 1;
+        const size_t per_frame = (size_t)(g->conn_chunks + 2 * T.n_conn) * C;
+        if (e == hipSuccess) e = hipMalloc((void**)&g->conn_table, sizeof(int) * (table.empty() ? 4 : table.size()));
+        if (e == hipSuccess && !table.empty()) e = hipMemcpy(g->conn_table, table.data(), sizeof(int) * table.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&g->conn_scratch, sizeof(float) * per_frame * g->conn_cap * QUEUE_SLOTS);
+    }
     if (any_diag) {
         g->hybrid = 1;
         g->nnz = (int64_t)h_colidx.size();
@@ -520,6 +566,8 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
         if (g->walk_counters) (void)hipFree(g->walk_counters);
         if (g->rowptr) (void)hipFree(g->rowptr);
         if (g->colidx) (void)hipFree(g->colidx);
+        if (g->conn_table) (void)hipFree(g->conn_table);
+        if (g->conn_scratch) (void)hipFree(g->conn_scratch);
         delete g;
         return set_error(EG_ERR_HIP, std::string("eg_topo_create: ") + hipGetErrorString(e));
     }
@@ -655,6 +703,8 @@ int eg_graph_destroy(eg_graph* g) {
         if (g->slot_event[i]) (void)hipEventDestroy(g->slot_event[i]);
     if (g->rowptr) (void)hipFree(g->rowptr);
     if (g->colidx) (void)hipFree(g->colidx);
+    if (g->conn_table) (void)hipFree(g->conn_table);
+    if (g->conn_scratch) (void)hipFree(g->conn_scratch);
     delete g;
     return EG_OK;
 }

@@ -44,12 +44,13 @@ def _topo_graph(spec: TopologySpec, device) -> ops.Graph:
     device = torch.device(device)
     diag_main = spec.main_graph_type == "grid-diagonal"
     diag_aux = spec.aux_graph_type == "grid-diagonal" and not spec.use_main_graph_only
+    conn = spec.use_connection_nodes and not spec.use_main_graph_only
     key = (spec.frame_size, 0 if spec.use_main_graph_only else spec.num_aux_graphs, spec.use_main_graph_only,
-           spec.use_coordinate_graph and not spec.use_main_graph_only, diag_main, diag_aux, device)
+           spec.use_coordinate_graph and not spec.use_main_graph_only, conn, diag_main, diag_aux, device)
     g = _TOPO_GRAPHS.get(key)
     if g is None:
         g = ops.Graph.topo(spec.frame_size, spec.num_aux_graphs, spec.use_main_graph_only, spec.use_coordinate_graph,
-                           device=device, diag_main=diag_main, diag_aux=diag_aux)
+                           device=device, use_connection_nodes=conn, diag_main=diag_main, diag_aux=diag_aux)
         _TOPO_GRAPHS[key] = g
     return g
 

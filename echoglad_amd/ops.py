@@ -67,8 +67,8 @@ class Graph:
     def topo(cls, frame_size: int, num_aux_graphs: int, use_main_graph_only: bool = False,
              use_coordinate_graph: bool = False, device=None, use_connection_nodes: bool = False, diag_main: bool = False,
              diag_aux: bool = False) -> "Graph":
-        """Implicit-stencil handle of the closed-form topology ('grid' or 'grid-diagonal' levels).  Connection nodes raise
-        (EG_ERR_UNSUPPORTED): those graphs run on a CSR handle (``Graph.csr``)."""
+        """Implicit-stencil handle of the closed-form topology ('grid' or 'grid-diagonal' levels, with or without coordinate /
+        connection nodes: every flag of the reference's builder)."""
         lib = _lib.load()
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         h = ct.c_void_p()
@@ -77,7 +77,7 @@ class Graph:
                                           int(use_coordinate_graph), int(use_connection_nodes), int(diag_main), int(diag_aux),
                                           ct.byref(h)), "eg_topo_create")
         g = cls(h, True, int(lib.eg_graph_num_nodes(h)), device)
-        g.hybrid = bool(diag_main or (diag_aux and not use_main_graph_only))
+        g.hybrid = bool(diag_main or ((diag_aux or use_connection_nodes) and not use_main_graph_only))
         return g
 
     @classmethod

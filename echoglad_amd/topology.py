@@ -246,11 +246,10 @@ class HierTopology:
         return np.asarray(rows, dtype=np.int32)
 
     def is_structured(self) -> bool:
-        """True when the implicit-stencil kernels cover this graph: 4-neighbour or
-        'grid-diagonal' (8-neighbour) grids, no connection nodes, and a crop that is one
-        contiguous run of the last aux level (always the case with Python slices of a range)."""
-        if self.n_conn:
-            return False
+        """True when the implicit-stencil kernels cover this graph: 4-neighbour or 'grid-diagonal'
+        (8-neighbour) grids, with or without coordinate / connection nodes (round 4; every closed
+        form of the reference's builder), and a crop that is one contiguous run of the last aux
+        level (always the case with Python slices of a range)."""
         return True
 
 
@@ -268,12 +267,12 @@ def candidate_specs(num_rows: int, num_directed_edges: int, max_frame: int = 409
     if num_rows <= 0 or num_directed_edges <= 0 or num_directed_edges % 2:
         return out
     F = np.arange(2, max_frame + 1, dtype=np.int64)
-    variants = [(True, 1, 0)] + [(False, a, c) for a in range(1, max_aux + 1) for c in (0, 4)]
-    for main_only, naux, n_coord in variants:
+    variants = [(True, 1, 0, 0)] + [(False, a, c, k) for a in range(1, max_aux + 1) for c in (0, 4) for k in (0, a + 1)]
+    for main_only, naux, n_coord, n_conn in variants:
         aux_nodes = 0 if main_only else sum(4 ** k for k in range(1, naux + 1))
-        n = aux_nodes + F * F + n_coord
+        n = aux_nodes + F * F + n_coord + n_conn
         for f in F[(n <= num_rows) & (num_rows % n == 0)]:
-            for spec in graph_type_variants(TopologySpec(int(f), naux, main_only, n_coord > 0)):
+            for spec in graph_type_variants(TopologySpec(int(f), naux, main_only, n_coord > 0, n_conn > 0)):
                 topo = HierTopology(spec)
                 batch = num_rows // topo.num_nodes
                 if 2 * batch * topo.count_undirected_edges() == num_directed_edges:

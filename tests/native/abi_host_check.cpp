@@ -21,7 +21,6 @@ int main() {
     EXPECT(eg_topo_create(0, 7, 0, 0, 0, 0, 0, &g) != EG_OK && g == nullptr, "eg_topo_create(frame = 0)");
     EXPECT(eg_topo_create(224, 99, 0, 0, 0, 0, 0, &g) != EG_OK && g == nullptr, "eg_topo_create(naux = 99)");
     EXPECT(eg_topo_create(-5, 3, 0, 0, 0, 0, 0, &g) != EG_OK && g == nullptr, "eg_topo_create(frame < 0)");
-    EXPECT(eg_topo_create(224, 7, 0, 0, 1, 0, 0, &g) == EG_ERR_UNSUPPORTED && g == nullptr, "eg_topo_create(connection nodes): caller builds a CSR handle");
     EXPECT(eg_graph_destroy(nullptr) == EG_OK, "eg_graph_destroy(NULL)");
     EXPECT(eg_graph_num_nodes(nullptr) == -1, "eg_graph_num_nodes(NULL)");
     EXPECT(eg_graph_kidsum_rows(nullptr) == 0, "eg_graph_kidsum_rows(NULL)");
@@ -47,17 +46,20 @@ int main() {
     EXPECT(std::strlen(eg_last_error()) > 0, "eg_last_error carries the last message");
     // ---- topology tables: every BASELINE shape and the odd ones of the parity tests (host tables are complete before the first
     // device call; a box without a GPU then reports the HIP error and must have freed everything)
-    // {frame, naux, main_only, coordinate nodes, grid-diagonal main, grid-diagonal aux}
-    const int cfgs[][6] = {{224, 7, 0, 0, 0, 0}, {224, 7, 0, 1, 0, 0}, {224, 7, 1, 0, 0, 0}, {448, 8, 0, 0, 0, 0}, {448, 7, 0, 0, 0, 0},
-                           {64, 2, 0, 0, 0, 0}, {64, 6, 0, 0, 0, 0}, {30, 3, 0, 0, 0, 0}, {17, 3, 0, 0, 0, 0}, {8, 1, 0, 0, 0, 0},
-                           {8, 2, 0, 0, 0, 0}, {16, 2, 1, 0, 0, 0}, {32, 4, 0, 1, 0, 0}, {16, 3, 0, 1, 0, 0},
+    // {frame, naux, main_only, coordinate nodes, grid-diagonal main, grid-diagonal aux, connection nodes}
+    const int cfgs[][7] = {{224, 7, 0, 0, 0, 0, 0}, {224, 7, 0, 1, 0, 0, 0}, {224, 7, 1, 0, 0, 0, 0}, {448, 8, 0, 0, 0, 0, 0}, {448, 7, 0, 0, 0, 0, 0},
+                           {64, 2, 0, 0, 0, 0, 0}, {64, 6, 0, 0, 0, 0, 0}, {30, 3, 0, 0, 0, 0, 0}, {17, 3, 0, 0, 0, 0, 0}, {8, 1, 0, 0, 0, 0, 0},
+                           {8, 2, 0, 0, 0, 0, 0}, {16, 2, 1, 0, 0, 0, 0}, {32, 4, 0, 1, 0, 0, 0}, {16, 3, 0, 1, 0, 0, 0},
                            // 'grid-diagonal' levels (stencil tables + the per-frame CSR of such handles)
-                           {224, 7, 0, 0, 1, 1}, {224, 7, 0, 1, 1, 0}, {224, 7, 1, 0, 1, 0}, {64, 5, 0, 0, 0, 1}, {30, 3, 0, 0, 1, 1},
-                           {17, 3, 0, 1, 1, 1}, {8, 2, 0, 0, 1, 1}, {448, 8, 0, 0, 1, 1}};
+                           {224, 7, 0, 0, 1, 1, 0}, {224, 7, 0, 1, 1, 0, 0}, {224, 7, 1, 0, 1, 0, 0}, {64, 5, 0, 0, 0, 1, 0}, {30, 3, 0, 0, 1, 1, 0},
+                           {17, 3, 0, 1, 1, 1, 0}, {8, 2, 0, 0, 1, 1, 0}, {448, 8, 0, 0, 1, 1, 0},
+                           // connection nodes (pre-pass tables, hub pseudo-tiles), alone and with everything else
+                           {224, 7, 0, 0, 0, 0, 1}, {224, 7, 0, 1, 1, 1, 1}, {64, 5, 0, 0, 0, 0, 1}, {16, 3, 0, 1, 0, 0, 1}, {448, 8, 0, 0, 0, 0, 1},
+                           {8, 2, 0, 0, 0, 0, 1}, {16, 2, 1, 0, 0, 0, 1}};
     int created = 0;
     for (const auto& c : cfgs) {
         g = nullptr;
-        const int rc = eg_topo_create(c[0], c[1], c[2], c[3], 0, c[4], c[5], &g);
+        const int rc = eg_topo_create(c[0], c[1], c[2], c[3], c[6], c[4], c[5], &g);
         if (rc == EG_OK) {
             ++created;
             EXPECT(g != nullptr && eg_graph_num_nodes(g) > 0 && eg_graph_num_tiles(g) > 0, "eg_topo_create handle");

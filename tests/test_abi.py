@@ -71,11 +71,9 @@ def test_bad_arguments_return_error_codes(built_lib):
     assert lib.eg_topo_create(1, 7, 0, 0, 0, 0, 0, ctypes.byref(h)) == _lib.EG_ERR_ARG          # frame < 2
     assert "frame" in _lib.last_error()
     assert lib.eg_topo_create(224, 40, 0, 0, 0, 0, 0, ctypes.byref(h)) == _lib.EG_ERR_ARG        # naux too large
-    # connection nodes are an argument of the builder; no stencil tables -> -2, caller uses CSR
-    assert lib.eg_topo_create(224, 7, 0, 0, 1, 0, 0, ctypes.byref(h)) == _lib.EG_ERR_UNSUPPORTED and not h.value
-    assert "eg_csr_create" in _lib.last_error()
-    # 'grid-diagonal' levels have stencil tables (round 4): the host tables are built, then -- without a GPU -- the device allocation fails
-    for flags in ((0, 1, 0), (0, 0, 1), (0, 1, 1)):
+    # every flag of the reference's builder has stencil tables (round 4: connection nodes, 'grid-diagonal' levels): the
+    # host tables are built, then -- without a GPU -- the device allocation fails
+    for flags in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)):
         rc = lib.eg_topo_create(64, 5, 0, 0, *flags, ctypes.byref(h))
         assert rc in (_lib.EG_OK, _lib.EG_ERR_HIP), (flags, rc, _lib.last_error())
         if rc == _lib.EG_OK:

@@ -1,4 +1,5 @@
-"""-m gpu: 'grid-diagonal' levels (8-neighbour grids, reference src/core/datasets.py:1469-1475, :1494-1500) on the implicit-stencil
+"""-m gpu: 'grid-diagonal' levels (8-neighbour grids, reference src/core/datasets.py:1469-1475, :1494-1500) and connection nodes
+(:1450-1456, :1512-1515: a node per aux level wired to every node of it; level sums by a pre-pass, conn.hip) on the implicit-stencil
 path.  A topology handle with diagonal levels runs its fused layers on the producer/consumer kernel (seg_wide.h segp_diag_rows)
 and everything else on the CSR of one frame it carries; every entry point is compared with a CSR handle built from the oracle's
 edge_index for the same graph (the arbitrary-graph path, itself checked against the dense fp64 form in test_gpu_layer.py)."""
@@ -14,21 +15,25 @@ from echoglad_amd.topology import HierTopology, TopologySpec
 
 pytestmark = pytest.mark.gpu
 
-# (frame, naux, main_only, coord, diag_main, diag_aux)
+# (frame, naux, main_only, coord, diag_main, diag_aux[, connection nodes])
 DIAG_CASES = [(16, 3, False, False, True, True), (64, 5, False, False, True, True), (64, 6, False, False, False, True),
               (64, 6, False, False, True, False), (30, 3, False, False, True, True), (17, 3, False, True, True, True),
               (32, 4, False, True, True, True), (16, 2, True, False, True, False), (8, 2, False, False, True, True),
               (100, 5, False, False, True, True)]
+CONN = {}          # cases with connection nodes: the flag travels beside the tuple (keeps the parametrisation ids readable)
+for _c in ((16, 3, False, False, False, False), (64, 5, False, False, False, False), (64, 5, False, False, True, True),
+           (32, 4, False, True, False, False), (8, 2, False, False, False, False), (30, 3, False, True, True, False)):
+    CONN[_c] = True
 
 
 def _types(dm, da):
     return ("grid-diagonal" if dm else "grid"), ("grid-diagonal" if da else "grid")
 
 
-def _graphs(frame, naux, main_only, coord, dm, da, B):
+def _graphs(frame, naux, main_only, coord, dm, da, B, conn=False):
     mt, at = _types(dm, da)
-    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=coord, main_only=main_only, main_type=mt, aux_type=at)
-    g = ops.Graph.topo(frame, naux, main_only, coord, diag_main=dm, diag_aux=da)
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=coord, main_only=main_only, conn=conn, main_type=mt, aux_type=at)
+    g = ops.Graph.topo(frame, naux, main_only, coord, use_connection_nodes=conn, diag_main=dm, diag_aux=da)
     c = ops.Graph.csr(ei.to(DEV), B * topo.num_nodes)
     return topo, ei, g, c
 
@@ -165,6 +170,112 @@ def test_model_on_a_diagonal_graph_takes_the_stencil_and_matches_the_oracle(fram
             m.p = 0.0
     if frame > 64:
         return
+    hip.train(); ref.train()
+    want, wc = ref.forward_nodes(feats, ei, nt, B, None if c0 is None else c0.clone())
+    got, gc = hip.forward_nodes(feats.to(DEV), ei.to(DEV), B, None if c0 is None else c0.clone().to(DEV))
+    assert float((got.detach().cpu() - want.detach()).abs().max()) < 2e-4
+    ((want ** 2).mean() + (0 if wc is None else (wc ** 2).mean() * 1e-3)).backward()
+    ((got ** 2).mean() + (0 if gc is None else (gc ** 2).mean() * 1e-3)).backward()
+    rg = dict(ref.named_parameters())
+    for name, p in hip.named_parameters():
+        err = float((p.grad.cpu() - rg[name].grad).abs().max())
+        assert err < 5e-3 * float(rg[name].grad.abs().max()) + 1e-6, (name, err)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# connection nodes
+# ---------------------------------------------------------------------------------------------------------------------------------
+CONN_CASES = sorted(CONN)
+
+
+@pytest.mark.parametrize("frame,naux,main_only,coord,dm,da", CONN_CASES + [(224, 7, False, False, False, False)])
+def test_connection_node_handle_and_degrees(frame, naux, main_only, coord, dm, da):
+    mt, at = _types(dm, da)
+    topo = HierTopology(TopologySpec(frame, naux, main_only, coord, True, mt, at))
+    assert topo.is_structured() and topo.n_conn == naux + 1
+    g = ops.Graph.topo(frame, naux, main_only, coord, use_connection_nodes=True, diag_main=dm, diag_aux=da)
+    assert g.structured and g.hybrid and g.num_nodes == topo.num_nodes and not g.fused_classifier_ok
+    assert np.allclose(g.deg_inv_sqrt().cpu().numpy(), topo.deg_inv_sqrt(), rtol=1e-7, atol=0)
+    want = sum(((lv.side + 7) // 8) ** 2 for lv in topo.aux_levels + [topo.main]) + (1 if topo.n_coord else 0) + (topo.n_conn + 7) // 8
+    assert _lib.load().eg_graph_num_tiles(g._h) == want
+
+
+@pytest.mark.parametrize("frame,naux,main_only,coord,dm,da", CONN_CASES)
+def test_connection_nodes_fused_layer_and_chain_vs_csr(frame, naux, main_only, coord, dm, da):
+    B = 3
+    topo, ei, g, c = _graphs(frame, naux, main_only, coord, dm, da, B, conn=True)
+    rows = B * topo.num_nodes
+    x = rand_rows(rows, seed=frame + naux).to(DEV)
+    assert float((ops.gcn_aggregate(g, B, x) - ops.gcn_aggregate(c, 1, x)).abs().max()) < 5e-5        # per-frame CSR of the handle
+    ws = [rand_rows(128, seed=20 + i).to(DEV) * 0.08 for i in range(3)]
+    sc = rand_rows(1, seed=30).to(DEV).reshape(128) * 0.1 + 1.0
+    sh = rand_rows(1, seed=31).to(DEV).reshape(128) * 0.1
+    before = g.ps_launches
+    got = ops.gcn_layer_fwd(g, B, x, ws[0], sc, sh, x, relu=True)
+    assert g.ps_launches == before + 1
+    want = ops.gcn_layer_fwd(c, 1, x, ws[0], sc, sh, x, relu=True)
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) < 5e-5 * scale
+    # the connection nodes' own rows (the first naux + 1 of every frame: sums over whole levels) and the levels they feed
+    n = topo.num_nodes
+    assert float((got.view(B, n, 128)[:, :topo.n_conn] - want.view(B, n, 128)[:, :topo.n_conn]).abs().max()) < 5e-5 * scale
+    assert torch.equal(got, ops.gcn_layer_fwd(g, B, x, ws[0], sc, sh, x, relu=True))                    # deterministic
+    # frames are independent: frame 1 alone
+    one = ops.gcn_layer_fwd(g, 1, x[n:2 * n].contiguous(), ws[0], sc, sh, x[n:2 * n].contiguous(), relu=True)
+    assert torch.equal(one, got[n:2 * n])
+    want3 = x
+    for i, w in enumerate(ws):
+        want3 = ops.gcn_layer_fwd(c, 1, want3, w, sc, sh, want3, relu=i < 2)
+    if g.kidsum_rows:
+        ka, kb = ops.new_kidsum(g, B), ops.new_kidsum(g, B)
+        h1 = ops.gcn_layer_fwd(g, B, x, ws[0], sc, sh, x, relu=True, kidsum_out=ka)
+        h2 = ops.gcn_layer_fwd(g, B, h1, ws[1], sc, sh, h1, relu=True, kidsum_in=ka, kidsum_out=kb)
+        h3 = ops.gcn_layer_fwd(g, B, h2, ws[2], sc, sh, h2, relu=False, kidsum_in=kb)
+        assert float((h3 - want3).abs().max()) < 1e-4 * max(1.0, float(want3.abs().max()))
+    # the backward's form: transposed weight, a residual of its own
+    dy = rand_rows(rows, seed=9).to(DEV)
+    gt = ops.gcn_layer_fwd(g, B, x, ws[0], None, None, dy, relu=False, transpose_w=True)
+    wt = ops.gcn_layer_fwd(c, 1, x, ws[0], None, None, dy, relu=False, transpose_w=True)
+    assert float((gt - wt).abs().max()) < 5e-5 * max(1.0, float(wt.abs().max()))
+
+
+def test_connection_node_scratch_grows_with_the_batch():
+    """The handle's scratch for the level sums starts at 8 frames per launch and grows when a launch brings more (conn.hip)."""
+    g = ops.Graph.topo(32, 4, use_connection_nodes=True)
+    topo = HierTopology(TopologySpec(32, 4, use_connection_nodes=True))
+    w = rand_rows(128, seed=2).to(DEV) * 0.08
+    ref = None
+    for B in (2, 11, 40, 3):
+        x = rand_rows(B * topo.num_nodes, seed=4).to(DEV)
+        got = ops.gcn_layer_fwd(g, B, x, w, None, None, x, relu=True)
+        one = ops.gcn_layer_fwd(g, 1, x[:topo.num_nodes].contiguous(), w, None, None, x[:topo.num_nodes].contiguous(), relu=True)
+        assert torch.equal(got[:topo.num_nodes], one)
+        ref = one if ref is None else ref
+        assert torch.equal(one, ref)                                   # (rand_rows(seed) starts every batch with the same frame)
+
+
+@pytest.mark.parametrize("frame,naux,coord,dm,da,B", [(16, 3, False, False, False, 2), (64, 5, True, False, False, 2), (64, 5, False, True, True, 2),
+                                                     (224, 7, False, False, False, 2)])
+def test_model_with_connection_nodes_takes_the_stencil_and_matches_the_oracle(frame, naux, coord, dm, da, B):
+    mt, at = _types(dm, da)
+    hip, ref = model_pair(frame, naux, 3, coord=coord, seed=frame + 2, use_connection_nodes=True)
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=coord, conn=True, main_type=mt, aux_type=at)
+    feats = synthetic_node_feats(B * topo.num_nodes, 128, seed=9)
+    from fixtures_util import initial_coords
+    c0 = initial_coords(B, frame) if coord else None
+    with torch.no_grad():
+        want, wc = ref.forward_nodes(feats, ei, nt, B, None if c0 is None else c0.clone())
+        got, gc = hip.forward_nodes(feats.to(DEV), ei.to(DEV), B, None if c0 is None else c0.clone().to(DEV))
+    graph, gb = hip._resolver.resolve(ei.to(DEV), feats.shape[0])
+    assert graph.structured and graph.hybrid and gb == B
+    assert got.shape == want.shape == (B * topo.num_valid_nodes, 4)
+    assert float((got.cpu() - want).abs().max()) < 1e-4
+    assert torch.equal(O.landmark_argmax(got.cpu(), B, frame), O.landmark_argmax(want, B, frame))
+    if frame > 64:
+        return
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
     hip.train(); ref.train()
     want, wc = ref.forward_nodes(feats, ei, nt, B, None if c0 is None else c0.clone())
     got, gc = hip.forward_nodes(feats.to(DEV), ei.to(DEV), B, None if c0 is None else c0.clone().to(DEV))

@@ -109,6 +109,6 @@ def test_deg_inv_sqrt_matches_degree():
 
 def test_structured_flag():
     assert HierTopology(TopologySpec(16, 3)).is_structured()
-    assert not HierTopology(TopologySpec(16, 3, use_connection_nodes=True)).is_structured()
+    assert HierTopology(TopologySpec(16, 3, use_connection_nodes=True)).is_structured()                 # connection nodes: pre-pass + stencil (round 4)
     assert HierTopology(TopologySpec(16, 3, main_graph_type="grid-diagonal")).is_structured()          # 8-neighbour stencil (round 4)
     assert HierTopology(TopologySpec(16, 3, aux_graph_type="grid-diagonal")).is_structured()
