@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from fixtures_util import synthetic_node_feats
-from gpu_util import DEV, dense_ahat, graph_tensors, model_pair, rand_rows
+from gpu_util import DEV, assert_param_grads_close, dense_ahat, graph_tensors, model_pair, rand_rows
 from oracle import gnn_oracle as O
 from echoglad_amd import _lib, ops
 from echoglad_amd.topology import HierTopology, TopologySpec
@@ -176,10 +176,7 @@ def test_model_on_a_diagonal_graph_takes_the_stencil_and_matches_the_oracle(fram
     assert float((got.detach().cpu() - want.detach()).abs().max()) < 2e-4
     ((want ** 2).mean() + (0 if wc is None else (wc ** 2).mean() * 1e-3)).backward()
     ((got ** 2).mean() + (0 if gc is None else (gc ** 2).mean() * 1e-3)).backward()
-    rg = dict(ref.named_parameters())
-    for name, p in hip.named_parameters():
-        err = float((p.grad.cpu() - rg[name].grad).abs().max())
-        assert err < 5e-3 * float(rg[name].grad.abs().max()) + 1e-6, (name, err)
+    assert_param_grads_close(hip, ref)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -282,7 +279,4 @@ def test_model_with_connection_nodes_takes_the_stencil_and_matches_the_oracle(fr
     assert float((got.detach().cpu() - want.detach()).abs().max()) < 2e-4
     ((want ** 2).mean() + (0 if wc is None else (wc ** 2).mean() * 1e-3)).backward()
     ((got ** 2).mean() + (0 if gc is None else (gc ** 2).mean() * 1e-3)).backward()
-    rg = dict(ref.named_parameters())
-    for name, p in hip.named_parameters():
-        err = float((p.grad.cpu() - rg[name].grad).abs().max())
-        assert err < 5e-3 * float(rg[name].grad.abs().max()) + 1e-6, (name, err)
+    assert_param_grads_close(hip, ref)
