@@ -762,7 +762,7 @@ def main_infer(args, world, rank, device, dist_info):
             del pm, fm, ws, bs
             # SURVEY 8(d), context: frame -> logits END TO END through the UNet variant the reference's default.yml names
             # (echoglad_amd/examples.py: stock PyTorch-ROCm convolutions in front, the fused tail, then the stack above)
-            if args.frame == 224 and args.naux == 7:
+            if args.frame == 224 and args.naux == 7 and not args.no_other_configs:
                 from echoglad_amd.examples import UNetNodeFeatureModel
                 um = UNetNodeFeatureModel(**kw).to(device).eval()
                 fr = torch.randn(B, 4, args.frame, args.frame, device=device)

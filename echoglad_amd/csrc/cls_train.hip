@@ -347,7 +347,7 @@ __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const f
     const long long n_tiles = (rows + TILE - 1) / TILE;
     // The row loads of a tile (z1: 8, z2: 4 float4 per thread, 4 dlogits) are issued one tile ahead, right behind the first
     // barrier of the tile before: their round trip runs under that tile's products instead of in front of this one's.
-    f32x4 pz1[8], pz2[4];
+    f32x4 pz1[8], pz2[4], cz1[8];
     float pdl[4];
     auto issue = [&](long long tile) {
         const long long row0 = tile * TILE;
@@ -380,6 +380,7 @@ __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const f
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (r < rows_here) v = hidden_act4(pz1[it], sc, sh, d1, (unsigned long long)(row0 + r) * H1 + c4);
                 *reinterpret_cast<f32x4*>(&s_h[r * LDA + c4]) = v;
+                cz1[it] = pz1[it];                     // this tile's z1 stays in registers for the BatchNorm sums at the end of the tile
             }
         }
 #pragma unroll
@@ -448,9 +449,10 @@ __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const f
             if (r < rows_here) {
                 const f32x4 dv = *reinterpret_cast<const f32x4*>(&s_h[r * LDA + c4]);
                 *reinterpret_cast<f32x4*>(dh1 + (size_t)(row0 + r) * H1 + c4) = dv;
-                // z1 of this element again (the tile was read a moment ago: an L2 hit) for the mask and xhat
+                // z1 of this element again for the mask and xhat: from the registers it arrived in (re-read from memory it was
+                // 1.18 GB of HBM traffic per launch at batch 32 -- the tile had left the L2 by then, profiles/r04_train_pmc.json)
                 const size_t off = (size_t)(row0 + r) * H1 + c4;
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(z1 + off);
+                const f32x4 zz = cz1[it];
                 const f32x4 kk = d1.p > 0.f ? keep_scale4(d1.seed, (unsigned long long)off, d1.p, d1.inv_keep) : f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

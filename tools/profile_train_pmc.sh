@@ -7,7 +7,7 @@ B=${2:-32}
 OUT=$PWD/gpurun_out/profiles
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="bench.py --mode train --batch $B --steps 5 --warmup 2"   # STEPS below = 5 + 2
+CMD="bench.py --mode train --batch $B --steps 5 --warmup 2 --no-other-configs"   # STEPS below = 2 warm-up + 5 timed + 5 on the rank's own clock
 rm -rf /tmp/prof_train_pmc
 for pmc in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" GRBM_GUI_ACTIVE; do
   n=$(echo $pmc | tr ' ' '_')
@@ -17,7 +17,7 @@ python3 - <<PY
 import csv, glob, collections, json, re
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 total = collections.defaultdict(lambda: [0.0, 0])
-STEPS = 5 + 2            # bench.py --mode train runs max(warmup, 2) + steps steps, all of them inside the profiled process
+STEPS = 2 + 5 + 5        # bench.py --mode train runs max(warmup, 2) + steps + min(steps, 5) steps, all of them inside the profiled process
 for f in glob.glob("/tmp/prof_train_pmc/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]

@@ -16,8 +16,8 @@ from echoglad_amd.synthetic import synthetic_node_feats  # noqa: E402
 DEV = "cuda:0"
 
 
-def soak(frame, naux, B, mode, reps, main_only=False):
-    g = ops.Graph.topo(frame, naux, main_only)
+def soak(frame, naux, B, mode, reps, main_only=False, diag=False, conn=False):
+    g = ops.Graph.topo(frame, naux, main_only, diag_main=diag, diag_aux=diag and not main_only, use_connection_nodes=conn)
     n = g.num_nodes
     x = synthetic_node_feats(B * n, 128, seed=1).to(DEV)
     w = (synthetic_node_feats(128, 128, seed=2) * 0.1).to(DEV)
@@ -36,7 +36,8 @@ def soak(frame, naux, B, mode, reps, main_only=False):
             first = out.clone()
         elif not torch.equal(out, first):
             bad += 1
-    print(f"{frame}x{frame} naux={naux} main_only={main_only} B={B} {mode}: {bad} of {reps - 1} launches differ from the first")
+    print(f"{frame}x{frame} naux={naux} main_only={main_only} diagonal={diag} connection_nodes={conn} B={B} {mode}: {bad} of {reps - 1} "
+          "launches differ from the first", flush=True)
     return bad
 
 
@@ -77,5 +78,8 @@ if __name__ == "__main__":
         total += soak(224, 7, 8, mode, reps)
         total += soak(224, 7, 32, mode, reps, main_only=True)
         total += soak(448, 8, 8, mode, max(reps // 4, 2))
+        total += soak(224, 7, 8, mode, reps, diag=True)                 # 'grid-diagonal' levels (round 4)
+        total += soak(224, 7, 8, mode, reps, conn=True)                 # connection nodes: pre-pass + stencil
+        total += soak(224, 7, 8, mode, max(reps // 2, 2), diag=True, conn=True)
     total += soak_train(max(reps // 10, 3))
     sys.exit(1 if total else 0)
