@@ -579,8 +579,12 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
         }
         __syncthreads();                          // tile in LDS; s_o of the tile before has been stored
         if (t + gridDim.x < n_tiles) issue(t + gridDim.x);
+#ifndef FB_ABL
+#define FB_ABL 0            // timing-only ablations: 1 no weight-gradient product, 2 no dh product, 3 neither
+#endif
         if constexpr (!GEMM2) {
             const int i = lane & 31, kh = lane >> 5;
+            if (!(FB_ABL & 1))
 #pragma unroll 4
             for (int s = 0; s < TILE / 2; ++s) {
                 const int r = 2 * s + kh;
@@ -596,7 +600,7 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
                 f32x16 o;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[e] = 0.f;
-                mfma_rowblock(s_g, 32 * rb, lane, wreg, o);
+                if (!(FB_ABL & 2)) mfma_rowblock(s_g, 32 * rb, lane, wreg, o);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<f32x4*>(&s_o[(32 * rb + j) * LDA + 32 * w + 4 * hh + 8 * g]) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};

@@ -78,9 +78,13 @@ const char* eg_last_error(void);
  * aux levels 2^k x 2^k (k = 1..naux), main grid frame x frame, 4-neighbour
  * edges, parent<->child edges, centre-crop link with Python slice semantics,
  * optional isolated K4 of coordinate nodes.  The signature is SURVEY 8(b)'s: every flag of the reference's builder is an
- * argument.  conn_nodes (datasets.py:1452-1456, :1512-1515) and diag_main / diag_aux ('grid-diagonal', :1469-1475,
- * :1494-1500) have no implicit-stencil tables yet: != 0 returns EG_ERR_UNSUPPORTED, the caller's cue to build the same
- * graph with eg_csr_create (what nn.GraphResolver does). */
+ * argument, and every flag has implicit-stencil tables (round 4):
+ *   diag_main / diag_aux ('grid-diagonal', datasets.py:1469-1475, :1494-1500): 8-neighbour levels; the stencil of such a handle
+ *     lives in the fused (producer/consumer) layer kernel, every other path reads the CSR of one frame the handle carries;
+ *   conn_nodes (datasets.py:1450-1456, :1512-1515): naux + 1 connection nodes at the head of every frame; a pre-pass in front of
+ *     each layer launch sums every wired level once (handle-owned scratch, one slice per slot of the queue ring, grown on demand --
+ *     the one allocation a launch may make, once per new maximum batch, never inside a stream capture).
+ * Arbitrary graphs: eg_csr_create. */
 int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn_nodes, int diag_main, int diag_aux,
                    eg_graph** out);
 
