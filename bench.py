@@ -259,7 +259,7 @@ def train_layer_roofline(B, topo, device, layers):
     rf["traffic"], rf["mfma_busy_frac"], rf["traffic_source"] = None, None, src
     if pm is not None:
         for k, v in pm.items():
-            if isinstance(v, dict) and k.startswith("k_gcn_layer_ps<false, false, 1>"):
+            if isinstance(v, dict) and k.startswith("k_gcn_layer_ps<false, false, 1"):
                 rf["traffic"] = int(v.get("hbm_bytes_per_launch", 0)) or None
                 rf["mfma_busy_frac"] = round(v["mfma_busy_frac"], 4) if "mfma_busy_frac" in v else None
     return rf
@@ -367,9 +367,9 @@ def cpu_baseline(args, kw, state_dict):
                       f"(fastest of the probed thread counts {sorted(probe)} on {avail} host cores)"}, out, feats, ei
 
 
-DOMINANT_KERNEL_SOURCES = ("gcn_layer_ps.hip", "seg_wide.h", "tile.h", "common.h", "graph.hip")
-TRAIN_KERNEL_SOURCES = ("gcn_layer.hip", "gcn_layer_ps.hip", "train.hip", "cls_train.hip", "train_common.h", "seg_wide.h",
-                        "tile.h", "common.h", "graph.hip")
+DOMINANT_KERNEL_SOURCES = ("gcn_layer_ps.hip", "seg_wide.h", "tile.h", "common.h", "graph.hip", "conn.hip")
+TRAIN_KERNEL_SOURCES = ("gcn_layer.hip", "gcn_layer_ps.hip", "train.hip", "bn_act_tiles.hip", "cls_train.hip", "train_common.h",
+                        "seg_wide.h", "tile.h", "common.h", "graph.hip", "conn.hip")
 
 
 def kernel_source_digest(sources=DOMINANT_KERNEL_SOURCES) -> str:

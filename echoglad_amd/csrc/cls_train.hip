@@ -47,10 +47,20 @@ struct LinMapDims {
     int in_stride, in_lo, out_stride, out_lo;
 };
 
-template <bool STATS>
+// ACT: the input rows do not exist yet -- x = relu|id(dropout(z * scale + shift)) + residual is the activation pass of the
+// GNN layer in front of the heads (eg_gcn_layer_train_fwd with out == NULL left z and the statistics).  The tiles then cover
+// EVERY row of a frame (the heads' filter only masks the product's output rows), each row of x is written to `h` on the way
+// into LDS, and the separate activation pass + its 512 B per row of re-read are gone.
+struct LinAct {
+    const float *z, *scale, *shift, *residual;
+    float* h;
+    ActArgs a;
+};
+
+template <bool STATS, bool ACT>
 __global__ __launch_bounds__(512, 4) void k_lin128_map(const float* __restrict__ x, const float* __restrict__ W,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       float* __restrict__ partial, const LinMapDims a) {
+                                                       float* __restrict__ partial, const LinMapDims a, const LinAct act) {
     __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA + 4];
     const int tid = threadIdx.x, lane_k = tid & 63, wave = wave_id();
     float wreg[32];
@@ -64,12 +74,39 @@ __global__ __launch_bounds__(512, 4) void k_lin128_map(const float* __restrict__
         asm volatile("" : "+v"(lane));
         const int frame = tile / a.tiles_per_frame;
         const int n0 = (tile - frame * a.tiles_per_frame) * TILE;
-        const int rows_here = (a.n_valid - n0) < TILE ? (a.n_valid - n0) : TILE;
-        const float* __restrict__ xf = x + ((size_t)frame * a.in_stride + a.in_lo + n0) * C;
-        float* __restrict__ of = out + ((size_t)frame * a.out_stride + a.out_lo + n0) * C;
+        const int span = ACT ? a.in_stride : a.n_valid;    // rows of a frame the tiles walk over
+        const int rows_here = (span - n0) < TILE ? (span - n0) : TILE;
+        // rows [lo, hi) of the tile have an output row (ACT: the heads' row filter; otherwise all of them)
+        const int lo = ACT ? (a.in_lo > n0 ? a.in_lo - n0 : 0) : 0;
+        const int hi = ACT ? ((a.in_lo + a.n_valid - n0) < rows_here ? (a.in_lo + a.n_valid - n0) : rows_here) : rows_here;
+        const size_t in_row0 = (size_t)frame * a.in_stride + (ACT ? 0 : a.in_lo) + n0;
+        float* __restrict__ of = out + ((size_t)frame * a.out_stride + a.out_lo) * C + ((long long)n0 - (ACT ? a.in_lo : 0)) * C;
         const int rl0 = 8 * wave;
         const PairLane pl{lane >> 5, lane & 31};
-        {
+        if (ACT) {
+            f32x4 zz[4], rr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rl0 + 2 * k + pl.h;
+                const size_t off = (in_row0 + (unsigned)(r < rows_here ? r : rows_here - 1)) * C + 4u * pl.q;
+                zz[k] = ldnt4(act.z + off);
+                rr[k] = act.residual ? ldnt4(act.residual + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(act.scale + 4 * pl.q);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(act.shift + 4 * pl.q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rl0 + 2 * k + pl.h;
+                const size_t off = (in_row0 + (unsigned)(r < rows_here ? r : rows_here - 1)) * C + 4u * pl.q;
+                f32x4 v = zz[k] * sc + sh;
+                if (act.a.p > 0.f) v *= keep_scale4(act.a.seed, (unsigned long long)off, act.a.p, act.a.inv_keep);
+                if (act.a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                v += rr[k];
+                *reinterpret_cast<f32x4*>(act.h + off) = v;             // (a missing row: the last row's value once more)
+                *reinterpret_cast<f32x4*>(&s_a[(rl0 + 2 * k + pl.h) * LDA + 4 * pl.q]) = v;
+            }
+        } else {
+            const float* __restrict__ xf = x + in_row0 * C;
             f32x4 v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -96,7 +133,14 @@ __global__ __launch_bounds__(512, 4) void k_lin128_map(const float* __restrict__
             }
         }
         __syncthreads();
-        if (rl0 < rows_here) {                              // (uniform per wave) whole 512-B rows, a duplicate store for a missing row
+        if (ACT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rl0 + 2 * k + pl.h;
+                if (r >= lo && r < hi)
+                    *reinterpret_cast<f32x4*>(of + (long long)r * C + 4 * pl.q) = *reinterpret_cast<const f32x4*>(&s_a[r * LDA + 4 * pl.q]);
+            }
+        } else if (rl0 < rows_here) {                       // (uniform per wave) whole 512-B rows, a duplicate store for a missing row
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = rl0 + 2 * k + pl.h;
@@ -108,7 +152,7 @@ __global__ __launch_bounds__(512, 4) void k_lin128_map(const float* __restrict__
             const int c = tid & 127, r0 = 16 * (tid >> 7);
 #pragma unroll 4
             for (int r = r0; r < r0 + 16; ++r) {
-                const float v = r < rows_here ? s_a[r * LDA + c] : 0.f;
+                const float v = (r >= lo && r < hi) ? s_a[r * LDA + c] : 0.f;
                 cs += v; cq += v * v;
             }
         }
@@ -711,10 +755,11 @@ static const size_t CLS_WS_SHARED = CLS_WS_PARTIAL + CLS_WS_TOTALS;
 
 size_t eg_classifier_train_workspace_bytes(void) { return CLS_WS_SHARED + eg_workspace_bytes(); }
 
-int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
-                            const eg_cls_train_params* P, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
-                            float* logits, eg_stream_t stream_) {
-    if (!h || !P || !workspace || !z1 || !z2 || !bn || !logits) return set_error(EG_ERR_ARG, "NULL argument");
+// h != NULL: the rows exist; otherwise act describes how they come to be (and where they are written)
+static int classifier_train_fwd(const float* h, const LinAct* act, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                                const eg_cls_train_params* P, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
+                                float* logits, eg_stream_t stream_) {
+    if (!P || !workspace || !z1 || !z2 || !bn || !logits) return set_error(EG_ERR_ARG, "NULL argument");
     if (batch < 1 || n_per_frame < 1 || row_lo < 0 || n_valid < 1 || row_lo + n_valid > n_per_frame)
         return set_error(EG_ERR_ARG, "bad row range");
     if (n_per_frame * (int64_t)batch >= (1ll << 31)) return set_error(EG_ERR_ARG, "batch * nodes exceeds int32");
@@ -725,11 +770,14 @@ int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int6
     double* totals = (double*)((char*)workspace + CLS_WS_PARTIAL);
     // ---- first layers + BatchNorm1d(128) statistics
     LinMapDims d{};
-    d.n_valid = (int)n_valid; d.tiles_per_frame = (int)((n_valid + TILE - 1) / TILE); d.batch = batch; d.transpose_w = 0;
+    d.n_valid = (int)n_valid; d.tiles_per_frame = (int)(((act ? n_per_frame : n_valid) + TILE - 1) / TILE); d.batch = batch;
+    d.transpose_w = 0;
     d.in_stride = (int)n_per_frame; d.in_lo = (int)row_lo; d.out_stride = (int)n_valid; d.out_lo = 0;
     const long long n_tiles = (long long)d.tiles_per_frame * batch;
+    if (n_tiles >= (1ll << 31)) return set_error(EG_ERR_ARG, "too many row tiles");
     const int g1 = (int)(n_tiles < LIN_GRID ? n_tiles : LIN_GRID);
-    hipLaunchKernelGGL(k_lin128_map<true>, dim3(g1), dim3(512), 0, stream, h, P->w1, P->b1, z1, partial, d);
+    if (act) hipLaunchKernelGGL((k_lin128_map<true, true>), dim3(g1), dim3(512), 0, stream, (const float*)nullptr, P->w1, P->b1, z1, partial, d, *act);
+    else hipLaunchKernelGGL((k_lin128_map<true, false>), dim3(g1), dim3(512), 0, stream, h, P->w1, P->b1, z1, partial, d, LinAct{});
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3(8), dim3(256), 0, stream, partial, g1, 256, totals);
     BnFinalize f1{totals, rows, H1, P->gamma1, P->beta1, P->eps1, P->momentum1, P->running_mean1, P->running_var1,
                   bn + 0 * H1, bn + 1 * H1, bn + 2 * H1, bn + 3 * H1};
@@ -751,6 +799,27 @@ int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int6
                        P->w3, P->b3, sigmoid, logits);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
+}
+
+int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                            const eg_cls_train_params* P, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
+                            float* logits, eg_stream_t stream) {
+    if (!h) return set_error(EG_ERR_ARG, "NULL argument");
+    return classifier_train_fwd(h, nullptr, batch, n_per_frame, row_lo, n_valid, P, workspace, z1, z2, bn, sigmoid, logits, stream);
+}
+
+int eg_classifier_train_fwd_act(const float* z, const float* layer_bn, const float* residual, int relu, float dropout_p, uint64_t seed,
+                                float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                                const eg_cls_train_params* P, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
+                                float* logits, eg_stream_t stream) {
+    if (!z || !layer_bn || !h) return set_error(EG_ERR_ARG, "NULL argument");
+    if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    if (h == z || h == residual) return set_error(EG_ERR_ARG, "h must not alias z or the residual");
+    LinAct act{};
+    act.z = z; act.scale = layer_bn + 2 * C; act.shift = layer_bn + 3 * C; act.residual = residual; act.h = h;
+    act.a.rows = (long long)batch * n_per_frame; act.a.relu = relu; act.a.p = dropout_p;
+    act.a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f; act.a.seed = seed;
+    return classifier_train_fwd(nullptr, &act, batch, n_per_frame, row_lo, n_valid, P, workspace, z1, z2, bn, sigmoid, logits, stream);
 }
 
 int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
@@ -826,8 +895,8 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
     d.n_valid = (int)n_valid; d.tiles_per_frame = (int)((n_valid + TILE - 1) / TILE); d.batch = batch; d.transpose_w = 1;
     d.in_stride = (int)n_valid; d.in_lo = 0; d.out_stride = (int)n_per_frame; d.out_lo = (int)row_lo;
     const long long n_tiles = (long long)d.tiles_per_frame * batch;
-    hipLaunchKernelGGL(k_lin128_map<false>, dim3((unsigned)(n_tiles < LIN_GRID ? n_tiles : LIN_GRID)), dim3(512), 0, stream, dh1_scratch,
-                       P->w1, (const float*)nullptr, dh, (float*)nullptr, d);
+    hipLaunchKernelGGL((k_lin128_map<false, false>), dim3((unsigned)(n_tiles < LIN_GRID ? n_tiles : LIN_GRID)), dim3(512), 0, stream, dh1_scratch,
+                       P->w1, (const float*)nullptr, dh, (float*)nullptr, d, LinAct{});
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

@@ -125,19 +125,8 @@ __global__ void k_stats_final(const double* __restrict__ totals, long long rows,
 }
 
 // ---- BN affine + dropout + ReLU + residual, forward ------------------------------------------------
-struct ActArgs {
-    long long rows;
-    int relu;
-    float p, inv_keep;
-    unsigned long long seed;
-};
-
 // Streaming pass: every operand is read once (non-temporal loads keep them out of the caches' way) and four 16-B loads per
 // stream are in flight per lane before the first use.
-__device__ inline f32x4 ldnt4(const float* p) {
-    return f32x4{__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
-                 __builtin_nontemporal_load(p + 3)};
-}
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ z, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ residual,
                                                     float* __restrict__ out, const ActArgs a) {

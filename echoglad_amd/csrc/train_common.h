@@ -39,6 +39,20 @@ __device__ inline f32x2 keep_scale2(unsigned long long seed, unsigned long long 
     return f32x2{keep_field(w, u, thr, inv_keep), keep_field(w, u + 1, thr, inv_keep)};
 }
 
+// arguments of the BN affine + dropout + ReLU (+ residual) activation
+struct ActArgs {
+    long long rows;
+    int relu;
+    float p, inv_keep;
+    unsigned long long seed;
+};
+
+// non-temporal 16-B load of a streaming pass (every operand is read once)
+__device__ inline f32x4 ldnt4(const float* p) {
+    return f32x4{__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
+                 __builtin_nontemporal_load(p + 3)};
+}
+
 // Compact row r of a per-frame row filter -> row of the unfiltered [batch * stride, .] array:
 //   (r / n_valid) * stride + lo + r % n_valid        (models.py:485: the node-type filter keeps a contiguous range per frame)
 struct RowMap {

@@ -377,6 +377,85 @@ class _CoordClassifierTrainFn(torch.autograd.Function):
             _unstack_head_grads(g)
 
 
+class _LastLayerHeadsTrainFn(torch.autograd.Function):
+    """The LAST train-mode layer and the classifier heads as one node, so that the layer's activation pass runs inside the heads'
+    first kernel (eg_classifier_train_fwd_act: h is written once and never read back for the heads' first product):
+        (h_prev [B*N,128], coords_prev [B,4,2] | None) -> (logits, coords [B,4,2] | None).
+    With the coordinate graph the node also carries the update in front of the layer (of layer L - 2, on h_prev; absent when
+    L = 1) and the one behind it (of layer L - 1, on h), exactly as _CoordLayerTrainFn / _CoordClassifierTrainFn do.
+    cfg = (graph, batch, relu, p, momentum, eps, seed, residual, kid_in, dims5, sigmoid, cls_cfg, coord_dims | None,
+           mlp_prev_cfg | None, mlp_cfg | None); params = [10 tensors of the MLP in front] + [10 of the MLP behind] + 40 head tensors."""
+
+    @staticmethod
+    def forward(ctx, h_prev, coords_prev, weight, bias, gamma, beta, running_mean, running_var, cfg, *params):
+        (graph, batch, relu, p, momentum, eps, seed, residual, kid_in, dims5, sigmoid, cls_cfg, cdims, mlp_prev_cfg, mlp_cfg) = cfg
+        has_coord, has_prev = mlp_cfg is not None, mlp_prev_cfg is not None
+        k0 = 10 if has_prev else 0
+        k1 = k0 + (10 if has_coord else 0)
+        h_prev = h_prev.contiguous()
+        coords_mid, st_prev = coords_prev, None
+        if has_prev:
+            coords_mid, st_prev = _coord_update_fwd(h_prev, coords_prev, cdims, mlp_prev_cfg, params[:10])
+        need_w = weight.requires_grad
+        _, z, agg, bn = ops.gcn_layer_train_fwd(graph, batch, h_prev, weight.contiguous(), bias.contiguous(), gamma.contiguous(),
+                                                beta.contiguous(), running_mean, running_var, momentum, eps, relu, p, seed,
+                                                residual, want_agg=need_w, kidsum_in=kid_in, want_out=False)
+        B, n, row_lo, n_valid = dims5
+        P = _stack_head_params(params[k1:], cls_cfg)
+        h, logits, z1, z2, cbn = ops.classifier_train_fwd_act(z, bn, h_prev if residual else None, relu, p, seed, B, n, row_lo,
+                                                              n_valid, P, sigmoid)
+        new, st = None, None
+        if has_coord:
+            new, st = _coord_update_fwd(h, coords_mid, cdims, mlp_cfg, params[k0:k1])
+        ctx.P = {k: v for k, v in P.items() if not k.startswith("running")}
+        ctx.cfg = (graph, batch, relu, p, seed, residual, need_w, dims5, sigmoid, cdims, has_coord, has_prev,
+                   st[3] if has_coord else None, st_prev[3] if has_prev else None)
+        saved = [z, agg if agg is not None else z.new_zeros(0), weight.detach().contiguous(), gamma.detach().contiguous(),
+                 beta.detach().contiguous(), bn, h_prev, h, z1, z2, cbn, logits if sigmoid else logits.new_zeros(0)]
+        if has_coord:
+            saved += [new, st[0], st[1], *st[2]]
+        if has_prev:
+            saved += [coords_mid, st_prev[0], st_prev[1], *st_prev[2]]
+        ctx.n_saved2 = len(st[2]) if has_coord else 0
+        ctx.save_for_backward(*saved)
+        return logits, (new.view(B, 4, 2).clone() if has_coord else None)
+
+    @staticmethod
+    def backward(ctx, dy, dcoords):
+        (graph, batch, relu, p, seed, residual, had_agg, dims5, sigmoid, cdims, has_coord, has_prev, Pm, Pm_prev) = ctx.cfg
+        z, agg, weight, gamma, beta, bn, h_prev, h, z1, z2, cbn, y, *rest = ctx.saved_tensors
+        B, n, row_lo, n_valid = dims5
+        if dy is None:
+            dy = torch.zeros(B * n_valid, 4, dtype=torch.float32, device=h.device)
+        dl = dy.contiguous()
+        if sigmoid:
+            dl = dl * y * (1.0 - y)
+        dh, g = ops.classifier_bwd(dl, h, B, n, row_lo, n_valid, ctx.P, z1, z2, cbn, True)         # (a buffer of this node)
+        dmid, gm, gm_prev = None, None, None
+        if has_coord:
+            new, lm, flat = rest[0], rest[1], rest[2]
+            saved2 = tuple(rest[3:3 + ctx.n_saved2])
+            rest = rest[3 + ctx.n_saved2:]
+            dmid, gm = _coord_update_bwd(dh, None if dcoords is None else dcoords.reshape(B * 4, 2), h, new, lm, flat, saved2, Pm,
+                                         cdims, has_prev or ctx.needs_input_grad[1], sampled_rows_used=False)
+        need_x = has_prev or ctx.needs_input_grad[0]
+        need_w, need_b = ctx.needs_input_grad[2] and had_agg, ctx.needs_input_grad[3]
+        dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dh, z, agg if had_agg else None, weight, gamma, beta, bn,
+                                                      relu, p, seed, residual, need_x, need_w)
+        dprev = dmid
+        if has_prev:
+            new1, lm1, flat1 = rest[0], rest[1], rest[2]
+            dprev, gm_prev = _coord_update_bwd(dx, dmid, h_prev, new1, lm1, flat1, tuple(rest[3:]), Pm_prev, cdims,
+                                               ctx.needs_input_grad[1])
+        out = (dx if ctx.needs_input_grad[0] else None, None if dprev is None else dprev.view(B, 4, 2), dw,
+               db if need_b else None, dgamma, dbeta, None, None, None)
+        if has_prev:
+            out += _mlp_grads(gm_prev)
+        if has_coord:
+            out += _mlp_grads(gm)
+        return out + _unstack_head_grads(g)
+
+
 class _CoordMlpFn(torch.autograd.Function):
     """models.py:441-453 in train mode as one autograd node over eg_coord_mlp_fwd / eg_coord_mlp_bwd:
     (landmark rows [4B,128], coords [B,4,2]) -> clamp(coords + node_coordinate_mlp(cat(lm, pairwise offsets)), 0, frame-1).
@@ -739,10 +818,23 @@ class HierarchicalPatchModel(nn.Module):
         dims = (B, n, main_base, self.frame_size, coord_base)
         kids = self._train_kidsums(graph, gb)
         h, coords = x0.contiguous(), node_coords
-        for i in range(self.num_gnn_layers):
+        L = self.num_gnn_layers
+        act_in_heads = os.environ.get("EG_ACT_HEADS", "1") != "0"      # the last layer's activation pass inside the heads' first kernel
+        for i in range(L):
             conv, bn, relu, p, seed = self._layer_cfg(i)
             _, momentum = _bn_step(bn)
             kid = (kids[(i + 1) & 1] if i > 0 else None, kids[i & 1] if i < self.num_gnn_layers - 1 else None)
+            if i == L - 1 and act_in_heads:
+                mlp_prev_cfg, mlp_prev = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i - 1]) if i > 0 else (None, [])
+                mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i])
+                cls_cfg, head_params, finish = self._classifier_train_cfg()
+                cfg = (graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid[0], (B, n, n_conn, n_valid),
+                       self.output_activation == "sigmoid", cls_cfg, dims, mlp_prev_cfg, mlp_cfg)
+                logits, coords = _LastLayerHeadsTrainFn.apply(h, coords, conv.lin.weight, conv.bias, bn.weight, bn.bias,
+                                                              bn.running_mean, bn.running_var, cfg, *mlp_prev, *mlp_params,
+                                                              *head_params)
+                finish()
+                return logits.squeeze(1), coords.reshape(B * 4, -1)
             if i == 0:
                 h = _LayerTrainFn.apply(h, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                         graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid)
@@ -824,6 +916,17 @@ class HierarchicalPatchModel(nn.Module):
                                       relu=not last, kidsum_in=kid[(i + 1) & 1] if i > 0 else None,
                                       kidsum_out=None if last else kid[i & 1], jk_in=jk_prev,
                                       jk_out=jkb[i & 1] if jk_fused else None)
+            elif self.training and i == self.num_gnn_layers - 1 and self._act_in_heads_ok():
+                # the last layer and the heads as one node: the layer's activation pass runs inside the heads' first kernel
+                conv, bn, relu, p, seed = self._layer_cfg(i)
+                _, momentum = _bn_step(bn)
+                cls_cfg, head_params, finish = self._classifier_train_cfg()
+                cfg = (graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), train_kids[(i + 1) & 1] if i > 0 else None,
+                       (B, n, n_conn, n_valid), self.output_activation == "sigmoid", cls_cfg, None, None, None)
+                out, _ = _LastLayerHeadsTrainFn.apply(x_in, None, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                                      bn.running_var, cfg, *head_params)
+                finish()
+                return out.squeeze(1), None
             elif self.training:
                 tk = train_kids if not self.use_coordinate_graph else (None, None)      # (the explicit coordinate update rewrites rows)
                 h = self._layer_train(i, x_in, graph, gb, (tk[(i + 1) & 1] if i > 0 else None,
@@ -853,6 +956,11 @@ class HierarchicalPatchModel(nn.Module):
         if self.use_coordinate_graph:
             node_coords = node_coords.reshape(B * 4, -1)
         return out.squeeze(1), node_coords
+
+    def _act_in_heads_ok(self) -> bool:
+        """Train mode without the coordinate graph: may the last layer + the heads run as _LastLayerHeadsTrainFn?"""
+        return (not self.use_coordinate_graph and self.layer_output_hook is None and self.jk is None and self._stacked_heads_ok()
+                and self._layer_cfg_static_ok(self.num_gnn_layers - 1) and os.environ.get("EG_ACT_HEADS", "1") != "0")
 
     # ---- the 4 classifier heads in train mode as ONE stacked network ----------------------------------------
     def _stacked_heads_ok(self) -> bool:

@@ -446,6 +446,29 @@ def classifier_train_fwd(h, batch: int, n_per_frame: int, row_lo: int, n_valid: 
     return logits, z1, z2, bn
 
 
+def classifier_train_fwd_act(z, layer_bn, residual, relu: bool, dropout_p: float, seed: int, batch: int, n_per_frame: int,
+                             row_lo: int, n_valid: int, P: dict, sigmoid: bool):
+    """The heads' train forward with the last GNN layer's activation pass folded in (eg_classifier_train_fwd_act): z, layer_bn =
+    what gcn_layer_train_fwd(..., want_out=False) returned, residual = that layer's input rows or None.
+    -> (h [batch*n_per_frame,128], logits [batch*n_valid,4], z1, z2, bn [768])"""
+    _check_rows(z, "z", batch * n_per_frame)
+    if residual is not None:
+        _check_rows(residual, "residual", batch * n_per_frame)
+    rows = batch * n_valid
+    dev = z.device
+    h = torch.empty_like(z)
+    z1 = torch.empty(rows, C, dtype=torch.float32, device=dev)
+    z2 = torch.empty(rows, 64, dtype=torch.float32, device=dev)
+    bn = torch.empty(4 * C + 4 * 64, dtype=torch.float32, device=dev)
+    logits = torch.empty(rows, 4, dtype=torch.float32, device=dev)
+    s = _cls_params(P)
+    _lib.check(_lib.load().eg_classifier_train_fwd_act(
+        _ptr(z), _ptr(layer_bn), _ptr(residual), int(relu), float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(h), batch,
+        n_per_frame, row_lo, n_valid, ct.byref(s), _ptr(_cls_workspace(dev)), _ptr(z1), _ptr(z2), _ptr(bn), int(sigmoid),
+        _ptr(logits), _stream()), "eg_classifier_train_fwd_act")
+    return h, logits, z1, z2, bn
+
+
 def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_valid: int, P: dict, z1, z2, bn, need_dh: bool):
     """-> (dh | None [batch*n_per_frame,128], grads [19076] packed as in include/echoglad_hip.h)"""
     rows = batch * n_valid

@@ -59,8 +59,8 @@ extern "C" {
  * EG_ABI_VERSION the binding was written for (echoglad_amd/_lib.py refuses to load anything else: a stale .so would accept
  * the new calls with shifted arguments).  130: eg_topo_create with the reference builder's full flag set, jk_in inside
  * eg_gcn_layer_cls_fwd, eg_graph_set_precision removed (round 3); train-forward child sums, fused heads backward, the
- * 64-slice queue ring refuses instead of corrupting (round 4). */
-#define EG_ABI_VERSION 130
+ * 64-slice queue ring refuses instead of corrupting (round 4).  131: eg_classifier_train_fwd_act. */
+#define EG_ABI_VERSION 131
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
 
@@ -294,6 +294,16 @@ size_t eg_classifier_train_workspace_bytes(void);
 int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                             const eg_cls_train_params* params, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
                             float* logits, eg_stream_t stream);
+/* The same with the activation pass of the LAST GNN layer folded into the first heads' kernel: the rows of h do not exist yet,
+ *   h = relu|id(dropout(z * scale + shift)) + residual          (scale / shift = layer_bn + 256 / + 384, the bn array
+ *                                                                 eg_gcn_layer_train_fwd(..., out = NULL, ...) left)
+ * is computed tile by tile on the way into the heads' first product and written to h [batch*n_per_frame,128] (every row, also
+ * the ones the filter drops).  One read of h less than eg_gcn_layer_train_fwd(out = h) + eg_classifier_train_fwd(h).
+ * residual: NULL or the layer's input rows; (relu, dropout_p, seed) as given to the layer.  h must not alias z / residual. */
+int eg_classifier_train_fwd_act(const float* z, const float* layer_bn, const float* residual, int relu, float dropout_p, uint64_t seed,
+                                float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                                const eg_cls_train_params* params, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
+                                float* logits, eg_stream_t stream);
 int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                       const eg_cls_train_params* params, const float* z1, const float* z2, const float* bn, void* workspace,
                       float* dh1_scratch, float* dh, float* grads, eg_stream_t stream);

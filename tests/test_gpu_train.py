@@ -572,6 +572,80 @@ def test_chained_train_step_equals_unchained(monkeypatch):
             assert float((a[2][k] - b[2][k]).abs().max()) < 2e-4 * float(b[2][k].abs().max()) + 1e-7, k
 
 
+@pytest.mark.parametrize("n,row_lo,n_valid,B,relu,p,with_res", [(340, 0, 340, 2, True, 0.0, True), (344, 0, 340, 3, False, 0.5, True),
+                                                                (348, 4, 340, 2, True, 0.3, False), (5000, 0, 4996, 2, False, 0.5, True),
+                                                                (64, 0, 64, 1, True, 0.0, True), (72024, 0, 72020, 2, False, 0.5, True)])
+def test_heads_forward_with_the_layer_activation_folded_in(n, row_lo, n_valid, B, relu, p, with_res):
+    """eg_classifier_train_fwd_act == eg_bn_act_fwd + eg_classifier_train_fwd, bit for bit (the same expression per element
+    of h, the same products behind it; the statistics too when the filter starts on a tile boundary), for row filters at either
+    end of a frame and ragged last tiles."""
+    hip, _ = model_pair(16, 3, 1, seed=n + B)
+    hip.train()
+    cfg, params, _ = hip._classifier_train_cfg()
+    from echoglad_amd.nn import _stack_head_params
+    P = _stack_head_params([q.detach() for q in params], cfg)
+    P.update(seed1=11, seed2=12)
+    rs = np.random.RandomState(n)
+    z = (rand_rows(B * n, seed=n + 1) * 1.3).to(DEV)
+    res = rand_rows(B * n, seed=n + 2).to(DEV) if with_res else None
+    bn = torch.zeros(4, 128, device=DEV)
+    bn[2] = torch.from_numpy(1 + 0.3 * rs.standard_normal(128).astype(np.float32)).to(DEV)
+    bn[3] = torch.from_numpy(0.2 * rs.standard_normal(128).astype(np.float32)).to(DEV)
+    h0 = ops.bn_act_fwd(z, bn[2].contiguous(), bn[3].contiguous(), res, relu, p, 777)
+    running = {k: P[k].clone() for k in P if k.startswith("running")}
+    l0, z10, z20, cb0 = ops.classifier_train_fwd(h0, B, n, row_lo, n_valid, P, False)
+    after0 = {k: P[k].clone() for k in running}
+    for k, v in running.items():
+        P[k].copy_(v)
+    h1, l1, z11, z21, cb1 = ops.classifier_train_fwd_act(z, bn, res, relu, p, 777, B, n, row_lo, n_valid, P, False)
+    assert torch.equal(h0, h1) and torch.equal(z10, z11)
+    if row_lo % 64 == 0:
+        assert torch.equal(z20, z21) and torch.equal(cb0, cb1) and torch.equal(l0, l1)
+        for k in running:
+            assert torch.equal(after0[k], P[k]), k
+    else:
+        # the tiles start at the frame's first row, not at the filter's: the column sums of z1 group the rows differently
+        assert torch.allclose(cb0, cb1, rtol=1e-5, atol=1e-6) and torch.allclose(z20, z21, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(l0, l1, rtol=1e-4, atol=1e-5)
+        for k in running:
+            assert torch.allclose(after0[k], P[k], rtol=1e-5, atol=1e-7), k
+    with pytest.raises(RuntimeError):
+        ops.classifier_train_fwd_act(z[:-1], bn, res, relu, p, 777, B, n, row_lo, n_valid, P, False)
+
+
+@pytest.mark.parametrize("coord,L", [(True, 3), (False, 3), (True, 1), (False, 1)])
+def test_train_step_with_the_activation_inside_the_heads_equals_the_separate_pass(monkeypatch, coord, L):
+    """The training step with the last layer + heads as one node (default) against EG_ACT_HEADS=0 (activation pass of its own,
+    two nodes): the same arithmetic in the same order -- logits, coordinates, running statistics and every gradient bit for bit,
+    dropout on."""
+    frame, naux, B = 32, 4, 3
+    hip, _ = model_pair(frame, naux, L, coord=coord, seed=43)
+    hip.train()
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=coord)
+    x = synthetic_node_feats(B * topo.num_nodes, 128, seed=3).to(DEV)
+    coords0 = initial_coords(B, frame).to(DEV) if coord else None
+    state = {k: v.clone() for k, v in hip.state_dict().items()}
+    res = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("EG_ACT_HEADS", knob)
+        hip.load_state_dict(state)
+        for q in hip.parameters():
+            q.grad = None
+        torch.manual_seed(99)
+        got, gc = hip.forward_nodes(x, ei.to(DEV), B, None if coords0 is None else coords0.clone())
+        ((got ** 2).mean() + (0 if gc is None else (gc ** 2).mean() * 1e-3)).backward()
+        res[knob] = (got.detach().clone(), None if gc is None else gc.detach().clone(),
+                     {k: q.grad.clone() for k, q in hip.named_parameters()}, {k: v.clone() for k, v in hip.state_dict().items()})
+    a, b = res["1"], res["0"]
+    assert torch.equal(a[0], b[0])
+    if coord:
+        assert torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+
+
 def test_layer_train_composites_on_a_directed_graph():
     """A_hat of a directed edge_index is not symmetric: forward aggregates over in-edges, backward over out-edges
     (eg_csr_create_transposed)."""
