@@ -58,10 +58,13 @@ class ExpectedLandmarkMSE:
         self.levels = level_grids(frame_size, num_aux_graphs, use_main_graph_only)
         self.grid_sizes = [s for _, s in self.levels]
         self.end_indices = [st + s * s for st, s in self.levels]
+        self._side = {}                    # device -> [1,L,1,1] level sides (built once: a host list -> device tensor is a blocking copy)
 
     def compute(self, pred_y, y, valid):
         expect, gt, vmean = ops.heatmap_expect(_rows4(pred_y), self.batch_size, self.levels, _rows4(y), _rows4(valid))
-        side = torch.tensor(self.grid_sizes, dtype=torch.float32, device=expect.device).view(1, -1, 1, 1)
+        side = self._side.get(expect.device)
+        if side is None:
+            side = self._side[expect.device] = torch.tensor(self.grid_sizes, dtype=torch.float32, device=expect.device).view(1, -1, 1, 1)
         nv = vmean.sum(dim=0, keepdim=True)                                    # [1,L,4]
         nv = torch.where(nv == 0, torch.ones_like(nv), nv)
         d = ((expect / side - gt / side) ** 2) * vmean.unsqueeze(-1)           # [B,L,4,2]
