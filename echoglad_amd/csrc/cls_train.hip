@@ -177,25 +177,6 @@ __device__ inline f32x4 hidden_act4(const f32x4& z, const f32x4& scale, const f3
     return v;
 }
 
-// 64 rows of z1 -> h1 tile in LDS (row stride LDA); rows >= rows_here are zero
-__device__ inline void load_h1_tile(const float* __restrict__ z1, long long row0, int rows_here, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, const ClsDrop& d, float* s_h, int tid) {
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int e = tid + CT_THREADS * it;                // float4 index inside the tile: row e / 32, channels 4 (e % 32)
-        const int r = e >> 5, c4 = (e & 31) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < rows_here) {
-            const f32x4 zz = *reinterpret_cast<const f32x4*>(z1 + (size_t)(row0 + r) * H1 + c4);
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4);
-            const unsigned long long idx = (unsigned long long)(row0 + r) * H1 + c4;
-            v = hidden_act4(zz, sc, sh, d, idx);
-        }
-        *reinterpret_cast<f32x4*>(&s_h[r * LDA + c4]) = v;
-    }
-}
-
 // ---- forward, second layers: z2 = h1 W2^T + b2 (block diagonal: head = wave), column sums of z2 -----------------------
 __global__ __launch_bounds__(CT_THREADS) void k_cls_mid_fwd(const float* __restrict__ z1, long long rows, const float* __restrict__ w2,
                                                             const float* __restrict__ b2, const ClsBn bn1, const ClsDrop d1,
@@ -213,11 +194,35 @@ __global__ __launch_bounds__(CT_THREADS) void k_cls_mid_fwd(const float* __restr
     const f32x4 b2v = *reinterpret_cast<const f32x4*>(b2 + head * 16 + 4 * (lane >> 4));
     float cs = 0.f, cq = 0.f;                               // thread -> channel tid & 63, rows 16 (tid >> 6) ..
     const long long n_tiles = (rows + TILE - 1) / TILE;
+    // the 8 row loads per thread of a tile are issued one tile ahead (behind the first barrier of the tile before): their round
+    // trip runs under that tile's products and write-back instead of in front of this tile's
+    f32x4 pz1[8];
+    auto issue = [&](long long tile) {
+        const long long row0 = tile * TILE;
+        const int rows_here = (int)((rows - row0) < TILE ? (rows - row0) : TILE);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = tid + CT_THREADS * it, r = e >> 5, c4 = (e & 31) * 4;
+            pz1[it] = r < rows_here ? ldnt4(z1 + (size_t)(row0 + r) * H1 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if ((long long)blockIdx.x < n_tiles) issue(blockIdx.x);
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long row0 = tile * TILE;
         const int rows_here = (int)((rows - row0) < TILE ? (rows - row0) : TILE);
-        load_h1_tile(z1, row0, rows_here, bn1.scale, bn1.shift, d1, s_h, tid);
+        {
+            const int c4 = (tid & 31) * 4;                   // (a thread always owns the same 4 channels)
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(bn1.scale + c4), sh = *reinterpret_cast<const f32x4*>(bn1.shift + c4);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = (tid + CT_THREADS * it) >> 5;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < rows_here) v = hidden_act4(pz1[it], sc, sh, d1, (unsigned long long)(row0 + r) * H1 + c4);
+                *reinterpret_cast<f32x4*>(&s_h[r * LDA + c4]) = v;
+            }
+        }
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) issue(tile + gridDim.x);
         const int j = lane & 15, kq = lane >> 4;
 #pragma unroll
         for (int b4 = 0; b4 < 4; ++b4) {
@@ -361,6 +366,9 @@ __global__ __launch_bounds__(CT_THREADS) void k_cls_out_bwd_sums(const float* __
 #ifndef MID_BWD_WGS
 #define MID_BWD_WGS 2               // workgroups per CU (register budget 256 / 168 VGPRs for 2 / 3)
 #endif
+// MASKED: what is written is g1 = dh1 * mask1 (the masked gradient the first layers' BatchNorm backward starts from -- this kernel
+// forms it anyway for its sums), so that k_cls_first_bwd need not regenerate the dropout / ReLU mask per element.
+template <bool MASKED>
 __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const float* __restrict__ dlogits, const float* __restrict__ z2,
                                                             const float* __restrict__ z1, long long rows, const ClsBn bn1, const ClsDrop d1,
                                                             const ClsBn bn2, const ClsDrop d2, const float* __restrict__ w2,
@@ -492,19 +500,22 @@ __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const f
             const int e = tid + CT_THREADS * it, r = e >> 5, c4 = (e & 31) * 4;
             if (r < rows_here) {
                 const f32x4 dv = *reinterpret_cast<const f32x4*>(&s_h[r * LDA + c4]);
-                *reinterpret_cast<f32x4*>(dh1 + (size_t)(row0 + r) * H1 + c4) = dv;
+                if (!MASKED) *reinterpret_cast<f32x4*>(dh1 + (size_t)(row0 + r) * H1 + c4) = dv;
                 // z1 of this element again for the mask and xhat: from the registers it arrived in (re-read from memory it was
                 // 1.18 GB of HBM traffic per launch at batch 32 -- the tile had left the L2 by then, profiles/r04_train_pmc.json)
                 const size_t off = (size_t)(row0 + r) * H1 + c4;
                 const f32x4 zz = cz1[it];
                 const f32x4 kk = d1.p > 0.f ? keep_scale4(d1.seed, (unsigned long long)off, d1.p, d1.inv_keep) : f32x4{1.f, 1.f, 1.f, 1.f};
+                f32x4 gv;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float v = zz[u] * sc1[u] + sh1[u];                      // (hidden_act4's expression: the same mask)
                     const float g = v > 0.f ? dv[u] * kk[u] : 0.f;
+                    gv[u] = g;
                     sg1[u] += g;
                     sx1[u] += g * ((zz[u] - mn1[u]) * is1[u]);
                 }
+                if (MASKED) *reinterpret_cast<f32x4*>(dh1 + off) = gv;
             }
         }
         __syncthreads();
@@ -543,6 +554,7 @@ struct FirstBwdArgs {
     ClsDrop d1;
     float* dh;
     float* partial_dw1;
+    int masked;                 // dh1 holds g1 = dh1 * mask1 already (k_cls_mid_bwd<true>)
 };
 
 // The two roles run separate instantiations of the tile loop (so that neither carries the other's persistent registers: the
@@ -608,13 +620,21 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
                 f32x4 vg = {0.f, 0.f, 0.f, 0.f};
                 if (r < rows) {
                     f32x4 d = pd[q];
-                    if (a.d1.p > 0.f) d *= keep_scale4(a.d1.seed, (unsigned long long)r * C + c4, a.d1.p, a.d1.inv_keep);
+                    if (a.masked) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float xh = (pz[q][u] - mn[u]) * is[u];
-                        const float v = xh * ga[u] + be[u];
-                        const float g = v > 0.f ? d[u] : 0.f;
-                        vg[u] = ga[u] * is[u] * (g - mg[u] - xh * mgx[u]);
+                        for (int u = 0; u < 4; ++u) {
+                            const float xh = (pz[q][u] - mn[u]) * is[u];
+                            vg[u] = ga[u] * is[u] * (d[u] - mg[u] - xh * mgx[u]);
+                        }
+                    } else {
+                        if (a.d1.p > 0.f) d *= keep_scale4(a.d1.seed, (unsigned long long)r * C + c4, a.d1.p, a.d1.inv_keep);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float xh = (pz[q][u] - mn[u]) * is[u];
+                            const float v = xh * ga[u] + be[u];
+                            const float g = v > 0.f ? d[u] : 0.f;
+                            vg[u] = ga[u] * is[u] * (g - mg[u] - xh * mgx[u]);
+                        }
                     }
                 }
                 *reinterpret_cast<f32x4*>(&s_g[rl * LDA + c4]) = vg;
@@ -848,16 +868,19 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
     float* partial2 = partial + (size_t)CT_MAX_BLOCKS * OUT_SUMS;
     float* partial_bn1 = partial2 + (size_t)768 * (4 * 16 * 32);               // [gb][2][128]
     double* tot_bn1 = totals + 256 + 4 * 16 * 32;
-    hipLaunchKernelGGL(k_cls_mid_bwd, dim3(gb), dim3(CT_THREADS), 0, stream, dlogits, z2, z1, rows, bn1, d1, bn2, d2, P->w2, P->w3,
-                       totals, dh1_scratch, partial2, partial_bn1);
+    const RowMap xm{(int)n_valid, (int)n_per_frame, (int)row_lo};
+    static const bool fused_first = !(getenv("EG_CLS_FUSED_BWD") && atoi(getenv("EG_CLS_FUSED_BWD")) == 0);
+    static const bool masked_handoff = !(getenv("EG_CLS_MASKED") && atoi(getenv("EG_CLS_MASKED")) == 0);
+    const bool fused = dh && fused_first && n_valid >= TILE && (long long)batch * n_per_frame * C < (1ll << 32) && rows * C < (1ll << 32);
+    const bool masked = fused && masked_handoff;      // (the unfused route below applies the mask itself)
+    hipLaunchKernelGGL(masked ? k_cls_mid_bwd<true> : k_cls_mid_bwd<false>, dim3(gb), dim3(CT_THREADS), 0, stream, dlogits, z2, z1, rows,
+                       bn1, d1, bn2, d2, P->w2, P->w3, totals, dh1_scratch, partial2, partial_bn1);
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4 * 16 * 32 / 32), dim3(256), 0, stream, partial2, gb, 4 * 16 * 32, totals + 256);
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(256), 0, stream, partial_bn1, gb, 2 * H1, tot_bn1);
     hipLaunchKernelGGL(k_cls_grads_final, dim3(8), dim3(256), 0, stream, totals, totals + 256, tot_bn1, grads);
     EG_HIP_TRY(hipGetLastError());
     // ---- first layers: dz1 formed on the fly, dW1 = dz1^T h[valid rows] and dh[valid rows] = dz1 W1 in ONE kernel
-    const RowMap xm{(int)n_valid, (int)n_per_frame, (int)row_lo};
-    static const bool fused_first = !(getenv("EG_CLS_FUSED_BWD") && atoi(getenv("EG_CLS_FUSED_BWD")) == 0);
-    if (dh && fused_first && n_valid >= TILE && (long long)batch * n_per_frame * C < (1ll << 32) && rows * C < (1ll << 32)) {
+    if (fused) {
         if (n_valid < n_per_frame)
             hipLaunchKernelGGL(k_zero_rows, dim3(64), dim3(256), 0, stream, dh, batch, (int)n_per_frame, (int)row_lo, (int)n_valid);
         {
@@ -873,7 +896,7 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
         const int nf = (int)(nt < FB_BLOCKS ? nt : FB_BLOCKS);
         float* slabs = (float*)((char*)shared + eg_workspace_bytes() - (size_t)FB_BLOCKS * C * C * sizeof(float));
         const size_t lds = (size_t)(3 * TILE * LDA + 6 * H1) * sizeof(float);
-        const FirstBwdArgs fa{dh1_scratch, z1, h, P->w1, (const double*)tot_bn1, rows, xm, d1, dh, slabs};
+        const FirstBwdArgs fa{dh1_scratch, z1, h, P->w1, (const double*)tot_bn1, rows, xm, d1, dh, slabs, masked ? 1 : 0};
         hipLaunchKernelGGL(k_cls_first_bwd, dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
         hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(256), 0, stream, (const float*)slabs, nf, grads);
         EG_HIP_TRY(hipGetLastError());
