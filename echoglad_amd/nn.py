@@ -161,14 +161,18 @@ class _GCNConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-def _bn_step(bn: nn.BatchNorm1d):
+def _bn_step(bn: nn.BatchNorm1d, pending: Optional[list] = None):
     """What nn.BatchNorm1d.forward decides before calling F.batch_norm: (use batch statistics?, update factor | None).
-    Counts the batch in ``num_batches_tracked``; ``momentum=None`` is the cumulative moving average."""
+    Counts the batch in ``num_batches_tracked``; ``momentum=None`` is the cumulative moving average.  ``pending``: a list that
+    collects the counters instead (the caller bumps them all with one multi-tensor add: a launch per BatchNorm otherwise)."""
     use_batch = bn.training or bn.running_mean is None
     factor = None
     if bn.training and bn.track_running_stats and bn.running_mean is not None:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
+        if pending is not None and bn.momentum is not None:
+            pending.append(bn.num_batches_tracked)
+        else:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
         factor = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else float(bn.momentum)
     return use_batch, factor
 
@@ -322,12 +326,26 @@ class _ClassifierTrainFn(torch.autograd.Function):
         return (dh, None, None, None, None, None, None) + _unstack_head_grads(g)
 
 
+# per-head sizes of the 10 parameters in _HEAD_PARAM_IDX order, and where the stacked arrays start in one flat buffer (the layout
+# of eg_classifier_bwd's packed gradients, include/echoglad_hip.h)
+_HEAD_SIZES = (32 * C, 32, 32, 32, 16 * 32, 16, 16, 16, 16, 1)
+_HEAD_NAMES = ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3", "b3")
+_HEAD_SHAPES = ((4 * 32, C), (128,), (128,), (128,), (4, 16, 32), (64,), (64,), (64,), (64,), (4,))
+
+
 def _stack_head_params(params, cfg):
-    heads = [params[10 * k:10 * k + 10] for k in range(4)]
-    cat = lambda j: torch.cat([hd[j].reshape(-1) if hd[j].dim() == 1 else hd[j] for hd in heads], dim=0).contiguous()
+    """The 4 x 10 head parameters as the stacked arrays the kernels take: ONE flat buffer filled by one multi-tensor copy (a
+    torch.cat / stack per array was 10 launches per step), the arrays are views of it."""
+    flat = torch.empty(4 * sum(_HEAD_SIZES), dtype=torch.float32, device=params[0].device)
+    dst, src, start = [], [], 0
     P = dict(cfg)
-    P.update(w1=cat(0), b1=cat(1), gamma1=cat(2), beta1=cat(3), w2=torch.stack([hd[4] for hd in heads]).contiguous(),
-             b2=cat(5), gamma2=cat(6), beta2=cat(7), w3=cat(8), b3=cat(9))
+    for j, (size, name, shape) in enumerate(zip(_HEAD_SIZES, _HEAD_NAMES, _HEAD_SHAPES)):
+        P[name] = flat[start:start + 4 * size].view(shape)
+        for k in range(4):
+            dst.append(flat[start + k * size:start + (k + 1) * size])
+            src.append(params[10 * k + j].detach().reshape(-1))
+        start += 4 * size
+    torch._foreach_copy_(dst, src)
     return P
 
 
@@ -764,13 +782,13 @@ class HierarchicalPatchModel(nn.Module):
                    running_var2=bn2.running_var)
         return cfg, params
 
-    def _coord_mlp_train_cfg(self, mlp: nn.Sequential):
+    def _coord_mlp_train_cfg(self, mlp: nn.Sequential, pending: Optional[list] = None):
         """The same with this step's dropout seeds drawn and the BatchNorm batches counted (call once per forward)."""
         cfg, params = self._coord_mlp_cfg(mlp)
         if cfg["p1"] > 0 or cfg["p2"] > 0:
             cfg["seed1"], cfg["seed2"] = torch.randint(0, 2 ** 62, (2,)).tolist()     # host RNG, like the layers
-        _, cfg["momentum1"] = _bn_step(mlp[1])
-        _, cfg["momentum2"] = _bn_step(mlp[5])
+        _, cfg["momentum1"] = _bn_step(mlp[1], pending)
+        _, cfg["momentum2"] = _bn_step(mlp[5], pending)
         return cfg, params
 
     def _coord_mlp_kernel(self, mlp: nn.Sequential, lm: torch.Tensor, node_coords: torch.Tensor, batch: int, frame: int):
@@ -819,35 +837,36 @@ class HierarchicalPatchModel(nn.Module):
         kids = self._train_kidsums(graph, gb)
         h, coords = x0.contiguous(), node_coords
         L = self.num_gnn_layers
+        counters = []                      # num_batches_tracked of every BatchNorm of the step: bumped together by finish(counters)
         act_in_heads = os.environ.get("EG_ACT_HEADS", "1") != "0"      # the last layer's activation pass inside the heads' first kernel
         for i in range(L):
             conv, bn, relu, p, seed = self._layer_cfg(i)
-            _, momentum = _bn_step(bn)
+            _, momentum = _bn_step(bn, counters)
             kid = (kids[(i + 1) & 1] if i > 0 else None, kids[i & 1] if i < self.num_gnn_layers - 1 else None)
             if i == L - 1 and act_in_heads:
-                mlp_prev_cfg, mlp_prev = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i - 1]) if i > 0 else (None, [])
-                mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i])
+                mlp_prev_cfg, mlp_prev = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i - 1], counters) if i > 0 else (None, [])
+                mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i], counters)
                 cls_cfg, head_params, finish = self._classifier_train_cfg()
                 cfg = (graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid[0], (B, n, n_conn, n_valid),
                        self.output_activation == "sigmoid", cls_cfg, dims, mlp_prev_cfg, mlp_cfg)
                 logits, coords = _LastLayerHeadsTrainFn.apply(h, coords, conv.lin.weight, conv.bias, bn.weight, bn.bias,
                                                               bn.running_mean, bn.running_var, cfg, *mlp_prev, *mlp_params,
                                                               *head_params)
-                finish()
+                finish(counters)
                 return logits.squeeze(1), coords.reshape(B * 4, -1)
             if i == 0:
                 h = _LayerTrainFn.apply(h, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                         graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid)
             else:
-                mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i - 1])
+                mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i - 1], counters)
                 cfg = (graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), dims, mlp_cfg, kid)
                 h, coords = _CoordLayerTrainFn.apply(h, coords, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                                      bn.running_var, cfg, *mlp_params)
-        mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[self.num_gnn_layers - 1])
+        mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[self.num_gnn_layers - 1], counters)
         cls_cfg, head_params, finish = self._classifier_train_cfg()
         logits, coords = _CoordClassifierTrainFn.apply(h, coords, (B, n, n_conn, n_valid), self.output_activation == "sigmoid",
                                                        cls_cfg, dims, mlp_cfg, *mlp_params, *head_params)
-        finish()
+        finish(counters)
         return logits.squeeze(1), coords.reshape(B * 4, -1)
 
     def _train_kidsums(self, graph: ops.Graph, gb: int):
@@ -978,19 +997,22 @@ class HierarchicalPatchModel(nn.Module):
         bn1, bn2 = [hd[1] for hd in heads], [hd[5] for hd in heads]
         p1, p2 = float(heads[0][3].p), float(heads[0][7].p)
         seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if (p1 > 0 or p2 > 0) else [0, 0]      # host RNG, like the layers
-        with torch.no_grad():
-            rm1, rv1 = torch.cat([b.running_mean for b in bn1]), torch.cat([b.running_var for b in bn1])
-            rm2, rv2 = torch.cat([b.running_mean for b in bn2]), torch.cat([b.running_var for b in bn2])
+        with torch.no_grad():                              # stacked copies of the running statistics: one multi-tensor copy
+            stats = torch.empty(2 * 128 + 2 * 64, dtype=torch.float32, device=bn1[0].running_mean.device)
+            rm1, rv1, rm2, rv2 = stats[:128], stats[128:256], stats[256:320], stats[320:384]
+            torch._foreach_copy_(list(rm1.split(32)) + list(rv1.split(32)) + list(rm2.split(16)) + list(rv2.split(16)),
+                                 [b.running_mean for b in bn1] + [b.running_var for b in bn1] +
+                                 [b.running_mean for b in bn2] + [b.running_var for b in bn2])
         cfg = dict(running_mean1=rm1, running_var1=rv1, running_mean2=rm2, running_var2=rv2, eps1=bn1[0].eps, eps2=bn2[0].eps,
                    momentum1=bn1[0].momentum, momentum2=bn2[0].momentum, p1=p1, p2=p2, seed1=seeds[0], seed2=seeds[1])
         params = [getattr(hd[j], name) for hd in heads for j, name in _HEAD_PARAM_IDX]
 
-        def finish():
+        def finish(more_counters=()):
             with torch.no_grad():
                 torch._foreach_copy_([b.running_mean for b in bn1] + [b.running_var for b in bn1] +
                                      [b.running_mean for b in bn2] + [b.running_var for b in bn2],
                                      list(rm1.split(32)) + list(rv1.split(32)) + list(rm2.split(16)) + list(rv2.split(16)))
-                torch._foreach_add_([b.num_batches_tracked for b in bn1 + bn2], 1)
+                torch._foreach_add_([b.num_batches_tracked for b in bn1 + bn2] + list(more_counters), 1)
         return cfg, params, finish
 
     def _classifier_train(self, h: torch.Tensor, B: int, n: int, row_lo: int, n_valid: int) -> torch.Tensor:
