@@ -555,11 +555,17 @@ struct FirstBwdArgs {
     float* dh;
     float* partial_dw1;
     int masked;                 // dh1 holds g1 = dh1 * mask1 already (k_cls_mid_bwd<true>)
+    // SUMS: the BatchNorm-backward sums of the GNN layer in front of the heads (sum g, sum g xhat over the rows dh is written to,
+    // g = dh * that layer's dropout / ReLU mask), taken in the tile's store phase where dh passes through registers anyway:
+    // the layer's own sums pass (a read of dh and z: 2.4 GB at batch 32) then only has the filtered-out rows left
+    const float *lz, *lmean, *linvstd, *lgamma, *lbeta;      // the layer's z [batch * stride, 128] and BatchNorm vectors
+    ActArgs la;                                              // its (relu, p, seed)
+    float* partial_lsums;                                    // [blocks][2][128]
 };
 
 // The two roles run separate instantiations of the tile loop (so that neither carries the other's persistent registers: the
 // [32 x 128] accumulators of the weight gradient / the W1 slice); both execute the same two workgroup barriers per tile.
-template <bool GEMM2>
+template <bool GEMM2, bool SUMS>
 __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* s_x, float* s_o, const float* s_c, int wave) {
     const int tid = threadIdx.x, lane_k = tid & 63;
     const int c4 = (tid & 31) * 4;
@@ -575,6 +581,8 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
     const long long rows = a.rows;
     const long long n_tiles = (rows + TILE - 1) / TILE;
     f32x4 pd[4], pz[4], px[4];
+    f32x4 pl[SUMS ? 4 : 1], cl[SUMS ? 4 : 1];     // SUMS: the layer's z rows, prefetched with the others / of the current tile
+    f32x4 lsg = {0.f, 0.f, 0.f, 0.f}, lsx = lsg;
     // Row of the unfiltered array behind compact row r of tile t: the tile's first row is decoded once (a 32-bit division on the
     // scalar unit), a row of the tile lies in that frame or the next one (n_valid >= 64 is checked on the host).  A 64-bit
     // division per row -- map_row -- cost more instructions than the rest of the tile's address arithmetic together.
@@ -600,7 +608,9 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
                 const unsigned off = (unsigned)r * (unsigned)C + (unsigned)c4;
                 pd[q] = *reinterpret_cast<const f32x4*>(a.dh1 + off);
                 pz[q] = *reinterpret_cast<const f32x4*>(a.z1 + off);
-                px[q] = *reinterpret_cast<const f32x4*>(a.h + (mapped(f0, in0, (tid >> 5) + 16 * q) * (unsigned)C + (unsigned)c4));
+                const unsigned hoff = mapped(f0, in0, (tid >> 5) + 16 * q) * (unsigned)C + (unsigned)c4;
+                px[q] = *reinterpret_cast<const f32x4*>(a.h + hoff);
+                if (SUMS) pl[q] = *reinterpret_cast<const f32x4*>(a.lz + hoff);
             }
         }
     };
@@ -639,6 +649,7 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
                 }
                 *reinterpret_cast<f32x4*>(&s_g[rl * LDA + c4]) = vg;
                 *reinterpret_cast<f32x4*>(&s_x[rl * LDA + c4]) = px[q];
+                if (SUMS) cl[q] = pl[q];
             }
         }
         __syncthreads();                          // tile in LDS; s_o of the tile before has been stored
@@ -678,10 +689,43 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
             for (int q = 0; q < 4; ++q) {
                 const int rl = (tid >> 5) + 16 * q;
                 const long long r = r0 + rl;
-                if (r < rows)
-                    *reinterpret_cast<f32x4*>(a.dh + (mapped(f0, in0, rl) * (unsigned)C + (unsigned)c4)) = *reinterpret_cast<const f32x4*>(&s_o[rl * LDA + c4]);
+                if (r < rows) {
+                    const unsigned hoff = mapped(f0, in0, rl) * (unsigned)C + (unsigned)c4;
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(&s_o[rl * LDA + c4]);
+                    *reinterpret_cast<f32x4*>(a.dh + hoff) = dv;
+                    if (SUMS) {                   // k_bn_bwd_partial's expression per element (train.hip), on the row just written
+                        const f32x4 lm = *reinterpret_cast<const f32x4*>(s_c + 6 * H1 + c4), li = *reinterpret_cast<const f32x4*>(s_c + 7 * H1 + c4);
+                        const f32x4 lg = *reinterpret_cast<const f32x4*>(s_c + 8 * H1 + c4), lb = *reinterpret_cast<const f32x4*>(s_c + 9 * H1 + c4);
+                        f32x4 g = dv;
+                        if (a.la.p > 0.f) g *= keep_scale4(a.la.seed, (unsigned long long)hoff, a.la.p, a.la.inv_keep);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float xh = (cl[q][u] - lm[u]) * li[u];
+                            const float v = xh * lg[u] + lb[u];
+                            float ge = g[u];
+                            if (a.la.relu) ge = v > 0.f ? ge : 0.f;
+                            lsg[u] += ge;
+                            lsx[u] += ge * xh;
+                        }
+                    }
+                }
             }
         }
+    }
+    if constexpr (SUMS) {                         // the 16 threads that share a channel group (both roles), in a fixed order
+        __syncthreads();
+        float* red = s_g;                         // [16][2][128]
+        const int rg = tid >> 5;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { red[(rg * 2 + 0) * H1 + c4 + u] = lsg[u]; red[(rg * 2 + 1) * H1 + c4 + u] = lsx[u]; }
+        __syncthreads();
+        if (tid < 2 * H1) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k * 2 * H1 + tid];
+            a.partial_lsums[(size_t)blockIdx.x * 2 * H1 + tid] = t;
+        }
+        __syncthreads();
     }
     if constexpr (!GEMM2) {
         const int i = lane_k & 31, kh = lane_k >> 5;
@@ -696,12 +740,13 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
     }
 }
 
+template <bool SUMS>
 __global__ __launch_bounds__(512) void k_cls_first_bwd(const FirstBwdArgs a, const ClsBn bn1, const float* __restrict__ beta1) {
     extern __shared__ __attribute__((aligned(16))) float fb_smem[];
     float* s_g = fb_smem;                         // [64][LDA]  dz1 tile
     float* s_x = fb_smem + TILE * LDA;            // [64][LDA]  h tile (valid rows)
     float* s_o = fb_smem + 2 * TILE * LDA;        // [64][LDA]  dh tile on its way out
-    float* s_c = fb_smem + 3 * TILE * LDA;        // [6][128]   mean, invstd, gamma, beta, mean g, mean g xhat
+    float* s_c = fb_smem + 3 * TILE * LDA;        // [6 | 10][128]   mean, invstd, gamma, beta, mean g, mean g xhat (+ SUMS: the layer's mean, invstd, gamma, beta)
     const int tid = threadIdx.x, wave = wave_id();
     if (tid < H1) {
         const double inv_n = 1.0 / (double)a.rows;
@@ -711,10 +756,16 @@ __global__ __launch_bounds__(512) void k_cls_first_bwd(const FirstBwdArgs a, con
         s_c[3 * H1 + tid] = beta1[tid];
         s_c[4 * H1 + tid] = (float)(a.tot[tid] * inv_n);
         s_c[5 * H1 + tid] = (float)(a.tot[H1 + tid] * inv_n);
+        if (SUMS) {
+            s_c[6 * H1 + tid] = a.lmean[tid];
+            s_c[7 * H1 + tid] = a.linvstd[tid];
+            s_c[8 * H1 + tid] = a.lgamma[tid];
+            s_c[9 * H1 + tid] = a.lbeta[tid];
+        }
     }
     __syncthreads();
-    if (wave < 4) first_bwd_role<false>(a, s_g, s_x, s_o, s_c, wave);
-    else first_bwd_role<true>(a, s_g, s_x, s_o, s_c, wave);
+    if (wave < 4) first_bwd_role<false, SUMS>(a, s_g, s_x, s_o, s_c, wave);
+    else first_bwd_role<true, SUMS>(a, s_g, s_x, s_o, s_c, wave);
 }
 
 __global__ void k_zero_rows(float* __restrict__ x, int batch, int stride, int lo, int n_valid) {
@@ -763,7 +814,8 @@ using namespace eg;
 // internal launchers of train.hip
 int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, int relu, float dropout_p, unsigned long long seed, void* workspace, float* dz,
-                     float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream);
+                     float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream,
+                     const double* presum = nullptr, const eg::RowMap* presum_rows = nullptr, int presum_frames = 0);
 
 extern "C" {
 
@@ -842,13 +894,29 @@ int eg_classifier_train_fwd_act(const float* z, const float* layer_bn, const flo
     return classifier_train_fwd(nullptr, &act, batch, n_per_frame, row_lo, n_valid, P, workspace, z1, z2, bn, sigmoid, logits, stream);
 }
 
-int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
-                      const eg_cls_train_params* P, const float* z1, const float* z2, const float* bn, void* workspace,
-                      float* dh1_scratch, float* dh, float* grads, eg_stream_t stream_) {
+struct LayerSumsReq {               // eg_classifier_bwd_sums: the layer in front of the heads
+    const float *z, *bn, *gamma, *beta;
+    int relu;
+    float p;
+    uint64_t seed;
+    double* sums;                   // out [2][128]
+};
+
+static bool first_bwd_covers(const float* dh, int batch, int64_t n_per_frame, int64_t n_valid) {
+    static const bool fused_first = !(getenv("EG_CLS_FUSED_BWD") && atoi(getenv("EG_CLS_FUSED_BWD")) == 0);
+    const long long rows = (long long)batch * n_valid;
+    return dh && fused_first && n_valid >= TILE && (long long)batch * n_per_frame * C < (1ll << 32) && rows * C < (1ll << 32);
+}
+
+static int classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                          const eg_cls_train_params* P, const float* z1, const float* z2, const float* bn, void* workspace,
+                          float* dh1_scratch, float* dh, float* grads, const LayerSumsReq* ls, eg_stream_t stream_) {
     if (!dlogits || !h || !P || !z1 || !z2 || !bn || !workspace || !dh1_scratch || !grads)
         return set_error(EG_ERR_ARG, "NULL argument");
     if (batch < 1 || n_per_frame < 1 || row_lo < 0 || n_valid < 1 || row_lo + n_valid > n_per_frame)
         return set_error(EG_ERR_ARG, "bad row range");
+    if (ls && !first_bwd_covers(dh, batch, n_per_frame, n_valid))
+        return set_error(EG_ERR_UNSUPPORTED, "the layer's sums come out of the fused first-layers kernel: dh wanted, n_valid >= 64, < 2^32 elements");
     hipStream_t stream = (hipStream_t)stream_;
     const long long rows = (long long)batch * n_valid;
     float* partial = (float*)workspace;
@@ -869,9 +937,8 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
     float* partial_bn1 = partial2 + (size_t)768 * (4 * 16 * 32);               // [gb][2][128]
     double* tot_bn1 = totals + 256 + 4 * 16 * 32;
     const RowMap xm{(int)n_valid, (int)n_per_frame, (int)row_lo};
-    static const bool fused_first = !(getenv("EG_CLS_FUSED_BWD") && atoi(getenv("EG_CLS_FUSED_BWD")) == 0);
     static const bool masked_handoff = !(getenv("EG_CLS_MASKED") && atoi(getenv("EG_CLS_MASKED")) == 0);
-    const bool fused = dh && fused_first && n_valid >= TILE && (long long)batch * n_per_frame * C < (1ll << 32) && rows * C < (1ll << 32);
+    const bool fused = first_bwd_covers(dh, batch, n_per_frame, n_valid);
     const bool masked = fused && masked_handoff;      // (the unfused route below applies the mask itself)
     hipLaunchKernelGGL(masked ? k_cls_mid_bwd<true> : k_cls_mid_bwd<false>, dim3(gb), dim3(CT_THREADS), 0, stream, dlogits, z2, z1, rows,
                        bn1, d1, bn2, d2, P->w2, P->w3, totals, dh1_scratch, partial2, partial_bn1);
@@ -888,16 +955,26 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
             int dev = 0;
             EG_HIP_TRY(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-                EG_HIP_TRY(hipFuncSetAttribute((const void*)k_cls_first_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                EG_HIP_TRY(hipFuncSetAttribute((const void*)k_cls_first_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                EG_HIP_TRY(hipFuncSetAttribute((const void*)k_cls_first_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
             }
         }
         const long long nt = (rows + TILE - 1) / TILE;
         const int nf = (int)(nt < FB_BLOCKS ? nt : FB_BLOCKS);
         float* slabs = (float*)((char*)shared + eg_workspace_bytes() - (size_t)FB_BLOCKS * C * C * sizeof(float));
-        const size_t lds = (size_t)(3 * TILE * LDA + 6 * H1) * sizeof(float);
-        const FirstBwdArgs fa{dh1_scratch, z1, h, P->w1, (const double*)tot_bn1, rows, xm, d1, dh, slabs, masked ? 1 : 0};
-        hipLaunchKernelGGL(k_cls_first_bwd, dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
+        const size_t lds = (size_t)(3 * TILE * LDA + 10 * H1) * sizeof(float);
+        FirstBwdArgs fa{dh1_scratch, z1, h, P->w1, (const double*)tot_bn1, rows, xm, d1, dh, slabs, masked ? 1 : 0};
+        if (ls) {
+            fa.lz = ls->z; fa.lmean = ls->bn; fa.linvstd = ls->bn + C; fa.lgamma = ls->gamma; fa.lbeta = ls->beta;
+            fa.la.rows = (long long)batch * n_per_frame; fa.la.relu = ls->relu; fa.la.p = ls->p;
+            fa.la.inv_keep = ls->p > 0.f ? 1.0f / (1.0f - ls->p) : 1.0f; fa.la.seed = ls->seed;
+            fa.partial_lsums = partial_bn1;                                       // (reduced into tot_bn1 already)
+            hipLaunchKernelGGL(k_cls_first_bwd<true>, dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
+            hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(256), 0, stream, (const float*)partial_bn1, nf, 2 * H1, ls->sums);
+        } else {
+            hipLaunchKernelGGL(k_cls_first_bwd<false>, dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
+        }
         hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(256), 0, stream, (const float*)slabs, nf, grads);
         EG_HIP_TRY(hipGetLastError());
         return EG_OK;
@@ -922,6 +999,23 @@ int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n
                        P->w1, (const float*)nullptr, dh, (float*)nullptr, d, LinAct{});
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
+}
+
+int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                      const eg_cls_train_params* P, const float* z1, const float* z2, const float* bn, void* workspace,
+                      float* dh1_scratch, float* dh, float* grads, eg_stream_t stream) {
+    return classifier_bwd(dlogits, h, batch, n_per_frame, row_lo, n_valid, P, z1, z2, bn, workspace, dh1_scratch, dh, grads, nullptr, stream);
+}
+
+int eg_classifier_bwd_sums(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                           const eg_cls_train_params* P, const float* z1, const float* z2, const float* bn, void* workspace,
+                           float* dh1_scratch, float* dh, float* grads, const float* layer_z, const float* layer_bn,
+                           const float* layer_gamma, const float* layer_beta, int layer_relu, float layer_dropout_p,
+                           uint64_t layer_seed, double* layer_sums, eg_stream_t stream) {
+    if (!layer_z || !layer_bn || !layer_gamma || !layer_beta || !layer_sums) return set_error(EG_ERR_ARG, "NULL argument");
+    if (layer_dropout_p < 0.f || layer_dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    const LayerSumsReq ls{layer_z, layer_bn, layer_gamma, layer_beta, layer_relu, layer_dropout_p, layer_seed, layer_sums};
+    return classifier_bwd(dlogits, h, batch, n_per_frame, row_lo, n_valid, P, z1, z2, bn, workspace, dh1_scratch, dh, grads, &ls, stream);
 }
 
 }  // extern "C"

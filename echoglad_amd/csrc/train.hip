@@ -228,6 +228,44 @@ __global__ __launch_bounds__(RED_THREADS) void k_bn_bwd_partial(const float* __r
     }
 }
 
+// The sums pass when the caller already holds the sums over rows [lo, lo + n_valid) of every frame (taken where dy was produced:
+// eg_classifier_bwd_sums): totals = presum + the sums over the other rows of every frame (coordinate / connection nodes: a few
+// rows per frame).  One workgroup: thread (channel c, row group t >> 7), fp64, fixed order.
+__global__ __launch_bounds__(1024) void k_bn_bwd_presum(const double* __restrict__ presum, const float* __restrict__ dy,
+                                                        const float* __restrict__ z, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const RowMap m, int batch,
+                                                        double* __restrict__ totals, const ActArgs a) {
+    __shared__ double s_red[8][2][C];
+    const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    const int extra = m.stride - m.n_valid;                                    // rows per frame outside the range
+    const long long n = (long long)batch * extra;
+    const float mn = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    double sg = 0.0, sx = 0.0;
+#pragma unroll 4
+    for (long long i = grp; i < n; i += 8) {
+        const long long f = i / extra;
+        const int e = (int)(i - f * extra);
+        const size_t off = (size_t)(f * m.stride + (e < m.lo ? e : e + m.n_valid)) * C + c;
+        float g = dy[off];
+        if (a.p > 0.f) g *= keep_scale(a.seed, (unsigned long long)off, a.p, a.inv_keep);
+        const float xh = (z[off] - mn) * is;
+        const float v = xh * ga + be;
+        if (a.relu) g = v > 0.f ? g : 0.f;
+        sg += (double)g;
+        sx += (double)(g * xh);
+    }
+    s_red[grp][0][c] = sg;
+    s_red[grp][1][c] = sx;
+    __syncthreads();
+    if (grp < 2) {
+        double t = presum[grp * C + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s_red[k][grp][c];
+        totals[grp * C + c] = t;
+    }
+}
+
 __global__ void k_bn_bwd_final(const double* __restrict__ totals, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int c = threadIdx.x;
     if (c < C) { dbeta[c] = (float)totals[c]; dgamma[c] = (float)totals[C + c]; }
@@ -495,7 +533,8 @@ static ActArgs make_act(int64_t rows, int relu, float p, uint64_t seed) {
 // sums pass -> (dgamma, dbeta) -> apply pass writing dz (and accumulating dW when x / dw are given).
 int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, int relu, float dropout_p, unsigned long long seed, void* workspace, float* dz,
-                     float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream) {
+                     float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream,
+                     const double* presum, const eg::RowMap* presum_rows, int presum_batch) {
     if (!dy || !z || !mean || !invstd || !gamma || !beta || !workspace || !dgamma || !dbeta || rows < 1)
         return set_error(EG_ERR_ARG, "bad argument");
     if (!dz && !(dw && x)) return set_error(EG_ERR_ARG, "dz may only be NULL when the fused weight gradient is computed");
@@ -504,8 +543,13 @@ int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const floa
     double* partial = (double*)workspace;
     const int nb = red_blocks(rows);
     double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
-    hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nb), dim3(RED_THREADS), 0, stream, dy, z, mean, invstd, gamma, beta, partial, a);
-    hipLaunchKernelGGL(k_reduce_partials<2>, dim3(2 * C / 8), dim3(256), 0, stream, partial, nb, totals);
+    if (presum) {          // the sums over most rows exist: add the few rows they leave out
+        hipLaunchKernelGGL(k_bn_bwd_presum, dim3(1), dim3(1024), 0, stream, presum, dy, z, mean, invstd, gamma, beta, *presum_rows,
+                           presum_batch, totals, a);
+    } else {
+        hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nb), dim3(RED_THREADS), 0, stream, dy, z, mean, invstd, gamma, beta, partial, a);
+        hipLaunchKernelGGL(k_reduce_partials<2>, dim3(2 * C / 8), dim3(256), 0, stream, partial, nb, totals);
+    }
     hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(128), 0, stream, totals, dgamma, dbeta);
     if (dw && x) {
         long long nt = (rows + DW_ROWS - 1) / DW_ROWS;
@@ -577,7 +621,7 @@ int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* me
                   const float* gamma, const float* beta, int relu, float dropout_p, uint64_t seed, void* workspace,
                   float* dz, float* dgamma, float* dbeta, eg_stream_t stream) {
     return eg_launch_bn_bwd(dy, z, rows, mean, invstd, gamma, beta, relu, dropout_p, seed, workspace, dz, dgamma, dbeta, nullptr,
-                            nullptr, nullptr, (hipStream_t)stream);
+                            nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0);
 }
 
 int eg_dweight128(const float* g, const float* x, int64_t rows, void* workspace, float* dw, eg_stream_t stream) {
@@ -633,10 +677,10 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
     return eg_bn_act_fwd(z, rows, bn + 2 * C, bn + 3 * C, residual ? x : nullptr, relu, dropout_p, seed, out, stream_);
 }
 
-int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
-                     const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
-                     int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
-                     float* dbeta, eg_stream_t stream_) {
+static int gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
+                         const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
+                         int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
+                         float* dbeta, const double* presum, const RowMap* presum_rows, int presum_frames, eg_stream_t stream_) {
     if (!g_bwd || !dy || !z || !W || !gamma || !beta || !bn || !workspace || !dgamma || !dbeta)
         return set_error(EG_ERR_ARG, "NULL argument");
     if (!dz_scratch && (dx || !dw)) return set_error(EG_ERR_ARG, "dz_scratch may only be NULL when dx is not wanted and dw is");
@@ -644,7 +688,7 @@ int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const fl
     hipStream_t stream = (hipStream_t)stream_;
     const long long rows = (long long)g_bwd->n_nodes * batch;
     int rc = eg_launch_bn_bwd(dy, z, rows, bn, bn + C, gamma, beta, relu, dropout_p, seed, workspace, dz_scratch, dgamma, dbeta,
-                              dw ? agg : nullptr, nullptr, dw, stream);
+                              dw ? agg : nullptr, nullptr, dw, stream, presum, presum_rows, presum_frames);
     if (rc != EG_OK) return rc;
     if (dx) {
         // dX = (A_hat dz) W + dy: the producer / consumer kernel with the residual as a tensor of its own (implicit topologies)
@@ -659,6 +703,28 @@ int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const fl
     }
     if (db) EG_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * C, stream));     // a bias in front of a train-mode BatchNorm
     return EG_OK;
+}
+
+int eg_gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
+                     const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
+                     int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
+                     float* dbeta, eg_stream_t stream) {
+    return gcn_layer_bwd(g_bwd, batch, dy, z, agg, W, gamma, beta, bn, relu, dropout_p, seed, residual, workspace, dz_scratch, dx, dw,
+                         db, dgamma, dbeta, nullptr, nullptr, 0, stream);
+}
+
+int eg_gcn_layer_bwd_presummed(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
+                               const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
+                               int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
+                               float* dbeta, const double* dy_sums, int frames, int64_t row_lo, int64_t n_valid, eg_stream_t stream) {
+    if (!g_bwd || !dy_sums) return set_error(EG_ERR_ARG, "NULL argument");
+    if (frames < 1 || (long long)g_bwd->n_nodes * batch % frames != 0) return set_error(EG_ERR_ARG, "frames must divide the layer's rows");
+    const long long n_per_frame = (long long)g_bwd->n_nodes * batch / frames;
+    if (row_lo < 0 || n_valid < 1 || row_lo + n_valid > n_per_frame) return set_error(EG_ERR_ARG, "bad row range");
+    const RowMap m{(int)n_valid, (int)n_per_frame, (int)row_lo};
+    // (frames, not `batch`, counts the row ranges: a CSR handle of a whole batch has batch == 1)
+    return gcn_layer_bwd(g_bwd, batch, dy, z, agg, W, gamma, beta, bn, relu, dropout_p, seed, residual, workspace, dz_scratch, dx, dw,
+                         db, dgamma, dbeta, dy_sums, &m, frames, stream);
 }
 
 }  // extern "C"

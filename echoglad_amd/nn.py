@@ -448,7 +448,15 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
         dl = dy.contiguous()
         if sigmoid:
             dl = dl * y * (1.0 - y)
-        dh, g = ops.classifier_bwd(dl, h, B, n, row_lo, n_valid, ctx.P, z1, z2, cbn, True)         # (a buffer of this node)
+        # the layer's BatchNorm-backward sums over the heads' rows are taken where dh leaves the heads' backward (no separate
+        # sums pass over dh and z for the layer afterwards: only the rows the filter drops are added there)
+        presum = None
+        if ops.classifier_layer_sums_supported(B, n, n_valid) and os.environ.get("EG_LAYER_SUMS_IN_HEADS", "1") != "0":
+            dh, g, sums = ops.classifier_bwd(dl, h, B, n, row_lo, n_valid, ctx.P, z1, z2, cbn, True,
+                                             layer=(z, bn, gamma, beta, relu, p, seed))
+            presum = (sums, B, row_lo, n_valid)
+        else:
+            dh, g = ops.classifier_bwd(dl, h, B, n, row_lo, n_valid, ctx.P, z1, z2, cbn, True)     # (a buffer of this node)
         dmid, gm, gm_prev = None, None, None
         if has_coord:
             new, lm, flat = rest[0], rest[1], rest[2]
@@ -459,7 +467,7 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
         need_x = has_prev or ctx.needs_input_grad[0]
         need_w, need_b = ctx.needs_input_grad[2] and had_agg, ctx.needs_input_grad[3]
         dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dh, z, agg if had_agg else None, weight, gamma, beta, bn,
-                                                      relu, p, seed, residual, need_x, need_w)
+                                                      relu, p, seed, residual, need_x, need_w, dy_sums=presum)
         dprev = dmid
         if has_prev:
             new1, lm1, flat1 = rest[0], rest[1], rest[2]

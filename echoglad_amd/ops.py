@@ -6,6 +6,7 @@ tensors that own the output memory.  Inputs must be CUDA fp32 contiguous
 from __future__ import annotations
 
 import ctypes as ct
+import os
 from typing import Optional
 
 import torch
@@ -386,18 +387,27 @@ def gcn_layer_train_fwd(graph: Graph, batch: int, x, weight, bias, gamma, beta, 
 
 
 def gcn_layer_bwd(graph_bwd: Graph, batch: int, dy, z, agg, weight, gamma, beta, bn, relu: bool, dropout_p: float, seed: int,
-                  residual: bool, need_dx: bool, need_dw: bool):
-    """-> (dx | None, dw | None, db | None (zeros), dgamma, dbeta)"""
+                  residual: bool, need_dx: bool, need_dw: bool, dy_sums=None):
+    """-> (dx | None, dw | None, db | None (zeros), dgamma, dbeta).
+    dy_sums = (sums [256] float64, frames, row_lo, n_valid) from classifier_bwd(..., layer=...): the BatchNorm-backward sums over
+    those rows of every frame are given, the layer's own sums pass only adds the other rows (eg_gcn_layer_bwd_presummed)."""
     rows = graph_bwd.num_nodes * batch
     _check_rows(dy, "dy", rows)
     dz = torch.empty_like(dy) if (need_dx or not need_dw) else None       # dW alone comes out of the fused apply pass
     dx = torch.empty_like(dy) if need_dx else None
     dw = torch.empty(C, C, dtype=torch.float32, device=dy.device) if need_dw else None
     small = torch.empty(3, C, dtype=torch.float32, device=dy.device)           # db, dgamma, dbeta
-    _lib.check(_lib.load().eg_gcn_layer_bwd(
-        graph_bwd._h, batch, _ptr(dy), _ptr(z), _ptr(agg), _ptr(weight), _ptr(gamma), _ptr(beta), _ptr(bn), int(relu),
-        float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(residual), _ptr(_workspace(dy.device)), _ptr(dz), _ptr(dx),
-        _ptr(dw), _ptr(small[0]), _ptr(small[1]), _ptr(small[2]), _stream()), "eg_gcn_layer_bwd")
+    common = (graph_bwd._h, batch, _ptr(dy), _ptr(z), _ptr(agg), _ptr(weight), _ptr(gamma), _ptr(beta), _ptr(bn), int(relu),
+              float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(residual), _ptr(_workspace(dy.device)), _ptr(dz), _ptr(dx),
+              _ptr(dw), _ptr(small[0]), _ptr(small[1]), _ptr(small[2]))
+    if dy_sums is None:
+        _lib.check(_lib.load().eg_gcn_layer_bwd(*common, _stream()), "eg_gcn_layer_bwd")
+    else:
+        sums, frames, row_lo, n_valid = dy_sums
+        if sums.dtype != torch.float64 or sums.numel() != 2 * C or not sums.is_cuda or not sums.is_contiguous():
+            raise RuntimeError("dy_sums must be a contiguous CUDA float64 tensor of 256 elements")
+        _lib.check(_lib.load().eg_gcn_layer_bwd_presummed(*common, _ptr(sums), int(frames), int(row_lo), int(n_valid), _stream()),
+                   "eg_gcn_layer_bwd_presummed")
     return dx, dw, small[0], small[1], small[2]
 
 
@@ -469,8 +479,17 @@ def classifier_train_fwd_act(z, layer_bn, residual, relu: bool, dropout_p: float
     return h, logits, z1, z2, bn
 
 
-def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_valid: int, P: dict, z1, z2, bn, need_dh: bool):
-    """-> (dh | None [batch*n_per_frame,128], grads [19076] packed as in include/echoglad_hip.h)"""
+def classifier_layer_sums_supported(batch: int, n_per_frame: int, n_valid: int) -> bool:
+    """Does eg_classifier_bwd_sums cover this shape (the fused first-layers kernel: n_valid >= 64, < 2^32 elements)?"""
+    return n_valid >= 64 and batch * n_per_frame * C < (1 << 32) and os.environ.get("EG_CLS_FUSED_BWD", "1") != "0"
+
+
+def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_valid: int, P: dict, z1, z2, bn, need_dh: bool,
+                   layer=None):
+    """-> (dh | None [batch*n_per_frame,128], grads [19076] packed as in include/echoglad_hip.h)
+    layer = (z, bn, gamma, beta, relu, dropout_p, seed) of the GNN layer whose output h is: also returns that layer's
+    BatchNorm-backward sums over the heads' rows, -> (dh, grads, sums [256] float64) (eg_classifier_bwd_sums; needs need_dh and
+    classifier_layer_sums_supported)."""
     rows = batch * n_valid
     dev = h.device
     _check_logits(dlogits, "dlogits", rows)
@@ -478,10 +497,19 @@ def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_vali
     dh = torch.empty_like(h) if need_dh else None
     grads = torch.empty(CLS_GRADS_FLOATS, dtype=torch.float32, device=dev)
     s = _cls_params(P)
-    _lib.check(_lib.load().eg_classifier_bwd(_ptr(dlogits), _ptr(h), batch, n_per_frame, row_lo, n_valid, ct.byref(s), _ptr(z1),
-                                             _ptr(z2), _ptr(bn), _ptr(_cls_workspace(dev)), _ptr(dh1), _ptr(dh),
-                                             _ptr(grads), _stream()), "eg_classifier_bwd")
-    return dh, grads
+    common = (_ptr(dlogits), _ptr(h), batch, n_per_frame, row_lo, n_valid, ct.byref(s), _ptr(z1), _ptr(z2), _ptr(bn),
+              _ptr(_cls_workspace(dev)), _ptr(dh1), _ptr(dh), _ptr(grads))
+    if layer is None:
+        _lib.check(_lib.load().eg_classifier_bwd(*common, _stream()), "eg_classifier_bwd")
+        return dh, grads
+    lz, lbn, lgamma, lbeta, relu, p, seed = layer
+    _check_rows(lz, "layer z", batch * n_per_frame)
+    _check_vec(lgamma, "layer gamma", C)
+    _check_vec(lbeta, "layer beta", C)
+    sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+    _lib.check(_lib.load().eg_classifier_bwd_sums(*common, _ptr(lz), _ptr(lbn), _ptr(lgamma), _ptr(lbeta), int(relu), float(p),
+                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(sums), _stream()), "eg_classifier_bwd_sums")
+    return dh, grads, sums
 
 
 # ---------------------------------------------------------------------------

@@ -59,8 +59,9 @@ extern "C" {
  * EG_ABI_VERSION the binding was written for (echoglad_amd/_lib.py refuses to load anything else: a stale .so would accept
  * the new calls with shifted arguments).  130: eg_topo_create with the reference builder's full flag set, jk_in inside
  * eg_gcn_layer_cls_fwd, eg_graph_set_precision removed (round 3); train-forward child sums, fused heads backward, the
- * 64-slice queue ring refuses instead of corrupting (round 4).  131: eg_classifier_train_fwd_act. */
-#define EG_ABI_VERSION 131
+ * 64-slice queue ring refuses instead of corrupting (round 4).  131: eg_classifier_train_fwd_act.
+ * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed. */
+#define EG_ABI_VERSION 132
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
 
@@ -307,6 +308,24 @@ int eg_classifier_train_fwd_act(const float* z, const float* layer_bn, const flo
 int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                       const eg_cls_train_params* params, const float* z1, const float* z2, const float* bn, void* workspace,
                       float* dh1_scratch, float* dh, float* grads, eg_stream_t stream);
+
+/* The heads' backward that also takes the BatchNorm-backward sums of the GNN layer in front of the heads, where dh passes through
+ * registers on its way out: layer_sums [2][128] (double) = sum g, sum g * xhat over rows [row_lo, row_lo + n_valid) of every frame,
+ * g = dh * that layer's dropout / ReLU mask (layer_z, layer_bn = what eg_gcn_layer_train_fwd kept; layer_gamma / layer_beta its
+ * BatchNorm parameters; layer_relu, layer_dropout_p, layer_seed as given to it).  eg_gcn_layer_bwd_presummed then runs that
+ * layer's backward without its own sums pass over dy and z (2.4 GB of reads at batch 32): it only adds the rows the range
+ * leaves out (frames * (rows per frame - n_valid) of them; dy may have been changed there in between -- the coordinate update's
+ * backward does).  EG_ERR_UNSUPPORTED when the fused first-layers kernel does not cover the shape (dh NULL, n_valid < 64, 2^32
+ * elements and more): nothing was launched, call eg_classifier_bwd + eg_gcn_layer_bwd. */
+int eg_classifier_bwd_sums(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
+                           const eg_cls_train_params* params, const float* z1, const float* z2, const float* bn, void* workspace,
+                           float* dh1_scratch, float* dh, float* grads, const float* layer_z, const float* layer_bn,
+                           const float* layer_gamma, const float* layer_beta, int layer_relu, float layer_dropout_p,
+                           uint64_t layer_seed, double* layer_sums, eg_stream_t stream);
+int eg_gcn_layer_bwd_presummed(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
+                               const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
+                               int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
+                               float* dbeta, const double* dy_sums, int frames, int64_t row_lo, int64_t n_valid, eg_stream_t stream);
 
 /* ---- coordinate-graph landmark update (src/core/models.py:438-453) -----------------------------------
  * For the 4 landmark rows of every frame (R = 4 * batch rows):

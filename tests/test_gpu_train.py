@@ -617,7 +617,7 @@ def test_heads_forward_with_the_layer_activation_folded_in(n, row_lo, n_valid, B
 def test_train_step_with_the_activation_inside_the_heads_equals_the_separate_pass(monkeypatch, coord, L):
     """The training step with the last layer + heads as one node (default) against EG_ACT_HEADS=0 (activation pass of its own,
     two nodes): the same arithmetic in the same order -- logits, coordinates, running statistics and every gradient bit for bit,
-    dropout on."""
+    dropout on (frames of 32 x 32: n_valid >= 64, so the sums-in-heads route is exercised too)."""
     frame, naux, B = 32, 4, 3
     hip, _ = model_pair(frame, naux, L, coord=coord, seed=43)
     hip.train()
@@ -626,8 +626,9 @@ def test_train_step_with_the_activation_inside_the_heads_equals_the_separate_pas
     coords0 = initial_coords(B, frame).to(DEV) if coord else None
     state = {k: v.clone() for k, v in hip.state_dict().items()}
     res = {}
-    for knob in ("1", "0"):
-        monkeypatch.setenv("EG_ACT_HEADS", knob)
+    for knob in ("1", "0", "sums"):
+        monkeypatch.setenv("EG_ACT_HEADS", "0" if knob == "0" else "1")
+        monkeypatch.setenv("EG_LAYER_SUMS_IN_HEADS", "1" if knob == "sums" else "0")
         hip.load_state_dict(state)
         for q in hip.parameters():
             q.grad = None
@@ -644,6 +645,65 @@ def test_train_step_with_the_activation_inside_the_heads_equals_the_separate_pas
         assert torch.equal(a[2][k], b[2][k]), k
     for k in a[3]:
         assert torch.equal(a[3][k], b[3][k]), k
+    # the last layer's BatchNorm-backward sums taken inside the heads' backward (the default): the same step to rounding
+    c = res["sums"]
+    assert torch.equal(a[0], c[0])
+    for k in a[2]:
+        assert float((a[2][k] - c[2][k]).abs().max()) <= 5e-5 * float(a[2][k].abs().max()) + 1e-9, k
+
+
+@pytest.mark.parametrize("coord,conn,relu,p", [(True, False, False, 0.5), (True, False, True, 0.3), (False, False, False, 0.0),
+                                               (True, True, True, 0.5)])
+def test_layer_backward_with_sums_taken_in_the_heads_backward(coord, conn, relu, p):
+    """eg_classifier_bwd_sums + eg_gcn_layer_bwd_presummed against eg_classifier_bwd + eg_gcn_layer_bwd: the same dh and head
+    gradients bit for bit; the layer's sums (fp32 partials per workgroup instead of fp64 per thread) and everything behind them
+    to rounding; rows outside the heads' filter changed in between (what the coordinate update's backward does) are counted."""
+    frame, naux, B = 32, 4, 3
+    g = ops.Graph.topo(frame, naux, False, coord, use_connection_nodes=conn)
+    n = g.num_nodes
+    n_conn = (naux + 1) if conn else 0
+    n_valid = n - n_conn - (4 if coord else 0)
+    hip, _ = model_pair(16, 3, 1, seed=5)
+    hip.train()
+    cfg, params, _ = hip._classifier_train_cfg()
+    from echoglad_amd.nn import _stack_head_params
+    P = _stack_head_params([q.detach() for q in params], cfg)
+    P.update(seed1=21, seed2=22)
+    rs = np.random.RandomState(7)
+    W = torch.from_numpy(rs.uniform(-0.15, 0.15, (128, 128)).astype(np.float32)).to(DEV)
+    bias = torch.zeros(128, device=DEV)
+    gamma = torch.from_numpy(1 + 0.3 * rs.standard_normal(128).astype(np.float32)).to(DEV)
+    beta = torch.from_numpy(0.1 * rs.standard_normal(128).astype(np.float32)).to(DEV)
+    x = rand_rows(B * n, seed=3).to(DEV)
+    _, z, agg, bn = ops.gcn_layer_train_fwd(g, B, x, W, bias, gamma, beta, None, None, None, 1e-5, relu, p, 4321, True, want_out=False)
+    h, logits, z1, z2, cbn = ops.classifier_train_fwd_act(z, bn, x, relu, p, 4321, B, n, n_conn, n_valid, P, False)
+    dl = rand_rows(B * n_valid, seed=9)[:, :4].to(DEV).contiguous()
+    patch = rand_rows(B * (n - n_valid), seed=11).to(DEV) * 0.01
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[n_conn:n_conn + n_valid] = False
+
+    def run(with_sums):
+        if with_sums:
+            dh, gr, sums = ops.classifier_bwd(dl, h, B, n, n_conn, n_valid, P, z1, z2, cbn, True, layer=(z, bn, gamma, beta, relu, p, 4321))
+        else:
+            (dh, gr), sums = ops.classifier_bwd(dl, h, B, n, n_conn, n_valid, P, z1, z2, cbn, True), None
+        if n_valid < n:
+            dh.view(B, n, 128)[:, keep.to(DEV), :] += patch.view(B, n - n_valid, 128)
+        out = ops.gcn_layer_bwd(g.bwd, B, dh, z, agg, W, gamma, beta, bn, relu, p, 4321, True, True, True,
+                                dy_sums=None if sums is None else (sums, B, n_conn, n_valid))
+        return dh, gr, out
+
+    dh0, gr0, o0 = run(False)
+    dh1, gr1, o1 = run(True)
+    assert torch.equal(dh0, dh1) and torch.equal(gr0, gr1)
+    # (the sums are column sums of g = dh * mask: their rounding scales with sum |g|, not with the -- possibly cancelling -- result:
+    #  without dropout and ReLU, dbeta = sum of a BatchNorm backward's output, analytically zero)
+    noise = 2e-7 * float(dh0.abs().sum(0).max())
+    for a, b, name in zip(o0, o1, ("dx", "dw", "db", "dgamma", "dbeta")):
+        scale = max(float(a.abs().max()), 1e-12)
+        tol = 2e-5 * scale + (noise if name in ("dgamma", "dbeta") else noise / (B * n) * (128 if name == "dw" else 1) * 50)
+        assert float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), scale, tol)
+    assert torch.equal(run(True)[2][0], o1[0])                                 # deterministic
 
 
 def test_layer_train_composites_on_a_directed_graph():
