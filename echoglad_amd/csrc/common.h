@@ -174,14 +174,17 @@ struct Knobs {
     int layer_impl;     // EG_LAYER_IMPL  -1 auto, 0 symmetric kernel, 1 producer/consumer kernel for plain calls
     int ps_grid;        // EG_PS_GRID     persistent grid of the producer/consumer kernel (default 256 = 1 per CU)
     int ring_guard;     // EG_RING_GUARD  0: no event behind a launch (diagnostic: the queue ring is then unguarded, as before round 4)
+    int queue_self_reset;   // EG_QUEUE_SELF_RESET  1 (default): the producer/consumer kernel zeroes its queue slice on the way out; 0: a memset in front of every launch
 };
 Knobs read_knobs();
 const Knobs& process_knobs();
 
 // Tile-queue heads: 8 per-XCD counters, one 128-B line each = 256 ints per launch.  A handle owns a RING of such slices;
-// every launch takes the next slice (host atomic), zeroes it on its stream and hands it to its kernel, so launches on
+// every launch takes the next slice (host atomic) and hands it to its kernel (zeroed: by the producer / consumer kernel that used
+// it last, on its way out, or by a memset in front of the launch where the symmetric kernel left counters behind), so launches on
 // different streams that share a handle never touch the same counters.
 constexpr int QUEUE_SLICE_INTS = 8 * 32;
+constexpr int QUEUE_DONE_IDX = 1;       // (inside the first counter's 128-B line) workgroups that have left a self-resetting launch
 #ifdef EG_STAMP
 constexpr int QUEUE_SLOTS = 1;          // stamp builds keep their cycle sums right behind the (single) slice
 #else
@@ -242,6 +245,9 @@ struct eg_graph {
     mutable std::atomic<void*> only_stream;      // the one stream this handle has launched on so far ...
     mutable std::atomic<unsigned char> multi_stream;   // ... until a second one shows up: from then on every launch records its event
     mutable std::atomic<unsigned char> any_launch;
+    // A slice of the ring that its last user may have left with non-zero counters (the symmetric kernel's queue walk; the ring is
+    // zeroed at creation and the producer / consumer kernel zeroes its slice itself on the way out): memset before the next use.
+    mutable std::atomic<unsigned char> slot_dirty[eg::QUEUE_SLOTS];
 
     // the slice of the queue ring for one launch on `stream` (graph.hip); EG_OK / EG_ERR_UNSUPPORTED / EG_ERR_HIP
     int acquire_queue_slice(hipStream_t stream, int** slice, int* slot) const;

@@ -364,8 +364,10 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out
     // bit-reproducible (tests/test_gpu_train.py::test_cfg4_train_full_batch_32_properties).
     if (a.stats_partial && a.d.walk_mode == WALK_QUEUE) a.d.walk_mode = WALK_MOD8;
     a.d.stagger = a.knobs.stagger;
-    if (a.d.walk_mode == WALK_QUEUE)
+    if (a.d.walk_mode == WALK_QUEUE) {
         EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
+        if (a.graph && slot >= 0) a.graph->slot_dirty[slot].store(1, std::memory_order_relaxed);     // (this kernel leaves its counters behind)
+    }
     const bool res_lds = (a.residual == nullptr) || (a.residual == a.x);     // epilogue residual from the LDS stash / none
     switch (agg) {
         case AGG_NONE: hipLaunchKernelGGL((k_gcn_layer<AGG_NONE, true>), grid, block, 0, stream, LAYER_KARGS); break;

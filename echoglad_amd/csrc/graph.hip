@@ -31,6 +31,7 @@ Knobs read_knobs() {
     k.layer_impl = env_int("EG_LAYER_IMPL", -1);
     k.ps_grid = env_int("EG_PS_GRID", 256);
     k.ring_guard = env_int("EG_RING_GUARD", 1);
+    k.queue_self_reset = env_int("EG_QUEUE_SELF_RESET", 1) != 0;
     // the static tile walk of the train forward labels chunks with blockIdx % 8 (a grid below 8 would leave chunks without
     // an owner) and its statistics partials fill at most 2048 slabs of the workspace
     if (k.ps_grid < 8) k.ps_grid = 8;
