@@ -11,6 +11,9 @@ namespace eg {
 // backward kernels regenerate the same mask, nothing is stored.  (The 64-bit multiplies are quarter-rate VALU work; one hash
 // per element cost 0.7 ms of a 20 ms training step.)
 __device__ inline unsigned long long mask_word(unsigned long long seed, unsigned long long group) {
+#ifdef EG_ABL_HASH          // timing-only ablation: what would a free mask be worth?  (not a usable mask)
+    return (seed ^ group) * 0x0001000100010001ull;
+#endif
     unsigned long long z = seed + group * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
