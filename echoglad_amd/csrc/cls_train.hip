@@ -167,6 +167,121 @@ __global__ __launch_bounds__(512, 4) void k_lin128_map(const float* __restrict__
     }
 }
 
+// The ACT + STATS form as a kernel of its own: 4 waves (each owns two 16-channel groups of the product, W slices in 64 VGPRs),
+// two workgroups per CU, and the 16 row loads per thread of the NEXT tile (z and the residual) issued right behind the first
+// barrier of the current one -- their round trip runs under this tile's products and write-back instead of in front of the next
+// tile's activation (k_lin128_map<true, true>, 8 waves without the prefetch: 1.07 ms at batch 32; this one: see DESIGN 3.3).
+// Same tiles per workgroup, same MFMA chain per output block, same per-thread sums as k_lin128_map: the results are the bits
+// eg_bn_act_fwd + eg_classifier_train_fwd give.
+__global__ __launch_bounds__(256, 2) void k_act_lin128(const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out,
+                                                       float* __restrict__ partial, const LinMapDims a, const LinAct act) {
+    __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA + 4];
+    const int tid = threadIdx.x, lane_k = tid & 63, wave = wave_id();
+    float wreg0[32], wreg1[32];
+    load_w_slice16(W, 2 * wave, lane_k, 0, wreg0);
+    load_w_slice16(W, 2 * wave + 1, lane_k, 0, wreg1);
+    const int ch_d = 32 * wave + 4 * (lane_k >> 4);
+    const f32x4 bv0 = bias ? *reinterpret_cast<const f32x4*>(bias + ch_d) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 bv1 = bias ? *reinterpret_cast<const f32x4*>(bias + ch_d + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};          // thread -> channel tid & 127, rows 16 g .. 16 g + 15, g = (tid >> 7) + 2 u
+    const int n_tiles = a.tiles_per_frame * a.batch;
+    const PairLane pl{lane_k >> 5, lane_k & 31};
+    const int rl0 = 16 * wave;
+    f32x4 pz[8], pr[8];
+    auto issue = [&](int tile) {
+        const int frame = tile / a.tiles_per_frame;
+        const int n0 = (tile - frame * a.tiles_per_frame) * TILE;
+        const int rows_here = (a.in_stride - n0) < TILE ? (a.in_stride - n0) : TILE;
+        const size_t in_row0 = (size_t)frame * a.in_stride + n0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = rl0 + 2 * k + pl.h;
+            const size_t off = (in_row0 + (unsigned)(r < rows_here ? r : rows_here - 1)) * C + 4u * pl.q;
+            pz[k] = ldnt4(act.z + off);
+            pr[k] = act.residual ? ldnt4(act.residual + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) issue(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
+        const int frame = tile / a.tiles_per_frame;
+        const int n0 = (tile - frame * a.tiles_per_frame) * TILE;
+        const int rows_here = (a.in_stride - n0) < TILE ? (a.in_stride - n0) : TILE;
+        const int lo = a.in_lo > n0 ? a.in_lo - n0 : 0;
+        const int hi = (a.in_lo + a.n_valid - n0) < rows_here ? (a.in_lo + a.n_valid - n0) : rows_here;
+        const size_t in_row0 = (size_t)frame * a.in_stride + n0;
+        float* __restrict__ of = out + ((size_t)frame * a.out_stride + a.out_lo) * C + ((long long)n0 - a.in_lo) * C;
+        {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(act.scale + 4 * pl.q);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(act.shift + 4 * pl.q);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = rl0 + 2 * k + pl.h;
+                const size_t off = (in_row0 + (unsigned)(r < rows_here ? r : rows_here - 1)) * C + 4u * pl.q;
+                f32x4 v = pz[k] * sc + sh;
+                if (act.a.p > 0.f) v *= keep_scale4(act.a.seed, (unsigned long long)off, act.a.p, act.a.inv_keep);
+                if (act.a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                v += pr[k];
+                *reinterpret_cast<f32x4*>(act.h + off) = v;             // (a missing row: the last row's value once more)
+                *reinterpret_cast<f32x4*>(&s_a[r * LDA + 4 * pl.q]) = v;
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) issue(tile + gridDim.x);
+        f32x4v acc0[4], acc1[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc0[b] = acc1[b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        mfma16_pair<false>(s_a, 0, lane, wreg0, acc0[0], acc0[1]);
+        mfma16_pair<false>(s_a, 0, lane, wreg1, acc1[0], acc1[1]);
+        if (rows_here > 32) {
+            mfma16_pair<false>(s_a, 32, lane, wreg0, acc0[2], acc0[3]);
+            mfma16_pair<false>(s_a, 32, lane, wreg1, acc1[2], acc1[3]);
+        }
+        __syncthreads();
+        {
+            const int j = lane & 15, q4 = lane >> 4;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                f32x4v o0, o1;
+                o0.x = acc0[b].x + bv0.x; o0.y = acc0[b].y + bv0.y; o0.z = acc0[b].z + bv0.z; o0.w = acc0[b].w + bv0.w;
+                o1.x = acc1[b].x + bv1.x; o1.y = acc1[b].y + bv1.y; o1.z = acc1[b].z + bv1.z; o1.w = acc1[b].w + bv1.w;
+                *reinterpret_cast<f32x4v*>(&s_a[(16 * b + j) * LDA + 32 * wave + 4 * q4]) = o0;
+                *reinterpret_cast<f32x4v*>(&s_a[(16 * b + j) * LDA + 32 * wave + 16 + 4 * q4]) = o1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = rl0 + 2 * k + pl.h;
+            if (r >= lo && r < hi)
+                *reinterpret_cast<f32x4*>(of + (long long)r * C + 4 * pl.q) = *reinterpret_cast<const f32x4*>(&s_a[r * LDA + 4 * pl.q]);
+        }
+        {
+            const int c = tid & 127;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r0 = 16 * ((tid >> 7) + 2 * u);
+#pragma unroll 4
+                for (int r = r0; r < r0 + 16; ++r) {
+                    const float v = (r >= lo && r < hi) ? s_a[r * LDA + c] : 0.f;
+                    cs[u] += v; cq[u] += v * v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* red = s_a;                                       // [4 row groups][2][128]
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int g = (tid >> 7) + 2 * u;
+        red[g * 256 + (tid & 127)] = cs[u];
+        red[g * 256 + 128 + (tid & 127)] = cq[u];
+    }
+    __syncthreads();
+    partial[(size_t)blockIdx.x * 256 + tid] = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+}
+
 // ---- hidden activation of a BN-ReLU-Dropout block, recomputed from z ------------------------------------------------
 // (4 consecutive channels; idx = element index of the first, a multiple of 4)
 __device__ inline f32x4 hidden_act4(const f32x4& z, const f32x4& scale, const f32x4& shift, const ClsDrop& d, unsigned long long idx) {
@@ -848,7 +963,9 @@ static int classifier_train_fwd(const float* h, const LinAct* act, int batch, in
     const long long n_tiles = (long long)d.tiles_per_frame * batch;
     if (n_tiles >= (1ll << 31)) return set_error(EG_ERR_ARG, "too many row tiles");
     const int g1 = (int)(n_tiles < LIN_GRID ? n_tiles : LIN_GRID);
-    if (act) hipLaunchKernelGGL((k_lin128_map<true, true>), dim3(g1), dim3(512), 0, stream, (const float*)nullptr, P->w1, P->b1, z1, partial, d, *act);
+    static const bool act4 = !(getenv("EG_ACT_LIN4") && atoi(getenv("EG_ACT_LIN4")) == 0);      // (0: the 8-wave form without the prefetch)
+    if (act && act4) hipLaunchKernelGGL(k_act_lin128, dim3(g1), dim3(256), 0, stream, P->w1, P->b1, z1, partial, d, *act);
+    else if (act) hipLaunchKernelGGL((k_lin128_map<true, true>), dim3(g1), dim3(512), 0, stream, (const float*)nullptr, P->w1, P->b1, z1, partial, d, *act);
     else hipLaunchKernelGGL((k_lin128_map<true, false>), dim3(g1), dim3(512), 0, stream, h, P->w1, P->b1, z1, partial, d, LinAct{});
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3(8), dim3(256), 0, stream, partial, g1, 256, totals);
     BnFinalize f1{totals, rows, H1, P->gamma1, P->beta1, P->eps1, P->momentum1, P->running_mean1, P->running_var1,
