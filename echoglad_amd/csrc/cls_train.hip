@@ -537,6 +537,7 @@ __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const f
     for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long row0 = tile * TILE;
         const int rows_here = (int)((rows - row0) < TILE ? (rows - row0) : TILE);
+        unsigned keep1 = 0u;                           // dropout keep flags of this thread's 32 elements of the tile (bit 4 it + u)
         {   // h1 tile from the prefetched z1 (rows >= rows_here are zero)
             int c4o = c4s;
             asm volatile("" : "+v"(c4o));
@@ -545,7 +546,17 @@ __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const f
             for (int it = 0; it < 8; ++it) {
                 const int e = tid + CT_THREADS * it, r = e >> 5, c4 = (e & 31) * 4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (r < rows_here) v = hidden_act4(pz1[it], sc, sh, d1, (unsigned long long)(row0 + r) * H1 + c4);
+                if (r < rows_here) {                   // hidden_act4 with the dropout keep flags kept (4 bits per float4) for the end of the tile
+                    v = pz1[it] * sc + sh;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+                    if (d1.p > 0.f) {
+                        const f32x4 kk = keep_scale4(d1.seed, (unsigned long long)(row0 + r) * H1 + c4, d1.p, d1.inv_keep);
+                        v *= kk;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) keep1 |= (kk[u] != 0.f ? 1u : 0u) << (4 * it + u);
+                    }
+                }
                 *reinterpret_cast<f32x4*>(&s_h[r * LDA + c4]) = v;
                 cz1[it] = pz1[it];                     // this tile's z1 stays in registers for the BatchNorm sums at the end of the tile
             }
@@ -620,7 +631,11 @@ __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const f
                 // 1.18 GB of HBM traffic per launch at batch 32 -- the tile had left the L2 by then, profiles/r04_train_pmc.json)
                 const size_t off = (size_t)(row0 + r) * H1 + c4;
                 const f32x4 zz = cz1[it];
-                const f32x4 kk = d1.p > 0.f ? keep_scale4(d1.seed, (unsigned long long)off, d1.p, d1.inv_keep) : f32x4{1.f, 1.f, 1.f, 1.f};
+                f32x4 kk = {1.f, 1.f, 1.f, 1.f};       // (the flags of the tile's first phase: no second hash per element)
+                if (d1.p > 0.f) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) kk[u] = ((keep1 >> (4 * it + u)) & 1u) ? d1.inv_keep : 0.f;
+                }
                 f32x4 gv;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
