@@ -982,7 +982,7 @@ static int classifier_train_fwd(const float* h, const LinAct* act, int batch, in
     if (act && act4) hipLaunchKernelGGL(k_act_lin128, dim3(g1), dim3(256), 0, stream, P->w1, P->b1, z1, partial, d, *act);
     else if (act) hipLaunchKernelGGL((k_lin128_map<true, true>), dim3(g1), dim3(512), 0, stream, (const float*)nullptr, P->w1, P->b1, z1, partial, d, *act);
     else hipLaunchKernelGGL((k_lin128_map<true, false>), dim3(g1), dim3(512), 0, stream, h, P->w1, P->b1, z1, partial, d, LinAct{});
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(8), dim3(256), 0, stream, partial, g1, 256, totals);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(8), dim3(RED_F32_THREADS), 0, stream, partial, g1, 256, totals);
     BnFinalize f1{totals, rows, H1, P->gamma1, P->beta1, P->eps1, P->momentum1, P->running_mean1, P->running_var1,
                   bn + 0 * H1, bn + 1 * H1, bn + 2 * H1, bn + 3 * H1};
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(128), 0, stream, f1);
@@ -992,7 +992,7 @@ static int classifier_train_fwd(const float* h, const LinAct* act, int batch, in
     const ClsDrop d1{P->p1, P->p1 > 0.f ? 1.0f / (1.0f - P->p1) : 1.0f, P->seed1};
     const int g2 = grid_for(rows, TILE, 768);
     hipLaunchKernelGGL(k_cls_mid_fwd, dim3(g2), dim3(CT_THREADS), 0, stream, z1, rows, P->w2, P->b2, bn1, d1, z2, partial);
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4), dim3(256), 0, stream, partial, g2, 128, totals + 256);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4), dim3(RED_F32_THREADS), 0, stream, partial, g2, 128, totals + 256);
     BnFinalize f2{totals + 256, rows, H2, P->gamma2, P->beta2, P->eps2, P->momentum2, P->running_mean2, P->running_var2,
                   bn2p + 0 * H2, bn2p + 1 * H2, bn2p + 2 * H2, bn2p + 3 * H2};
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, stream, f2);
@@ -1062,7 +1062,7 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
     // ---- third layers: sums
     const int ga = grid_for(rows * 4, CT_THREADS * 8, CT_MAX_BLOCKS);
     hipLaunchKernelGGL(k_cls_out_bwd_sums, dim3(ga), dim3(CT_THREADS), 0, stream, dlogits, z2, rows, bn2, d2, P->w3, partial);
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3((OUT_SUMS + 31) / 32), dim3(256), 0, stream, partial, ga, OUT_SUMS, totals);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3((OUT_SUMS + 31) / 32), dim3(RED_F32_THREADS), 0, stream, partial, ga, OUT_SUMS, totals);
     // ---- second layers: dz2, dW2, dh1 -- and the sums of the first layers' BatchNorm backward over g1 = dh1 * mask1
     const int gb = grid_for(rows, TILE, 256 * MID_BWD_WGS);
     float* partial2 = partial + (size_t)CT_MAX_BLOCKS * OUT_SUMS;
@@ -1074,8 +1074,8 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
     const bool masked = fused && masked_handoff;      // (the unfused route below applies the mask itself)
     hipLaunchKernelGGL(masked ? k_cls_mid_bwd<true> : k_cls_mid_bwd<false>, dim3(gb), dim3(CT_THREADS), 0, stream, dlogits, z2, z1, rows,
                        bn1, d1, bn2, d2, P->w2, P->w3, totals, dh1_scratch, partial2, partial_bn1);
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4 * 16 * 32 / 32), dim3(256), 0, stream, partial2, gb, 4 * 16 * 32, totals + 256);
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(256), 0, stream, partial_bn1, gb, 2 * H1, tot_bn1);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4 * 16 * 32 / 32), dim3(RED_F32_THREADS), 0, stream, partial2, gb, 4 * 16 * 32, totals + 256);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(RED_F32_THREADS), 0, stream, partial_bn1, gb, 2 * H1, tot_bn1);
     hipLaunchKernelGGL(k_cls_grads_final, dim3(8), dim3(256), 0, stream, totals, totals + 256, tot_bn1, grads);
     EG_HIP_TRY(hipGetLastError());
     // ---- first layers: dz1 formed on the fly, dW1 = dz1^T h[valid rows] and dh[valid rows] = dz1 W1 in ONE kernel
@@ -1103,11 +1103,11 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
             fa.la.inv_keep = ls->p > 0.f ? 1.0f / (1.0f - ls->p) : 1.0f; fa.la.seed = ls->seed;
             fa.partial_lsums = partial_bn1;                                       // (reduced into tot_bn1 already)
             hipLaunchKernelGGL(k_cls_first_bwd<true>, dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
-            hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(256), 0, stream, (const float*)partial_bn1, nf, 2 * H1, ls->sums);
+            hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)partial_bn1, nf, 2 * H1, ls->sums);
         } else {
             hipLaunchKernelGGL(k_cls_first_bwd<false>, dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
         }
-        hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(256), 0, stream, (const float*)slabs, nf, grads);
+        hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nf, grads);
         EG_HIP_TRY(hipGetLastError());
         return EG_OK;
     }

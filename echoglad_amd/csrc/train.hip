@@ -40,18 +40,20 @@ __device__ inline void column_partials(long long rows, double* __restrict__ part
     }
 }
 
-// one workgroup (256 threads) per 32 columns: thread (col = t & 31, slice = t >> 5) sums every 8th partial in ascending
-// order, the 8 slice sums are added in a fixed tree: the same bits on every run.  Launch with ceil(n / 32) workgroups.
-__global__ __launch_bounds__(256) void k_reduce_f32_partials(const float* __restrict__ partial, int nblocks, int n, double* __restrict__ totals) {
-    __shared__ double red[256];
+// one workgroup (RED_F32_THREADS = 1024 threads) per 32 columns: thread (col = t & 31, slice = t >> 5) sums every 32nd partial
+// in ascending order, the 32 slice sums are added in a fixed tree: the same bits on every run.  Launch with ceil(n / 32)
+// workgroups.  (8 slices of 256 threads made every one of these launches a 20 - 40 us chain of dependent adds -- nine of them per
+// training step.)
+__global__ __launch_bounds__(RED_F32_THREADS) void k_reduce_f32_partials(const float* __restrict__ partial, int nblocks, int n, double* __restrict__ totals) {
+    __shared__ double red[RED_F32_THREADS];
     const int t = threadIdx.x, col = blockIdx.x * 32 + (t & 31), sl = t >> 5;
     double s = 0.0;
     if (col < n)
-        for (int b = sl; b < nblocks; b += 8) s += (double)partial[(size_t)b * n + col];
+        for (int b = sl; b < nblocks; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * n + col];
     red[t] = s;
     __syncthreads();
 #pragma unroll
-    for (int st = 4; st > 0; st >>= 1) {
+    for (int st = RED_F32_THREADS / 64; st > 0; st >>= 1) {
         if (sl < st) red[t] += red[t + 32 * st];
         __syncthreads();
     }
@@ -351,15 +353,15 @@ __global__ __launch_bounds__(256) void k_dweight_partial(const float* __restrict
 }
 
 // fixed-order sum of the per-workgroup slabs: workgroup = 32 elements x 8 slices of the slab list (launch with C*C/32 workgroups)
-__global__ __launch_bounds__(256) void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw) {
-    __shared__ double red[256];
+__global__ __launch_bounds__(RED_F32_THREADS) void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw) {
+    __shared__ double red[RED_F32_THREADS];
     const int t = threadIdx.x, idx = blockIdx.x * 32 + (t & 31), sl = t >> 5;
     double s = 0.0;
-    for (int b = sl; b < nblocks; b += 8) s += (double)partial[(size_t)b * C * C + idx];
+    for (int b = sl; b < nblocks; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * C * C + idx];
     red[t] = s;
     __syncthreads();
 #pragma unroll
-    for (int st = 4; st > 0; st >>= 1) {
+    for (int st = RED_F32_THREADS / 64; st > 0; st >>= 1) {
         if (sl < st) red[t] += red[t + 32 * st];
         __syncthreads();
     }
@@ -518,7 +520,7 @@ int eg_launch_dweight(const float* g, const float* x, long long rows, const eg::
     const RowMap xm = xmap ? *xmap : RowMap{0, 0, 0};
     float* slabs = (float*)((char*)workspace + WS_RED_BYTES);
     hipLaunchKernelGGL(k_dweight_partial, dim3(nb), dim3(256), 0, stream, g, x, rows, slabs, xm);
-    hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(256), 0, stream, (const float*)slabs, nb, dw);
+    hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nb, dw);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }
@@ -563,7 +565,7 @@ int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const floa
         // with a row map (the heads' filtered rows) the flat-address form is the faster one (1.12 vs 1.35 ms at B = 32)
         if (direct && xm.n_valid == 0) launch(k_bn_bwd_apply_dw<true, false>);
         else launch(k_bn_bwd_apply_dw<false, true>);                   // (the generic form reads the map at run time)
-        hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(256), 0, stream, (const float*)slabs, nd, dw);
+        hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nd, dw);
     } else {
         long long blocks = (rows + 3) / 4;
         if (blocks > 4096) blocks = 4096;
@@ -662,7 +664,7 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
     if (rc == EG_ERR_UNSUPPORTED) rc = eg_launch_layer_sym(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, agg, partial, &grid, stream);
     if (rc != EG_OK) return public_rc(rc);
     const long long rows = (long long)g->n_nodes * batch;
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * C / 32), dim3(256), 0, stream, partial, grid, 2 * C, totals);
+    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * C / 32), dim3(RED_F32_THREADS), 0, stream, partial, grid, 2 * C, totals);
     BnFinalize f{totals, rows, C, gamma, beta, eps, momentum, running_mean, running_var, bn, bn + C, bn + 2 * C, bn + 3 * C};
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(128), 0, stream, f);
     EG_HIP_TRY(hipGetLastError());

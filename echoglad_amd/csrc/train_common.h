@@ -67,6 +67,7 @@ __device__ inline long long map_row(const RowMap& m, long long r) {
 }
 
 // stage 2 of every column reduction: partial float [nblocks][n] -> totals double [n], fixed order (bitwise reproducible)
+constexpr int RED_F32_THREADS = 1024;      // k_reduce_f32_partials, k_dweight_final: 32 columns x 32 slices of the partial list
 __global__ void k_reduce_f32_partials(const float* __restrict__ partial, int nblocks, int n, double* __restrict__ totals);
 
 // fixed-order sum of per-workgroup [128,128] float slabs -> dw (launch with 128 * 128 / 32 workgroups of 256 threads; train.hip)
