@@ -999,7 +999,7 @@ static int classifier_train_fwd(const float* h, const LinAct* act, int batch, in
     // ---- third layers
     const ClsBn bn2{bn2p + 0 * H2, bn2p + 1 * H2, bn2p + 2 * H2, bn2p + 3 * H2, P->gamma2};
     const ClsDrop d2{P->p2, P->p2 > 0.f ? 1.0f / (1.0f - P->p2) : 1.0f, P->seed2};
-    hipLaunchKernelGGL(k_cls_out_fwd, dim3(grid_for(rows * 4, CT_THREADS, 4096)), dim3(CT_THREADS), 0, stream, z2, rows, bn2, d2,
+    hipLaunchKernelGGL(k_cls_out_fwd, dim3(grid_for(rows * 4, CT_THREADS, 65536)), dim3(CT_THREADS), 0, stream, z2, rows, bn2, d2,
                        P->w3, P->b3, sigmoid, logits);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;

@@ -200,22 +200,38 @@ __global__ __launch_bounds__(HM_THREADS) void k_hm_bwd(const float* __restrict__
 }
 
 // ---- weighted BCE with logits ---------------------------------------------------------------------------------
-constexpr int BCE_BLOCKS = 512;
+constexpr int BCE_BLOCKS = 2048;
 
 __device__ inline float bce_logits(float x, float y) { return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))); }
 
+// 16 B per operand and lane, two float4 groups in flight per stream (one element per lane and iteration made the pass a chain
+// of dependent memory round trips: 84 us for 110 MB at batch 32); n4 = n / 4 whole groups, the last n % 4 elements by lane 0 of
+// the last workgroup.  fp64 sums per lane, fixed tree per workgroup, fixed order over workgroups (k_bce_final).
 __global__ __launch_bounds__(HM_THREADS) void k_bce_partial(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ valid, long long n, float ones_weight,
                                                             double* __restrict__ part) {
     __shared__ double red[HM_THREADS];
     const int tid = threadIdx.x;
     double a = 0, v = 0;
-    for (long long i = (long long)blockIdx.x * HM_THREADS + tid; i < n; i += (long long)gridDim.x * HM_THREADS) {
-        const float yi = y[i], vi = valid ? valid[i] : 1.0f;
+    auto one = [&](float xi, float yi, float vi) {
         const float w = (ones_weight > 1.0f && yi == 1.0f) ? ones_weight : 1.0f;
-        a += (double)(w * bce_logits(x[i], yi)) * vi;
+        a += (double)(w * bce_logits(xi, yi)) * vi;
         v += vi;
+    };
+    const long long n4 = n >> 2, stride = (long long)gridDim.x * HM_THREADS;
+    const float4 ones = {1.f, 1.f, 1.f, 1.f};
+    for (long long i = (long long)blockIdx.x * HM_THREADS + tid; i < n4; i += 2 * stride) {
+        const long long j = i + stride;
+        const bool two = j < n4;
+        const float4 x0 = reinterpret_cast<const float4*>(x)[i], y0 = reinterpret_cast<const float4*>(y)[i];
+        const float4 v0 = valid ? reinterpret_cast<const float4*>(valid)[i] : ones;
+        const float4 x1 = two ? reinterpret_cast<const float4*>(x)[j] : ones, y1 = two ? reinterpret_cast<const float4*>(y)[j] : ones;
+        const float4 v1 = (two && valid) ? reinterpret_cast<const float4*>(valid)[j] : ones;
+        one(x0.x, y0.x, v0.x); one(x0.y, y0.y, v0.y); one(x0.z, y0.z, v0.z); one(x0.w, y0.w, v0.w);
+        if (two) { one(x1.x, y1.x, v1.x); one(x1.y, y1.y, v1.y); one(x1.z, y1.z, v1.z); one(x1.w, y1.w, v1.w); }
     }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0)
+        for (long long i = n4 << 2; i < n; ++i) one(x[i], y[i], valid ? valid[i] : 1.0f);
     a = block_sum(a, red, tid);
     v = block_sum(v, red, tid);
     if (tid == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = v; }
@@ -309,7 +325,9 @@ int eg_heatmap_expect_bwd(const float* logits, const float* expect, const float*
 int eg_bce_logits_fwd(const float* logits, const float* labels, const float* valid, int64_t n, float ones_weight,
                       void* workspace, float* out3, eg_stream_t stream) {
     if (!logits || !labels || !workspace || !out3 || n < 1) return set_error(EG_ERR_ARG, "bad argument");
-    long long blocks = (n + HM_THREADS - 1) / HM_THREADS;
+    if (((uintptr_t)logits | (uintptr_t)labels | (uintptr_t)valid) & 15) return set_error(EG_ERR_ARG, "logits / labels / valid must be 16-byte aligned");
+    long long blocks = ((n >> 2) + 2 * HM_THREADS - 1) / (2 * HM_THREADS);
+    if (blocks < 1) blocks = 1;
     if (blocks > BCE_BLOCKS) blocks = BCE_BLOCKS;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bce_partial, dim3((unsigned)blocks), dim3(HM_THREADS), 0, s, logits, labels, valid, (long long)n,
