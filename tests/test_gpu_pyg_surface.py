@@ -317,15 +317,18 @@ def test_queue_slices_are_left_zeroed_by_the_kernel_itself():
     """The producer / consumer kernel zeroes its slice of the tile-queue ring on the way out (no memset in front of a launch):
     the ring wraps many times with identical results, also at the full persistent grid, and a slice the symmetric kernel has used
     in between (it leaves its counters behind) is cleaned by the next launch that takes it."""
-    for frame, naux, B in ((32, 4, 2), (224, 7, 4)):
+    for frame, naux, B in ((64, 6, 2), (224, 7, 4)):
         g = ops.Graph.topo(frame, naux)
         x = synthetic_node_feats(B * g.num_nodes, 128, seed=1).to(DEV)
         rs = np.random.RandomState(3)
         w = torch.from_numpy(rs.uniform(-0.1, 0.1, (128, 128)).astype(np.float32)).to(DEV)
-        want = ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True)
+        ka, kb = ops.new_kidsum(g, B), ops.new_kidsum(g, B)                  # chained calls run on the producer / consumer kernel
+        one, zero = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+        h = ops.gcn_layer_fwd(g, B, x, w, one, zero, x, relu=True, kidsum_out=ka)
+        want = ops.gcn_layer_fwd(g, B, h, w, one, zero, h, relu=True, kidsum_in=ka, kidsum_out=kb)
         before = g.ps_launches
         for k in range(300):
-            got = ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True)
+            got = ops.gcn_layer_fwd(g, B, h, w, one, zero, h, relu=True, kidsum_in=ka, kidsum_out=kb)
             if k % 37 == 0:
                 assert torch.equal(got, want), k
             if k % 50 == 49:                                         # a launch of the symmetric kernel takes a slice in between
