@@ -264,6 +264,7 @@ struct ClsArgs {
     const float *w1, *s1, *t1, *w2, *s2, *t2, *w3, *b3;
     float* logits;
     int sigmoid;
+    int row_lo, n_valid;        // the heads' node-type filter: rows [row_lo, row_lo + n_valid) of a frame have a logits row (logits is [batch * n_valid, 4])
 };
 }  // namespace eg
 // symmetric 8-wave layer kernel (gcn_layer.hip) for any handle; agg_out (nullable) receives the aggregated rows A_hat x,

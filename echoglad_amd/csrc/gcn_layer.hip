@@ -469,7 +469,7 @@ int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const f
 }
 
 int eg_graph_fused_classifier_ok(const eg_graph* g) {
-    return g && g->kind == GRAPH_TOPO && (g->kid_rows > 0 || g->flat) && g->topo.coord_base >= g->n_nodes && g->topo.n_conn == 0;
+    return g && g->kind == GRAPH_TOPO && (g->kid_rows > 0 || g->flat) && g->topo.coord_base >= g->n_nodes;
 }
 
 int eg_gcn_layer_fwd_jk(const eg_graph* g, int batch, const float* x, const float* W, const float* scale, const float* shift,
@@ -498,9 +498,10 @@ int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const flo
                          const float* w3, const float* b3, int sigmoid, float* logits, eg_stream_t stream) {
     if (!x || !W || !logits || !w1 || !s1 || !t1 || !w2 || !s2 || !t2 || !w3 || !b3) return set_error(EG_ERR_ARG, "NULL argument");
     if (!g || batch <= 0) return set_error(EG_ERR_ARG, "bad graph handle or batch");
-    if (g->kind != GRAPH_TOPO || g->topo.coord_base < g->n_nodes || g->topo.n_conn > 0)
-        return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs a topology handle whose rows are all valid nodes (no coordinate / connection nodes)");
-    eg::ClsArgs c{w1, s1, t1, w2, s2, t2, w3, b3, logits, sigmoid};
+    if (g->kind != GRAPH_TOPO || g->topo.coord_base < g->n_nodes)
+        return set_error(EG_ERR_UNSUPPORTED, "the fused classifier needs a topology handle without coordinate nodes");
+    // connection nodes (the first n_conn rows of a frame) are dropped by the heads' node-type filter: logits is [batch * (n - n_conn), 4]
+    eg::ClsArgs c{w1, s1, t1, w2, s2, t2, w3, b3, logits, sigmoid, g->topo.n_conn, (int)g->n_nodes - g->topo.n_conn};
     const int rc = eg_launch_layer_ps(g, batch, x, W, scale, shift, residual, relu, 0, nullptr, kidsum_in, nullptr, &c,
                                       (hipStream_t)stream, jk_in, nullptr);
     if (rc == EG_ERR_UNSUPPORTED)

@@ -519,15 +519,17 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 // on the accumulator (4 outputs per lane, two cross-lane adds), as in classifier.hip
                 // logits leave as buffer stores off a frame descriptor: lane (kq = 0, j16) owns node (patch row 2 b4 + (j16 >> 3),
                 // column j16 & 7); every other lane, and columns past the segment's count, get offset -1 (out of range: dropped)
+                // (the node-type filter: a frame's logits start at its row row_lo; rows in front of it get a negative offset, rows
+                // behind the range one past the descriptor's end -- both out of range for the unsigned bounds check: dropped)
                 const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
-                    ca.logits + (size_t)frame * a.n_per_frame * 4, 0, a.n_per_frame * 16, 0x00020000);
+                    ca.logits + (size_t)frame * ca.n_valid * 4, 0, ca.n_valid * 16, 0x00020000);
                 int lvoff[4];
 #pragma unroll
                 for (int b4 = 0; b4 < 4; ++b4) {
                     const bool hi = (j16 >> 3) != 0;
                     const int first = hi ? seg_first[2 * b4 + 1] : seg_first[2 * b4];
                     const int cnt = hi ? seg_cnt[2 * b4 + 1] : seg_cnt[2 * b4];
-                    lvoff[b4] = (kq == 0 && (j16 & 7) < cnt) ? (first + (j16 & 7)) * 16 + wave * 4 : -1;
+                    lvoff[b4] = (kq == 0 && (j16 & 7) < cnt) ? (first + (j16 & 7) - ca.row_lo) * 16 + wave * 4 : -1;
                 }
                 f32x4v z[4];
 #pragma unroll

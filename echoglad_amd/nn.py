@@ -921,7 +921,7 @@ class HierarchicalPatchModel(nn.Module):
             if self.chain_layers and not self.use_coordinate_graph and graph.kidsum_rows > 0 and self.num_gnn_layers > 1:
                 kid = self._kidsum_buffers(graph, gb)
         fuse_cls = (fused and self.fuse_classifier and graph.fused_classifier_ok and not self.use_coordinate_graph
-                    and (kid[0] is not None or graph.kidsum_rows == 0) and n_conn == 0 and n_valid == n
+                    and (kid[0] is not None or graph.kidsum_rows == 0) and n_conn == graph.num_conn and n_valid == n - n_conn
                     and self.num_output_channels == 4 and self.classifier_hidden_dim == 32)
         jkb = self._jk_buffers(graph, gb, node_feats) if jk_fused else None
         train_kids = (None, None)

@@ -61,6 +61,7 @@ class Graph:
         self.kidsum_rows = int(_lib.load().eg_graph_kidsum_rows(handle)) if structured else 0
         # a closed-form topology with 'grid-diagonal' levels: stencil in the producer/consumer kernel, per-frame CSR elsewhere
         self.hybrid = False
+        self.num_conn = 0           # connection nodes at the head of every frame (rows the heads' node-type filter drops)
         # the handle whose aggregation is A_hat^T (what a backward pass needs): the handle itself unless edge_index is directed
         self.bwd: "Graph" = self
 
@@ -79,6 +80,7 @@ class Graph:
                                           ct.byref(h)), "eg_topo_create")
         g = cls(h, True, int(lib.eg_graph_num_nodes(h)), device)
         g.hybrid = bool(diag_main or ((diag_aux or use_connection_nodes) and not use_main_graph_only))
+        g.num_conn = (num_aux_graphs + 1) if (use_connection_nodes and not use_main_graph_only) else 0
         return g
 
     @classmethod
@@ -192,7 +194,8 @@ def gcn_layer_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tenso
 def gcn_layer_cls_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.Tensor, scale, shift, residual, relu: bool,
                       packed: dict, sigmoid: bool = False, kidsum_in: Optional[torch.Tensor] = None,
                       jk_in: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Last layer + node-type filter + 4 classifier heads in one kernel -> logits [batch * num_nodes, 4].
+    """Last layer + node-type filter + 4 classifier heads in one kernel -> logits [batch * (num_nodes - num_conn), 4] (the
+    connection nodes at the head of every frame have no logits row).
     jk_in: running JumpingKnowledge('max') maximum of the earlier embeddings: the heads then see max(jk_in, layer output)."""
     rows = graph.num_nodes * batch
     _check_rows(x, "x", rows)
@@ -206,7 +209,7 @@ def gcn_layer_cls_fwd(graph: Graph, batch: int, x: torch.Tensor, weight: torch.T
         _check_rows(kidsum_in, "kidsum_in", graph.kidsum_rows * batch)
     if jk_in is not None:
         _check_rows(jk_in, "jk_in", rows)
-    out = torch.empty(rows, 4, dtype=torch.float32, device=x.device)
+    out = torch.empty((graph.num_nodes - graph.num_conn) * batch, 4, dtype=torch.float32, device=x.device)
     p = packed
     _lib.check(_lib.load().eg_gcn_layer_cls_fwd(graph._h, batch, _ptr(x), _ptr(weight), _ptr(scale), _ptr(shift), _ptr(residual),
                                                 int(relu), _ptr(kidsum_in), _ptr(jk_in), _ptr(p["w1"]), _ptr(p["s1"]), _ptr(p["t1"]),

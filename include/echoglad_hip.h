@@ -160,12 +160,13 @@ int eg_gcn_layer_fwd_chain(const eg_graph* g, int batch, const float* x, const f
                            const float* kidsum_in, float* kidsum_out, eg_stream_t stream);
 
 /* Last layer of a stack + node-type filter + the 4 classifier heads in ONE kernel (models.py:431-435 last iteration,
- * :485-490): the layer's output tile never leaves the chip, logits [batch * num_nodes, 4] are the only output.
+ * :485-490): the layer's output tile never leaves the chip, logits [batch * n_valid, 4] are the only output, n_valid = the
+ * handle's nodes per frame minus its connection nodes (the filter drops them: the first naux + 1 rows of a frame; a handle
+ * without connection nodes has n_valid = eg_graph_num_nodes).
  * Layer arguments as eg_gcn_layer_fwd (W^T form), kidsum_in as eg_gcn_layer_fwd_chain (or NULL), jk_in: NULL or the running
- * JumpingKnowledge maximum (below); classifier
- * arguments as eg_classifier_fwd.  Needs a topology handle with eg_graph_kidsum_rows(g) > 0 whose rows are all
- * valid nodes (no coordinate / connection nodes) and residual in {NULL, x}; EG_ERR_UNSUPPORTED otherwise (run
- * eg_gcn_layer_fwd + eg_classifier_fwd instead). */
+ * JumpingKnowledge maximum (below); classifier arguments as eg_classifier_fwd.  Needs a topology handle with
+ * eg_graph_kidsum_rows(g) > 0 and no coordinate nodes (eg_graph_fused_classifier_ok) and residual in {NULL, x};
+ * EG_ERR_UNSUPPORTED otherwise (run eg_gcn_layer_fwd + eg_classifier_fwd instead). */
 int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                          const float* shift, const float* residual, int relu, const float* kidsum_in, const float* jk_in,
                          const float* w1, const float* s1, const float* t1, const float* w2, const float* s2, const float* t2,

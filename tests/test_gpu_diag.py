@@ -191,7 +191,8 @@ def test_connection_node_handle_and_degrees(frame, naux, main_only, coord, dm, d
     topo = HierTopology(TopologySpec(frame, naux, main_only, coord, True, mt, at))
     assert topo.is_structured() and topo.n_conn == naux + 1
     g = ops.Graph.topo(frame, naux, main_only, coord, use_connection_nodes=True, diag_main=dm, diag_aux=da)
-    assert g.structured and g.hybrid and g.num_nodes == topo.num_nodes and not g.fused_classifier_ok
+    assert g.structured and g.hybrid and g.num_nodes == topo.num_nodes and g.num_conn == topo.n_conn
+    assert g.fused_classifier_ok == (not coord and g.kidsum_rows > 0)           # (the heads' row filter drops the connection rows inside the fused kernel)
     assert np.allclose(g.deg_inv_sqrt().cpu().numpy(), topo.deg_inv_sqrt(), rtol=1e-7, atol=0)
     want = sum(((lv.side + 7) // 8) ** 2 for lv in topo.aux_levels + [topo.main]) + (1 if topo.n_coord else 0) + (topo.n_conn + 7) // 8
     assert _lib.load().eg_graph_num_tiles(g._h) == want
@@ -280,3 +281,22 @@ def test_model_with_connection_nodes_takes_the_stencil_and_matches_the_oracle(fr
     ((want ** 2).mean() + (0 if wc is None else (wc ** 2).mean() * 1e-3)).backward()
     ((got ** 2).mean() + (0 if gc is None else (gc ** 2).mean() * 1e-3)).backward()
     assert_param_grads_close(hip, ref)
+
+
+@pytest.mark.parametrize("frame,naux,dm,da,B", [(64, 5, False, False, 3), (224, 7, False, False, 2), (64, 5, True, True, 2)])
+def test_fused_classifier_on_a_connection_node_handle(frame, naux, dm, da, B):
+    """eg_gcn_layer_cls_fwd on a handle with connection nodes: the heads' node-type filter (the first naux + 1 rows of a frame
+    have no logits row) inside the fused last-layer kernel == the layer kernel + eg_classifier_fwd with the row range."""
+    mt, at = _types(dm, da)
+    hip, _ = model_pair(frame, naux, 3, seed=frame + 5, use_connection_nodes=True)
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, conn=True, main_type=mt, aux_type=at)
+    feats = synthetic_node_feats(B * topo.num_nodes, 128, seed=4).to(DEV)
+    graph, _ = hip._resolver.resolve(ei.to(DEV), feats.shape[0])
+    assert graph.num_conn == naux + 1 and graph.fused_classifier_ok
+    outs = {}
+    for fuse in (True, False):
+        hip.fuse_classifier = fuse
+        with torch.no_grad():
+            outs[fuse] = hip.forward_nodes(feats, ei.to(DEV), B)[0]
+    assert outs[True].shape == outs[False].shape == (B * topo.num_valid_nodes, 4)
+    assert float((outs[True] - outs[False]).abs().max()) < 2e-5 * max(1.0, float(outs[False].abs().max()))
