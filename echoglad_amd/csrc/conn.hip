@@ -19,8 +19,22 @@ __global__ __launch_bounds__(256) void k_conn_partial(const float* __restrict__ 
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int row0 = table[4 * chunk + 1], rows = table[4 * chunk + 2];
     const float* __restrict__ xf = x + (size_t)frame * n_per_frame * C;
-    f32x2 acc = {0.f, 0.f};
-    for (int r = wave; r < rows; r += 4) acc += dis[row0 + r] * load_row2(xf, row0 + r, lane);
+    // four rows in flight per wave (one row per iteration made the launch a chain of memory round trips: 29 us at batch 8)
+    f32x2 a4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    for (int r = wave; r < rows; r += 16) {
+        f32x2 v[4];
+        float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + 4 * u;
+            const bool ok = rr < rows;
+            d[u] = ok ? dis[row0 + rr] : 0.f;
+            v[u] = load_row2(xf, row0 + (ok ? rr : r), lane);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a4[u] += d[u] * v[u];
+    }
+    const f32x2 acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     s_red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0) {
