@@ -500,7 +500,7 @@ def other_configs(args, device):
     gc.collect()
     torch.cuda.empty_cache()
     what = ("configs[1] through the GENERIC path: the same 224x224 / 7-aux-level batch of 8 with its edge_index turned into a CSR "
-            "handle (what grid-diagonal graphs, connection nodes or arbitrary edge_index take): 3 x eg_gcn_layer_fwd + eg_classifier_fwd")
+            "handle (what an arbitrary edge_index takes; every flag of the reference's builder has a stencil handle): 3 x eg_gcn_layer_fwd + eg_classifier_fwd")
     try:
         from echoglad_amd import ops
         model, kw, topo, feats, ei, _ = infer_workload(224, 7, args.layers, False, 8, device, 0, hip_graph=False)
