@@ -454,7 +454,7 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
         if ops.classifier_layer_sums_supported(B, n, n_valid) and os.environ.get("EG_LAYER_SUMS_IN_HEADS", "1") != "0":
             dh, g, sums = ops.classifier_bwd(dl, h, B, n, row_lo, n_valid, ctx.P, z1, z2, cbn, True,
                                              layer=(z, bn, gamma, beta, relu, p, seed))
-            presum = (sums, B, row_lo, n_valid)
+            presum = None if sums is None else (sums, B, row_lo, n_valid)
         else:
             dh, g = ops.classifier_bwd(dl, h, B, n, row_lo, n_valid, ctx.P, z1, z2, cbn, True)     # (a buffer of this node)
         dmid, gm, gm_prev = None, None, None

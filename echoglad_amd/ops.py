@@ -491,8 +491,8 @@ def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_vali
                    layer=None):
     """-> (dh | None [batch*n_per_frame,128], grads [19076] packed as in include/echoglad_hip.h)
     layer = (z, bn, gamma, beta, relu, dropout_p, seed) of the GNN layer whose output h is: also returns that layer's
-    BatchNorm-backward sums over the heads' rows, -> (dh, grads, sums [256] float64) (eg_classifier_bwd_sums; needs need_dh and
-    classifier_layer_sums_supported)."""
+    BatchNorm-backward sums over the heads' rows, -> (dh, grads, sums [256] float64 | None) (eg_classifier_bwd_sums; None where
+    the entry point does not cover the shape -- see classifier_layer_sums_supported -- and the plain backward ran instead)."""
     rows = batch * n_valid
     dev = h.device
     _check_logits(dlogits, "dlogits", rows)
@@ -510,8 +510,12 @@ def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_vali
     _check_vec(lgamma, "layer gamma", C)
     _check_vec(lbeta, "layer beta", C)
     sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
-    _lib.check(_lib.load().eg_classifier_bwd_sums(*common, _ptr(lz), _ptr(lbn), _ptr(lgamma), _ptr(lbeta), int(relu), float(p),
-                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(sums), _stream()), "eg_classifier_bwd_sums")
+    rc = _lib.load().eg_classifier_bwd_sums(*common, _ptr(lz), _ptr(lbn), _ptr(lgamma), _ptr(lbeta), int(relu), float(p),
+                                            int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(sums), _stream())
+    if rc == _lib.EG_ERR_UNSUPPORTED:           # nothing was launched (include/echoglad_hip.h): the plain backward, no sums
+        _lib.check(_lib.load().eg_classifier_bwd(*common, _stream()), "eg_classifier_bwd")
+        return dh, grads, None
+    _lib.check(rc, "eg_classifier_bwd_sums")
     return dh, grads, sums
 
 
