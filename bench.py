@@ -58,6 +58,9 @@ def parse():
     p.add_argument("--force-collective", action="store_true",
                    help="train mode: initialise torch.distributed (nccl = RCCL) and run the gradient reducer's collectives even "
                         "at world size 1 -- the single-GPU way through the code path the multi-GPU step takes")
+    p.add_argument("--train-leg", action="store_true",
+                   help="infer mode at world size 1: also run the short configs[3] training measurement the default run takes on ALL ranks "
+                        "at world > 1 (other_configs.cfg4_train_dpN), on a one-rank RCCL group -- the single-GPU way through that code")
     p.add_argument("--bucket-kb", type=int, default=0,
                    help="train mode: size of a gradient all-reduce bucket in KiB (0: the reducer's default, max(total / 2, 64 KiB) "
                         "capped at 8 MiB); the first multi-GPU run can sweep it")
@@ -65,6 +68,33 @@ def parse():
                    help="infer (default): BASELINE configs[1], the metric's configuration.  train: one full training "
                         "step of the GNN stack on configs[3] (coordinate graph; SURVEY 8d), reported under its own metric name")
     return p.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stdout carries ONE line: the JSON result.  Native libraries write there too (RCCL prints a five-line version banner to
+# stdout the first time a communicator is created -- block-buffered, so behind a pipe it lands AFTER the result line): file
+# descriptor 1 is pointed at stderr for the whole run and the result goes to a private copy of the real stdout.
+# ---------------------------------------------------------------------------------------------------------------------
+_REAL_STDOUT = None
+
+
+def guard_stdout() -> None:
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(result: dict) -> None:
+    line = (json.dumps(result) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+        return
+    sys.stdout.flush()
+    while line:
+        line = line[os.write(_REAL_STDOUT, line):]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -318,7 +348,59 @@ def main_train(args, world, rank, device, dist_info):
                 out["roofline"] = train_layer_roofline(B, topo, device, args.layers)
             except Exception as ex:
                 out["roofline"] = {"error": repr(ex)}
-        print(json.dumps(out), flush=True)
+        emit(out)
+
+
+def train_leg_all_ranks(args, world, rank, device):
+    """The default (inference) run has no collective at all -- frames are independent.  So that a multi-GPU run of the DEFAULT
+    command still shows what the gradient all-reduce costs over xGMI, every rank also takes a short configs[3] training
+    measurement (batch 32 per GPU, weak scaling): K = 8 steps timed like the headline (barrier + synchronize on both sides, max
+    over ranks), each rank's own-clock step time and the time its compute stream waited in finish() behind the collectives,
+    and the same K steps with the bucket all-reduces issued AFTER backward instead of from inside it (hooks detached): the
+    difference is what the overlap buys -- or costs, next to persistent one-workgroup-per-CU launches.
+    Every rank must call this (collectives); rank 0 gets the dictionary, the others None."""
+    import gc
+    import torch
+    B, K = 32, 8
+    step, topo = train_workload(224, 7, args.layers, B, device, world, rank, force_collective=(world == 1), bucket_kb=args.bucket_kb)
+    red = step.reducer
+    for _ in range(3):
+        loss = step()
+    red.collective_wait_ms()
+    elapsed, loss = timed_loop(step, K, world, device)
+    torch.cuda.synchronize()
+    own = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        own.append(1e3 * (time.perf_counter() - t0))
+    wait_ms = red.collective_wait_ms()
+    red.detach_hooks()                                   # same buckets, issued from finish(): nothing overlaps the backward
+    for _ in range(2):
+        step()
+    red.collective_wait_ms()
+    elapsed_after, _ = timed_loop(step, K, world, device)
+    wait_after = red.collective_wait_ms()
+    mine = {"rank": rank, "ms_per_step_alone": round(min(own), 3), "ms_in_finish_behind_collectives": None if wait_ms is None else round(wait_ms, 4),
+            "ms_in_finish_collectives_after_backward": None if wait_after is None else round(wait_after, 4)}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine)
+    out = None
+    if rank == 0:
+        out = {"workload": f"configs[3]: 224x224, 7 aux levels + coordinate graph, batch {B} per GPU x {world} GPUs (weak scaling), one training "
+                           "step (fwd + 3 losses + bwd + gradient all-reduce + Adam); frames are independent: the all-reduce is the only collective",
+               "n_gpus": world, "steps": K, "ms_per_step": round(1e3 * elapsed / K, 3), "frames_s": round(world * B * K / elapsed, 1),
+               "ms_per_step_collectives_after_backward": round(1e3 * elapsed_after / K, 3), "scaling": "weak",
+               "gradient_collectives": red.describe(), "per_rank": per_rank, "final_loss": float(loss.detach()),
+               "note": "ms_per_step: bucket all-reduces issued from inside backward on a side stream; ..._after_backward: the same buckets "
+                       "issued from finish(); per_rank: own-clock step time and the time the compute stream waited behind the collectives"}
+    del step, red
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(args, kw, state_dict):
@@ -567,6 +649,7 @@ def main():
         # no GPU call has happened in this process; the ranks are children, this process only waits for them
         sys.exit(spawn_ranks(args.gpus))
 
+    guard_stdout()                       # from here on only emit() reaches the real stdout
     import numpy as np  # noqa: F401
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -577,7 +660,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist_info = {"world_size": 1, "backend": None, "allreduce_check": None}
-    use_dist = world > 1 or (args.force_collective and args.mode == "train")
+    use_dist = world > 1 or (args.force_collective and args.mode == "train") or (args.train_leg and args.mode == "infer")
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -588,7 +671,9 @@ def main():
                 os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)          # "nccl" IS RCCL on ROCm
+        import datetime
+        # (a bounded timeout: a collective that never completes must end the run with an error, not hold a node for ten minutes)
+        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))          # "nccl" IS RCCL on ROCm
         one = torch.ones(1, device=device)
         dist.all_reduce(one)
         dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
@@ -652,6 +737,14 @@ def main_infer(args, world, rank, device, dist_info):
                              shard_digest_mismatch_ranks=bad)
             if bad:
                 print(f"warning: ranks {bad} computed other logits for their shard than rank 0 does for the same frames", file=sys.stderr)
+    # ---- world > 1 (or --train-leg): the short training measurement every rank takes part in (the only collective of this framework)
+    train_leg = None
+    if (args.train_leg or (world > 1 and not args.no_other_configs)) and args.frame == 224 and args.naux == 7 and not args.main_only \
+            and os.environ.get("EG_BENCH_TRAIN_LEG", "1") != "0":
+        try:
+            train_leg = train_leg_all_ranks(args, world, rank, device)
+        except Exception as ex:                               # (a failure here must not cost the headline line)
+            train_leg = {"error": repr(ex)}
     if rank != 0:
         return
     # ---- dominant kernel: the fused GCN layer, timed with HIP events on the launch stream
@@ -797,7 +890,9 @@ def main_infer(args, world, rank, device, dist_info):
     if world == 1 and not args.no_other_configs:
         del buf
         result["other_configs"] = other_configs(args, device)
-    print(json.dumps(result), flush=True)
+    if train_leg is not None:
+        result.setdefault("other_configs", {})[f"cfg4_train_dp{world}"] = train_leg
+    emit(result)
 
 
 if __name__ == "__main__":

@@ -71,3 +71,24 @@ def test_bench_line_contract():
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
     assert d["repeats"]["n"] == 2 and d["repeats"]["ms_per_step"]["min"] <= d["repeats"]["ms_per_step"]["max"]
+
+
+def test_only_the_result_line_reaches_stdout():
+    """bench.py prints ONE JSON line.  Native libraries write to stdout as well (RCCL's version banner, block-buffered: behind a
+    pipe it lands after the result): guard_stdout() points descriptor 1 at stderr, emit() writes the line to the real stdout."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent(f'''
+        import ctypes, importlib.util, sys
+        spec = importlib.util.spec_from_file_location("bench_module", {os.path.join(ROOT, "bench.py")!r})
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+        b.guard_stdout()
+        ctypes.CDLL(None).printf(b"native banner line\\n")
+        print("a python print")
+        b.emit({{"ok": 1}})
+    ''')
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert r.stdout == '{"ok": 1}\n'
+    assert "native banner line" in r.stderr and "a python print" in r.stderr

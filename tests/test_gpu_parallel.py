@@ -107,3 +107,30 @@ def _main():
 
 if __name__ == "__main__":
     _main()
+
+
+def test_default_bench_takes_the_training_leg_on_every_rank():
+    """`bench.py --gpus N` (N > 1) is the inference headline -- no collective in it -- plus a short configs[3] training
+    measurement on ALL ranks, so that the driver's multi-GPU run of the default command also meets the gradient all-reduce.
+    `--train-leg` runs that code at world size 1 on a one-rank RCCL group: the line carries other_configs.cfg4_train_dp1 with
+    both timings (collectives from inside backward / after it), the per-rank diagnostics and the collectives' sizes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--train-leg", "--steps", "3", "--warmup", "1", "--repeats", "0",
+                        "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    js = [l for l in r.stdout.splitlines() if l.startswith("{")]          # (RCCL may print its version banner around the line)
+    assert js, (r.stdout[-500:], r.stderr[-500:])
+    line = json.loads(js[-1])
+    leg = line["other_configs"]["cfg4_train_dp1"]
+    assert "error" not in leg, leg
+    assert leg["n_gpus"] == 1 and leg["steps"] == 8 and leg["ms_per_step"] > 0 and leg["ms_per_step_collectives_after_backward"] > 0
+    assert leg["gradient_collectives"]["collectives_per_step"] >= 1 and leg["gradient_collectives"]["bytes_per_step"] > 0
+    assert len(leg["per_rank"]) == 1 and leg["per_rank"][0]["ms_in_finish_behind_collectives"] is not None
+    assert line["distributed"]["backend"] == "nccl" and line["distributed"]["allreduce_check"] is True
+    assert leg["final_loss"] == leg["final_loss"] and abs(leg["final_loss"]) < 1e30
