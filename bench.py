@@ -771,7 +771,42 @@ def main_infer(args, world, rank, device, dist_info):
         for f in forms:
             ops.gcn_layer_fwd(graph, gb, feats, w, scale, shift, feats, relu=True, out=buf, **f)
 
-    layer_ms = time_steps(layer_launches, iters=args.kernel_iters, warm=3) / len(forms)
+    timing_note = "each form of the launch on the step's input, back to back (HIP events around the loop)"
+    if chained and fused_cls and args.layers >= 2 and model.jk is None:
+        # The step itself, launch by launch: layer 1 -> ... -> last layer + heads, every launch reading what the one before it wrote
+        # (as the replayed graph does), HIP events between the launches; the dominant kernel's average duration is the mean over the
+        # step's plain-layer launches.  (Each form timed alone on the same input measured 4 - 6 % more than the same launches take
+        # inside the step -- profiles/r04_infer_step_sequence.txt -- and would not be what a kernel trace of this command shows.)
+        folded, packed = model._folded_layers(), model._packed_classifier()
+        bufs = [torch.empty_like(feats) for _ in range(2)]
+        n_plain = args.layers - 1
+
+        def step_launches(events=None):
+            x = feats
+            for i in range(n_plain):
+                wi, si, hi = folded[i]
+                if events is not None:
+                    events[i].record()
+                x = ops.gcn_layer_fwd(graph, gb, x, wi, si, hi, x, relu=True, out=bufs[i & 1], kidsum_in=(ka, kb)[(i + 1) & 1] if i > 0 else None,
+                                      kidsum_out=(ka, kb)[i & 1])
+            if events is not None:
+                events[n_plain].record()
+            wl, sl, hl = folded[args.layers - 1]
+            return ops.gcn_layer_cls_fwd(graph, gb, x, wl, sl, hl, x, False, packed, sigmoid=False, kidsum_in=(ka, kb)[(n_plain + 1) & 1])
+
+        for _ in range(3):
+            step_launches()
+        torch.cuda.synchronize()
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(n_plain + 1)] for _ in range(args.kernel_iters)]
+        for it in range(args.kernel_iters):
+            step_launches(evs[it])
+        torch.cuda.synchronize()
+        layer_ms = sum(e[i].elapsed_time(e[i + 1]) for e in evs for i in range(n_plain)) / (n_plain * args.kernel_iters)
+        timing_note = ("the step's launches in sequence (each reads what the one before it wrote), HIP events between them: mean over the "
+                       f"step's {n_plain} plain-layer launches x {args.kernel_iters} steps")
+        del bufs
+    else:
+        layer_ms = time_steps(layer_launches, iters=args.kernel_iters, warm=3) / len(forms)
     e_dir = 2 * topo.num_undirected_edges
     flops = B * (N * 2 * C * C + (e_dir + N) * 2 * C)             # SURVEY §8(d) per-layer FLOPs
     bytes_alg = B * N * 2 * C * 4                                  # read x once + write out once
@@ -787,7 +822,7 @@ def main_infer(args, world, rank, device, dist_info):
                 # node update alone -- what the MFMA pipe executes -- against the same roof:
                 "frac_mfma_only": round(B * N * 2 * C * C / (layer_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": round(layer_ms, 4),
+                "avg_launch_ms": round(layer_ms, 4), "avg_launch_timing": timing_note,
                 "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": bytes_alg}}
     stack_bytes, stack_flops = stack_work(topo, args.layers)
