@@ -209,7 +209,7 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
         reducer = GradientAllReducer(params, force_collective=force_collective,
                                      bucket_bytes=(bucket_kb << 10) if bucket_kb > 0 else None)
         reducer.attach_hooks()
-        reducer.profile = True
+        reducer.profile = False          # (two timing events per step while on: switched on around the measured steps only)
 
     def step():
         preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0.clone())
@@ -253,36 +253,49 @@ def timed_loop(step, steps, world, device):
     return elapsed, out
 
 
-def train_layer_roofline(B, topo, device, layers):
+def train_layer_roofline(B, topo, device, layers, step=None):
     """The dominant kernel of the training step -- the train-forward layer kernel (k_gcn_layer_ps<false, false, 1>: aggregation,
-    128x128 node update, BatchNorm partial sums; 3 launches per step) -- timed live with HIP events on the launch stream.
-    eg_gcn_layer_train_fwd with out = NULL runs that kernel and the two tiny launches that reduce its statistics, not the
-    activation pass.  Algorithmic bytes per launch: read x, write z, write A_hat x (kept for dW) = 3 * B * N * 512 B; the
-    chained form (layers 2, 3 of a step) also reads the child sums of x."""
+    128x128 node update, BatchNorm partial sums; 3 launches per step) -- timed live with HIP events on the launch stream INSIDE
+    real training steps (`step`: eg_debug_layer_timing_* puts an event pair around every layer-kernel launch, also those issued
+    from autograd nodes), so `avg_launch_ms` is what a kernel trace of the step shows.  Algorithmic bytes per launch: read x,
+    write z, write A_hat x (kept for dW) = 3 * B * N * 512 B; layers 2, 3 of a step also read the child sums of x."""
     import torch
     from echoglad_amd import ops
-    g = ops.Graph.topo(topo.spec.frame_size, topo.spec.num_aux_graphs, False, True, device=device)
     rows = B * topo.num_nodes
-    x = torch.randn(rows, C, device=device)
-    W = torch.randn(C, C, device=device) * 0.08
-    one, zero = torch.ones(C, device=device), torch.zeros(C, device=device)
-    kin = ops.new_kidsum(g, B)
-    forms = [dict()] + ([dict(kidsum_in=kin)] * (layers - 1) if kin is not None else [dict()] * (layers - 1))
+    dx_ms = None
+    if step is not None:
+        n_steps = 6
+        with ops.layer_timing(256) as tm:
+            for _ in range(n_steps):
+                step()
+            torch.cuda.synchronize()
+        ms = tm.mean_ms("ps_train_fwd")
+        dx_ms = tm.mean_ms("ps_dx")
+        n_timed = sum(1 for k, _ in tm.launches if k == "ps_train_fwd")
+        timing = (f"HIP events around the kernel's launches inside {n_steps} real training steps "
+                  f"({n_timed} launches: layer 1 pulls child rows, layers 2-3 read child sums)")
+    if step is None or ms is None:
+        g = ops.Graph.topo(topo.spec.frame_size, topo.spec.num_aux_graphs, False, True, device=device)
+        x = torch.randn(rows, C, device=device)
+        W = torch.randn(C, C, device=device) * 0.08
+        one, zero = torch.ones(C, device=device), torch.zeros(C, device=device)
+        kin = ops.new_kidsum(g, B)
+        forms = [dict()] + ([dict(kidsum_in=kin)] * (layers - 1) if kin is not None else [dict()] * (layers - 1))
 
-    def launches():
-        for f in forms:
-            ops.gcn_layer_train_fwd(g, B, x, W, zero, one, zero, None, None, None, 1e-5, True, 0.0, 0, True, want_out=False, **f)
+        def launches():
+            for f in forms:
+                ops.gcn_layer_train_fwd(g, B, x, W, zero, one, zero, None, None, None, 1e-5, True, 0.0, 0, True, want_out=False, **f)
 
-    ms = time_steps(launches, iters=10, warm=2) / len(forms)
+        ms = time_steps(launches, iters=10, warm=2) / len(forms)
+        timing = "the kernel alone on fresh rows (+ the 2 tiny launches that reduce its BatchNorm partial sums, ~25 us)"
     n, e_dir = topo.num_nodes, 2 * topo.num_undirected_edges
     bytes_alg = 3 * rows * C * 4
     flops = B * (n * 2 * C * C + (e_dir + n) * 2 * C)
     tf, gbs = flops / (ms * 1e-3) / 1e12, bytes_alg / (ms * 1e-3) / 1e9
     rf = {"bound": "hbm", "kernel": "k_gcn_layer_ps<false, false, 1> (train-forward layer kernel, 3 launches per step)",
           "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-          "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_alg,
-          "note": "avg over the step's 3 forms (first layer pulls child rows, layers 2-3 read child sums); the timed call also "
-                  "runs the 2 launches that reduce the kernel's BatchNorm partial sums (~25 us)",
+          "avg_launch_ms": round(ms, 4), "avg_launch_timing": timing, "algorithmic_bytes_per_launch": bytes_alg,
+          "dx_launch_ms": None if dx_ms is None else round(dx_ms, 4),
           "mfma": {"achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TF, 4),
                    "frac_mfma_only": round(B * n * 2 * C * C / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4)}}
     pm, src = _pmc_summary(r"r\d+_train_pmc\.json", TRAIN_KERNEL_SOURCES)
@@ -302,7 +315,7 @@ def main_train(args, world, rank, device, dist_info):
     for _ in range(max(args.warmup, 2)):
         loss = step()
     if step.reducer is not None:
-        step.reducer.collective_wait_ms()                    # drop the warm-up steps' events
+        step.reducer.profile = True                          # (events from here on: the measured steps)
     elapsed, loss = timed_loop(step, args.steps, world, device)
     # per rank: its own clock over the same K steps (the reported time is the maximum), and how long its compute stream sat in
     # finish() behind the gradient collectives -- what to look at first when the scaling curve bends
@@ -345,7 +358,7 @@ def main_train(args, world, rank, device, dist_info):
                                      "side stream); ms_per_step_alone = this rank's own synchronised step time")}
         if world == 1 and not args.no_other_configs:
             try:
-                out["roofline"] = train_layer_roofline(B, topo, device, args.layers)
+                out["roofline"] = train_layer_roofline(B, topo, device, args.layers, step)
             except Exception as ex:
                 out["roofline"] = {"error": repr(ex)}
         emit(out)
@@ -362,11 +375,30 @@ def train_leg_all_ranks(args, world, rank, device):
     import gc
     import torch
     B, K = 32, 8
+    # Agree across ranks BEFORE the first collective step: a rank that cannot run the step at all (out of memory, an unsupported
+    # shape) would otherwise leave the others inside an all-reduce until the process group's timeout aborts the job -- and the
+    # headline line with it.  Every rank takes one local step without any collective, then one MIN all-reduce of an ok flag
+    # (which every rank reaches: the probe is wrapped) decides for all of them.
+    ok, err = 1, None
+    try:
+        probe, _ = train_workload(224, 7, args.layers, B, device, 1, rank)
+        probe()
+        torch.cuda.synchronize()
+        del probe
+    except Exception as ex:
+        ok, err = 0, repr(ex)
+    gc.collect()
+    torch.cuda.empty_cache()
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return {"skipped": True, "error": err or "another rank failed its local probe step"} if rank == 0 else None
     step, topo = train_workload(224, 7, args.layers, B, device, world, rank, force_collective=(world == 1), bucket_kb=args.bucket_kb)
     red = step.reducer
     for _ in range(3):
         loss = step()
-    red.collective_wait_ms()
+    red.profile = True
     elapsed, loss = timed_loop(step, K, world, device)
     torch.cuda.synchronize()
     own = []
@@ -526,63 +558,135 @@ def time_steps(step, iters=20, warm=5):
     return e0.elapsed_time(e1) / iters
 
 
+def _infer_entry(args, device, what, frame, naux, main_only, B, **kw):
+    """One inference side configuration timed like the headline (HIP-graph replay, inputs resident in HBM)."""
+    import gc
+    import torch
+    try:
+        model, _, topo, feats, ei, step = infer_workload(frame, naux, args.layers, main_only, B, device, 0, **kw)
+        ms = time_steps(step, iters=20, warm=5)
+        graph, _ = model._resolver.resolve(ei, feats.shape[0])
+        sb, sf = stack_work(topo, args.layers)
+        fps = B / (ms * 1e-3)
+        out = {"workload": what, "ms_per_step": round(ms, 4), "frames_s": round(fps, 1),
+               "mfma_frac": round(fps * sf / 1e12 / PEAK_F32_MFMA_TF, 4), "hbm_frac": round(fps * sb / 1e9 / PEAK_HBM_GBS, 4),
+               "nodes_per_frame": topo.num_nodes, "stencil_handle": bool(graph.structured)}
+        del model, feats, ei, step
+    except Exception as ex:
+        out = {"workload": what, "error": repr(ex)}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def pyg_surface_entry(args, device, B=8):
+    """INTEGRATION route B timed: the reference's forward loop (models.py:426-435 layer call + residual, :485 node-type
+    filter, :488-490 four heads + cat) written as the reference writes it, over this package's torch_geometric-shaped modules
+    (Sequential('x, edge_index', [GCNConv, BatchNorm1d, Dropout, ReLU]) -> one fused launch per layer); the residual add, the
+    row filter and the heads stay the torch ops the unchanged models.py issues.  Eval mode, configs[1] shape."""
+    import gc
+    import torch
+    what = f"configs[1] via the reference-shaped loop (route B), batch {B}, eval"
+    try:
+        model, _, topo, feats, ei, _ = infer_workload(224, 7, args.layers, False, B, device, 0, hip_graph=False)
+        n, n_valid = topo.num_nodes, topo.num_valid_nodes
+        node_type = torch.from_numpy(__import__("numpy").tile(topo.node_type(), B)).to(device)
+        keep = torch.nonzero(node_type == 0).squeeze(1)               # (static per topology: the reference re-derives it with a host sync)
+        from echoglad_amd import nn as egnn
+
+        def layers_only():
+            hidden = [feats]
+            for i in range(args.layers):
+                h = model.gnn_layers[i](hidden[i], ei)
+                h = h + hidden[i]
+                hidden.append(h)
+            return hidden[-1]
+
+        def step():
+            h = layers_only()
+            h = h[keep]
+            return torch.cat([clf(h) for clf in model.node_classifiers], dim=1).squeeze(1)
+
+        graph, gb = egnn._SHARED_RESOLVER.resolve(ei, feats.shape[0])
+        with torch.no_grad():
+            l0, p0 = graph.layer_launches, graph.ps_launches
+            got = step()
+            per_step = (graph.layer_launches - l0, graph.ps_launches - p0)
+            ms = time_steps(step, iters=20, warm=5)
+            ms_layers = time_steps(layers_only, iters=20, warm=3)
+            os.environ["EG_SEQ_FUSED"] = "0"
+            try:
+                ms_unfused = time_steps(step, iters=10, warm=3)
+            finally:
+                del os.environ["EG_SEQ_FUSED"]
+            same = float((got - model.forward_nodes(feats, ei, B)[0]).abs().max())
+        sb, sf = stack_work(topo, args.layers)
+        fps = B / (ms * 1e-3)
+        out = {"workload": what, "ms_per_step": round(ms, 4), "frames_s": round(fps, 1),
+               "mfma_frac": round(fps * sf / 1e12 / PEAK_F32_MFMA_TF, 4), "hbm_frac": round(fps * sb / 1e9 / PEAK_HBM_GBS, 4),
+               "ms_layers_and_residual_adds": round(ms_layers, 4), "ms_per_step_module_by_module": round(ms_unfused, 4),
+               "launches": {"fused_layer_launches_per_step": per_step[0], "of_them_producer_consumer": per_step[1],
+                            "torch": f"{args.layers} residual adds, 1 row gather, 4 heads x (3 Linear + 2 BatchNorm1d + 2 ReLU) + cat"},
+               "stencil_handle": bool(graph.structured), "max_abs_diff_vs_route_A": same}
+        del model, feats, ei
+    except Exception as ex:
+        out = {"workload": what, "error": repr(ex)}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def train_entry(args, device, B, what, roofline=False):
+    import gc
+    import torch
+    try:
+        step, topo = train_workload(224, 7, args.layers, B, device, 1, 0)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 8
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        sb, sf = stack_work(topo, args.layers)
+        fps = B / (ms * 1e-3)
+        out = {"workload": what, "ms_per_step": round(ms, 3), "frames_s": round(fps, 1),
+               "mfma_frac": round(fps * 3 * sf / 1e12 / PEAK_F32_MFMA_TF, 4), "hbm_frac": round(fps * 3 * sb / 1e9 / PEAK_HBM_GBS, 4),
+               "nodes_per_frame": topo.num_nodes, "floor": "3 x forward bytes / FLOPs (SURVEY 8d)"}
+        if roofline:
+            tb, tsrc = train_pmc_traffic()
+            out.update({"traffic_bytes_per_step": tb, "traffic_source": tsrc, "algorithmic_bytes_per_step": 3 * sb * B})
+            out["roofline"] = train_layer_roofline(B, topo, device, args.layers, step)
+        del step
+    except Exception as ex:
+        out = {"workload": what, "error": repr(ex)}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def other_configs(args, device):
     """The BASELINE configs the metric is not quoted on, timed like the headline (HIP-graph replay, inputs in HBM);
-    reported beside it, never inside `value`."""
+    reported beside it, never inside `value`.  (What each entry is: DESIGN.md section 4; the strings here stay short so that the
+    one JSON line fits the driver's tail window.)"""
     import gc
     import torch
     out = {}
-    for key, frame, naux, main_only, B, what in (
-            ("cfg3", 224, 7, True, 32, "configs[2]: use_main_graph_only, 224x224, batch 32, eval"),
-            ("cfg5", 448, 8, False, 8, "configs[4]: 448x448, 8 aux levels (N = 288,084 per frame), batch 8 per GPU, eval")):
-        try:
-            model, kw, topo, feats, ei, step = infer_workload(frame, naux, args.layers, main_only, B, device, 0)
-            ms = time_steps(step, iters=20, warm=5)
-            sb, sf = stack_work(topo, args.layers)
-            fps = B / (ms * 1e-3)
-            out[key] = {"workload": what, "ms_per_step": round(ms, 4), "frames_s": round(fps, 1),
-                        "mfma_frac": round(fps * sf / 1e12 / PEAK_F32_MFMA_TF, 4),
-                        "hbm_frac": round(fps * sb / 1e9 / PEAK_HBM_GBS, 4), "nodes_per_frame": topo.num_nodes}
-            del model, feats, ei, step
-        except Exception as ex:
-            out[key] = {"workload": what, "error": repr(ex)}
-        gc.collect()
-        torch.cuda.empty_cache()
-    what = ("configs[1]'s shape with 'grid-diagonal' levels (datasets.py:1469-1475, :1494-1500: 8-neighbour grids, E_dir = 858,"
-            "312 per frame), batch 8, eval: the implicit stencil of the producer/consumer kernel (round 3: CSR fallback)")
-    try:
-        model, kw, topo, feats, ei, step = infer_workload(224, 7, args.layers, False, 8, device, 0, graph_type="grid-diagonal")
-        ms = time_steps(step, iters=20, warm=5)
-        graph, _ = model._resolver.resolve(ei, feats.shape[0])
-        sb, sf = stack_work(topo, args.layers)
-        fps = 8 / (ms * 1e-3)
-        out["cfg2_diagonal"] = {"workload": what, "ms_per_step": round(ms, 4), "frames_s": round(fps, 1),
-                                "mfma_frac": round(fps * sf / 1e12 / PEAK_F32_MFMA_TF, 4),
-                                "hbm_frac": round(fps * sb / 1e9 / PEAK_HBM_GBS, 4), "stencil_handle": bool(graph.structured),
-                                "directed_edges_per_frame": 2 * topo.num_undirected_edges}
-        del model, feats, ei, step
-    except Exception as ex:
-        out["cfg2_diagonal"] = {"workload": what, "error": repr(ex)}
-    gc.collect()
-    torch.cuda.empty_cache()
-    what = ("configs[1]'s shape with use_connection_nodes=True (datasets.py:1450-1456, :1512-1515: 8 connection nodes per frame, each "
-            "wired to a whole aux level), batch 8, eval: level sums by a pre-pass, then the stencil kernel (round 3: CSR fallback)")
-    try:
-        model, kw, topo, feats, ei, step = infer_workload(224, 7, args.layers, False, 8, device, 0, conn=True)
-        ms = time_steps(step, iters=20, warm=5)
-        graph, _ = model._resolver.resolve(ei, feats.shape[0])
-        sb, sf = stack_work(topo, args.layers)
-        fps = 8 / (ms * 1e-3)
-        out["cfg2_connection_nodes"] = {"workload": what, "ms_per_step": round(ms, 4), "frames_s": round(fps, 1),
-                                        "mfma_frac": round(fps * sf / 1e12 / PEAK_F32_MFMA_TF, 4),
-                                        "hbm_frac": round(fps * sb / 1e9 / PEAK_HBM_GBS, 4), "stencil_handle": bool(graph.structured)}
-        del model, feats, ei, step
-    except Exception as ex:
-        out["cfg2_connection_nodes"] = {"workload": what, "error": repr(ex)}
-    gc.collect()
-    torch.cuda.empty_cache()
-    what = ("configs[1] through the GENERIC path: the same 224x224 / 7-aux-level batch of 8 with its edge_index turned into a CSR "
-            "handle (what an arbitrary edge_index takes; every flag of the reference's builder has a stencil handle): 3 x eg_gcn_layer_fwd + eg_classifier_fwd")
+    out["cfg3"] = _infer_entry(args, device, "configs[2]: main grid only, 224x224, batch 32, eval", 224, 7, True, 32)
+    out["cfg5"] = _infer_entry(args, device, "configs[4]: 448x448, 8 aux levels, batch 8 per GPU, eval", 448, 8, False, 8)
+    out["cfg2_diagonal"] = _infer_entry(args, device, "configs[1] shape, 'grid-diagonal' levels, batch 8, eval", 224, 7, False, 8,
+                                        graph_type="grid-diagonal")
+    out["cfg2_connection_nodes"] = _infer_entry(args, device, "configs[1] shape, use_connection_nodes, batch 8, eval", 224, 7, False, 8,
+                                                conn=True)
+    # the reference's own operating point: batch_size 1 (configs/default.yml:27)
+    b1 = _infer_entry(args, device, "configs[1] shape at batch 1 (default.yml:27), eval", 224, 7, False, 1)
+    if "ms_per_step" in b1:
+        b1["us_per_frame"] = round(1e3 * b1["ms_per_step"], 1)
+    out["cfg2_b1"] = b1
+    out["cfg2_pyg_surface"] = pyg_surface_entry(args, device)
+    what = "configs[1] through a CSR handle (arbitrary edge_index), batch 8, eval"
     try:
         from echoglad_amd import ops
         model, kw, topo, feats, ei, _ = infer_workload(224, 7, args.layers, False, 8, device, 0, hip_graph=False)
@@ -609,37 +713,8 @@ def other_configs(args, device):
         out["cfg2_csr_fallback"] = {"workload": what, "error": repr(ex)}
     gc.collect()
     torch.cuda.empty_cache()
-    what = ("configs[3]: 224x224, 7 aux levels + coordinate graph, batch 32 per GPU, one training step "
-            "(fwd + 3 losses + bwd + Adam; dropout 0.5, batch-stat BN)")
-    try:
-        B = 32
-        step, topo = train_workload(224, 7, args.layers, B, device, 1, 0)
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 8
-        for _ in range(n):
-            step()
-        torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / n
-        sb, sf = stack_work(topo, args.layers)
-        fps = B / (ms * 1e-3)
-        out["cfg4_train"] = {"workload": what, "ms_per_step": round(ms, 3), "frames_s": round(fps, 1),
-                             "mfma_frac": round(fps * 3 * sf / 1e12 / PEAK_F32_MFMA_TF, 4),
-                             "hbm_frac": round(fps * 3 * sb / 1e9 / PEAK_HBM_GBS, 4), "nodes_per_frame": topo.num_nodes,
-                             "floor": "3 x the forward's algorithmic bytes / FLOPs (SURVEY 8d)"}
-        tb, tsrc = train_pmc_traffic()
-        out["cfg4_train"].update({"traffic_bytes_per_step": tb, "traffic_source": tsrc,
-                                  "algorithmic_bytes_per_step": 3 * sb * B})
-        del step
-        gc.collect()
-        torch.cuda.empty_cache()
-        out["cfg4_train"]["roofline"] = train_layer_roofline(B, topo, device, args.layers)
-    except Exception as ex:
-        out["cfg4_train"] = {"workload": what, "error": repr(ex)}
-    gc.collect()
-    torch.cuda.empty_cache()
+    out["cfg4_train"] = train_entry(args, device, 32, "configs[3]: 224/7 + coordinate graph, batch 32 per GPU, one train step", roofline=True)
+    out["cfg4_train_b1"] = train_entry(args, device, 1, "configs[3] shape at batch 1 (default.yml:27), one train step")
     return out
 
 

@@ -15,7 +15,7 @@ LIB_PATH = Path(os.environ.get("ECHOGLAD_LIB", _PKG / "lib" / "libechoglad_hip.s
 HEADER_PATH = _PKG.parent / "include" / "echoglad_hip.h"
 
 EG_OK, EG_ERR_ARG, EG_ERR_UNSUPPORTED, EG_ERR_HIP = 0, -1, -2, -3
-ABI_VERSION = 132          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
+ABI_VERSION = 133          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
 
 _lib: Optional[ct.CDLL] = None
 
@@ -50,6 +50,8 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_graph_deg_inv_sqrt": (_i, [_p, _p, _p]),
     "eg_edge_hash": (_i, [_p, _i64, _p, _p]),
     "eg_debug_xcc": (_i, [_p, _i, _p]),
+    "eg_debug_layer_timing_begin": (_i, [_i]),
+    "eg_debug_layer_timing_end": (_i, [ct.POINTER(ct.c_float), ct.POINTER(ct.c_int), _i]),
     "eg_debug_phase_cycles": (_i, [_p, ct.POINTER(ct.c_uint64), _i]),
     "eg_gcn_layer_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "eg_graph_kidsum_rows": (_i64, [_p]),
@@ -58,6 +60,7 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_gcn_layer_cls_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "eg_gcn_layer_fwd_jk": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "eg_graph_ps_launches": (ct.c_uint, [_p]),
+    "eg_graph_layer_launches": (ct.c_uint, [_p]),
     "eg_gcn_aggregate": (_i, [_p, _i, _p, _p, _p]),
     "eg_linear128_fwd": (_i, [_p, _i64, _p, _p, _p, _p, _i, _i, _p, _p]),
     "eg_classifier_fwd": (_i, [_p, _i, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/echoglad_hip.h"
 
@@ -174,15 +175,17 @@ struct Knobs {
     int layer_impl;     // EG_LAYER_IMPL  -1 auto, 0 symmetric kernel, 1 producer/consumer kernel for plain calls
     int ps_grid;        // EG_PS_GRID     persistent grid of the producer/consumer kernel (default 256 = 1 per CU)
     int ring_guard;     // EG_RING_GUARD  0: no event behind a launch (diagnostic: the queue ring is then unguarded, as before round 4)
-    int queue_self_reset;   // EG_QUEUE_SELF_RESET  1 (default): the producer/consumer kernel zeroes its queue slice on the way out; 0: a memset in front of every launch
+    int queue_self_reset;   // EG_QUEUE_SELF_RESET  1 (default): the layer kernels zero their queue slice on the way out; 0: a memset in front of every launch
 };
 Knobs read_knobs();
 const Knobs& process_knobs();
 
 // Tile-queue heads: 8 per-XCD counters, one 128-B line each = 256 ints per launch.  A handle owns a RING of such slices;
-// every launch takes the next slice (host atomic) and hands it to its kernel (zeroed: by the producer / consumer kernel that used
-// it last, on its way out, or by a memset in front of the launch where the symmetric kernel left counters behind), so launches on
-// different streams that share a handle never touch the same counters.
+// every launch takes the next slice (host atomic) and hands it to its kernel, so launches on different streams that share a handle
+// never touch the same counters.  DEVICE INVARIANT: a slice is all zero whenever no launch is using it -- the ring is zeroed at
+// creation and every kernel that walks a queue (both layer kernels) zeroes its slice on the way out (last workgroup out, atomics
+// only).  No host-side state says whether a slice is clean, so a launch recorded into a HIP graph and replayed later sees exactly
+// what an eager launch sees.
 constexpr int QUEUE_SLICE_INTS = 8 * 32;
 constexpr int QUEUE_DONE_IDX = 1;       // (inside the first counter's 128-B line) workgroups that have left a self-resetting launch
 #ifdef EG_STAMP
@@ -218,11 +221,14 @@ struct eg_graph {
     int n_conn;               // connection nodes per frame
     int conn_chunks;          // chunks of <= 256 rows the hub-wired levels are cut into (per frame)
     int* conn_table;          // device [conn_chunks][4] = {level index, first row, rows, 0}
-    // device [QUEUE_SLOTS][conn_cap][conn_chunks + 2 n_conn][128]; grown (under conn_mutex, after a device synchronisation) the
-    // first time a launch brings more frames than it holds -- the one place a launch may allocate, once per new maximum
+    // device [QUEUE_SLOTS][conn_cap][conn_chunks + 2 n_conn][128]; a LARGER one is allocated (under conn_mutex) the first time a
+    // launch brings more frames than it holds -- the one place a launch may allocate, once per new maximum.  The smaller ones are
+    // never freed before eg_graph_destroy (conn_retired): a HIP graph captured at a smaller batch keeps replaying on the slice it
+    // was given, and a launch on another thread may still be between taking its slice pointer and enqueueing its kernels.
     mutable float* conn_scratch;
     mutable int conn_cap;
     mutable std::mutex conn_mutex;
+    mutable std::vector<float*> conn_retired;
     int flat;                 // 1: a single grid level (use_main_graph_only): no parents, no children; the producer/consumer
                               //    kernel needs no child sums there and is the default layer kernel when its tables fit LDS
     int n_tiles;
@@ -234,6 +240,7 @@ struct eg_graph {
     int* walk_counters;       // device [QUEUE_SLOTS][8 x 32] ring of per-launch tile-queue heads (+ QUEUE_TAIL_INTS)
     mutable std::atomic<unsigned> launch_seq;   // next slice of the ring (the only host state a launch touches)
     mutable std::atomic<unsigned> ps_launches;  // launches of the producer/consumer kernel on this handle (eg_graph_ps_launches)
+    mutable std::atomic<unsigned> layer_launches;   // launches of either layer kernel on this handle (eg_graph_layer_launches)
     eg::Knobs knobs;          // environment knobs, read once at creation
 
     // Guard of the ring: an event per slice, recorded behind the launch that used it, and the stream it was recorded on.
@@ -245,15 +252,22 @@ struct eg_graph {
     mutable std::atomic<void*> only_stream;      // the one stream this handle has launched on so far ...
     mutable std::atomic<unsigned char> multi_stream;   // ... until a second one shows up: from then on every launch records its event
     mutable std::atomic<unsigned char> any_launch;
-    // A slice of the ring that its last user may have left with non-zero counters (the symmetric kernel's queue walk; the ring is
-    // zeroed at creation and the producer / consumer kernel zeroes its slice itself on the way out): memset before the next use.
-    mutable std::atomic<unsigned char> slot_dirty[eg::QUEUE_SLOTS];
 
     // the slice of the queue ring for one launch on `stream` (graph.hip); EG_OK / EG_ERR_UNSUPPORTED / EG_ERR_HIP
     int acquire_queue_slice(hipStream_t stream, int** slice, int* slot) const;
     // to be called right after the launch that uses the slice
     void commit_queue_slice(int slot, hipStream_t stream) const;
 };
+
+// eg_debug_layer_timing_* (graph.hip): a pair of events around a layer-kernel launch while a measurement is armed
+namespace eg {
+struct LaunchTimer {
+    int idx;
+    hipStream_t stream;
+    LaunchTimer(int kind, hipStream_t s);     // records the start event (no-op unless armed and not capturing)
+    ~LaunchTimer();                           // records the stop event
+};
+}  // namespace eg
 
 // producer/consumer layer kernel (gcn_layer_ps.hip); EG_ERR_UNSUPPORTED -> caller uses the symmetric kernel
 namespace eg {

@@ -86,17 +86,18 @@ int eg_launch_conn_prepass(const eg_graph* g, int batch, const float* x, int slo
         std::lock_guard<std::mutex> lock(g->conn_mutex);
         if (batch > g->conn_cap || !g->conn_scratch) {
             // more frames than the scratch holds: a larger one.  Not while a stream is being captured into a HIP graph (no allocation
-            // there; nn's warm-up run in front of a capture has grown it), and only after everything in flight has drained.
+            // there; nn's warm-up run in front of a capture has grown it).  The smaller scratch is RETIRED, not freed: HIP graphs
+            // captured earlier hold its slices in their kernel nodes and replay on them, and a launch on another thread may have
+            // taken its slice pointer already (eg_graph_destroy frees the retired ones).
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
             if (cs != hipStreamCaptureStatusNone)
                 return set_error(EG_ERR_UNSUPPORTED, "connection-node scratch too small for this batch during stream capture: run the call once outside the capture");
             int cap = g->conn_cap > 0 ? g->conn_cap : 8;
             while (cap < batch) cap *= 2;
-            EG_HIP_TRY(hipDeviceSynchronize());
             float* bigger = nullptr;
             EG_HIP_TRY(hipMalloc((void**)&bigger, sizeof(float) * (size_t)per_frame * cap * QUEUE_SLOTS));
-            if (g->conn_scratch) (void)hipFree(g->conn_scratch);
+            if (g->conn_scratch) g->conn_retired.push_back(g->conn_scratch);
             g->conn_scratch = bigger;
             g->conn_cap = cap;
         }

@@ -28,6 +28,7 @@ struct LayerDims {
     int transpose_w;
     int walk_mode;
     int stagger;           // experiment knob: the second half of the grid starts this many s_sleep(127) late
+    int self_reset;        // queue walk: the last workgroup out zeroes the launch's slice of the queue ring (common.h: device invariant)
 };
 
 struct LayerArgs {         // host-side bundle only
@@ -300,6 +301,17 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
             }
         }
     }
+    // queue walk: thread 0 -- the claiming thread, all of whose claims have returned -- counts its workgroup out; the last one
+    // puts the eight queue heads and the exit counter back to 0 (atomics only: no XCD's L2 holds the line dirty), so the slice is
+    // clean for whoever takes it next, eagerly or in a HIP-graph replay
+    if (a.self_reset && tid == 0) {
+        const int done = atomicAdd(&walk_counters[QUEUE_DONE_IDX], 1);
+        if (done == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int q = 0; q < WALK_GROUPS; ++q) atomicExch(&walk_counters[q * WALK_CTR_STRIDE], 0);
+            atomicExch(&walk_counters[QUEUE_DONE_IDX], 0);
+        }
+    }
 #ifdef EG_STAMP
     if (lane_k == 0) {
         unsigned long long* stats = reinterpret_cast<unsigned long long*>(walk_counters + WALK_GROUPS * WALK_CTR_STRIDE);
@@ -364,11 +376,17 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out
     // bit-reproducible (tests/test_gpu_train.py::test_cfg4_train_full_batch_32_properties).
     if (a.stats_partial && a.d.walk_mode == WALK_QUEUE) a.d.walk_mode = WALK_MOD8;
     a.d.stagger = a.knobs.stagger;
-    if (a.d.walk_mode == WALK_QUEUE) {
+    // queue walk: the kernel leaves its slice zeroed (last workgroup out), like the producer / consumer kernel -- the slice it is
+    // handed is clean by the same invariant (common.h); EG_QUEUE_SELF_RESET=0 / stamp builds: a memset in front instead
+#ifdef EG_STAMP
+    a.d.self_reset = 0;
+#else
+    a.d.self_reset = (a.d.walk_mode == WALK_QUEUE && a.knobs.queue_self_reset != 0) ? 1 : 0;
+#endif
+    if (a.d.walk_mode == WALK_QUEUE && !a.d.self_reset)
         EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
-        if (a.graph && slot >= 0) a.graph->slot_dirty[slot].store(1, std::memory_order_relaxed);     // (this kernel leaves its counters behind)
-    }
     const bool res_lds = (a.residual == nullptr) || (a.residual == a.x);     // epilogue residual from the LDS stash / none
+    eg::LaunchTimer timer(EG_LAUNCH_SYMMETRIC, stream);
     switch (agg) {
         case AGG_NONE: hipLaunchKernelGGL((k_gcn_layer<AGG_NONE, true>), grid, block, 0, stream, LAYER_KARGS); break;
         case AGG_CSR:
@@ -381,7 +399,10 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out
             else hipLaunchKernelGGL((k_gcn_layer<AGG_STENCIL, true>), grid, block, 0, stream, LAYER_KARGS);
             break;
     }
-    if (a.graph) a.graph->commit_queue_slice(slot, stream);
+    if (a.graph) {
+        a.graph->commit_queue_slice(slot, stream);
+        a.graph->layer_launches.fetch_add(1u, std::memory_order_relaxed);
+    }
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }
@@ -510,6 +531,7 @@ int eg_gcn_layer_cls_fwd(const eg_graph* g, int batch, const float* x, const flo
 }
 
 unsigned eg_graph_ps_launches(const eg_graph* g) { return g ? g->ps_launches.load(std::memory_order_relaxed) : 0u; }
+unsigned eg_graph_layer_launches(const eg_graph* g) { return g ? g->layer_launches.load(std::memory_order_relaxed) : 0u; }
 
 
 int eg_gcn_aggregate(const eg_graph* g, int batch, const float* x, float* out, eg_stream_t stream) {

@@ -868,16 +868,14 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
         const int rc = g->acquire_queue_slice(stream, &queue, &slot);
         if (rc != EG_OK) return rc == EG_ERR_UNSUPPORTED ? EG_ERR_RING : rc;
     }
-    // the kernel zeroes its slice on the way out (see its last lines): a memset only where somebody else left counters behind
+    // every queue-walking kernel zeroes its slice on the way out (see this kernel's last lines and k_gcn_layer's): a slice is clean
+    // whenever it is handed out -- a device invariant, so nothing here depends on host state that a HIP-graph replay would not see
 #ifdef EG_STAMP
     const bool self_reset = false;
 #else
     const bool self_reset = g->knobs.queue_self_reset != 0;
 #endif
-    if (!self_reset || g->slot_dirty[slot].load(std::memory_order_relaxed)) {
-        EG_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
-        if (self_reset) g->slot_dirty[slot].store(0, std::memory_order_relaxed);
-    }
+    if (!self_reset) EG_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
     a.self_reset = self_reset ? 1 : 0;
     if (g->n_conn > 0) {                                          // connection nodes: level sums of THIS launch's input first (conn.hip)
         const float* slice = nullptr;
@@ -897,6 +895,7 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
                            (const int*)g->rowptr, (const int*)g->colidx);
     };
     if (grid_out) *grid_out = (int)grid;
+    eg::LaunchTimer timer(train ? EG_LAUNCH_PS_TRAIN_FWD : rsep ? EG_LAUNCH_PS_DX : cls ? EG_LAUNCH_PS_CLS : EG_LAUNCH_PS_PLAIN, stream);
     if (diag) {
         if (train) launch(k_gcn_layer_ps<false, false, 1, true>);
         else if (rsep) launch(k_gcn_layer_ps<false, false, 2, true>);
@@ -908,6 +907,7 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     else { if (jk) launch(k_gcn_layer_ps<false, true>); else launch(k_gcn_layer_ps<false, false>); }
     g->commit_queue_slice(slot, stream);
     g->ps_launches.fetch_add(1u, std::memory_order_relaxed);
+    g->layer_launches.fetch_add(1u, std::memory_order_relaxed);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

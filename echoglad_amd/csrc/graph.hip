@@ -236,11 +236,61 @@ static int csr_build(const int64_t* ei, int64_t n_nodes, int64_t n_edges, hipStr
 
 }  // namespace eg
 
+// ---- eg_debug_layer_timing_*: events around layer-kernel launches while armed (bench.py's in-step kernel durations) ----
+namespace {
+constexpr int TIMING_MAX = 256;
+std::atomic<int> g_timing_armed{0};        // launches still to be timed
+std::atomic<int> g_timing_count{0};
+hipEvent_t g_timing_ev[2 * TIMING_MAX];
+int g_timing_kind[TIMING_MAX];
+bool g_timing_have_events = false;
+}  // namespace
+
+eg::LaunchTimer::LaunchTimer(int kind, hipStream_t s) : idx(-1), stream(s) {
+    if (g_timing_armed.load(std::memory_order_relaxed) <= 0) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cs != hipStreamCaptureStatusNone) return;
+    if (g_timing_armed.fetch_sub(1, std::memory_order_relaxed) <= 0) return;
+    const int i = g_timing_count.fetch_add(1, std::memory_order_relaxed);
+    if (i >= TIMING_MAX) return;
+    g_timing_kind[i] = kind;
+    if (hipEventRecord(g_timing_ev[2 * i], s) == hipSuccess) idx = i;
+}
+eg::LaunchTimer::~LaunchTimer() {
+    if (idx >= 0) (void)hipEventRecord(g_timing_ev[2 * idx + 1], stream);
+}
+
 using namespace eg;
 
 extern "C" {
 
 int eg_version(void) { return EG_ABI_VERSION; }
+
+int eg_debug_layer_timing_begin(int max_launches) {
+    if (max_launches < 1 || max_launches > TIMING_MAX) return eg::set_error(EG_ERR_ARG, "max_launches must be in [1, 256]");
+    if (!g_timing_have_events) {
+        for (int i = 0; i < 2 * TIMING_MAX; ++i) EG_HIP_TRY(hipEventCreate(&g_timing_ev[i]));
+        g_timing_have_events = true;
+    }
+    g_timing_count.store(0, std::memory_order_relaxed);
+    g_timing_armed.store(max_launches, std::memory_order_relaxed);
+    return EG_OK;
+}
+
+int eg_debug_layer_timing_end(float* ms, int* kinds, int cap) {
+    g_timing_armed.store(0, std::memory_order_relaxed);
+    int n = g_timing_count.load(std::memory_order_relaxed);
+    if (n > TIMING_MAX) n = TIMING_MAX;
+    if (!ms || !kinds || cap < n) return eg::set_error(EG_ERR_ARG, "ms / kinds too small");
+    for (int i = 0; i < n; ++i) {
+        EG_HIP_TRY(hipEventSynchronize(g_timing_ev[2 * i + 1]));
+        EG_HIP_TRY(hipEventElapsedTime(&ms[i], g_timing_ev[2 * i], g_timing_ev[2 * i + 1]));
+        kinds[i] = g_timing_kind[i];
+    }
+    g_timing_count.store(0, std::memory_order_relaxed);
+    return n;
+}
 
 const char* eg_last_error(void) { return g_last_error.c_str(); }
 
@@ -706,6 +756,7 @@ int eg_graph_destroy(eg_graph* g) {
     if (g->colidx) (void)hipFree(g->colidx);
     if (g->conn_table) (void)hipFree(g->conn_table);
     if (g->conn_scratch) (void)hipFree(g->conn_scratch);
+    for (float* p : g->conn_retired) (void)hipFree(p);
     delete g;
     return EG_OK;
 }

@@ -477,13 +477,26 @@ __device__ inline void load_w_slice(const float* __restrict__ W, int wave, int l
 // acc[m][n]: n = lane&31 = row (row0 + n), m = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel within the wave's 32.
 // The 16 ds_read_b128 are software-pipelined in chunks of 4 (two named fragment sets) so that at most
 // 32 VGPRs hold A fragments while the 64-cycle MFMAs of the previous chunk cover the LDS latency.
+// EG_YIELD (experiment): a vector-class instruction of the MFMA wave's own between two MFMAs is what hands the
+// SIMD's other wave its issue slots (tools/micro_coissue5.hip: v_nop behind an MFMA: +16 cycles for the chain, ~10 instructions
+// for the partner instead of ~1).  EG_YIELD = n puts a v_nop behind every n-th MFMA of a chunk (n in 1, 2, 4).
+#ifdef EG_YIELD
+#define EG_YIELD_POINT(i) do { if ((i) % EG_YIELD == EG_YIELD - 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("v_nop"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define EG_YIELD_POINT(i) do {} while (0)
+#endif
+template <bool YIELD = false>
 __device__ inline void mfma_chunk(const f32x4 (&av)[4], const float (&wreg)[64], int t0, f32x16& acc) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 0], av[t].x, acc, 0, 0, 0);
+        if (YIELD) EG_YIELD_POINT(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 1], av[t].y, acc, 0, 0, 0);
+        if (YIELD) EG_YIELD_POINT(1);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 2], av[t].z, acc, 0, 0, 0);
+        if (YIELD) EG_YIELD_POINT(2);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[4 * (t0 + t) + 3], av[t].w, acc, 0, 0, 0);
+        if (YIELD) EG_YIELD_POINT(3);
     }
 }
 
@@ -496,17 +509,17 @@ __device__ inline void mfma_rowblock(const float* s_a, int row0, int lane, const
 #pragma unroll
     for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a0, wreg, 0, acc);
+    mfma_chunk<true>(a0, wreg, 0, acc);
 #pragma unroll
     for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a1, wreg, 4, acc);
+    mfma_chunk<true>(a1, wreg, 4, acc);
 #pragma unroll
     for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a0, wreg, 8, acc);
+    mfma_chunk<true>(a0, wreg, 8, acc);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(a1, wreg, 12, acc);
+    mfma_chunk<true>(a1, wreg, 12, acc);
 }
 
 // Same chain; between(c) is emitted in the scheduling region of chunk c (c = 0..3) so that independent VALU / LDS /

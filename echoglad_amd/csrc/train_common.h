@@ -70,7 +70,7 @@ __device__ inline long long map_row(const RowMap& m, long long r) {
 constexpr int RED_F32_THREADS = 1024;      // k_reduce_f32_partials, k_dweight_final: 32 columns x 32 slices of the partial list
 __global__ void k_reduce_f32_partials(const float* __restrict__ partial, int nblocks, int n, double* __restrict__ totals);
 
-// fixed-order sum of per-workgroup [128,128] float slabs -> dw (launch with 128 * 128 / 32 workgroups of 256 threads; train.hip)
+// fixed-order sum of per-workgroup [128,128] float slabs -> dw (launch with 128 * 128 / 32 workgroups of RED_F32_THREADS = 1024 threads; train.hip)
 __global__ void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw);
 
 // Train-mode BatchNorm1d from column totals: totals[0..cc) = sum, totals[cc..2cc) = sum of squares over `rows` rows.

@@ -547,7 +547,18 @@ class GCNConv(nn.Module):
 
 class Sequential(nn.Module):
     """Counterpart of ``torch_geometric.nn.Sequential('x, edge_index', [(conv, 'x, edge_index -> x'), m, ...])``
-    (src/core/models.py:329-335): children are registered as ``module_{i}``."""
+    (src/core/models.py:329-335): children are registered as ``module_{i}``.
+
+    The reference's layer -- ``[GCNConv, BatchNorm1d(128), Dropout, ReLU | Identity]`` -- is recognised and runs as ONE
+    kernel launch through this module's own ``forward(x, edge_index)``, so the reference's ``models.py`` loop
+    (``self.gnn_layers[i](hidden_embeds[i], edge_index)``, :431) reaches the fused kernels unchanged:
+      * eval mode, no gradient wanted: ``eg_gcn_layer_fwd`` with bias + BatchNorm folded into scale / shift and the ReLU in
+        the kernel's epilogue (three ``[B*N,128]`` elementwise passes fewer per layer);
+      * train mode (BatchNorm on batch statistics, Dropout on): the ``_LayerTrainFn`` composite
+        (``eg_gcn_layer_train_fwd`` / ``eg_gcn_layer_bwd``) without a residual -- that stays the caller's
+        ``h + hidden_embeds[i]`` (:434-435);
+      * anything else (frozen sub-modules inside a training model, eval with gradients, forward hooks on a child, other
+        module lists): module by module, as before.  ``EG_SEQ_FUSED=0`` forces that route."""
 
     def __init__(self, input_args: str, modules: Sequence):
         super().__init__()
@@ -559,6 +570,7 @@ class Sequential(nn.Module):
                 takes = "edge_index" in desc.split("->")[0]
             self.add_module(f"module_{i}", m)
             self._takes_graph.append(takes)
+        self._fold: Optional[tuple] = None
 
     def __len__(self):
         return len(self._takes_graph)
@@ -566,13 +578,66 @@ class Sequential(nn.Module):
     def __getitem__(self, i):
         return getattr(self, f"module_{i}")
 
+    # ---- the reference's layer as one launch ------------------------------------------------------------------------
+    def _reference_layer(self):
+        """(conv, bn, dropout, relu?) when the children are exactly models.py:329-335's list and none of them is observed
+        through a hook (a hook must see the intermediate tensor it was registered for), else None."""
+        if self._takes_graph != [True, False, False, False] or os.environ.get("EG_SEQ_FUSED", "1") == "0":
+            return None
+        conv, bn, drop, act = self.module_0, self.module_1, self.module_2, self.module_3
+        if type(conv) is not GCNConv or type(bn) is not nn.BatchNorm1d or bn.num_features != C or type(drop) is not nn.Dropout \
+                or type(act) not in (nn.ReLU, nn.Identity):
+            return None
+        for m in (conv, bn, drop, act):
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+                return None
+        return conv, bn, drop, type(act) is nn.ReLU
+
+    def _folded(self, conv, bn):
+        key = _versions(self)
+        if self._fold is None or self._fold[0] != key:
+            with torch.no_grad():
+                gamma = bn.weight if bn.affine else torch.ones_like(bn.running_var)
+                scale = gamma / torch.sqrt(bn.running_var + bn.eps)
+                shift = (bn.bias if bn.affine else 0.0) - bn.running_mean * scale
+                if conv.bias is not None:
+                    shift = shift + conv.bias * scale
+                self._fold = (key, conv.lin.weight.detach().contiguous(), scale.contiguous(), shift.contiguous())
+        return self._fold[1:]
+
+    def _fused(self, x, graph: ops.Graph, batch: int):
+        """The layer as one launch, or None when this call is not one of the two fused cases."""
+        ref = self._reference_layer()
+        if ref is None or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != C:
+            return None
+        conv, bn, drop, relu = ref
+        wants_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not bn.training and bn.running_mean is not None and not wants_grad and not (drop.training and drop.p > 0):
+            w, scale, shift = self._folded(conv, bn)
+            return ops.gcn_layer_fwd(graph, batch, x.contiguous(), w, scale, shift, None, relu)
+        if bn.training and bn.affine and drop.training and torch.is_grad_enabled():
+            p = float(drop.p)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0          # host RNG, like the model's own route
+            _, momentum = _bn_step(bn)
+            return _LayerTrainFn.apply(x, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       graph, batch, relu, p, momentum, bn.eps, seed, False, (None, None))
+        return None
+
     def forward(self, x, edge_index):
+        if self._reference_layer() is not None:
+            graph, batch = _SHARED_RESOLVER.resolve(edge_index, x.shape[0])
+            out = self._fused(x, graph, batch)
+            if out is not None:
+                return out
         for i, takes in enumerate(self._takes_graph):
             m = getattr(self, f"module_{i}")
             x = m(x, edge_index) if takes else m(x)
         return x
 
     def forward_graph(self, x, graph: ops.Graph, batch: int):
+        out = self._fused(x, graph, batch)
+        if out is not None:
+            return out
         for i, takes in enumerate(self._takes_graph):
             m = getattr(self, f"module_{i}")
             x = m.forward_graph(x, graph, batch) if takes else m(x)

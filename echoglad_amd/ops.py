@@ -111,6 +111,11 @@ class Graph:
         """Launches of the producer/consumer (fused, chained) layer kernel on this handle so far."""
         return int(_lib.load().eg_graph_ps_launches(self._h))
 
+    @property
+    def layer_launches(self) -> int:
+        """Launches of either fused layer kernel (producer/consumer or symmetric) on this handle so far."""
+        return int(_lib.load().eg_graph_layer_launches(self._h))
+
     def deg_inv_sqrt(self) -> torch.Tensor:
         out = torch.empty(self.num_nodes, dtype=torch.float32, device=self.device)
         _lib.check(_lib.load().eg_graph_deg_inv_sqrt(self._h, _ptr(out), _stream()), "eg_graph_deg_inv_sqrt")
@@ -126,6 +131,36 @@ class Graph:
             self.close()
         except Exception:
             pass
+
+
+LAUNCH_KINDS = ("symmetric", "ps_plain", "ps_train_fwd", "ps_dx", "ps_cls")      # EG_LAUNCH_* of include/echoglad_hip.h
+
+
+class layer_timing:
+    """Context manager over eg_debug_layer_timing_begin / _end: HIP events around every fused-layer kernel launch issued inside
+    the block (up to `max_launches`), wherever it is issued from (autograd nodes included).  After the block, ``.launches`` is a
+    list of (kind, milliseconds).  A measurement tool (process-wide state), used by bench.py's roofline."""
+
+    def __init__(self, max_launches: int = 256):
+        self.max = int(max_launches)
+        self.launches = []
+
+    def __enter__(self):
+        _lib.check(_lib.load().eg_debug_layer_timing_begin(self.max), "eg_debug_layer_timing_begin")
+        return self
+
+    def __exit__(self, *exc):
+        ms = (ct.c_float * 256)()
+        kinds = (ct.c_int * 256)()
+        n = _lib.load().eg_debug_layer_timing_end(ms, kinds, 256)
+        if n < 0:
+            _lib.check(n, "eg_debug_layer_timing_end")
+        self.launches = [(LAUNCH_KINDS[kinds[i]], float(ms[i])) for i in range(n)]
+        return False
+
+    def mean_ms(self, kind: str) -> Optional[float]:
+        v = [m for k, m in self.launches if k == kind]
+        return sum(v) / len(v) if v else None
 
 
 def edge_hash(edge_index: torch.Tensor):
@@ -729,6 +764,8 @@ def bce_logits_fwd(logits, labels, valid, ones_weight: float) -> torch.Tensor:
             raise RuntimeError(f"{name} must be a contiguous CUDA float32 tensor")
     if labels.numel() != logits.numel() or (valid is not None and valid.numel() != logits.numel()):
         raise RuntimeError("logits, labels and valid must have the same number of elements")
+    # the kernel reads 16 bytes per lane: a contiguous view at an odd element offset (flat[1:], a slice of a packed buffer) is copied
+    logits, labels, valid = (t if t is None or t.data_ptr() % 16 == 0 else t.clone() for t in (logits, labels, valid))
     lib = _lib.load()
     one = (ct.c_int * 1)(1)
     ws = _hm_workspace(logits.device, int(lib.eg_heatmap_workspace_bytes(1, one, 1)))

@@ -26,8 +26,11 @@
  *     and on several streams at once, also with a SHARED graph handle: the
  *     only host state a launch touches is one atomic counter in the handle
  *     that picks the launch's own slice of the handle's tile-queue ring
- *     (64 slices; a slice is zeroed on the launch's stream right before its
- *     kernel).  The ring is guarded: once a handle has been used on more than
+ *     (64 slices; a slice is all zero whenever no launch uses it -- a DEVICE
+ *     invariant: the ring is zeroed at creation and every kernel that walks a
+ *     queue zeroes its slice on the way out, so a launch replayed from a HIP
+ *     graph finds what an eager launch finds; no host flag is involved).  The
+ *     ring is guarded: once a handle has been used on more than
  *     one stream every slice carries an event recorded behind its last
  *     launch (none before that: a single stream orders its launches), and a launch that would reuse a slice whose last
  *     user is still in flight on ANOTHER stream returns EG_ERR_UNSUPPORTED
@@ -35,7 +38,11 @@
  *     synchronise).  Launches recorded into a HIP graph carry no event: a
  *     captured launch keeps its slice for every replay, so replays of such a
  *     graph and more than 64 eager launches of the same handle on other
- *     streams must not overlap.  Process-wide state: the
+ *     streams must not overlap.  Connection-node handles own a scratch sized
+ *     for the largest batch seen so far; a launch with more frames allocates a
+ *     larger one (never inside a stream capture: EG_ERR_UNSUPPORTED there) and
+ *     the smaller ones stay allocated until eg_graph_destroy, so graphs
+ *     captured at a smaller batch keep replaying correctly.  Process-wide state: the
  *     thread-local error string, and an idempotent per-device "kernel
  *     attribute set" flag.  Environment knobs (EG_*) are read once, when a
  *     handle is created, never on a launch path.
@@ -60,8 +67,8 @@ extern "C" {
  * the new calls with shifted arguments).  130: eg_topo_create with the reference builder's full flag set, jk_in inside
  * eg_gcn_layer_cls_fwd, eg_graph_set_precision removed (round 3); train-forward child sums, fused heads backward, the
  * 64-slice queue ring refuses instead of corrupting (round 4).  131: eg_classifier_train_fwd_act.
- * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed. */
-#define EG_ABI_VERSION 132
+ * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_* (round 5). */
+#define EG_ABI_VERSION 133
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
 
@@ -124,6 +131,20 @@ int eg_debug_phase_cycles(eg_graph* g, uint64_t* out_host, int reset);
 /* Diagnostic: out_dev[b] = XCC (XCD) id workgroup b ran on, out_dev[nblocks + b] = its start time stamp. */
 int eg_debug_xcc(int* out_dev, int nblocks, eg_stream_t stream);
 
+/* Measurement (bench.py's roofline): HIP events around the next launches of the fused layer kernels -- of every handle, on
+ * whatever stream they are launched (not inside a stream capture) -- so that a kernel's duration is taken INSIDE a real step
+ * (a training step issues its layer launches from inside autograd nodes; timing the same kernel alone on fresh rows measured
+ * 8 - 13 % more than a kernel trace of the step shows).  eg_debug_layer_timing_begin(max) arms it for at most `max` launches
+ * (<= 256; process-wide, not thread-safe: a measurement tool); eg_debug_layer_timing_end synchronises the recorded events and
+ * returns how many launches were timed, their milliseconds in ms[] and their kind in kinds[] (EG_LAUNCH_*), both of capacity cap. */
+#define EG_LAUNCH_SYMMETRIC 0   /* k_gcn_layer (CSR graphs, plain calls on hierarchical handles) */
+#define EG_LAUNCH_PS_PLAIN 1    /* k_gcn_layer_ps, inference forms (plain / chained / running maximum) */
+#define EG_LAUNCH_PS_TRAIN_FWD 2
+#define EG_LAUNCH_PS_DX 3       /* residual as a tensor of its own: the backward's dX launch */
+#define EG_LAUNCH_PS_CLS 4      /* last layer + classifier heads */
+int eg_debug_layer_timing_begin(int max_launches);
+int eg_debug_layer_timing_end(float* ms, int* kinds, int cap);
+
 /* Order-independent digest of an edge_index [2, n_edges] int64 on the device:
  * out_dev[0] = n_edges, out_dev[1] = sum over edges of mix64(src, dst) (mod 2^64).
  * Used to verify an incoming PyG edge_index against the closed form once. */
@@ -182,6 +203,10 @@ int eg_gcn_layer_fwd_jk(const eg_graph* g, int batch, const float* x, const floa
                         const float* residual, int relu, float* out, const float* kidsum_in, float* kidsum_out,
                         const float* jk_in, float* jk_out, eg_stream_t stream);
 unsigned eg_graph_ps_launches(const eg_graph* g);
+/* launches of ANY fused layer kernel (producer/consumer or symmetric; forward, train forward, dX) on the handle so far: tests
+ * assert "one launch per layer" for callers that reach the kernels through the torch_geometric-shaped modules
+ * (Sequential('x, edge_index', [GCNConv, BatchNorm1d, Dropout, ReLU]) of src/core/models.py:329-335). */
+unsigned eg_graph_layer_launches(const eg_graph* g);
 
 /* out = A_hat x  (aggregation only; training / backward building block) */
 int eg_gcn_aggregate(const eg_graph* g, int batch, const float* x, float* out, eg_stream_t stream);

@@ -111,3 +111,20 @@ def test_decode_and_losses_vs_oracle_at_full_size(frame, naux, batch):
 def test_decode_rejects_cpu_tensors():
     with pytest.raises(RuntimeError):
         ops.heatmap_expect_fwd(torch.zeros(8, 4), 1, [(0, 2)])
+
+
+def test_bce_accepts_contiguous_views_at_odd_offsets():
+    """eg_bce_logits_fwd reads 16 bytes per lane and refuses unaligned pointers; the Python wrapper copies a
+    contiguous view that starts at an odd element offset instead of raising."""
+    rs = np.random.RandomState(3)
+    n = 4 * 1000 + 1
+    flat = torch.from_numpy(rs.standard_normal(n).astype(np.float32)).to(DEV)
+    lab = torch.from_numpy((rs.uniform(size=n) < 0.01).astype(np.float32)).to(DEV)
+    val = torch.ones(n, device=DEV)
+    x, y, v = flat[1:].view(-1, 4), lab[1:].view(-1, 4), val[1:].view(-1, 4)
+    assert x.data_ptr() % 16 != 0 and x.is_contiguous()
+    got = ops.bce_logits(x.clone().requires_grad_(True), y, v, 9000.0)
+    xv = x.detach().requires_grad_(True)
+    got_view = ops.bce_logits(xv, y, v, 9000.0)
+    got_view.backward()
+    assert torch.equal(got.detach(), got_view.detach()) and xv.grad is not None and torch.isfinite(xv.grad).all()

@@ -313,10 +313,10 @@ def test_queue_ring_refuses_a_slice_still_in_flight_on_another_stream():
     assert torch.equal(got, want)
 
 
-def test_queue_slices_are_left_zeroed_by_the_kernel_itself():
-    """The producer / consumer kernel zeroes its slice of the tile-queue ring on the way out (no memset in front of a launch):
-    the ring wraps many times with identical results, also at the full persistent grid, and a slice the symmetric kernel has used
-    in between (it leaves its counters behind) is cleaned by the next launch that takes it."""
+def test_queue_slices_are_left_zeroed_by_the_kernels_themselves():
+    """Both layer kernels zero their slice of the tile-queue ring on the way out (no memset in front of a launch, no host flag):
+    the ring wraps many times with identical results, also at the full persistent grid, with launches of the symmetric kernel
+    (plain eg_gcn_layer_fwd on a hierarchical handle: queue walk) taking slices in between."""
     for frame, naux, B in ((64, 6, 2), (224, 7, 4)):
         g = ops.Graph.topo(frame, naux)
         x = synthetic_node_feats(B * g.num_nodes, 128, seed=1).to(DEV)
@@ -326,12 +326,174 @@ def test_queue_slices_are_left_zeroed_by_the_kernel_itself():
         one, zero = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
         h = ops.gcn_layer_fwd(g, B, x, w, one, zero, x, relu=True, kidsum_out=ka)
         want = ops.gcn_layer_fwd(g, B, h, w, one, zero, h, relu=True, kidsum_in=ka, kidsum_out=kb)
-        before = g.ps_launches
+        want_sym = ops.gcn_layer_fwd(g, B, x, w, one, zero, x, relu=True)   # symmetric kernel
+        before, before_all = g.ps_launches, g.layer_launches
+        n_sym = 0
         for k in range(300):
             got = ops.gcn_layer_fwd(g, B, h, w, one, zero, h, relu=True, kidsum_in=ka, kidsum_out=kb)
             if k % 37 == 0:
                 assert torch.equal(got, want), k
-            if k % 50 == 49:                                         # a launch of the symmetric kernel takes a slice in between
-                agg = ops.gcn_aggregate(g, B, x)
-                assert agg.shape == x.shape
-        assert torch.equal(got, want) and g.ps_launches - before == 300
+            if k % 7 == 6:                                           # (7 and 64 are coprime: the symmetric kernel visits every slice)
+                got_sym = ops.gcn_layer_fwd(g, B, x, w, one, zero, x, relu=True)
+                n_sym += 1
+                if k % 49 == 48:
+                    assert torch.equal(got_sym, want_sym), k
+        assert torch.equal(got, want) and g.ps_launches - before == 300 and g.layer_launches - before_all == 300 + n_sym
+
+
+@pytest.mark.parametrize("captured", ["producer_consumer", "symmetric"])
+def test_hip_graph_replay_is_immune_to_eager_launches_on_the_same_handle(captured):
+    """a launch recorded into a HIP graph keeps its queue slice for every replay, and whether that slice is clean
+    must not depend on host state frozen at capture time.  Capture one launch, let 70 eager launches of the OTHER kernel wrap
+    the 64-slice ring (they use the captured slice too), replay on a changed input: the replay equals an eager launch."""
+    B = 2
+    g = ops.Graph.topo(64, 6)
+    rs = np.random.RandomState(5)
+    w = torch.from_numpy(rs.uniform(-0.1, 0.1, (128, 128)).astype(np.float32)).to(DEV)
+    x = synthetic_node_feats(B * g.num_nodes, 128, seed=1).to(DEV)
+    ka = ops.new_kidsum(g, B)
+    kw_cap = dict(kidsum_out=ka) if captured == "producer_consumer" else {}
+    kw_other = {} if captured == "producer_consumer" else dict(kidsum_out=ops.new_kidsum(g, B))
+    out = torch.empty_like(x)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True, out=out, **kw_cap)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True, out=out, **kw_cap)
+    for rnd in range(3):
+        for _ in range(70):
+            ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True, **kw_other)
+        x.copy_(synthetic_node_feats(B * g.num_nodes, 128, seed=10 + rnd).to(DEV))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True, **kw_cap)
+        assert torch.equal(out, want), rnd
+
+
+def test_connection_node_scratch_growth_keeps_captured_graphs_valid():
+    """a HIP graph captured at a small batch holds its slice of the connection-node scratch in its kernel
+    nodes; a later launch with more frames than the scratch holds allocates a larger one and must NOT free the old one."""
+    g = ops.Graph.topo(32, 4, use_connection_nodes=True)
+    rs = np.random.RandomState(7)
+    w = torch.from_numpy(rs.uniform(-0.1, 0.1, (128, 128)).astype(np.float32)).to(DEV)
+    B = 4
+    x = synthetic_node_feats(B * g.num_nodes, 128, seed=1).to(DEV)
+    out = torch.empty_like(x)
+    before = g.ps_launches
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    assert g.ps_launches == before + 1                                # (the connection-node stencil lives in the producer/consumer kernel)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True, out=out)
+    for big in (16, 40):                                              # default scratch: 8 frames -> grows twice
+        xb = synthetic_node_feats(big * g.num_nodes, 128, seed=big).to(DEV)
+        yb = ops.gcn_layer_fwd(g, big, xb, w, residual=xb, relu=True)
+        # frames are independent: frame 3 of the big batch alone gives the same rows
+        n = g.num_nodes
+        alone = ops.gcn_layer_fwd(g, 1, xb[3 * n:4 * n].contiguous(), w, residual=xb[3 * n:4 * n].contiguous(), relu=True)
+        assert torch.equal(yb[3 * n:4 * n], alone)
+        # fill fresh allocations (what a freed scratch would have become) and replay the old graph on new input
+        junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]
+        x.copy_(synthetic_node_feats(B * g.num_nodes, 128, seed=100 + big).to(DEV))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = ops.gcn_layer_fwd(g, B, x, w, residual=x, relu=True)
+        assert torch.equal(out, want), big
+        del junk
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_reference_loop_at_full_frame_size_is_one_launch_per_layer(train):
+    """INTEGRATION route B at the default frame: the reference's own constructor loop and forward loop (models.py:328-335,
+    :426-435) over this package's torch_geometric-shaped classes, 224x224 / 7 aux levels, 2 frames.  Sequential recognises the
+    reference's layer and runs it as ONE kernel launch per layer (eg_graph_layer_launches) -- eval: bias + BatchNorm + ReLU folded
+    into eg_gcn_layer_fwd; train (p = 0): the eg_gcn_layer_train_fwd / eg_gcn_layer_bwd composites -- with the module-by-module
+    route's values (EG_SEQ_FUSED=0) and the oracle's."""
+    L, B = 3, 2
+    hip = _stack(egnn.GCNConv, egnn.Sequential, egnn.JumpingKnowledge, L, "last")
+    ref = _stack(O.OracleGCNConv, O.OracleSequential, O.OracleJumpingKnowledge, L, "last")
+    fill_state_dict(ref, seed=23)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    hip = hip.to(DEV)
+    hip.train(train); ref.train(train)
+    topo, ei, nt, bi = graph_tensors(224, 7, B)
+    n = B * topo.num_nodes
+    x = synthetic_node_feats(n, 128, seed=4)
+    eih = ei.to(DEV)
+    graph, gb = egnn._SHARED_RESOLVER.resolve(eih, n)
+    assert graph.structured and gb == B
+    state = {k: v.clone() for k, v in hip.state_dict().items()}
+    xh = x.clone().to(DEV).requires_grad_(train)
+    before = graph.layer_launches
+    with torch.set_grad_enabled(train):
+        got = _loop(hip, xh, eih)
+    assert graph.layer_launches - before == L                         # one fused launch per layer, nothing else on the handle
+    if train:
+        (got ** 2).mean().backward()
+        fused_grads = {k: p.grad.clone() for k, p in hip.named_parameters()}
+        fused_xgrad = xh.grad.clone()
+    # the module-by-module route (GCNConv kernel, then torch BatchNorm1d / Dropout / ReLU) from the same state
+    hip.load_state_dict(state)
+    hip.zero_grad(set_to_none=True)
+    os.environ["EG_SEQ_FUSED"] = "0"
+    try:
+        xm = x.clone().to(DEV).requires_grad_(train)
+        with torch.set_grad_enabled(train):
+            unfused = _loop(hip, xm, eih)
+        if train:
+            (unfused ** 2).mean().backward()
+    finally:
+        del os.environ["EG_SEQ_FUSED"]
+    assert (got.detach() - unfused.detach()).abs().max() < 5e-5
+    # ... and the oracle
+    xr = x.clone().requires_grad_(train)
+    with torch.set_grad_enabled(train):
+        want = _loop(ref, xr, ei)
+    assert (got.detach().cpu() - want.detach()).abs().max() < 2e-4
+    if train:
+        (want ** 2).mean().backward()
+        assert (fused_xgrad.cpu() - xr.grad).abs().max() < 5e-3 * xr.grad.abs().max() + 1e-9
+        assert (fused_xgrad - xm.grad).abs().max() < 5e-3 * xm.grad.abs().max() + 1e-9
+        ref_grads = dict(ref.named_parameters())
+        for name, p in hip.named_parameters():
+            rg = ref_grads[name].grad
+            err = (fused_grads[name].cpu() - rg).abs().max().item()
+            assert err < 5e-3 * rg.abs().max().item() + 1e-6, (name, err, rg.abs().max().item())
+        # running statistics moved exactly as nn.BatchNorm1d moves them
+        for k, v in ref.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                assert (hip.state_dict()[k].cpu().double() - v.double()).abs().max() < 1e-4 * max(1.0, float(v.abs().max())), k
+
+
+def test_sequential_keeps_the_module_route_where_it_must():
+    """Forward hooks on a child, a frozen BatchNorm inside a training layer, eval with gradients, and module lists other than
+    the reference's: Sequential runs module by module (and gives the same values)."""
+    topo, ei, nt, bi = graph_tensors(16, 3, 2)
+    n = 2 * topo.num_nodes
+    x = synthetic_node_feats(n, 128, seed=2).to(DEV)
+    eih = ei.to(DEV)
+    seq = egnn.Sequential("x, edge_index", [(egnn.GCNConv(128, 128), "x, edge_index -> x"), nn.BatchNorm1d(128), nn.Dropout(p=0.0),
+                                             nn.ReLU(inplace=True)])
+    fill_state_dict(seq, seed=3)
+    seq = seq.to(DEV).eval()
+    with torch.no_grad():
+        fused = seq(x, eih)
+    seen = []
+    hook = seq.module_1.register_forward_hook(lambda m, i, o: seen.append(o.detach().clone()))
+    with torch.no_grad():
+        hooked = seq(x, eih)
+    hook.remove()
+    assert len(seen) == 1 and (fused - hooked).abs().max() < 2e-5 and (torch.relu(seen[0]) - hooked).abs().max() == 0
+    xg = x.clone().requires_grad_(True)
+    with_grad = seq(xg, eih)                                          # eval + autograd: module by module, differentiable
+    with_grad.sum().backward()
+    assert xg.grad is not None and (with_grad.detach() - fused).abs().max() < 2e-5
+    other = egnn.Sequential("x, edge_index", [(egnn.GCNConv(128, 128), "x, edge_index -> x"), nn.ReLU()])
+    assert other._reference_layer() is None
