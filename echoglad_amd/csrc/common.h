@@ -175,6 +175,8 @@ struct Knobs {
     int layer_impl;     // EG_LAYER_IMPL  -1 auto, 0 symmetric kernel, 1 producer/consumer kernel for plain calls
     int ps_grid;        // EG_PS_GRID     persistent grid of the producer/consumer kernel (default 256 = 1 per CU)
     int ring_guard;     // EG_RING_GUARD  0: no event behind a launch (diagnostic: the queue ring is then unguarded, as before round 4)
+    int csr_tiles;      // EG_CSR_TILES   CSR handles: 2 (default) clustered 64-node tiles with an LDS row stash, 1 the same stash over
+                        //                consecutive rows (no clustering), 0 the plain row-by-row aggregator
     int queue_self_reset;   // EG_QUEUE_SELF_RESET  1 (default): the layer kernels zero their queue slice on the way out; 0: a memset in front of every launch
 };
 Knobs read_knobs();
@@ -236,6 +238,15 @@ struct eg_graph {
     int* rowptr;              // device [n_nodes+1] kind == GRAPH_CSR
     int* colidx;              // device [nnz]
     int64_t nnz;
+    // kind == GRAPH_CSR, inference launches of the layer kernel: the same CSR regrouped into TILES of 64 nodes that are close in
+    // the graph (greedy breadth-first balls, graph.hip csr_tiles), so that most of a node's sources are rows of its own tile and
+    // come out of the tile's LDS stash instead of being loaded once per edge
+    int* t_rows;              // device [n_ctiles * 64]     node id of tile slot s (-1: padding at the end of the last tile)
+    int* t_rowptr;            // device [n_ctiles * 64 + 1] edges of slot s: [t_rowptr[s], t_rowptr[s + 1])
+    int* t_code;              // device [nnz]               source of the edge: -(slot + 1) inside the tile, else the node id
+    float* t_w;               // device [nnz]               (deg + 1)^-1/2 of the source
+    float* t_dis;             // device [n_ctiles * 64]     (deg + 1)^-1/2 of the slot's node (0: padding)
+    int n_ctiles;
     int symmetric;            // kind == GRAPH_CSR: the kept edge multiset equals its transpose (A_hat^T == A_hat)
     int* walk_counters;       // device [QUEUE_SLOTS][8 x 32] ring of per-launch tile-queue heads (+ QUEUE_TAIL_INTS)
     mutable std::atomic<unsigned> launch_seq;   // next slice of the ring (the only host state a launch touches)

@@ -18,6 +18,8 @@ struct GraphPtrs {
     const int* colidx;
     const Topo* topo;
     const TileDesc* tiles;
+    const int *t_rows, *t_rowptr, *t_code;      // AGG_CSRT: the CSR in clustered tiles (common.h eg_graph::t_*)
+    const float *t_w, *t_dis;
 };
 
 struct LayerDims {
@@ -92,11 +94,16 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
                                                    const float* __restrict__ dis, const int* __restrict__ rowptr,
                                                    const int* __restrict__ colidx, const Topo* __restrict__ T,
                                                    const TileDesc* __restrict__ tiles,
+                                                   const int* __restrict__ t_rows, const int* __restrict__ t_rowptr,
+                                                   const int* __restrict__ t_code, const float* __restrict__ t_w,
+                                                   const float* __restrict__ t_dis,
                                                    int* __restrict__ walk_counters, const LayerDims a) {
     __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA + 4];
     // raw self rows of the tile (implicit-topology path with residual == x): the epilogue's residual source
-    __shared__ __attribute__((aligned(16))) float s_xbuf[(AGG == AGG_STENCIL && !RES_GLOBAL) ? TILE * C : 4];
+    // (AGG_CSRT: the raw rows of the tile's 64 nodes, whatever the residual is: most sources of a tile's edges are its own rows)
+    __shared__ __attribute__((aligned(16))) float s_xbuf[((AGG == AGG_STENCIL && !RES_GLOBAL) || AGG == AGG_CSRT) ? TILE * C : 4];
     float* const s_x = (AGG == AGG_STENCIL && !RES_GLOBAL && residual) ? s_xbuf : nullptr;
+    __shared__ int s_ids[AGG == AGG_CSRT ? TILE : 1];            // AGG_CSRT: node id of every tile slot (-1: padding)
 
     const int tid = threadIdx.x;
     const int lane_k = tid & 63;
@@ -163,7 +170,45 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
             seg_rows = left < 0 ? 0 : (left > 8 ? 8 : left);
             blocks = (rows_here + 15) >> 4;
             const int last = a.n_per_frame - 1;
-            if constexpr (AGG == AGG_NONE) {
+            if constexpr (AGG == AGG_CSRT) {
+                // (1a) the wave's 8 slots: raw rows -> the tile's stash, ids -> s_ids; all 8 loads in flight
+                const int slot0 = t_in * TILE + rl0;
+                f32x2 raw[8];
+                int id[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    id[u] = t_rows[slot0 + u];                                   // scalar
+                    raw[u] = load_row2(xf, id[u] < 0 ? 0 : id[u], lane);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x2*>(&s_xbuf[(rl0 + u) * C + 2 * lane]) = raw[u];
+                if (lane < 8) s_ids[rl0 + lane] = t_rows[slot0 + lane];
+                __syncthreads();
+                // (1b) a row's edges in their CSR order (the old order of the sum), four sources in flight: a source inside the
+                // tile comes from the stash, the others from memory; the weights (deg + 1)^-1/2 of the sources sit beside the codes
+#pragma unroll 1
+                for (int u = 0; u < 8; ++u) {
+                    const int e0 = t_rowptr[slot0 + u], e1 = t_rowptr[slot0 + u + 1];
+                    const float dn = t_dis[slot0 + u];
+                    f32x2 acc = {0.f, 0.f};
+                    for (int e = e0; e < e1; e += 4) {
+                        f32x2 v[4];
+                        float w[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int ee = (e + k < e1) ? e + k : e1 - 1;
+                            const int code = t_code[ee];
+                            w[k] = (e + k < e1) ? t_w[ee] : 0.0f;
+                            if (code < 0) v[k] = *reinterpret_cast<const f32x2*>(&s_xbuf[(-code - 1) * C + 2 * lane]);     // (uniform branch)
+                            else v[k] = load_row2(xf, code, lane);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc += w[k] * v[k];
+                    }
+                    acc += dn * *reinterpret_cast<const f32x2*>(&s_xbuf[(rl0 + u) * C + 2 * lane]);      // the implied self loop comes last, as in gcn_norm
+                    *reinterpret_cast<f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]) = acc * dn;
+                }
+            } else if constexpr (AGG == AGG_NONE) {
                 const PairLane pl{lane >> 5, lane & 31};
                 f32x4 v[4];
 #pragma unroll
@@ -218,13 +263,20 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
         const int fix_row = pl.h < seg_rows ? pl.h : 0;
         f32x4 res[RES_GLOBAL ? 4 : 1];
         const size_t seg_off = (frame_row0 + seg_first) * C + 4 * pl.q;
+        // AGG_CSRT: the wave's 8 slots hold arbitrary nodes -- row offsets (in rows, relative to seg_first) of this lane's 4 rows
+        int rowoff[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = (2 * k + pl.h) < seg_rows ? 2 * k + pl.h : fix_row;
+            if constexpr (AGG == AGG_CSRT) rowoff[k] = (seg_rows > 0 ? s_ids[rl0 + row] : 0) - seg_first;
+            else rowoff[k] = row;
+        }
         if constexpr (RES_GLOBAL) {
             const float* rp = (residual ? residual : x) + seg_off;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
 #ifndef EG_ABL_NO_P3
-                const int row = (2 * k + pl.h) < seg_rows ? 2 * k + pl.h : fix_row;
-                res[k] = *reinterpret_cast<const f32x4*>(rp + (size_t)row * C);
+                res[k] = *reinterpret_cast<const f32x4*>(rp + (long long)rowoff[k] * C);
 #else
                 res[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
@@ -276,11 +328,10 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int row = (2 * k + pl.h) < seg_rows ? 2 * k + pl.h : fix_row;
 #ifndef EG_ABL_NO_P3
-                *reinterpret_cast<f32x4*>(op + (size_t)row * C) = v[k];
+                *reinterpret_cast<f32x4*>(op + (long long)rowoff[k] * C) = v[k];
 #else
-                if (v[k].x == 1234.5678f) *reinterpret_cast<f32x4*>(op + (size_t)row * C) = v[k];
+                if (v[k].x == 1234.5678f) *reinterpret_cast<f32x4*>(op + (long long)rowoff[k] * C) = v[k];
 #endif
             }
         }
@@ -355,7 +406,7 @@ static int grid_for_tiles(long long n_tiles, const Knobs& kn) {
     return (int)g;
 }
 
-#define LAYER_KARGS a.x, a.W, a.scale, a.shift, a.residual, a.out, a.agg_out, a.stats_partial, a.gp.dis, a.gp.rowptr, a.gp.colidx, a.gp.topo, a.gp.tiles, a.walk_counters, a.d
+#define LAYER_KARGS a.x, a.W, a.scale, a.shift, a.residual, a.out, a.agg_out, a.stats_partial, a.gp.dis, a.gp.rowptr, a.gp.colidx, a.gp.topo, a.gp.tiles, a.gp.t_rows, a.gp.t_rowptr, a.gp.t_code, a.gp.t_w, a.gp.t_dis, a.walk_counters, a.d
 
 static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out = nullptr) {
     const long long n_tiles = (long long)a.d.tiles_per_frame * a.d.batch;
@@ -390,7 +441,9 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out
     switch (agg) {
         case AGG_NONE: hipLaunchKernelGGL((k_gcn_layer<AGG_NONE, true>), grid, block, 0, stream, LAYER_KARGS); break;
         case AGG_CSR:
+        case AGG_CSRT:
             if (train) hipLaunchKernelGGL((k_gcn_layer<AGG_CSR, true, true>), grid, block, 0, stream, LAYER_KARGS);
+            else if (agg == AGG_CSRT) hipLaunchKernelGGL((k_gcn_layer<AGG_CSRT, true>), grid, block, 0, stream, LAYER_KARGS);
             else hipLaunchKernelGGL((k_gcn_layer<AGG_CSR, true>), grid, block, 0, stream, LAYER_KARGS);
             break;
         default:
@@ -423,6 +476,11 @@ static int fill_graph_args(const eg_graph* g, int batch, LayerArgs& a, int& agg)
     a.gp.tiles = g->tiles_dev;
     // (a 'grid-diagonal' topology handle carries the CSR of one frame for this kernel: its stencil lives in the producer/consumer kernel)
     agg = (g->kind == GRAPH_TOPO && !g->hybrid) ? AGG_STENCIL : AGG_CSR;
+    // a CSR handle's inference launches take the clustered tiles (the train forward keeps the row-by-row aggregator: launch_layer)
+    if (g->kind == GRAPH_CSR && g->t_rows) {
+        agg = AGG_CSRT;
+        a.gp.t_rows = g->t_rows; a.gp.t_rowptr = g->t_rowptr; a.gp.t_code = g->t_code; a.gp.t_w = g->t_w; a.gp.t_dis = g->t_dis;
+    }
     // implicit topology: one tile per 8x8 patch of a level; CSR: 64 consecutive rows
     a.d.tiles_per_frame = agg == AGG_STENCIL ? g->n_tiles : (int)((g->n_nodes + TILE - 1) / TILE);
     return EG_OK;

@@ -429,8 +429,25 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     for (int g = 0; g < 4; ++g) res[0][g] = *reinterpret_cast<const f32x4*>(s_x + (32 + j) * LDA + 32 * wave + 4 * h + 8 * g);
                 }
             };
+#if defined(EG_EPI_MID)      // experiment: block 0's whole epilogue as ONE piece between the two chains, chain 2 uninterrupted
+            mfma_rowblock(s_a, 0, lane, wreg, acc0);
+            asm volatile("" : "+v"(acc0));
+            __builtin_amdgcn_sched_barrier(0);
+            if (!CLS) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
+                read_segments(0); store_segments(); kout_half(0);
+            } else {
+                between(0); between(1); between(2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_rowblock(s_a, 32, lane, wreg, acc1);
+            asm volatile("" : "+v"(acc1));
+            __builtin_amdgcn_sched_barrier(0);
+#else
             mfma_rowblock(s_a, 0, lane, wreg, acc0);
             mfma_rowblock_with(s_a, 32, lane, wreg, acc1, between);
+#endif
 #else
             acc0[0] += wreg[0] + s_a[lane]; acc1[0] += wreg[63];
 #pragma unroll

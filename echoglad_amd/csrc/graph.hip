@@ -32,6 +32,7 @@ Knobs read_knobs() {
     k.ps_grid = env_int("EG_PS_GRID", 256);
     k.ring_guard = env_int("EG_RING_GUARD", 1);
     k.queue_self_reset = env_int("EG_QUEUE_SELF_RESET", 1) != 0;
+    k.csr_tiles = env_int("EG_CSR_TILES", 2);
     // the static tile walk of the train forward labels chunks with blockIdx % 8 (a grid below 8 would leave chunks without
     // an owner) and its statistics partials fill at most 2048 slabs of the workspace
     if (k.ps_grid < 8) k.ps_grid = 8;
@@ -230,6 +231,103 @@ __global__ void k_edge_sym(const int64_t* __restrict__ ei, int64_t n_edges, int6
     }
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], a); atomicAdd(&out[1], b); }
+}
+
+// ---- CSR regrouped into tiles of 64 nodes that are close in the graph ------------------------------------------------------
+// The layer kernel aggregates a tile of 64 rows per workgroup.  With 64 CONSECUTIVE node ids per tile almost every source row
+// of an edge lies outside the tile and is loaded once per edge (2.8x the bytes of the implicit stencil at configs[1]); if the
+// tile is a breadth-first ball of the graph most sources are the tile's own rows, which the kernel loads once into LDS.
+// Greedy graph growing: a tile is filled breadth-first from a seed (taken from the frontier the previous tile left behind, so
+// that consecutive tiles are neighbours too); what the queue still holds when the tile is full becomes that frontier.
+// order[s] = node of tile slot s (tile = s / 64); `cluster` = false: identity order (consecutive rows).
+static void csr_tile_order(int n, const std::vector<int>& rowptr, const std::vector<int>& colidx, bool cluster, std::vector<int>& order) {
+    order.clear();
+    order.reserve((size_t)n);
+    if (!cluster) {
+        for (int i = 0; i < n; ++i) order.push_back(i);
+        return;
+    }
+    std::vector<unsigned char> seen((size_t)n, 0);      // 1: placed or in the current queue
+    std::vector<int> frontier, q;
+    size_t fhead = 0;
+    int next_seed = 0;
+    while ((int)order.size() < n) {
+        int filled = 0;
+        q.clear();
+        size_t qhead = 0;
+        while (filled < TILE && (int)order.size() < n) {
+            if (qhead == q.size()) {                      // (the component is exhausted, or the tile starts): a new seed
+                int seed = -1;
+                while (fhead < frontier.size()) {
+                    const int c = frontier[fhead++];
+                    if (!seen[c]) { seed = c; break; }
+                }
+                if (seed < 0) {
+                    while (seen[next_seed]) ++next_seed;
+                    seed = next_seed;
+                }
+                seen[seed] = 1;
+                q.push_back(seed);
+            }
+            const int u = q[qhead++];
+            order.push_back(u);
+            ++filled;
+            for (int e = rowptr[u]; e < rowptr[u + 1]; ++e) {
+                const int v = colidx[e];
+                if (!seen[v]) { seen[v] = 1; q.push_back(v); }
+            }
+        }
+        // queued but not placed: the next tiles' seeds, nearest first
+        if (fhead > (1u << 20) && fhead * 2 > frontier.size()) { frontier.erase(frontier.begin(), frontier.begin() + (long)fhead); fhead = 0; }
+        for (size_t k = qhead; k < q.size(); ++k) { seen[q[k]] = 0; frontier.push_back(q[k]); }
+    }
+}
+
+// builds g->t_* from the handle's device CSR (host round trip: a set-up call); mode 1: consecutive rows, 2: clustered
+static int csr_tiles(eg_graph* g, int mode, hipStream_t stream) {
+    const int n = (int)g->n_nodes;
+    const size_t nnz = (size_t)g->nnz;
+    std::vector<int> rowptr((size_t)n + 1), colidx(nnz ? nnz : 1);
+    std::vector<float> dis((size_t)n);
+    EG_HIP_TRY(hipMemcpyAsync(rowptr.data(), g->rowptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, stream));
+    if (nnz) EG_HIP_TRY(hipMemcpyAsync(colidx.data(), g->colidx, sizeof(int) * nnz, hipMemcpyDeviceToHost, stream));
+    EG_HIP_TRY(hipMemcpyAsync(dis.data(), g->dis, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    EG_HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<int> order;
+    csr_tile_order(n, rowptr, colidx, mode >= 2, order);
+    const int n_tiles = (n + TILE - 1) / TILE;
+    const size_t slots = (size_t)n_tiles * TILE;
+    std::vector<int> slot_of((size_t)n), t_rows(slots, -1), t_rowptr(slots + 1, 0), t_code(nnz ? nnz : 1);
+    std::vector<float> t_w(nnz ? nnz : 1), t_dis(slots, 0.f);
+    for (int s = 0; s < n; ++s) slot_of[(size_t)order[(size_t)s]] = s;
+    size_t o = 0;
+    for (size_t s = 0; s < slots; ++s) {
+        t_rowptr[s] = (int)o;
+        if (s >= (size_t)n) continue;
+        const int u = order[s];
+        t_rows[s] = u;
+        t_dis[s] = dis[(size_t)u];
+        for (int e = rowptr[(size_t)u]; e < rowptr[(size_t)u + 1]; ++e) {      // (edge order kept: the sum of a row has the old order)
+            const int v = colidx[(size_t)e];
+            const int sv = slot_of[(size_t)v];
+            t_code[o] = (sv / TILE == (int)(s / TILE)) ? -(sv % TILE + 1) : v;
+            t_w[o] = dis[(size_t)v];
+            ++o;
+        }
+    }
+    t_rowptr[slots] = (int)o;
+    EG_HIP_TRY(hipMalloc((void**)&g->t_rows, sizeof(int) * slots));
+    EG_HIP_TRY(hipMalloc((void**)&g->t_rowptr, sizeof(int) * (slots + 1)));
+    EG_HIP_TRY(hipMalloc((void**)&g->t_code, sizeof(int) * t_code.size()));
+    EG_HIP_TRY(hipMalloc((void**)&g->t_w, sizeof(float) * t_w.size()));
+    EG_HIP_TRY(hipMalloc((void**)&g->t_dis, sizeof(float) * slots));
+    EG_HIP_TRY(hipMemcpy(g->t_rows, t_rows.data(), sizeof(int) * slots, hipMemcpyHostToDevice));
+    EG_HIP_TRY(hipMemcpy(g->t_rowptr, t_rowptr.data(), sizeof(int) * (slots + 1), hipMemcpyHostToDevice));
+    EG_HIP_TRY(hipMemcpy(g->t_code, t_code.data(), sizeof(int) * t_code.size(), hipMemcpyHostToDevice));
+    EG_HIP_TRY(hipMemcpy(g->t_w, t_w.data(), sizeof(float) * t_w.size(), hipMemcpyHostToDevice));
+    EG_HIP_TRY(hipMemcpy(g->t_dis, t_dis.data(), sizeof(float) * slots, hipMemcpyHostToDevice));
+    g->n_ctiles = n_tiles;
+    return EG_OK;
 }
 
 static int csr_build(const int64_t* ei, int64_t n_nodes, int64_t n_edges, hipStream_t stream, const eg_graph* base, eg_graph** out);
@@ -735,6 +833,10 @@ static int eg::csr_build(const int64_t* ei, int64_t n_nodes, int64_t n_edges, hi
     g->symmetric = base ? base->symmetric : (sym_host[0] == sym_host[1]);
     cleanup(false);
 #undef CSR_TRY
+    if (g->knobs.csr_tiles > 0) {
+        const int rc = csr_tiles(g, g->knobs.csr_tiles, stream);
+        if (rc != EG_OK) { eg_graph_destroy(g); return rc; }
+    }
     *out = g;
     return EG_OK;
 }
@@ -757,6 +859,8 @@ int eg_graph_destroy(eg_graph* g) {
     if (g->conn_table) (void)hipFree(g->conn_table);
     if (g->conn_scratch) (void)hipFree(g->conn_scratch);
     for (float* p : g->conn_retired) (void)hipFree(p);
+    for (void* p : {(void*)g->t_rows, (void*)g->t_rowptr, (void*)g->t_code, (void*)g->t_w, (void*)g->t_dis})
+        if (p) (void)hipFree(p);
     delete g;
     return EG_OK;
 }

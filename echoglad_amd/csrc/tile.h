@@ -23,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum Agg { AGG_NONE = 0, AGG_CSR = 1, AGG_STENCIL = 2 };
+enum Agg { AGG_NONE = 0, AGG_CSR = 1, AGG_STENCIL = 2, AGG_CSRT = 3 };     // CSRT: CSR in clustered 64-node tiles (graph.hip csr_tiles)
 
 // ---- wave-uniform helpers -------------------------------------------------------
 __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -524,6 +524,13 @@ __device__ inline void mfma_rowblock(const float* s_a, int row0, int lane, const
 
 // Same chain; between(c) is emitted in the scheduling region of chunk c (c = 0..3) so that independent VALU / LDS /
 // store work of the caller fills the issue slots the dependent 64-cycle MFMAs leave free.
+// EG_CLUMP (experiment): keep each between(c) piece in ONE place behind its chunk of the chain instead of letting the
+// scheduler spread it between the MFMAs -- an interruption of a chain costs 16 - 24 cycles however short it is (micro_coissue5)
+#ifdef EG_CLUMP
+#define EG_CLUMP_FENCE do { asm volatile("" : "+v"(acc)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define EG_CLUMP_FENCE do {} while (0)
+#endif
 template <typename F>
 __device__ inline void mfma_rowblock_with(const float* s_a, int row0, int lane, const float (&wreg)[64], f32x16& acc, F between) {
     const int j = lane & 31, h = lane >> 5;
@@ -535,20 +542,20 @@ __device__ inline void mfma_rowblock_with(const float* s_a, int row0, int lane, 
     for (int t = 0; t < 4; ++t) a1[t] = ap[4 + t];
     __builtin_amdgcn_sched_barrier(0);
     mfma_chunk(a0, wreg, 0, acc);
-    between(0);
+    EG_CLUMP_FENCE; between(0); EG_CLUMP_FENCE;
 #pragma unroll
     for (int t = 0; t < 4; ++t) a0[t] = ap[8 + t];
     __builtin_amdgcn_sched_barrier(0);
     mfma_chunk(a1, wreg, 4, acc);
-    between(1);
+    EG_CLUMP_FENCE; between(1); EG_CLUMP_FENCE;
 #pragma unroll
     for (int t = 0; t < 4; ++t) a1[t] = ap[12 + t];
     __builtin_amdgcn_sched_barrier(0);
     mfma_chunk(a0, wreg, 8, acc);
-    between(2);
+    EG_CLUMP_FENCE; between(2); EG_CLUMP_FENCE;
     __builtin_amdgcn_sched_barrier(0);
     mfma_chunk(a1, wreg, 12, acc);
-    between(3);
+    EG_CLUMP_FENCE; between(3); EG_CLUMP_FENCE;
 }
 
 // ---- 8-wave layout: wave w owns 16 output channels, v_mfma_f32_16x16x4_f32 ------------------------

@@ -748,6 +748,11 @@ class HierarchicalPatchModel(nn.Module):
         self._kidsum: Dict[tuple, tuple] = {}
         # optional callable (layer index, layer output incl. residual and coordinate rows) -> None, called by forward_nodes
         self.layer_output_hook = None
+        # optional callable (kind, module, seeds) -> None, called whenever a train-mode forward draws the seeds of a Dropout site:
+        # ("gnn", gnn_layers[i], (seed,)), ("coord_mlp", node_coordinate_mlp[i], (seed1, seed2)), ("heads", node_classifiers,
+        # (seed1, seed2)).  The mask of a site is a pure function of (seed, element index) (csrc/train_common.h): a test
+        # regenerates the kernels' masks from these seeds and injects them into the oracle
+        self.dropout_seed_hook = None
 
     def enable_hip_graph(self, flag: bool = True) -> "HierarchicalPatchModel":
         """Inference only: capture the kernel sequence of ``forward_nodes`` (3 fused layers + classifier
@@ -809,6 +814,8 @@ class HierarchicalPatchModel(nn.Module):
             return None
         p = float(drop.p)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0      # host RNG: reproducible under torch.manual_seed
+        if self.dropout_seed_hook is not None:
+            self.dropout_seed_hook("gnn", layer, (seed,))
         return conv, bn, i < self.num_gnn_layers - 1, p, seed
 
     def _layer_train(self, i: int, x_in: torch.Tensor, graph: ops.Graph, gb: int, kid=(None, None)):
@@ -860,6 +867,8 @@ class HierarchicalPatchModel(nn.Module):
         cfg, params = self._coord_mlp_cfg(mlp)
         if cfg["p1"] > 0 or cfg["p2"] > 0:
             cfg["seed1"], cfg["seed2"] = torch.randint(0, 2 ** 62, (2,)).tolist()     # host RNG, like the layers
+        if self.dropout_seed_hook is not None:
+            self.dropout_seed_hook("coord_mlp", mlp, (cfg["seed1"], cfg["seed2"]))
         _, cfg["momentum1"] = _bn_step(mlp[1], pending)
         _, cfg["momentum2"] = _bn_step(mlp[5], pending)
         return cfg, params
@@ -1070,6 +1079,8 @@ class HierarchicalPatchModel(nn.Module):
         bn1, bn2 = [hd[1] for hd in heads], [hd[5] for hd in heads]
         p1, p2 = float(heads[0][3].p), float(heads[0][7].p)
         seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if (p1 > 0 or p2 > 0) else [0, 0]      # host RNG, like the layers
+        if self.dropout_seed_hook is not None:
+            self.dropout_seed_hook("heads", self.node_classifiers, tuple(seeds))
         with torch.no_grad():                              # stacked copies of the running statistics: one multi-tensor copy
             stats = torch.empty(2 * 128 + 2 * 64, dtype=torch.float32, device=bn1[0].running_mean.device)
             rm1, rv1, rm2, rv2 = stats[:128], stats[128:256], stats[256:320], stats[320:384]

@@ -345,3 +345,37 @@ def randomize_biases(model: nn.Module, seed: int = 1) -> None:
         if isinstance(m, OracleGCNConv):
             with torch.no_grad():
                 m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+
+
+class InjectedDropout(nn.Module):
+    """Test infrastructure: a Dropout whose keep mask is GIVEN (entries 0 or 1 / (1 - p)), so that the oracle can follow a
+    train step of the HIP path with p > 0 -- the kernels' masks are a pure function of (seed, element index)
+    (echoglad_amd/csrc/train_common.h) and the test regenerates them on the device.  Eval mode: identity, like nn.Dropout."""
+
+    def __init__(self, mask: torch.Tensor):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        if self.mask.shape != x.shape:
+            raise RuntimeError(f"injected dropout mask {tuple(self.mask.shape)} does not fit the activation {tuple(x.shape)}")
+        return x * self.mask.to(x.dtype)
+
+
+def inject_dropout_masks(model: "OracleHierarchicalPatchModel", layer_masks, coord_masks=None, head_masks=None) -> None:
+    """Replace the Dropout modules of the oracle model by InjectedDropout: ``layer_masks[i]`` [B*N,128] for gnn_layers[i];
+    ``coord_masks[i] = (m1 [4B,32], m2 [4B,16])`` for node_coordinate_mlp[i]; ``head_masks = (m1 [R,128], m2 [R,64])`` in the
+    stacked-heads layout (head k owns columns 32k..32k+31 / 16k..16k+15; models.py:363-377 builds the heads separately)."""
+    for i, m in enumerate(layer_masks):
+        model.gnn_layers[i].module_2 = InjectedDropout(m)
+    for i, (m1, m2) in enumerate(coord_masks or []):
+        model.node_coordinate_mlp[i][3] = InjectedDropout(m1)
+        model.node_coordinate_mlp[i][7] = InjectedDropout(m2)
+    if head_masks is not None:
+        m1, m2 = head_masks
+        for k, hd in enumerate(model.node_classifiers):
+            hd[3] = InjectedDropout(m1[:, 32 * k:32 * k + 32])
+            hd[7] = InjectedDropout(m2[:, 16 * k:16 * k + 16])
+

@@ -267,3 +267,49 @@ def test_classifier_heads(rows_per_frame, row_lo, n_valid, batch, sigmoid):
         want = torch.cat([c(hv) for c in ref.node_classifiers], dim=1)
     assert got.shape == want.shape
     assert (got - want).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("kind", ["hierarchy", "multigraph", "directed", "tiny", "isolated"])
+def test_csr_layer_in_clustered_tiles_equals_the_row_by_row_aggregator(kind, monkeypatch):
+    """CSR handles regroup their rows into breadth-first tiles of 64 nodes and keep a tile's raw rows in LDS (graph.hip
+    csr_tiles, k_gcn_layer<AGG_CSRT>).  The edges of a row keep their order, so the layer output is BITWISE the output of the
+    row-by-row aggregator (EG_CSR_TILES=0) and of the stash over consecutive rows (EG_CSR_TILES=1) -- forward, transposed-weight
+    form and with a residual -- on the reference's hierarchy given as a plain edge_index, a random multigraph with duplicate
+    edges and self loops, a directed graph (the backward's transposed handle too), graphs smaller than a tile, isolated nodes."""
+    rs = np.random.RandomState(11)
+    if kind == "hierarchy":
+        topo = HierTopology(TopologySpec(64, 6, False, False))
+        ei = torch.from_numpy(topo.batched_edge_index(3))
+        n = 3 * topo.num_nodes
+    elif kind == "multigraph":
+        n = 5000
+        src, dst = rs.randint(0, n, 30000), rs.randint(0, n, 30000)
+        e = np.stack([np.concatenate([src, dst, src[:500], np.arange(0, n, 7)]), np.concatenate([dst, src, dst[:500], np.arange(0, n, 7)])])
+        ei = torch.from_numpy(e.astype(np.int64))
+    elif kind == "directed":
+        n = 3000
+        ei = torch.from_numpy(np.stack([rs.randint(0, n, 20000), rs.randint(0, n, 20000)]).astype(np.int64))
+    elif kind == "tiny":
+        n = 37
+        ei = torch.from_numpy(np.stack([rs.randint(0, n, 90), rs.randint(0, n, 90)]).astype(np.int64))
+    else:
+        n = 1000                                                     # only the first 100 nodes have edges
+        ei = torch.from_numpy(np.stack([rs.randint(0, 100, 600), rs.randint(0, 100, 600)]).astype(np.int64))
+    x = rand_rows(n, seed=3).to(DEV)
+    res = rand_rows(n, seed=4).to(DEV)
+    w = torch.from_numpy(rs.uniform(-0.1, 0.1, (128, 128)).astype(np.float32)).to(DEV)
+    sc, sh = torch.from_numpy(rs.uniform(0.5, 1.5, 128).astype(np.float32)).to(DEV), torch.from_numpy(rs.uniform(-0.2, 0.2, 128).astype(np.float32)).to(DEV)
+    outs = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("EG_CSR_TILES", mode)                     # (read when the handle is created)
+        g = ops.Graph.csr(ei.to(DEV), n)
+        outs[mode] = (ops.gcn_layer_fwd(g, 1, x, w, sc, sh, x, relu=True), ops.gcn_layer_fwd(g, 1, x, w, None, None, res, relu=False),
+                      ops.gcn_layer_fwd(g.bwd, 1, x, w, None, None, None, relu=False, transpose_w=True))
+        torch.cuda.synchronize()
+    for mode in ("1", "2"):
+        for a, b in zip(outs["0"], outs[mode]):
+            assert torch.equal(a, b), (kind, mode)
+    # and against the sparse oracle
+    want = O.gcn_conv_sparse(x.cpu(), ei, w.cpu(), torch.zeros(128))
+    got = ops.gcn_layer_fwd(ops.Graph.csr(ei.to(DEV), n), 1, x, w, None, None, None, relu=False)
+    assert (got.cpu() - want).abs().max() < 2e-4 * max(1.0, float(want.abs().max()))

@@ -459,13 +459,25 @@ def test_reference_loop_at_full_frame_size_is_one_launch_per_layer(train):
     assert (got.detach().cpu() - want.detach()).abs().max() < 2e-4
     if train:
         (want ** 2).mean().backward()
-        assert (fused_xgrad.cpu() - xr.grad).abs().max() < 5e-3 * xr.grad.abs().max() + 1e-9
-        assert (fused_xgrad - xm.grad).abs().max() < 5e-3 * xm.grad.abs().max() + 1e-9
+
+        # 18 M activations: a handful of pre-activations sit within rounding of the ReLU kink and two fp32 evaluations put them on
+        # different sides, which moves single gradient entries by a whole term -- so: the bulk tightly (Frobenius),
+        # no entry grossly, and per channel of a parameter as gpu_util.assert_param_grads_close does
+        def close(a, b, what):
+            a, b = a.detach().cpu().double(), b.detach().cpu().double()
+            assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-12, (what, float((a - b).norm()), float(b.norm()))
+            assert float((a - b).abs().max()) <= 5e-2 * float(b.abs().max()) + 1e-12, what
+
+        close(fused_xgrad, xr.grad, "dx vs oracle")
+        close(fused_xgrad, xm.grad, "dx vs module-by-module")
         ref_grads = dict(ref.named_parameters())
+        gmax = max(float(q.grad.abs().max()) for q in ref_grads.values())
         for name, p in hip.named_parameters():
             rg = ref_grads[name].grad
-            err = (fused_grads[name].cpu() - rg).abs().max().item()
-            assert err < 5e-3 * rg.abs().max().item() + 1e-6, (name, err, rg.abs().max().item())
+            if float(rg.abs().max()) < 1e-5 * gmax:          # the conv bias in front of a train-mode BatchNorm: analytically zero
+                assert float(fused_grads[name].abs().max()) <= 1e-4 * gmax, name
+                continue
+            close(fused_grads[name], rg, name)
         # running statistics moved exactly as nn.BatchNorm1d moves them
         for k, v in ref.state_dict().items():
             if "running" in k or "num_batches" in k:

@@ -882,3 +882,84 @@ def test_in_place_backward_leaves_retained_and_hooked_gradients_intact():
     for name, g in (("hook-kept", kept[1]), ("retain_grad", retained[1].grad)):
         err = float((g.cpu() - g_ref).abs().max())
         assert err < 5e-3 * scale + 1e-7, (name, err, scale)
+
+
+def _kernel_keep_mask(n_elements: int, cols: int, p: float, seed: int) -> torch.Tensor:
+    """The keep mask (0 or 1 / (1 - p)) the kernels generate for a Dropout site of `n_elements` elements laid out [rows, cols]:
+    a pure function of (seed, flat element index) (csrc/train_common.h), produced here BY the kernels' own code path --
+    eg_bn_act_fwd on ones (scale 1, shift 0, no ReLU) returns keep_scale of every element of a [n / 128, 128] array, and the
+    flat index of element (r, c) of a [rows, cols] site is r * cols + c whatever `cols` is."""
+    assert n_elements % 128 == 0 and n_elements % cols == 0
+    rows = n_elements // 128
+    ones, zero = torch.ones(rows, 128, device=DEV), torch.zeros(128, device=DEV)
+    m = ops.bn_act_fwd(ones, torch.ones(128, device=DEV), zero, None, False, p, seed)
+    return m.reshape(n_elements // cols, cols).cpu()
+
+
+def test_whole_train_step_with_dropout_against_the_oracle_under_the_kernels_masks(capsys):
+    """One FULL training step with dropout p = 0.5 at every site (3 GNN layers, 3 coordinate MLPs x 2, 4 heads x 2) at 64 / 6 +
+    coordinate graph, B = 2, pushed through the oracle with the masks the kernels generated: logits, coordinates and every
+    parameter gradient.  The seeds of every site are handed out by the model (dropout_seed_hook), the masks are regenerated from
+    them by the kernels' own hash on the device, and the oracle's Dropout modules are replaced by those masks.  Tolerances as in
+    test_cfg4_train_step_error_against_fp64...: logits / coordinates within 4 x the oracle's own fp32-vs-fp64 distance,
+    gradients channel-wise (gpu_util.assert_param_grads_close: a ReLU kink flip moves one channel)."""
+    from gpu_util import assert_param_grads_close
+    frame, naux, L, B, p = 64, 6, 3, 2, 0.5
+    hip, ref = model_pair(frame, naux, L, coord=True, seed=31)           # (model_pair: dropout p = 0.5 at every site)
+    ref64 = O.OracleHierarchicalPatchModel(frame_size=frame, gnn_dropout_p=p, classifier_dropout_p=p, node_embedding_dim=128,
+                                           node_hidden_dim=128, num_output_channels=4, num_gnn_layers=L, num_aux_graphs=naux,
+                                           classifier_hidden_dim=32, use_coordinate_graph=True, output_activation="logit").double()
+    ref64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+    hip.train(); ref.train(); ref64.train()
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+    n, n_valid = topo.num_nodes, topo.num_valid_nodes
+    feats = synthetic_node_feats(B * n, 128, seed=77)
+    c0 = initial_coords(B, frame)
+    seeds = {}
+    hip.dropout_seed_hook = lambda kind, module, s: seeds.__setitem__((kind, id(module)), s)
+    torch.manual_seed(1234)
+    got, gc = hip.forward_nodes(feats.to(DEV), ei.to(DEV), B, c0.clone().to(DEV))
+    loss = (got ** 2).mean() + (gc ** 2).mean() * 1e-3
+    loss.backward()
+    # every site drew a seed, all different
+    flat = [s for v in seeds.values() for s in v]
+    assert len(seeds) == L + L + 1 and len(set(flat)) == len(flat) == L + 2 * L + 2 and all(s > 0 for s in flat)
+    layer_masks = [_kernel_keep_mask(B * n * 128, 128, p, seeds[("gnn", id(hip.gnn_layers[i]))][0]) for i in range(L)]
+    coord_masks = []
+    for i in range(L):
+        s1, s2 = seeds[("coord_mlp", id(hip.node_coordinate_mlp[i]))]
+        coord_masks.append((_kernel_keep_mask(4 * B * 32, 32, p, s1), _kernel_keep_mask(4 * B * 16, 16, p, s2)))
+    h1, h2 = seeds[("heads", id(hip.node_classifiers))]
+    head_masks = (_kernel_keep_mask(B * n_valid * 128, 128, p, h1), _kernel_keep_mask(B * n_valid * 64, 64, p, h2))
+    for m in layer_masks + [head_masks[0]]:
+        keep = float((m > 0).float().mean())
+        assert abs(keep - 0.5) < 0.01 and set(torch.unique(m).tolist()) == {0.0, 2.0}
+    results = {}
+    for name, model, dt in (("fp32", ref, torch.float32), ("fp64", ref64, torch.float64)):
+        O.inject_dropout_masks(model, layer_masks, coord_masks, head_masks)
+        model.train()
+        want, wc = model.forward_nodes(feats.to(dt), ei, nt, B, c0.clone().to(dt))
+        ((want ** 2).mean() + (wc ** 2).mean() * 1e-3).backward()
+        results[name] = (want.detach(), wc.detach())
+    w32, c32 = results["fp32"]
+    w64, c64 = results["fp64"]
+    ulp = 2.0 ** -23
+    ref_err_l = float((w32.double() - w64).abs().max())
+    ref_err_c = float((c32.double() - c64).abs().max())
+    err_l = float((got.detach().cpu().double() - w64).abs().max())
+    err_c = float((gc.detach().cpu().double() - c64).abs().max())
+    with capsys.disabled():
+        print(f"\n  p = 0.5 train step vs fp64 oracle under the kernels' masks: logits |hip-fp64| {err_l:.3e} (oracle fp32: {ref_err_l:.3e}), "
+              f"coords {err_c:.3e} (oracle fp32: {ref_err_c:.3e})")
+    assert err_l <= 4 * ref_err_l + 8 * ulp * float(w64.abs().max()), (err_l, ref_err_l)
+    assert err_c <= 4 * ref_err_c + 8 * ulp * frame, (err_c, ref_err_c)
+    assert (got.detach().cpu() - w32).abs().max() < 2e-4 * max(1.0, float(w32.abs().max()))
+    assert_param_grads_close(hip, ref)
+    # the masks matter: without them the oracle (its own Bernoulli draws) is nowhere near
+    plain = O.OracleHierarchicalPatchModel(frame_size=frame, gnn_dropout_p=p, classifier_dropout_p=p, node_embedding_dim=128,
+                                           node_hidden_dim=128, num_output_channels=4, num_gnn_layers=L, num_aux_graphs=naux,
+                                           classifier_hidden_dim=32, use_coordinate_graph=True, output_activation="logit")
+    plain.load_state_dict(ref.state_dict())
+    plain.train()
+    other, _ = plain.forward_nodes(feats, ei, nt, B, c0.clone())
+    assert (other.detach() - w32).abs().max() > 100 * (got.detach().cpu() - w32).abs().max()

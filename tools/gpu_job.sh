@@ -6,6 +6,7 @@
 #        bench[:<args>] python bench.py <args> (commas = spaces)     -> gpurun_out/<tag>_bench.json / .log
 #        chain          tools/tools_chain.py (ECHOGLAD_LIB honoured) -> gpurun_out/<tag>_chain.txt
 #        py:<script>[:args]  python tools/<script> args              -> gpurun_out/<tag>_<script>.txt
+#        pmc:<c1>,<c2>,..[:train]  one rocprofv3 --pmc pass, per-kernel means of the counters
 #        ab:<variant>:<variant>[:...][:reps=N] same-box A/B of library builds ("base" = shipped) with tools_chain.py + bench --steps 300
 export TMPDIR=/tmp
 tag=$1; shift
@@ -28,6 +29,25 @@ for step in "$@"; do
     py)
       script=${rest%%:*}; args=${rest#*:}; [ "$args" == "$rest" ] && args=""
       timeout 900 python tools/$script ${args//,/ } > gpurun_out/${tag}_${script%.py}.txt 2>&1; tail -40 gpurun_out/${tag}_${script%.py}.txt ;;
+    pmc)
+      # pmc:<counter>,<counter>,...[:train]  one rocprofv3 --pmc pass over the default bench command (or the training step), per-kernel means
+      IFS=: read -r ctrs mode <<< "$rest"
+      cmd="bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --repeats 0"
+      [ "$mode" == "train" ] && cmd="bench.py --mode train --batch 32 --steps 5 --warmup 2 --no-other-configs"
+      rm -rf /tmp/pmc_$tag
+      timeout 600 rocprofv3 --pmc ${ctrs//,/ } --output-format csv -d /tmp/pmc_$tag -- python3 $cmd > gpurun_out/${tag}_pmc_run.log 2>&1
+      python3 - <<PY > gpurun_out/${tag}_pmc_${ctrs%%,*}.txt
+import csv, glob, collections, re
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob("/tmp/pmc_$tag/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").replace("eg::", "")
+        a = agg[k][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
+for k, cs in sorted(agg.items(), key=lambda kv: -max(v[0] for v in kv[1].values())):
+    if not k.startswith("k_"): continue
+    print(k[:70], {c: round(v / n, 1) for c, (v, n) in sorted(cs.items())}, "launches", max(n for _, n in cs.values()))
+PY
+      head -12 gpurun_out/${tag}_pmc_${ctrs%%,*}.txt ;;
     ab)
       # ab:<variant>:<variant>[:...][:reps=N]  ("base" = the shipped library); every variant in turn, N rounds (default 2)
       reps=2; vars=""
