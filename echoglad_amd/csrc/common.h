@@ -244,8 +244,9 @@ struct eg_graph {
     int* t_rows;              // device [n_ctiles * 64]     node id of tile slot s (-1: padding at the end of the last tile)
     int* t_rowptr;            // device [n_ctiles * 64 + 1] edges of slot s: [t_rowptr[s], t_rowptr[s + 1])
     int* t_code;              // device [nnz]               source of the edge: -(slot + 1) inside the tile, else the node id
-    float* t_w;               // device [nnz]               (deg + 1)^-1/2 of the source
-    float* t_dis;             // device [n_ctiles * 64]     (deg + 1)^-1/2 of the slot's node (0: padding)
+    int* t_tgt;               // device [nnz]               target of the edge: its slot modulo 8 (a wave of the layer kernel owns 8 slots)
+    float* t_w;               // device [nnz]               the edge's weight d_src d_tgt, d = (deg + 1)^-1/2
+    float* t_dis;             // device [n_ctiles * 64]     the self loop's weight d^2 of the slot's node (0: padding)
     int n_ctiles;
     int symmetric;            // kind == GRAPH_CSR: the kept edge multiset equals its transpose (A_hat^T == A_hat)
     int* walk_counters;       // device [QUEUE_SLOTS][8 x 32] ring of per-launch tile-queue heads (+ QUEUE_TAIL_INTS)

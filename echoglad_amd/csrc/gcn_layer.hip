@@ -18,7 +18,7 @@ struct GraphPtrs {
     const int* colidx;
     const Topo* topo;
     const TileDesc* tiles;
-    const int *t_rows, *t_rowptr, *t_code;      // AGG_CSRT: the CSR in clustered tiles (common.h eg_graph::t_*)
+    const int *t_rows, *t_rowptr, *t_code, *t_tgt;      // AGG_CSRT: the CSR in clustered tiles (common.h eg_graph::t_*)
     const float *t_w, *t_dis;
 };
 
@@ -95,8 +95,8 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
                                                    const int* __restrict__ colidx, const Topo* __restrict__ T,
                                                    const TileDesc* __restrict__ tiles,
                                                    const int* __restrict__ t_rows, const int* __restrict__ t_rowptr,
-                                                   const int* __restrict__ t_code, const float* __restrict__ t_w,
-                                                   const float* __restrict__ t_dis,
+                                                   const int* __restrict__ t_code, const int* __restrict__ t_tgt,
+                                                   const float* __restrict__ t_w, const float* __restrict__ t_dis,
                                                    int* __restrict__ walk_counters, const LayerDims a) {
     __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA + 4];
     // raw self rows of the tile (implicit-topology path with residual == x): the epilogue's residual source
@@ -139,6 +139,23 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
     __syncthreads();
     int tile = walk.fetch();
     __syncthreads();                       // everyone has read the slot before thread 0 overwrites it
+    // AGG_CSRT: the edge words of the wave's 8 slots (source code, weight, target slot: lane l holds edge l of the list) are
+    // fetched ONE TILE AHEAD -- right after the next tile is known, under this tile's matrix phase -- so that a tile's outside
+    // sources can be requested at its very top, together with its own rows (one memory round trip per tile, like the stencil)
+    int m_code = 0, m_tg = 0, m_elo = 0, m_cnt = 0;
+    float m_w = 0.f;
+    auto load_meta = [&](int tl) {
+        if constexpr (AGG == AGG_CSRT) {
+            const int fr = tl / a.tiles_per_frame;
+            const int slot0 = (tl - fr * a.tiles_per_frame) * TILE + 8 * wave;
+            m_elo = t_rowptr[slot0];
+            m_cnt = t_rowptr[slot0 + 8] - m_elo;
+            const int l = lane_k;
+            m_code = 0; m_tg = 0; m_w = 0.f;
+            if (l < m_cnt) { m_code = t_code[m_elo + l]; m_w = t_w[m_elo + l]; m_tg = t_tgt[m_elo + l]; }
+        }
+    };
+    if (tile >= 0) load_meta(tile);
     while (tile >= 0) {
         STAMP(0);
         walk.claim_issue();
@@ -171,43 +188,121 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
             blocks = (rows_here + 15) >> 4;
             const int last = a.n_per_frame - 1;
             if constexpr (AGG == AGG_CSRT) {
-                // (1a) the wave's 8 slots: raw rows -> the tile's stash, ids -> s_ids; all 8 loads in flight
+                // The wave's 8 slots as ONE edge list.  A row-by-row walk is a chain of dependent round trips (row pointers ->
+                // edge words -> source rows, a dozen per tile and wave): 0.52 ms per launch at configs[1] whether the sources come
+                // from memory or from LDS (tools/tools_csr.py).  Here the list's words (source code, weight d_src d_tgt, target
+                // slot) are fetched lane-parallel in one vector load, every source row outside the tile is requested at once
+                // (up to 16 in flight per wave), the sources inside the tile come out of the stash meanwhile, and a row's sum is
+                // kept in a running accumulator that is added to the row's LDS line when the target changes (edges are sorted by
+                // target).  Order of a row's sum: self, in-tile sources, outside sources, each group in edge_index order (fixed).
                 const int slot0 = t_in * TILE + rl0;
+                const int e_lo = m_elo, cnt = m_cnt;                                    // (fetched a tile ahead: load_meta)
                 f32x2 raw[8];
                 int id[8];
+                float ws[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     id[u] = t_rows[slot0 + u];                                   // scalar
+                    ws[u] = t_dis[slot0 + u];                                    // (deg + 1)^-1 of the slot's node: the self loop's weight
                     raw[u] = load_row2(xf, id[u] < 0 ? 0 : id[u], lane);
                 }
+                int code = m_code, tg = m_tg;
+                float wv = m_w;
+                constexpr int GMAX = 16;
+                f32x2 gv[GMAX];
+                auto issue = [&](unsigned long long mm) -> unsigned long long {          // up to GMAX outside sources, all in flight
 #pragma unroll
-                for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x2*>(&s_xbuf[(rl0 + u) * C + 2 * lane]) = raw[u];
+                    for (int k = 0; k < GMAX; ++k) {
+                        gv[k] = f32x2{0.f, 0.f};
+                        if (mm) {
+                            const int bit = __builtin_ctzll(mm);
+                            gv[k] = load_row2(xf, __builtin_amdgcn_readlane(code, bit), lane);
+                            mm &= mm - 1;
+                        }
+                    }
+                    return mm;
+                };
+                // the first 64 edges' outside sources are requested BEFORE the barrier (they do not depend on the stash)
+                unsigned long long mg = __builtin_amdgcn_ballot_w64(lane < cnt && code >= 0);
+                unsigned long long ml = __builtin_amdgcn_ballot_w64(lane < cnt && code < 0);
+                unsigned long long rest = issue(mg);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    *reinterpret_cast<f32x2*>(&s_xbuf[(rl0 + u) * C + 2 * lane]) = raw[u];
+                    *reinterpret_cast<f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]) = ws[u] * raw[u];
+                }
                 if (lane < 8) s_ids[rl0 + lane] = t_rows[slot0 + lane];
                 __syncthreads();
-                // (1b) a row's edges in their CSR order (the old order of the sum), four sources in flight: a source inside the
-                // tile comes from the stash, the others from memory; the weights (deg + 1)^-1/2 of the sources sit beside the codes
-#pragma unroll 1
-                for (int u = 0; u < 8; ++u) {
-                    const int e0 = t_rowptr[slot0 + u], e1 = t_rowptr[slot0 + u + 1];
-                    const float dn = t_dis[slot0 + u];
-                    f32x2 acc = {0.f, 0.f};
-                    for (int e = e0; e < e1; e += 4) {
-                        f32x2 v[4];
-                        float w[4];
+                int cur = -1;
+                f32x2 acc = {0.f, 0.f};
+                auto flush = [&]() {
+                    if (cur >= 0) {
+                        f32x2* p = reinterpret_cast<f32x2*>(&s_a[(rl0 + cur) * LDA + 2 * lane]);
+                        *p = *p + acc;
+                    }
+                };
+                auto add = [&](int u, const f32x2& val) {
+                    if (u != cur) { flush(); cur = u; acc = f32x2{0.f, 0.f}; }
+                    acc += val;
+                };
+                auto inside = [&](unsigned long long m) {                                // sources inside the tile: four stash reads in flight
+                    while (m) {
+                        f32x2 lv[4];
+                        float lw[4];
+                        int lu[4];
+                        bool on[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int ee = (e + k < e1) ? e + k : e1 - 1;
-                            const int code = t_code[ee];
-                            w[k] = (e + k < e1) ? t_w[ee] : 0.0f;
-                            if (code < 0) v[k] = *reinterpret_cast<const f32x2*>(&s_xbuf[(-code - 1) * C + 2 * lane]);     // (uniform branch)
-                            else v[k] = load_row2(xf, code, lane);
+                        for (int q = 0; q < 4; ++q) {
+                            on[q] = m != 0;
+                            lv[q] = f32x2{0.f, 0.f}; lw[q] = 0.f; lu[q] = 0;
+                            if (on[q]) {
+                                const int bit = __builtin_ctzll(m);
+                                m &= m - 1;
+                                const int src = -__builtin_amdgcn_readlane(code, bit) - 1;
+                                lw[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), bit));
+                                lu[q] = __builtin_amdgcn_readlane(tg, bit);
+                                lv[q] = *reinterpret_cast<const f32x2*>(&s_xbuf[src * C + 2 * lane]);
+                            }
                         }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) acc += w[k] * v[k];
+                        for (int q = 0; q < 4; ++q)
+                            if (on[q]) add(lu[q], lw[q] * lv[q]);
                     }
-                    acc += dn * *reinterpret_cast<const f32x2*>(&s_xbuf[(rl0 + u) * C + 2 * lane]);      // the implied self loop comes last, as in gcn_norm
-                    *reinterpret_cast<f32x2*>(&s_a[(rl0 + u) * LDA + 2 * lane]) = acc * dn;
+                };
+                auto consume = [&](unsigned long long mm) {                              // the rows issue(mm) requested, in the same order
+#pragma unroll
+                    for (int k = 0; k < GMAX; ++k) {
+                        if (mm) {
+                            const int bit = __builtin_ctzll(mm);
+                            const float wgt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), bit));
+                            add(__builtin_amdgcn_readlane(tg, bit), wgt * gv[k]);
+                            mm &= mm - 1;
+                        }
+                    }
+                };
+                inside(ml);
+                consume(mg);
+                while (rest) {                                                       // (more than GMAX outside sources among 64 edges)
+                    const unsigned long long m = rest;
+                    rest = issue(m);
+                    consume(m);
                 }
+                for (int base = 64; base < cnt; base += 64) {                            // (more than 64 edges into the wave's 8 rows)
+                    code = 0; tg = 0; wv = 0.f;
+                    if (base + lane < cnt) { code = t_code[e_lo + base + lane]; wv = t_w[e_lo + base + lane]; tg = t_tgt[e_lo + base + lane]; }
+                    const bool valid = base + lane < cnt;
+                    mg = __builtin_amdgcn_ballot_w64(valid && code >= 0);
+                    ml = __builtin_amdgcn_ballot_w64(valid && code < 0);
+                    rest = issue(mg);
+                    inside(ml);
+                    consume(mg);
+                    while (rest) {
+                        const unsigned long long m = rest;
+                        rest = issue(m);
+                        consume(m);
+                    }
+                }
+                flush();
             } else if constexpr (AGG == AGG_NONE) {
                 const PairLane pl{lane >> 5, lane & 31};
                 f32x4 v[4];
@@ -243,6 +338,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
         __syncthreads();
         STAMP(2);
         const int next_tile = walk.fetch();
+        if (next_tile >= 0) load_meta(next_tile);
 
         // ---- phase 2 (LDS rows without a node hold stale data; their accumulator columns are never read back)
         f32x4v acc[4];
@@ -271,12 +367,15 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
             if constexpr (AGG == AGG_CSRT) rowoff[k] = (seg_rows > 0 ? s_ids[rl0 + row] : 0) - seg_first;
             else rowoff[k] = row;
         }
+        // (AGG_CSRT with residual == x: the rows are the wave's own slots of the stash, read in phase 3)
+        const bool res_stash = AGG == AGG_CSRT && residual == x;
         if constexpr (RES_GLOBAL) {
             const float* rp = (residual ? residual : x) + seg_off;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
 #ifndef EG_ABL_NO_P3
-                res[k] = *reinterpret_cast<const f32x4*>(rp + (long long)rowoff[k] * C);
+                if (res_stash) res[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                else res[k] = *reinterpret_cast<const f32x4*>(rp + (long long)rowoff[k] * C);
 #else
                 res[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
@@ -308,7 +407,10 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
                 f32x4 t = *reinterpret_cast<const f32x4*>(&s_a[(rl0 + row) * LDA + 4 * pl.q]);
                 t = t * sc + sh;
                 if (a.relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
-                if constexpr (RES_GLOBAL) { if (residual) t += res[k]; }
+                if constexpr (RES_GLOBAL) {
+                    if (res_stash) t += *reinterpret_cast<const f32x4*>(&s_xbuf[(rl0 + row) * C + 4 * pl.q]);
+                    else if (residual) t += res[k];
+                }
                 else { if (s_x) t += *reinterpret_cast<const f32x4*>(&s_x[(rl0 + row) * C + 4 * pl.q]); }
                 v[k] = t;
             }
@@ -406,7 +508,7 @@ static int grid_for_tiles(long long n_tiles, const Knobs& kn) {
     return (int)g;
 }
 
-#define LAYER_KARGS a.x, a.W, a.scale, a.shift, a.residual, a.out, a.agg_out, a.stats_partial, a.gp.dis, a.gp.rowptr, a.gp.colidx, a.gp.topo, a.gp.tiles, a.gp.t_rows, a.gp.t_rowptr, a.gp.t_code, a.gp.t_w, a.gp.t_dis, a.walk_counters, a.d
+#define LAYER_KARGS a.x, a.W, a.scale, a.shift, a.residual, a.out, a.agg_out, a.stats_partial, a.gp.dis, a.gp.rowptr, a.gp.colidx, a.gp.topo, a.gp.tiles, a.gp.t_rows, a.gp.t_rowptr, a.gp.t_code, a.gp.t_tgt, a.gp.t_w, a.gp.t_dis, a.walk_counters, a.d
 
 static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out = nullptr) {
     const long long n_tiles = (long long)a.d.tiles_per_frame * a.d.batch;
@@ -479,7 +581,7 @@ static int fill_graph_args(const eg_graph* g, int batch, LayerArgs& a, int& agg)
     // a CSR handle's inference launches take the clustered tiles (the train forward keeps the row-by-row aggregator: launch_layer)
     if (g->kind == GRAPH_CSR && g->t_rows) {
         agg = AGG_CSRT;
-        a.gp.t_rows = g->t_rows; a.gp.t_rowptr = g->t_rowptr; a.gp.t_code = g->t_code; a.gp.t_w = g->t_w; a.gp.t_dis = g->t_dis;
+        a.gp.t_rows = g->t_rows; a.gp.t_rowptr = g->t_rowptr; a.gp.t_code = g->t_code; a.gp.t_tgt = g->t_tgt; a.gp.t_w = g->t_w; a.gp.t_dis = g->t_dis;
     }
     // implicit topology: one tile per 8x8 patch of a level; CSR: 64 consecutive rows
     a.d.tiles_per_frame = agg == AGG_STENCIL ? g->n_tiles : (int)((g->n_nodes + TILE - 1) / TILE);

@@ -297,7 +297,7 @@ static int csr_tiles(eg_graph* g, int mode, hipStream_t stream) {
     csr_tile_order(n, rowptr, colidx, mode >= 2, order);
     const int n_tiles = (n + TILE - 1) / TILE;
     const size_t slots = (size_t)n_tiles * TILE;
-    std::vector<int> slot_of((size_t)n), t_rows(slots, -1), t_rowptr(slots + 1, 0), t_code(nnz ? nnz : 1);
+    std::vector<int> slot_of((size_t)n), t_rows(slots, -1), t_rowptr(slots + 1, 0), t_code(nnz ? nnz : 1), t_tgt(nnz ? nnz : 1);
     std::vector<float> t_w(nnz ? nnz : 1), t_dis(slots, 0.f);
     for (int s = 0; s < n; ++s) slot_of[(size_t)order[(size_t)s]] = s;
     size_t o = 0;
@@ -306,12 +306,13 @@ static int csr_tiles(eg_graph* g, int mode, hipStream_t stream) {
         if (s >= (size_t)n) continue;
         const int u = order[s];
         t_rows[s] = u;
-        t_dis[s] = dis[(size_t)u];
+        t_dis[s] = dis[(size_t)u] * dis[(size_t)u];
         for (int e = rowptr[(size_t)u]; e < rowptr[(size_t)u + 1]; ++e) {      // (edge order kept: the sum of a row has the old order)
             const int v = colidx[(size_t)e];
             const int sv = slot_of[(size_t)v];
             t_code[o] = (sv / TILE == (int)(s / TILE)) ? -(sv % TILE + 1) : v;
-            t_w[o] = dis[(size_t)v];
+            t_w[o] = dis[(size_t)v] * dis[(size_t)u];
+            t_tgt[o] = (int)(s & 7);
             ++o;
         }
     }
@@ -319,11 +320,13 @@ static int csr_tiles(eg_graph* g, int mode, hipStream_t stream) {
     EG_HIP_TRY(hipMalloc((void**)&g->t_rows, sizeof(int) * slots));
     EG_HIP_TRY(hipMalloc((void**)&g->t_rowptr, sizeof(int) * (slots + 1)));
     EG_HIP_TRY(hipMalloc((void**)&g->t_code, sizeof(int) * t_code.size()));
+    EG_HIP_TRY(hipMalloc((void**)&g->t_tgt, sizeof(int) * t_tgt.size()));
     EG_HIP_TRY(hipMalloc((void**)&g->t_w, sizeof(float) * t_w.size()));
     EG_HIP_TRY(hipMalloc((void**)&g->t_dis, sizeof(float) * slots));
     EG_HIP_TRY(hipMemcpy(g->t_rows, t_rows.data(), sizeof(int) * slots, hipMemcpyHostToDevice));
     EG_HIP_TRY(hipMemcpy(g->t_rowptr, t_rowptr.data(), sizeof(int) * (slots + 1), hipMemcpyHostToDevice));
     EG_HIP_TRY(hipMemcpy(g->t_code, t_code.data(), sizeof(int) * t_code.size(), hipMemcpyHostToDevice));
+    EG_HIP_TRY(hipMemcpy(g->t_tgt, t_tgt.data(), sizeof(int) * t_tgt.size(), hipMemcpyHostToDevice));
     EG_HIP_TRY(hipMemcpy(g->t_w, t_w.data(), sizeof(float) * t_w.size(), hipMemcpyHostToDevice));
     EG_HIP_TRY(hipMemcpy(g->t_dis, t_dis.data(), sizeof(float) * slots, hipMemcpyHostToDevice));
     g->n_ctiles = n_tiles;
@@ -859,7 +862,7 @@ int eg_graph_destroy(eg_graph* g) {
     if (g->conn_table) (void)hipFree(g->conn_table);
     if (g->conn_scratch) (void)hipFree(g->conn_scratch);
     for (float* p : g->conn_retired) (void)hipFree(p);
-    for (void* p : {(void*)g->t_rows, (void*)g->t_rowptr, (void*)g->t_code, (void*)g->t_w, (void*)g->t_dis})
+    for (void* p : {(void*)g->t_rows, (void*)g->t_rowptr, (void*)g->t_code, (void*)g->t_tgt, (void*)g->t_w, (void*)g->t_dis})
         if (p) (void)hipFree(p);
     delete g;
     return EG_OK;

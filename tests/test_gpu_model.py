@@ -174,6 +174,14 @@ def _full_size_properties(frame, naux, B, main_only=False, layers=3, seed=5):
         d = hip.forward_nodes(x, ei.to(DEV), B)[0].clone()
         e = hip.forward_nodes(x, ei.to(DEV), B)[0].clone()
     assert torch.equal(d, a) and torch.equal(e, a)
+    # ... and at batch 1, the reference's own setting (configs/default.yml:27): the replayed single-frame step equals the eager
+    # single-frame step, i.e. that frame of the batch, bit for bit (what other_configs.cfg2_b1 of the bench line times)
+    x1 = x[f * n:(f + 1) * n].contiguous()
+    e1 = ei1.to(DEV)
+    with torch.no_grad():
+        r1 = hip.forward_nodes(x1, e1, 1)[0].clone()
+        r2 = hip.forward_nodes(x1, e1, 1)[0].clone()
+    assert torch.equal(r1, c) and torch.equal(r2, c)
 
 
 def test_cfg2_default_full_batch_8_graph_replay_vs_oracle():
