@@ -850,11 +850,14 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     if ((kin || kout) && g->kid_rows == 0) return EG_ERR_UNSUPPORTED;
     if (jk && g->kid_rows == 0 && !g->flat) return EG_ERR_UNSUPPORTED;
     if (cls && g->kid_rows == 0 && !g->flat) return EG_ERR_UNSUPPORTED;
-    // plain calls: this kernel by default on single-level topologies (no tiles that pull child rows), the symmetric
-    // kernel otherwise; EG_LAYER_IMPL = 0 / 1 forces one of them
+    // plain calls: this kernel by default wherever its fast paths cover the topology -- single-level grids and regular pyramids
+    // (child sums available); since the producers were rebuilt (round 3) its unchained form, which pulls the four child rows of
+    // an aux node, is faster than the symmetric kernel as well (0.280 vs 0.309 ms per launch at configs[1], round 5) -- and the
+    // symmetric kernel on irregular frames; EG_LAYER_IMPL = 0 / 1 forces one of them
     const bool diag = g->hybrid != 0;                             // 'grid-diagonal' levels: this kernel is the stencil path of such handles
     if (diag && jk) return EG_ERR_UNSUPPORTED;                    // (the running maximum has no diagonal instantiation: the caller takes it outside)
-    if (!chained && !cls && !train && !rsep && !diag && (g->knobs.layer_impl < 0 ? g->flat : g->knobs.layer_impl) == 0) return EG_ERR_UNSUPPORTED;
+    if (!chained && !cls && !train && !rsep && !diag &&
+        (g->knobs.layer_impl < 0 ? (g->flat || g->kid_rows > 0) : g->knobs.layer_impl != 0) == false) return EG_ERR_UNSUPPORTED;
     PsDims a{};
     a.n_per_frame = (int)g->n_nodes; a.batch = batch; a.tiles_per_frame = g->n_tiles;
     a.relu = relu; a.transpose_w = transpose_w; a.has_res = residual != nullptr;

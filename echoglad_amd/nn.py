@@ -299,6 +299,13 @@ _HEAD_PARAM_IDX = ((0, "weight"), (0, "bias"), (1, "weight"), (1, "bias"), (4, "
                    (5, "bias"), (8, "weight"), (8, "bias"))
 
 
+def _seq_params(seq: nn.Sequential):
+    """The 10 parameters of a Linear-BN-ReLU-Drop-Linear-BN-ReLU-Drop-Linear head in _HEAD_PARAM_IDX order (plain dict lookups:
+    this runs for 7 heads several times per training step, and at batch 1 the step is bound by the host)."""
+    m = seq._modules
+    return [m[str(j)]._parameters[name] for j, name in _HEAD_PARAM_IDX]
+
+
 class _ClassifierTrainFn(torch.autograd.Function):
     """models.py:363-377, :485-490 in train mode over eg_classifier_train_fwd / eg_classifier_bwd: node-type filter + the
     four heads as one stacked network (first layers one [128 -> 128] product, 4 x BatchNorm1d(32) == BatchNorm1d(128) on the
@@ -853,10 +860,11 @@ class HierarchicalPatchModel(nn.Module):
         """(cfg, params) of node_coordinate_mlp[i] for the kernels when every sub-module is in plain train state, else None."""
         if self.classifier_hidden_dim != 32 or self.node_embedding_dim != C or os.environ.get("EG_COORD_MLP_KERNEL", "1") == "0":
             return None
-        bn1, bn2, d1, d2 = mlp[1], mlp[5], mlp[3], mlp[7]
+        m = mlp._modules                       # (nn.Sequential.__getitem__ walks an islice: ~170 of them per step were 0.2 ms of host time)
+        bn1, bn2, d1, d2 = m["1"], m["5"], m["3"], m["7"]
         if not (bn1.affine and bn2.affine and bn1.training and bn2.training and d1.training and d2.training):
             return None
-        params = [getattr(mlp[j], name) for j, name in _HEAD_PARAM_IDX]
+        params = _seq_params(mlp)
         cfg = dict(eps1=bn1.eps, eps2=bn2.eps, p1=float(d1.p), p2=float(d2.p), seed1=0, seed2=0,
                    running_mean1=bn1.running_mean, running_var1=bn1.running_var, running_mean2=bn2.running_mean,
                    running_var2=bn2.running_var)
@@ -885,7 +893,7 @@ class HierarchicalPatchModel(nn.Module):
         if self._coord_mlp_cfg(mlp) is not None:
             cfg, params = self._coord_mlp_train_cfg(mlp)
             return _CoordMlpFn.apply(lm, node_coords, batch, frame, cfg, *params)
-        params = [getattr(mlp[j], name) for j, name in _HEAD_PARAM_IDX]
+        params = _seq_params(mlp)
         cfg = dict(eps1=bn1.eps, eps2=bn2.eps, p1=float(d1.p), p2=float(d2.p), seed1=0, seed2=0,
                    running_mean1=bn1.running_mean, running_var1=bn1.running_var, running_mean2=bn2.running_mean,
                    running_var2=bn2.running_var)
@@ -1065,10 +1073,11 @@ class HierarchicalPatchModel(nn.Module):
 
     # ---- the 4 classifier heads in train mode as ONE stacked network ----------------------------------------
     def _stacked_heads_ok(self) -> bool:
+        mods = [hd._modules for hd in self.node_classifiers]
+        ref = mods[0]["1"]
         plain_bn = all(m.training and m.affine and m.track_running_stats and m.momentum is not None and
-                       m.momentum == self.node_classifiers[0][1].momentum and m.eps == self.node_classifiers[0][1].eps
-                       for hd in self.node_classifiers for m in (hd[1], hd[5]))
-        drops_on = all(m.training for hd in self.node_classifiers for m in (hd[3], hd[7]))
+                       m.momentum == ref.momentum and m.eps == ref.eps for md in mods for m in (md["1"], md["5"]))
+        drops_on = all(m.training for md in mods for m in (md["3"], md["7"]))
         return (self.num_output_channels == 4 and self.classifier_hidden_dim == 32 and self.node_embedding_dim == C
                 and plain_bn and drops_on and os.environ.get("EG_STACKED_HEADS", "1") != "0")
 
@@ -1076,8 +1085,8 @@ class HierarchicalPatchModel(nn.Module):
         """(cfg, the 40 head parameters, finish()) for _ClassifierTrainFn / _CoordClassifierTrainFn.  Running statistics: the
         kernels update stacked copies, which finish() writes back to the 8 BatchNorm modules with two multi-tensor copies."""
         heads = list(self.node_classifiers)
-        bn1, bn2 = [hd[1] for hd in heads], [hd[5] for hd in heads]
-        p1, p2 = float(heads[0][3].p), float(heads[0][7].p)
+        bn1, bn2 = [hd._modules["1"] for hd in heads], [hd._modules["5"] for hd in heads]
+        p1, p2 = float(heads[0]._modules["3"].p), float(heads[0]._modules["7"].p)
         seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if (p1 > 0 or p2 > 0) else [0, 0]      # host RNG, like the layers
         if self.dropout_seed_hook is not None:
             self.dropout_seed_hook("heads", self.node_classifiers, tuple(seeds))
@@ -1089,7 +1098,7 @@ class HierarchicalPatchModel(nn.Module):
                                  [b.running_mean for b in bn2] + [b.running_var for b in bn2])
         cfg = dict(running_mean1=rm1, running_var1=rv1, running_mean2=rm2, running_var2=rv2, eps1=bn1[0].eps, eps2=bn2[0].eps,
                    momentum1=bn1[0].momentum, momentum2=bn2[0].momentum, p1=p1, p2=p2, seed1=seeds[0], seed2=seeds[1])
-        params = [getattr(hd[j], name) for hd in heads for j, name in _HEAD_PARAM_IDX]
+        params = [p for hd in heads for p in _seq_params(hd)]
 
         def finish(more_counters=()):
             with torch.no_grad():

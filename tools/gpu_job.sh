@@ -6,6 +6,7 @@
 #        bench[:<args>] python bench.py <args> (commas = spaces)     -> gpurun_out/<tag>_bench.json / .log
 #        chain          tools/tools_chain.py (ECHOGLAD_LIB honoured) -> gpurun_out/<tag>_chain.txt
 #        py:<script>[:args]  python tools/<script> args              -> gpurun_out/<tag>_<script>.txt
+#        trace:train|infer   kernel sequence of one step from a rocprofv3 --kernel-trace
 #        pmc:<c1>,<c2>,..[:train]  one rocprofv3 --pmc pass, per-kernel means of the counters
 #        ab:<variant>:<variant>[:...][:reps=N] same-box A/B of library builds ("base" = shipped) with tools_chain.py + bench --steps 300
 export TMPDIR=/tmp
@@ -29,6 +30,19 @@ for step in "$@"; do
     py)
       script=${rest%%:*}; args=${rest#*:}; [ "$args" == "$rest" ] && args=""
       timeout 900 python tools/$script ${args//,/ } > gpurun_out/${tag}_${script%.py}.txt 2>&1; tail -40 gpurun_out/${tag}_${script%.py}.txt ;;
+    trace)
+      # trace:train|infer   kernel sequence of one step (start, duration, gap in front) from a rocprofv3 --kernel-trace of bench.py
+      rm -rf /tmp/trace_$tag
+      if [ "$rest" == "train" ]; then
+        timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_$tag -- python3 bench.py --mode train --batch ${EG_B:-32} --steps 5 --warmup 2 --no-other-configs > gpurun_out/${tag}_trace_run.log 2>&1
+        python3 tools/trace_seq.py $(find /tmp/trace_$tag -name "*kernel_trace.csv" | head -1) > gpurun_out/${tag}_trace_train.txt 2>&1
+        python3 tools/trace_gaps.py $(find /tmp/trace_$tag -name "*kernel_trace.csv" | head -1) >> gpurun_out/${tag}_trace_train.txt 2>&1
+        tail -5 gpurun_out/${tag}_trace_train.txt
+      else
+        timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_$tag -- python3 bench.py --steps 60 --warmup 10 --repeats 0 --no-cpu-baseline --no-other-configs > gpurun_out/${tag}_trace_run.log 2>&1
+        python3 tools/trace_infer_seq.py $(find /tmp/trace_$tag -name "*kernel_trace.csv" | head -1) > gpurun_out/${tag}_trace_infer.txt 2>&1
+        tail -12 gpurun_out/${tag}_trace_infer.txt
+      fi ;;
     pmc)
       # pmc:<counter>,<counter>,...[:train]  one rocprofv3 --pmc pass over the default bench command (or the training step), per-kernel means
       IFS=: read -r ctrs mode <<< "$rest"
