@@ -208,7 +208,13 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
                 }
                 int code = m_code, tg = m_tg;
                 float wv = m_w;
-                constexpr int GMAX = 16;
+#ifndef EG_CSRT_GMAX
+#define EG_CSRT_GMAX 16
+#endif
+#ifndef EG_CSRT_LUNROLL
+#define EG_CSRT_LUNROLL 4
+#endif
+                constexpr int GMAX = EG_CSRT_GMAX;
                 f32x2 gv[GMAX];
                 auto issue = [&](unsigned long long mm) -> unsigned long long {          // up to GMAX outside sources, all in flight
 #pragma unroll
@@ -247,12 +253,13 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
                 };
                 auto inside = [&](unsigned long long m) {                                // sources inside the tile: four stash reads in flight
                     while (m) {
-                        f32x2 lv[4];
-                        float lw[4];
-                        int lu[4];
-                        bool on[4];
+                        constexpr int LU = EG_CSRT_LUNROLL;
+                        f32x2 lv[LU];
+                        float lw[LU];
+                        int lu[LU];
+                        bool on[LU];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < LU; ++q) {
                             on[q] = m != 0;
                             lv[q] = f32x2{0.f, 0.f}; lw[q] = 0.f; lu[q] = 0;
                             if (on[q]) {
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 4) void k_gcn_layer(const float* __r
                             }
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < LU; ++q)
                             if (on[q]) add(lu[q], lw[q] * lv[q]);
                     }
                 };

@@ -456,7 +456,14 @@ __global__ __launch_bounds__(256, 3) void k_bn_bwd_apply_dw(const float* __restr
             const long long r = r0 + e / 32;
             f32x4 vg = {0.f, 0.f, 0.f, 0.f};
             if (DIRECT || r < a.rows) {                   // (DIRECT: rows past the end hold zeros, their store is dropped)
+                // element index of this float4 (the dropout mask's counter): a uniform 64-bit tile base + the lane's 32-bit part --
+                // kept as a per-lane 64-bit value for every q it cost four spilled registers that were re-loaded inside the loop,
+                // each reload behind an s_waitcnt vmcnt(0) that also drained the next tile's prefetched rows
+#ifdef EG_OLD_DW_OFF           // (A/B: the round-4 form with its spills)
                 const size_t off = (size_t)r * C + c4;
+#else
+                const size_t off = DIRECT ? (size_t)r0 * C + (unsigned)(voff[q] >> 2) : (size_t)r * C + c4;
+#endif
                 const f32x4 zz = pz[q];
                 f32x4 d = pd[q];
                 if (a.p > 0.f) d *= keep_scale4(a.seed, (unsigned long long)off, a.p, a.inv_keep);
