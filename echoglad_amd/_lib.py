@@ -82,6 +82,10 @@ SIGNATURES: Dict[str, tuple] = {
                                         _i64, _i64, _p]),
     "eg_coord_mlp_fwd": (_i, [_p, _p, _i, _pp, _i, _i, _p, _p, _p, _p, _p, _p]),
     "eg_coord_mlp_bwd": (_i, [_p, _p, _p, _i, _pp, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "eg_coord_mlp_fwd_rows": (_i, [_p, _i64, _p, _p, _i, _pp, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "eg_coord_mlp_bwd_rows": (_i, [_p, _p, _p, _i, _pp, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),
+    "eg_bilinear4_fwd_rows": (_i, [_p, _p, _i, _i, _i64, _i64, _i, _p, _i64, _p]),
+    "eg_bilinear4_bwd_rows": (_i, [_p, _i64, _p, _p, _i, _i, _i64, _i64, _i, _p, _p, _p]),
     "eg_bilinear4_fwd": (_i, [_p, _p, _i, _i, _i64, _i64, _i, _p, _p]),
     "eg_bilinear4_bwd": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _i, _p, _p, _p]),
     "eg_pack_levels": (_i, [ct.POINTER(_p), ct.POINTER(_i), _i, _i, _i64, _i64, _p, _p]),
@@ -91,6 +95,7 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_heatmap_workspace_bytes": (ct.c_size_t, [_i, ct.POINTER(_i), _i]),
     "eg_heatmap_expect_fwd": (_i, [_p, _p, _p, _i, _i64, ct.POINTER(_i), ct.POINTER(_i), _i, _p, _p, _p, _p, _p, _p, _p]),
     "eg_heatmap_expect_bwd": (_i, [_p, _p, _p, _p, _i, _i64, ct.POINTER(_i), ct.POINTER(_i), _i, _p, _p]),
+    "eg_elm_reduce": (_i, [_p, _p, _p, _p, _i, _i, ct.c_float, _p, _p, _p]),
     "eg_bce_logits_fwd": (_i, [_p, _p, _p, _i64, ct.c_float, _p, _p, _p]),
     "eg_bce_logits_bwd": (_i, [_p, _p, _p, _i64, ct.c_float, _p, _p, _p]),
 }

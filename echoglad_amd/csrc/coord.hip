@@ -9,6 +9,7 @@ namespace eg {
 struct BilArgs {
     int batch, points, frame;     // points per frame (4 in the reference)
     long long n_per_frame, main_base;
+    long long row_stride;         // floats between two frames' sample rows in out / dout (points * 128: a packed [batch * points, 128] array)
 };
 
 struct Taps {
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void k_bilinear4_fwd(const float* __restrict__
             const f32x2 v = *reinterpret_cast<const f32x2*>(base + ((size_t)th.i[ka] * a.frame + tw.i[kb]) * C);
             acc += w * v;
         }
-    *reinterpret_cast<f32x2*>(out + (size_t)p * C + 2 * lane) = acc;
+    *reinterpret_cast<f32x2*>(out + (size_t)frame * a.row_stride + (size_t)(p - frame * a.points) * C + 2 * lane) = acc;
 }
 
 // one wave per FRAME walks its landmarks in order, so two landmarks that touch the same pixel never race
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void k_bilinear4_bwd(const float* __restrict__
     for (int q = 0; q < a.points; ++q) {
         const int p = frame * a.points + q;
         const Taps th = taps_1d(coords[2 * p + 0], a.frame), tw = taps_1d(coords[2 * p + 1], a.frame);
-        const f32x2 g = *reinterpret_cast<const f32x2*>(dout + (size_t)p * C + 2 * lane);
+        const f32x2 g = *reinterpret_cast<const f32x2*>(dout + (size_t)frame * a.row_stride + (size_t)q * C + 2 * lane);
         float gh = 0.f, gw = 0.f;
 #pragma unroll
         for (int ka = 0; ka < 2; ++ka)
@@ -93,28 +94,38 @@ using namespace eg;
 
 extern "C" {
 
-int eg_bilinear4_fwd(const float* h, const float* coords, int batch, int points, int64_t n_per_frame, int64_t main_base,
-                     int frame, float* out, eg_stream_t stream) {
+int eg_bilinear4_fwd_rows(const float* h, const float* coords, int batch, int points, int64_t n_per_frame, int64_t main_base,
+                          int frame, float* out, int64_t out_frame_stride, eg_stream_t stream) {
     if (!h || !coords || !out || batch < 1 || points < 1 || frame < 1 || main_base < 0 ||
-        main_base + (int64_t)frame * frame > n_per_frame)
+        main_base + (int64_t)frame * frame > n_per_frame || out_frame_stride < (int64_t)points * C)
         return set_error(EG_ERR_ARG, "bad argument");
-    const BilArgs a{batch, points, frame, (long long)n_per_frame, (long long)main_base};
+    const BilArgs a{batch, points, frame, (long long)n_per_frame, (long long)main_base, (long long)out_frame_stride};
     const int n = batch * points;
     hipLaunchKernelGGL(k_bilinear4_fwd, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, coords, out, a);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }
 
+int eg_bilinear4_fwd(const float* h, const float* coords, int batch, int points, int64_t n_per_frame, int64_t main_base,
+                     int frame, float* out, eg_stream_t stream) {
+    return eg_bilinear4_fwd_rows(h, coords, batch, points, n_per_frame, main_base, frame, out, (int64_t)points * C, stream);
+}
+
 /* dh (may be NULL) is ACCUMULATED into: dh[tap rows] += w * dout; dcoords (may be NULL) is overwritten. */
-int eg_bilinear4_bwd(const float* dout, const float* h, const float* coords, int batch, int points, int64_t n_per_frame,
-                     int64_t main_base, int frame, float* dh, float* dcoords, eg_stream_t stream) {
+int eg_bilinear4_bwd_rows(const float* dout, int64_t dout_frame_stride, const float* h, const float* coords, int batch, int points,
+                          int64_t n_per_frame, int64_t main_base, int frame, float* dh, float* dcoords, eg_stream_t stream) {
     if (!dout || !h || !coords || batch < 1 || points < 1 || frame < 1 || main_base < 0 ||
-        main_base + (int64_t)frame * frame > n_per_frame)
+        main_base + (int64_t)frame * frame > n_per_frame || dout_frame_stride < (int64_t)points * C)
         return set_error(EG_ERR_ARG, "bad argument");
-    const BilArgs a{batch, points, frame, (long long)n_per_frame, (long long)main_base};
+    const BilArgs a{batch, points, frame, (long long)n_per_frame, (long long)main_base, (long long)dout_frame_stride};
     hipLaunchKernelGGL(k_bilinear4_bwd, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, dout, h, coords, dh, dcoords, a);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
+}
+
+int eg_bilinear4_bwd(const float* dout, const float* h, const float* coords, int batch, int points, int64_t n_per_frame,
+                     int64_t main_base, int frame, float* dh, float* dcoords, eg_stream_t stream) {
+    return eg_bilinear4_bwd_rows(dout, (int64_t)points * C, h, coords, batch, points, n_per_frame, main_base, frame, dh, dcoords, stream);
 }
 
 }  // extern "C"

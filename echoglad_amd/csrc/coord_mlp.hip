@@ -31,7 +31,10 @@ struct CoordMlpW {
 };
 
 struct CoordMlpFwd {
-    const float *lm, *coords;                   // [R,128], [R,2]
+    const float *lm, *coords;                   // rows of 128 (frame f, landmark j at lm + f * lm_stride + j * 128), [R,2]
+    long long lm_stride;                        // floats between two frames' landmark rows (4 * 128: a packed [R,128] array)
+    float* lm_copy;                             // nullable: packed [R,128] copy of the landmark rows (kept for the backward when the
+                                                // rows themselves -- coordinate rows inside [B*N,128] -- are overwritten afterwards)
     int rows, train;
     CoordMlpW w;
     float *rm1, *rv1, *rm2, *rv2;
@@ -41,6 +44,8 @@ struct CoordMlpFwd {
 
 struct CoordMlpBwd {
     const float *dnew, *lm, *coords, *pre, *z1, *z2, *bn;
+    long long lm_stride, dlm_stride;            // floats between two frames' rows of lm / dlm (4 * 128: packed)
+    int dlm_acc;                                // dlm += instead of dlm =
     int rows;
     CoordMlpW w;
     float cmax;
@@ -48,17 +53,20 @@ struct CoordMlpBwd {
 };
 
 // input column i of row r = (frame f, landmark j): the landmark's features, then the offsets to the frame's 4 landmarks
-__device__ inline float mlp_in(const float* __restrict__ lm, const float* __restrict__ coords, int r, int i) {
-    if (i < C) return lm[(size_t)r * C + i];
+__device__ inline float mlp_in(const float* __restrict__ lm, long long lm_stride, const float* __restrict__ coords, int r, int i) {
+    if (i < C) return lm[(size_t)(r >> 2) * lm_stride + (r & 3) * C + i];
     const int k = (i - C) >> 1, d = i & 1;
     return coords[((r & ~3) + k) * 2 + d] - coords[r * 2 + d];
 }
 
 // rows row0 .. row0 + 63 of cat(lm, shape_feats) -> s_in[64][CM_LDI] (rows past the end: zeros)
-__device__ inline void stage_inputs(const float* __restrict__ lm, const float* __restrict__ coords, int row0, int R, float* s_in) {
+__device__ inline void stage_inputs(const float* __restrict__ lm, long long lm_stride, const float* __restrict__ coords, int row0, int R,
+                                    float* s_in, float* __restrict__ lm_copy = nullptr) {
     for (int e = threadIdx.x; e < CM_TILE * CM_IN; e += CM_THREADS) {
         const int r = e / CM_IN, i = e - r * CM_IN, row = row0 + r;
-        s_in[r * CM_LDI + i] = row < R ? mlp_in(lm, coords, row, i) : 0.f;
+        const float v = row < R ? mlp_in(lm, lm_stride, coords, row, i) : 0.f;
+        s_in[r * CM_LDI + i] = v;
+        if (lm_copy && i < C && row < R) lm_copy[(size_t)row * C + i] = v;
     }
 }
 
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd 
     // ---- z1 = in W1^T + b1, 64 rows at a time: thread -> (row t >> 5 and +32, output channel t & 31)
     for (int row0 = 0; row0 < R; row0 += CM_TILE) {
         __syncthreads();
-        stage_inputs(lm, coords, row0, R, s_in);
+        stage_inputs(lm, a.lm_stride, coords, row0, R, s_in, a.lm_copy);
         __syncthreads();
         const int o = t & 31;
         const float b = a.w.b1[o];
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         for (int row0 = 0; row0 < R; row0 += CM_TILE) {
             __syncthreads();
-            stage_inputs(lm, coords, row0, R, s_in);
+            stage_inputs(lm, a.lm_stride, coords, row0, R, s_in);
             for (int e = t; e < CM_TILE * CM_H1; e += CM_THREADS) {
                 const int r = e >> 5, i = e & 31;
                 s_dz[r * CM_LDH + i] = row0 + r < R ? a.scratch[(row0 + r) * CM_SCR + CM_H2 + i] : 0.f;
@@ -382,7 +390,8 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
                     float acc = 0.f;
 #pragma unroll
                     for (int o = 0; o < CM_H1; ++o) acc += s_dz[r * CM_LDH + o] * s_w1[o * CM_LDW1 + i];
-                    a.dlm[(size_t)(row0 + r) * C + i] = acc;
+                    float* dp = a.dlm + (size_t)((row0 + r) >> 2) * a.dlm_stride + ((row0 + r) & 3) * C + i;
+                    *dp = a.dlm_acc ? *dp + acc : acc;
                 }
             }
             if (t < CM_TILE * 8) {
@@ -432,15 +441,16 @@ using namespace eg;
 
 extern "C" {
 
-int eg_coord_mlp_fwd(const float* lm, const float* coords, int batch, const eg_cls_train_params* P, int train, int frame,
-                     float* z1, float* z2, float* bn, float* pre, float* new_coords, eg_stream_t stream) {
+int eg_coord_mlp_fwd_rows(const float* lm, int64_t lm_frame_stride, float* lm_copy, const float* coords, int batch,
+                          const eg_cls_train_params* P, int train, int frame, float* z1, float* z2, float* bn, float* pre,
+                          float* new_coords, eg_stream_t stream) {
     if (!lm || !coords || !z1 || !z2 || !bn || !new_coords || !params_ok(P)) return set_error(EG_ERR_ARG, "NULL argument");
-    if (batch < 1 || frame < 1 || batch > (1 << 20)) return set_error(EG_ERR_ARG, "bad batch / frame");
+    if (batch < 1 || frame < 1 || batch > (1 << 20) || lm_frame_stride < 4 * C) return set_error(EG_ERR_ARG, "bad batch / frame / stride");
     if (!train && (!P->running_mean1 || !P->running_var1 || !P->running_mean2 || !P->running_var2))
         return set_error(EG_ERR_ARG, "eval mode needs the running statistics");
     if (!(P->p1 >= 0.f && P->p1 < 1.f && P->p2 >= 0.f && P->p2 < 1.f)) return set_error(EG_ERR_ARG, "dropout p must be in [0, 1)");
     CoordMlpFwd a{};
-    a.lm = lm; a.coords = coords; a.rows = 4 * batch; a.train = train ? 1 : 0;
+    a.lm = lm; a.lm_stride = lm_frame_stride; a.lm_copy = lm_copy; a.coords = coords; a.rows = 4 * batch; a.train = train ? 1 : 0;
     a.w = weights_of(P, train != 0);
     a.rm1 = P->running_mean1; a.rv1 = P->running_var1; a.rm2 = P->running_mean2; a.rv2 = P->running_var2;
     a.eps1 = P->eps1; a.eps2 = P->eps2; a.mom1 = P->momentum1; a.mom2 = P->momentum2; a.cmax = (float)(frame - 1);
@@ -450,20 +460,31 @@ int eg_coord_mlp_fwd(const float* lm, const float* coords, int batch, const eg_c
     return EG_OK;
 }
 
-int eg_coord_mlp_bwd(const float* dnew_coords, const float* lm, const float* coords, int batch, const eg_cls_train_params* P,
-                     int frame, const float* z1, const float* z2, const float* bn, const float* pre, float* scratch, float* dlm,
-                     float* dcoords, float* grads, eg_stream_t stream) {
+int eg_coord_mlp_fwd(const float* lm, const float* coords, int batch, const eg_cls_train_params* P, int train, int frame,
+                     float* z1, float* z2, float* bn, float* pre, float* new_coords, eg_stream_t stream) {
+    return eg_coord_mlp_fwd_rows(lm, 4 * C, nullptr, coords, batch, P, train, frame, z1, z2, bn, pre, new_coords, stream);
+}
+
+int eg_coord_mlp_bwd_rows(const float* dnew_coords, const float* lm, const float* coords, int batch, const eg_cls_train_params* P,
+                          int frame, const float* z1, const float* z2, const float* bn, const float* pre, float* scratch, float* dlm,
+                          int64_t dlm_frame_stride, int dlm_accumulate, float* dcoords, float* grads, eg_stream_t stream) {
     if (!dnew_coords || !lm || !coords || !z1 || !z2 || !bn || !pre || !scratch || !grads || !params_ok(P))
         return set_error(EG_ERR_ARG, "NULL argument");
-    if (batch < 1 || frame < 1 || batch > (1 << 20)) return set_error(EG_ERR_ARG, "bad batch / frame");
+    if (batch < 1 || frame < 1 || batch > (1 << 20) || dlm_frame_stride < 4 * C) return set_error(EG_ERR_ARG, "bad batch / frame / stride");
     CoordMlpBwd a{};
-    a.dnew = dnew_coords; a.lm = lm; a.coords = coords; a.pre = pre; a.z1 = z1; a.z2 = z2; a.bn = bn; a.rows = 4 * batch;
+    a.dnew = dnew_coords; a.lm = lm; a.lm_stride = 4 * C; a.coords = coords; a.pre = pre; a.z1 = z1; a.z2 = z2; a.bn = bn; a.rows = 4 * batch;
     a.w = weights_of(P, true);
     a.cmax = (float)(frame - 1);
-    a.scratch = scratch; a.dlm = dlm; a.dcoords = dcoords; a.grads = grads;
+    a.scratch = scratch; a.dlm = dlm; a.dlm_stride = dlm_frame_stride; a.dlm_acc = dlm_accumulate ? 1 : 0; a.dcoords = dcoords; a.grads = grads;
     hipLaunchKernelGGL(k_coord_mlp_bwd, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
+}
+
+int eg_coord_mlp_bwd(const float* dnew_coords, const float* lm, const float* coords, int batch, const eg_cls_train_params* P,
+                     int frame, const float* z1, const float* z2, const float* bn, const float* pre, float* scratch, float* dlm,
+                     float* dcoords, float* grads, eg_stream_t stream) {
+    return eg_coord_mlp_bwd_rows(dnew_coords, lm, coords, batch, P, frame, z1, z2, bn, pre, scratch, dlm, 4 * C, 0, dcoords, grads, stream);
 }
 
 }  // extern "C"

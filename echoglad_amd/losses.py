@@ -58,36 +58,31 @@ class ExpectedLandmarkMSE:
         self.levels = level_grids(frame_size, num_aux_graphs, use_main_graph_only)
         self.grid_sizes = [s for _, s in self.levels]
         self.end_indices = [st + s * s for st, s in self.levels]
-        self._side = {}                    # device -> [1,L,1,1] 1 / level side (built once: a host list -> device tensor is a blocking copy)
+        self._side = {}                    # device -> [L] 1 / level side (built once: a host list -> device tensor is a blocking copy)
 
     def compute(self, pred_y, y, valid):
         expect, gt, vmean = ops.heatmap_expect(_rows4(pred_y), self.batch_size, self.levels, _rows4(y), _rows4(valid))
         inv_side = self._side.get(expect.device)
         if inv_side is None:
-            inv_side = self._side[expect.device] = 1.0 / torch.tensor(self.grid_sizes, dtype=torch.float32,
-                                                                      device=expect.device).view(1, -1, 1, 1)
+            inv_side = self._side[expect.device] = (1.0 / torch.tensor(self.grid_sizes, dtype=torch.float32,
+                                                                       device=expect.device)).contiguous()
         return _ElmReduceFn.apply(expect, gt, vmean, inv_side, float(self.loss_weight))
 
 
 class _ElmReduceFn(torch.autograd.Function):
     """criterion.py:133-151 on the per-(frame, level, channel) expectations:
         loss = w * sum_{l,c,xy} [ sum_b ((e - gt) / side)^2 * vmean ] / nv,    nv = sum_b vmean (1 where that is 0)
-    with the gradient written out: 9 small launches forward and 4 backward where autograd's graph of the same expression took
-    about 35 (each costs ~5 us of GPU time at this size, whatever it computes)."""
+    value AND gradient from one single-workgroup launch (eg_elm_reduce); the backward is one multiply.  (Autograd's graph of the
+    same expression took about 35 launches, round 4's hand-written torch form 13: each costs ~5 us of GPU time and ~10 us of host
+    time whatever it computes, and at batch 1 the training step is bound by the host.)"""
 
     @staticmethod
     def forward(ctx, expect, gt, vmean, inv_side, weight):
-        nv = vmean.sum(dim=0, keepdim=True)                                    # [1,L,4]
-        nv = torch.where(nv == 0, torch.ones_like(nv), nv)
-        diff = (expect - gt) * inv_side                                        # [B,L,4,2]
-        wv = (vmean / nv).unsqueeze(-1)                                        # [B,L,4,1]
-        ctx.save_for_backward(diff, wv, inv_side)
-        ctx.weight = weight
-        return (diff * diff * wv).sum() * weight
+        loss, d = ops.elm_reduce(expect.contiguous(), gt.contiguous(), vmean.contiguous(), inv_side, weight)
+        ctx.save_for_backward(d)
+        return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        diff, wv, inv_side = ctx.saved_tensors
-        d = diff * wv
-        d.mul_(inv_side).mul_(g * (2.0 * ctx.weight))
-        return d, None, None, None, None
+        (d,) = ctx.saved_tensors
+        return d * g, None, None, None, None

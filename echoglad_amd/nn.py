@@ -224,13 +224,14 @@ _MLP_NAMES = ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3"
 def _coord_update_fwd(h, coords_prev, dims, mlp_cfg, mlp_params, want_backward=True):
     """h [B*N,128] (coordinate rows overwritten IN PLACE) -> (new coords [4B,2], state for _coord_update_bwd)."""
     B, n, main_base, frame, coord_base = dims
-    lm = h.view(B, n, C)[:, coord_base:coord_base + 4, :].reshape(B * 4, C).clone()     # (a COPY also at B = 1, where the slice is contiguous: the rows change below)
     P = dict(mlp_cfg)
     P.update({k: p.detach().contiguous() for k, p in zip(_MLP_NAMES, mlp_params)})
     flat = coords_prev.reshape(B * 4, 2).contiguous()
-    new, saved = ops.coord_mlp_fwd(lm, flat, B, P, True, frame, want_backward)
-    rows = ops.bilinear4_fwd(h, new, B, n, main_base, frame)
-    h.view(B, n, C)[:, coord_base:coord_base + 4, :] = rows.view(B, 4, C)
+    # the MLP reads the coordinate rows where they live (and leaves the packed copy the backward needs: the rows change below),
+    # the samples are written straight into them: no gather / scatter launches around the two kernels
+    lm = torch.empty(B * 4, C, dtype=torch.float32, device=h.device)
+    new, saved = ops.coord_mlp_fwd(lm, flat, B, P, True, frame, want_backward, in_rows=(h, n, coord_base))
+    ops.bilinear4_fwd(h, new, B, n, main_base, frame, out_rows=(h, n, coord_base))
     return new, (lm, flat, saved, {k: v for k, v in P.items() if not k.startswith("running")})
 
 
@@ -238,20 +239,17 @@ def _coord_update_bwd(dx, dcoords_new, h, new, lm, flat, saved, P, dims, need_dp
     """dx: gradient w.r.t. the tensor AFTER the overwrite, a buffer the caller has just allocated; turned IN PLACE into the
     gradient w.r.t. the tensor BEFORE it.  -> (dcoords_prev [4B,2] | None, packed MLP gradients)."""
     B, n, main_base, frame, coord_base = dims
-    rows = dx.view(B, n, C)[:, coord_base:coord_base + 4, :]
     total = dcoords_new
     if sampled_rows_used:
-        dnew = rows.reshape(B * 4, C).clone()                    # gradient of the sampled rows (a copy also at B = 1)
-        rows.zero_()                                             # (their old values were overwritten)
-        dbil = ops.bilinear4_bwd(dnew, h, new, B, n, main_base, frame, dh=dx, want_dcoords=True)      # 16 taps per frame into dx
+        # the sampled rows' gradient is read where it lies (the coordinate rows of dx), 16 taps per frame go into dx's main-grid
+        # rows; the coordinate rows themselves are overwritten below (their old values were overwritten in the forward)
+        dbil = ops.bilinear4_bwd(None, h, new, B, n, main_base, frame, dh=dx, want_dcoords=True, dout_rows=(dx, n, coord_base))
         total = dbil if total is None else total + dbil
     if total is None:
         total = torch.zeros(B * 4, 2, dtype=torch.float32, device=dx.device)
-    dlm, dprev, g = ops.coord_mlp_bwd(total.contiguous().view(B * 4, 2), lm, flat, B, P, frame, saved, True, need_dprev)
-    if sampled_rows_used:
-        rows.copy_(dlm.view(B, 4, C))                            # the coordinate rows fed the MLP, nothing else
-    else:
-        rows.add_(dlm.view(B, 4, C))
+    # d lm goes straight into the coordinate rows: they fed the MLP and nothing else (= when their samples were used, += otherwise)
+    _, dprev, g = ops.coord_mlp_bwd(total.contiguous().view(B * 4, 2), lm, flat, B, P, frame, saved, True, need_dprev,
+                                    out_rows=(dx, n, coord_base), accumulate=not sampled_rows_used)
     return dprev, g
 
 

@@ -560,40 +560,67 @@ def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_vali
 COORD_MLP_GRADS_FLOATS = 5042
 
 
-def coord_mlp_fwd(lm, coords, batch: int, P: dict, train: bool, frame: int, want_backward: bool):
+def _frame_rows_ptr(h, batch: int, n_per_frame: int, row0: int):
+    """(pointer to row `row0` of frame 0, floats between two frames) of a [batch * n_per_frame, 128] node array: where the 4
+    coordinate rows of every frame live (eg_*_rows entry points)."""
+    _check_rows(h, "h", batch * n_per_frame)
+    if row0 < 0 or row0 + 4 > n_per_frame:
+        raise RuntimeError("the 4 rows must lie inside a frame")
+    return ct.c_void_p(h.data_ptr() + row0 * C * 4), n_per_frame * C
+
+
+def coord_mlp_fwd(lm, coords, batch: int, P: dict, train: bool, frame: int, want_backward: bool, in_rows=None):
     """lm [4*batch,128], coords [4*batch,2] -> (new_coords [4*batch,2], saved = (z1, z2, bn, pre) | None).
-    P: the _cls_params dictionary with the 136-32-16-2 head's tensors."""
+    P: the _cls_params dictionary with the 136-32-16-2 head's tensors.
+    in_rows = (h, n_per_frame, row0): the landmark rows are rows row0 .. row0 + 3 of every frame of h (no gathered copy); `lm`
+    is then an OUTPUT -- the packed copy of those rows the backward needs -- or None."""
     rows = 4 * batch
-    if not lm.is_cuda or lm.dtype != torch.float32 or not lm.is_contiguous() or tuple(lm.shape) != (rows, C):
+    if lm is not None and (not lm.is_cuda or lm.dtype != torch.float32 or not lm.is_contiguous() or tuple(lm.shape) != (rows, C)):
         raise RuntimeError(f"lm must be a contiguous CUDA float32 [{rows}, {C}] tensor")
+    if lm is None and in_rows is None:
+        raise RuntimeError("lm or in_rows")
     _check_coords(coords, batch, 4)
     for k, shape in (("w1", (32, C + 8)), ("w2", (16, 32)), ("w3", (2, 16))):
         if tuple(P[k].shape) != shape:
             raise RuntimeError(f"coordinate MLP {k} must be {shape}, got {tuple(P[k].shape)}")
-    dev = lm.device
+    dev = coords.device
     z1 = torch.empty(rows, 32, dtype=torch.float32, device=dev)
     z2 = torch.empty(rows, 16, dtype=torch.float32, device=dev)
     bn = torch.empty(96, dtype=torch.float32, device=dev)
     pre = torch.empty(rows, 2, dtype=torch.float32, device=dev) if want_backward else None
     new = torch.empty(rows, 2, dtype=torch.float32, device=dev)
     s = _cls_params(P)
-    _lib.check(_lib.load().eg_coord_mlp_fwd(_ptr(lm), _ptr(coords), batch, ct.byref(s), int(train), frame, _ptr(z1), _ptr(z2),
-                                            _ptr(bn), _ptr(pre), _ptr(new), _stream()), "eg_coord_mlp_fwd")
+    if in_rows is not None:
+        ptr, stride = _frame_rows_ptr(in_rows[0], batch, in_rows[1], in_rows[2])
+        _lib.check(_lib.load().eg_coord_mlp_fwd_rows(ptr, stride, _ptr(lm), _ptr(coords), batch, ct.byref(s), int(train), frame,
+                                                     _ptr(z1), _ptr(z2), _ptr(bn), _ptr(pre), _ptr(new), _stream()), "eg_coord_mlp_fwd_rows")
+    else:
+        _lib.check(_lib.load().eg_coord_mlp_fwd(_ptr(lm), _ptr(coords), batch, ct.byref(s), int(train), frame, _ptr(z1), _ptr(z2),
+                                                _ptr(bn), _ptr(pre), _ptr(new), _stream()), "eg_coord_mlp_fwd")
     return new, ((z1, z2, bn, pre) if want_backward else None)
 
 
-def coord_mlp_bwd(dnew, lm, coords, batch: int, P: dict, frame: int, saved, need_dlm: bool, need_dcoords: bool):
-    """-> (dlm | None, dcoords | None, grads [5042] packed as in include/echoglad_hip.h)"""
+def coord_mlp_bwd(dnew, lm, coords, batch: int, P: dict, frame: int, saved, need_dlm: bool, need_dcoords: bool, out_rows=None,
+                  accumulate: bool = False):
+    """-> (dlm | None, dcoords | None, grads [5042] packed as in include/echoglad_hip.h)
+    out_rows = (dh, n_per_frame, row0): dlm is written (accumulate: added) into rows row0 .. row0 + 3 of every frame of dh
+    instead of being returned."""
     rows = 4 * batch
     z1, z2, bn, pre = saved
     dev = lm.device
     if not dnew.is_cuda or dnew.dtype != torch.float32 or not dnew.is_contiguous() or dnew.numel() != rows * 2:
         raise RuntimeError(f"dnew must be contiguous CUDA float32 with {rows * 2} elements")
     scratch = torch.empty(rows, 56, dtype=torch.float32, device=dev)
-    dlm = torch.empty(rows, C, dtype=torch.float32, device=dev) if need_dlm else None
+    dlm = torch.empty(rows, C, dtype=torch.float32, device=dev) if (need_dlm and out_rows is None) else None
     dcoords = torch.empty(rows, 2, dtype=torch.float32, device=dev) if need_dcoords else None
     grads = torch.empty(COORD_MLP_GRADS_FLOATS, dtype=torch.float32, device=dev)
     s = _cls_params(P)
+    if out_rows is not None:
+        ptr, stride = _frame_rows_ptr(out_rows[0], batch, out_rows[1], out_rows[2])
+        _lib.check(_lib.load().eg_coord_mlp_bwd_rows(_ptr(dnew), _ptr(lm), _ptr(coords), batch, ct.byref(s), frame, _ptr(z1), _ptr(z2),
+                                                     _ptr(bn), _ptr(pre), _ptr(scratch), ptr, stride, int(accumulate), _ptr(dcoords),
+                                                     _ptr(grads), _stream()), "eg_coord_mlp_bwd_rows")
+        return None, dcoords, grads
     _lib.check(_lib.load().eg_coord_mlp_bwd(_ptr(dnew), _ptr(lm), _ptr(coords), batch, ct.byref(s), frame, _ptr(z1), _ptr(z2),
                                             _ptr(bn), _ptr(pre), _ptr(scratch), _ptr(dlm), _ptr(dcoords), _ptr(grads),
                                             _stream()), "eg_coord_mlp_bwd")
@@ -609,20 +636,32 @@ def _check_coords(coords, batch, points):
         raise RuntimeError(f"coords must be contiguous CUDA float32 with {batch * points * 2} elements")
 
 
-def bilinear4_fwd(h, coords, batch, n_per_frame, main_base, frame, points=4) -> torch.Tensor:
+def bilinear4_fwd(h, coords, batch, n_per_frame, main_base, frame, points=4, out_rows=None) -> torch.Tensor:
+    """out_rows = (dst, n_per_frame, row0): the samples are written into rows row0 .. of every frame of dst (None is returned)."""
     _check_rows(h, "h", batch * n_per_frame)
     _check_coords(coords, batch, points)
+    if out_rows is not None:
+        ptr, stride = _frame_rows_ptr(out_rows[0], batch, out_rows[1], out_rows[2])
+        _lib.check(_lib.load().eg_bilinear4_fwd_rows(_ptr(h), _ptr(coords), batch, points, n_per_frame, main_base, frame, ptr, stride,
+                                                     _stream()), "eg_bilinear4_fwd_rows")
+        return None
     out = torch.empty(batch * points, C, dtype=torch.float32, device=h.device)
     _lib.check(_lib.load().eg_bilinear4_fwd(_ptr(h), _ptr(coords), batch, points, n_per_frame, main_base, frame,
                                             _ptr(out), _stream()), "eg_bilinear4_fwd")
     return out
 
 
-def bilinear4_bwd(dout, h, coords, batch, n_per_frame, main_base, frame, dh=None, want_dcoords=True, points=4):
+def bilinear4_bwd(dout, h, coords, batch, n_per_frame, main_base, frame, dh=None, want_dcoords=True, points=4, dout_rows=None):
+    """dout_rows = (src, n_per_frame, row0): the samples' gradient is read from rows row0 .. of every frame of src (dout is None)."""
     _check_rows(h, "h", batch * n_per_frame)
     _check_coords(coords, batch, points)
-    dout = dout.contiguous()
     dcoords = torch.empty(batch * points, 2, dtype=torch.float32, device=h.device) if want_dcoords else None
+    if dout_rows is not None:
+        ptr, stride = _frame_rows_ptr(dout_rows[0], batch, dout_rows[1], dout_rows[2])
+        _lib.check(_lib.load().eg_bilinear4_bwd_rows(ptr, stride, _ptr(h), _ptr(coords), batch, points, n_per_frame, main_base, frame,
+                                                     _ptr(dh), _ptr(dcoords), _stream()), "eg_bilinear4_bwd_rows")
+        return dcoords
+    dout = dout.contiguous()
     _lib.check(_lib.load().eg_bilinear4_bwd(_ptr(dout), _ptr(h), _ptr(coords), batch, points, n_per_frame, main_base,
                                             frame, _ptr(dh), _ptr(dcoords), _stream()), "eg_bilinear4_bwd")
     return dcoords
@@ -755,6 +794,22 @@ class _HeatmapExpectFn(torch.autograd.Function):
 def heatmap_expect(logits, batch: int, levels, labels=None, valid=None):
     """(expect, gt, vmean) with autograd through `expect` (d/d logits)."""
     return _HeatmapExpectFn.apply(logits, batch, tuple(levels), labels, valid)
+
+
+def elm_reduce(expect, gt, vmean, inv_side, weight: float):
+    """ExpectedLandmarkMSE's combination of the per-(frame, level, channel) expectations and its gradient in one launch
+    (eg_elm_reduce) -> (loss [1], d loss / d expect [B, L, 4, 2])."""
+    B, L = int(expect.shape[0]), int(expect.shape[1])
+    for name, t, shape in (("expect", expect, (B, L, 4, 2)), ("gt", gt, (B, L, 4, 2)), ("vmean", vmean, (B, L, 4)), ("inv_side", inv_side, None)):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or (shape is not None and tuple(t.shape) != shape):
+            raise RuntimeError(f"{name} must be a contiguous CUDA float32 tensor" + (f" of shape {shape}" if shape else ""))
+    if inv_side.numel() != L:
+        raise RuntimeError("inv_side must hold one value per level")
+    loss = torch.empty(1, dtype=torch.float32, device=expect.device)
+    d = torch.empty_like(expect)
+    _lib.check(_lib.load().eg_elm_reduce(_ptr(expect), _ptr(gt), _ptr(vmean), _ptr(inv_side), B, L, ct.c_float(weight), _ptr(loss),
+                                         _ptr(d), _stream()), "eg_elm_reduce")
+    return loss, d
 
 
 def bce_logits_fwd(logits, labels, valid, ones_weight: float) -> torch.Tensor:

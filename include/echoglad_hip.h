@@ -67,7 +67,7 @@ extern "C" {
  * the new calls with shifted arguments).  130: eg_topo_create with the reference builder's full flag set, jk_in inside
  * eg_gcn_layer_cls_fwd, eg_graph_set_precision removed (round 3); train-forward child sums, fused heads backward, the
  * 64-slice queue ring refuses instead of corrupting (round 4).  131: eg_classifier_train_fwd_act.
- * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_* (round 5). */
+ * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_*, eg_elm_reduce, eg_coord_mlp_*_rows, eg_bilinear4_*_rows (round 5). */
 #define EG_ABI_VERSION 133
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
@@ -372,6 +372,18 @@ int eg_coord_mlp_fwd(const float* lm, const float* coords, int batch, const eg_c
 int eg_coord_mlp_bwd(const float* dnew_coords, const float* lm, const float* coords, int batch,
                      const eg_cls_train_params* params, int frame, const float* z1, const float* z2, const float* bn,
                      const float* pre, float* scratch, float* dlm, float* dcoords, float* grads, eg_stream_t stream);
+/* The same two with the landmark rows where they LIVE -- the 4 coordinate rows of every frame inside the [B*N,128] node array
+ * (models.py:447: h[node_type == 1]) -- instead of a gathered copy: frame f's rows start at lm + f * lm_frame_stride (floats;
+ * 4 * 128 = a packed array).  lm_copy (nullable): packed [R,128] copy of the rows as the MLP read them, for the backward (the
+ * coordinate update overwrites the rows afterwards, :473).  Backward: dlm is written (dlm_accumulate: added) with the same
+ * frame stride, i.e. straight into the coordinate rows of the gradient array.  No gather / scatter launches around the MLP. */
+int eg_coord_mlp_fwd_rows(const float* lm, int64_t lm_frame_stride, float* lm_copy, const float* coords, int batch,
+                          const eg_cls_train_params* params, int train, int frame, float* z1, float* z2, float* bn, float* pre,
+                          float* new_coords, eg_stream_t stream);
+int eg_coord_mlp_bwd_rows(const float* dnew_coords, const float* lm, const float* coords, int batch,
+                          const eg_cls_train_params* params, int frame, const float* z1, const float* z2, const float* bn,
+                          const float* pre, float* scratch, float* dlm, int64_t dlm_frame_stride, int dlm_accumulate,
+                          float* dcoords, float* grads, eg_stream_t stream);
 
 /* ---- coordinate-graph resampling (src/core/models.py:539-553 as a 4-tap gather) -------------------
  * coords [batch*points, 2] in (h, w) order; out[p,:] = bilinear sample of frame p/points' main grid
@@ -381,6 +393,12 @@ int eg_bilinear4_fwd(const float* h, const float* coords, int batch, int points,
 /* dh (nullable) is accumulated into (+=) at the touched rows; dcoords (nullable) [batch*points,2] is overwritten */
 int eg_bilinear4_bwd(const float* dout, const float* h, const float* coords, int batch, int points, int64_t n_per_frame,
                      int64_t main_base, int frame, float* dh, float* dcoords, eg_stream_t stream);
+/* ... with the sample rows of frame f at out / dout + f * frame_stride (floats): the samples land in (their gradient is read
+ * from) the coordinate rows of the node array itself (models.py:473 h[node_type == 1] = new features). */
+int eg_bilinear4_fwd_rows(const float* h, const float* coords, int batch, int points, int64_t n_per_frame, int64_t main_base,
+                          int frame, float* out, int64_t out_frame_stride, eg_stream_t stream);
+int eg_bilinear4_bwd_rows(const float* dout, int64_t dout_frame_stride, const float* h, const float* coords, int batch, int points,
+                          int64_t n_per_frame, int64_t main_base, int frame, float* dh, float* dcoords, eg_stream_t stream);
 
 /* ---- losses on the logits and landmark decode (the steps right after the hot path) ---------------------
  * Reference: src/core/criterion.py:13-27 (WeightedBCEWithLogitsLoss), :93-151 (ExpectedLandmarkMSE),
@@ -407,6 +425,11 @@ int eg_heatmap_expect_fwd(const float* logits, const float* labels, const float*
 int eg_heatmap_expect_bwd(const float* logits, const float* expect, const float* stats, const float* d_expect, int batch,
                           int64_t n_rows, const int* level_start, const int* level_side, int n_levels, float* d_logits,
                           eg_stream_t stream);
+/* ExpectedLandmarkMSE's combination of those expectations (criterion.py:133-151) and its gradient in one launch:
+ *   loss[0] = weight * sum_{l,c,xy} [ sum_b ((expect - gt) * inv_side[l])^2 * vmean ] / nv,  nv = sum_b vmean (1 where 0);
+ *   d_expect [batch,n_levels,4,2] = d loss / d expect.  inv_side: DEVICE array [n_levels] = 1 / level side. */
+int eg_elm_reduce(const float* expect, const float* gt, const float* vmean, const float* inv_side, int batch, int n_levels,
+                  float weight, float* loss, float* d_expect, eg_stream_t stream);
 int eg_bce_logits_fwd(const float* logits, const float* labels, const float* valid, int64_t n, float ones_weight,
                       void* workspace, float* out3, eg_stream_t stream);
 int eg_bce_logits_bwd(const float* logits, const float* labels, const float* valid, int64_t n, float ones_weight,
