@@ -41,6 +41,29 @@ def soak(frame, naux, B, mode, reps, main_only=False, diag=False, conn=False):
     return bad
 
 
+def soak_csr(reps, B=8):
+    """configs[1]'s batch as a plain edge_index: the CSR handle's clustered tiles (round 5) and, on the stencil handle, the
+    unchained producer/consumer launch that plain calls take since round 5."""
+    from echoglad_amd.topology import TopologySpec, get_topology
+    topo = get_topology(TopologySpec(224, 7, False, False))
+    ei = torch.from_numpy(topo.batched_edge_index(B)).to(DEV)
+    n = B * topo.num_nodes
+    x = synthetic_node_feats(n, 128, seed=1).to(DEV)
+    w = (synthetic_node_feats(128, 128, seed=2) * 0.1).to(DEV)
+    total = 0
+    for label, g, gb in (("CSR handle (clustered tiles)", ops.Graph.csr(ei, n), 1), ("stencil handle, plain call", ops.Graph.topo(224, 7), B)):
+        first, bad = None, 0
+        for _ in range(reps):
+            out = ops.gcn_layer_fwd(g, gb, x, w, None, None, x, relu=True)
+            if first is None:
+                first = out.clone()
+            elif not torch.equal(out, first):
+                bad += 1
+        print(f"224x224 naux=7 B={B} {label}: {bad} of {reps - 1} launches differ from the first", flush=True)
+        total += bad
+    return total
+
+
 def soak_train(reps):
     """One configs[3] training step (224/7 + coordinate graph, batch 32, dropout 0.5) repeated from the same state and host
     RNG seed: logits, coordinates and every parameter gradient must come out bit-identical."""
@@ -81,5 +104,6 @@ if __name__ == "__main__":
         total += soak(224, 7, 8, mode, reps, diag=True)                 # 'grid-diagonal' levels (round 4)
         total += soak(224, 7, 8, mode, reps, conn=True)                 # connection nodes: pre-pass + stencil
         total += soak(224, 7, 8, mode, max(reps // 2, 2), diag=True, conn=True)
+    total += soak_csr(reps)
     total += soak_train(max(reps // 10, 3))
     sys.exit(1 if total else 0)
