@@ -177,7 +177,8 @@ struct Knobs {
     int ring_guard;     // EG_RING_GUARD  0: no event behind a launch (diagnostic: the queue ring is then unguarded, as before round 4)
     int csr_tiles;      // EG_CSR_TILES   CSR handles: 2 (default) clustered 64-node tiles with an LDS row stash, 1 the same stash over
                         //                consecutive rows (no clustering), 0 the plain row-by-row aggregator
-    int queue_self_reset;   // EG_QUEUE_SELF_RESET  1 (default): the layer kernels zero their queue slice on the way out; 0: a memset in front of every launch
+    int queue_self_reset;   // EG_QUEUE_SELF_RESET  the layer kernels always zero their queue slice on the way out; 0 (diagnostic): a memset in front
+                            //                      of every eager launch as well (never recorded into a captured graph)
 };
 Knobs read_knobs();
 const Knobs& process_knobs();

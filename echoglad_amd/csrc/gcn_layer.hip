@@ -540,11 +540,15 @@ static int launch_layer(int agg, LayerArgs& a, hipStream_t stream, int* grid_out
     // handed is clean by the same invariant (common.h); EG_QUEUE_SELF_RESET=0 / stamp builds: a memset in front instead
 #ifdef EG_STAMP
     a.d.self_reset = 0;
+    if (a.d.walk_mode == WALK_QUEUE) EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
 #else
-    a.d.self_reset = (a.d.walk_mode == WALK_QUEUE && a.knobs.queue_self_reset != 0) ? 1 : 0;
+    a.d.self_reset = a.d.walk_mode == WALK_QUEUE ? 1 : 0;
+    if (a.d.walk_mode == WALK_QUEUE && a.knobs.queue_self_reset == 0) {      // (diagnostic: an extra memset in front of EAGER launches; gcn_layer_ps.hip)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
+    }
 #endif
-    if (a.d.walk_mode == WALK_QUEUE && !a.d.self_reset)
-        EG_HIP_TRY(hipMemsetAsync(a.walk_counters, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
     const bool res_lds = (a.residual == nullptr) || (a.residual == a.x);     // epilogue residual from the LDS stash / none
     eg::LaunchTimer timer(EG_LAUNCH_SYMMETRIC, stream);
     switch (agg) {

@@ -890,12 +890,21 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     }
     // every queue-walking kernel zeroes its slice on the way out (see this kernel's last lines and k_gcn_layer's): a slice is clean
     // whenever it is handed out -- a device invariant, so nothing here depends on host state that a HIP-graph replay would not see
+    // EG_QUEUE_SELF_RESET=0 (diagnostic) puts a memset in front of every EAGER launch in addition; the kernel resets its slice all
+    // the same, and a launch that is being captured never records a memset node: a graph of memset + kernel nodes captured after
+    // the handle had launched on another stream replayed WITHOUT running its tiles (round 5, `tools/gpu_job.sh` knob matrix:
+    // the GPU suite under every run-time knob), so replays must not depend on one
 #ifdef EG_STAMP
     const bool self_reset = false;
+    EG_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
 #else
-    const bool self_reset = g->knobs.queue_self_reset != 0;
+    const bool self_reset = true;
+    if (g->knobs.queue_self_reset == 0) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) EG_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
+    }
 #endif
-    if (!self_reset) EG_HIP_TRY(hipMemsetAsync(queue, 0, sizeof(int) * QUEUE_SLICE_INTS, stream));
     a.self_reset = self_reset ? 1 : 0;
     if (g->n_conn > 0) {                                          // connection nodes: level sums of THIS launch's input first (conn.hip)
         const float* slice = nullptr;

@@ -512,8 +512,12 @@ def test_layer_train_composites_vs_torch_autograd(frame, naux, coord, relu, resi
     dy = rand_rows(B * n, seed=4).to(DEV)
     dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(g.bwd, B, dy, z, agg, W, gamma, beta, bn, relu, p, seed, residual, True, True)
     (want * dy).sum().backward()
+    # (a pre-activation within rounding of the ReLU kink that the kernel and the fp32 reference put on different sides moves single
+    # entries by a whole term, DESIGN 5.33 -- seen on the symmetric-kernel route, EG_TRAIN_PS=0, at 64 / 6: 0.6 % of the largest dx
+    # entry in a handful of entries -- so: the bulk tightly, no entry grossly)
     for got, ref, name in ((dx, xr.grad, "dx"), (dw, Wr.grad, "dw"), (dgamma, gr.grad, "dgamma"), (dbeta, ber.grad, "dbeta")):
-        assert (got - ref).abs().max() < 5e-3 * ref.abs().max() + 1e-6, name
+        assert (got - ref).norm() < 2e-3 * ref.norm() + 1e-6, name
+        assert (got - ref).abs().max() < 2e-2 * ref.abs().max() + 1e-6, name
     assert db.abs().max() == 0 and br.grad.abs().max() < 1e-3 * dw.abs().max()      # the bias gradient is analytically zero
 
 
@@ -586,12 +590,12 @@ def test_chained_train_step_equals_unchained(monkeypatch):
             for q in hip.parameters():
                 q.grad = None
             g = hip._resolver.resolve(ei.to(DEV), x.shape[0])[0]
-            before = g.ps_launches
+            before = g.layer_launches
             got, gc = hip.forward_nodes(x, ei.to(DEV), B, None if coords0 is None else coords0.clone())
             ((got ** 2).mean() + (0 if gc is None else (gc ** 2).mean() * 1e-3)).backward()
             res[chain] = (got.detach().clone(), None if gc is None else gc.detach().clone(),
                           {k: q.grad.clone() for k, q in hip.named_parameters()})
-            assert g.ps_launches > before
+            assert g.layer_launches > before               # (the producer / consumer kernel by default, the symmetric one under EG_TRAIN_PS=0)
         assert hip._train_kidsums(hip._resolver.resolve(ei.to(DEV), x.shape[0])[0], B)[0] is None       # knob off now
         a, b = res["1"], res["0"]
         assert float((a[0] - b[0]).abs().max()) < 2e-5 * max(1.0, float(b[0].abs().max()))
@@ -954,7 +958,10 @@ def test_whole_train_step_with_dropout_against_the_oracle_under_the_kernels_mask
     assert err_l <= 4 * ref_err_l + 8 * ulp * float(w64.abs().max()), (err_l, ref_err_l)
     assert err_c <= 4 * ref_err_c + 8 * ulp * frame, (err_c, ref_err_c)
     assert (got.detach().cpu() - w32).abs().max() < 2e-4 * max(1.0, float(w32.abs().max()))
-    assert_param_grads_close(hip, ref)
+    # (9.8 M pre-activations per layer: about 8 of them lie within an fp32 ulp of the ReLU kink, and each one that the kernel and
+    # the fp32 oracle put on different sides moves ONE channel of a weight gradient by ~2e-3 of its largest entry, DESIGN 5.33 --
+    # the default route met 2 flipped channels per parameter with this seed, the symmetric-kernel route (EG_TRAIN_PS=0) 16)
+    assert_param_grads_close(hip, ref, flipped_channels=24)
     # the masks matter: without them the oracle (its own Bernoulli draws) is nowhere near
     plain = O.OracleHierarchicalPatchModel(frame_size=frame, gnn_dropout_p=p, classifier_dropout_p=p, node_embedding_dim=128,
                                            node_hidden_dim=128, num_output_channels=4, num_gnn_layers=L, num_aux_graphs=naux,
