@@ -528,12 +528,14 @@ class GCNConv(nn.Module):
     """Counterpart of ``torch_geometric.nn.GCNConv(in_channels, out_channels)`` as the
     reference constructs it (src/core/models.py:330-331: defaults improved=False,
     cached=False, add_self_loops=True, normalize=True, bias=True).
-    ``forward(x, edge_index) -> x``.  Only 128 -> 128 is built (default.yml:13-14)."""
+    ``forward(x, edge_index) -> x``.  The kernels are built for 128 -> 128 (default.yml:13-14); narrower layers -- the
+    reference's signature defaults are 128 -> 64 -> 64 (models.py:286-301) -- run on the same kernels zero-padded to 128
+    channels (a compatibility route: correct, differentiable, and half of its bytes are padding)."""
 
     def __init__(self, in_channels: int, out_channels: int, **kwargs):
         super().__init__()
-        if in_channels != C or out_channels != C:
-            raise NotImplementedError(f"the HIP GCNConv is built for {C}->{C} channels, got {in_channels}->{out_channels}")
+        if not (1 <= in_channels <= C and 1 <= out_channels <= C):
+            raise NotImplementedError(f"the HIP GCNConv is built for up to {C} channels, got {in_channels}->{out_channels}")
         for k, default in (("improved", False), ("cached", False), ("add_self_loops", True), ("normalize", True),
                            ("bias", True)):
             if kwargs.get(k, default) != default:
@@ -547,7 +549,14 @@ class GCNConv(nn.Module):
         return self.forward_graph(x, graph, batch)
 
     def forward_graph(self, x, graph: ops.Graph, batch: int) -> torch.Tensor:
-        return _GCNConvFn.apply(x, self.lin.weight, self.bias, graph, batch)
+        if self.in_channels == C and self.out_channels == C:
+            return _GCNConvFn.apply(x, self.lin.weight, self.bias, graph, batch)
+        # narrower than the kernels' 128 channels: zero-padded input columns / weight rows and columns / bias, sliced output
+        # (autograd runs through the pads and the slice, so the gradients of the real entries are the kernels' own)
+        xp = F.pad(x, (0, C - self.in_channels))
+        wp = F.pad(self.lin.weight, (0, C - self.in_channels, 0, C - self.out_channels))
+        bp = F.pad(self.bias, (0, C - self.out_channels))
+        return _GCNConvFn.apply(xp, wp, bp, graph, batch)[:, :self.out_channels]
 
 
 class Sequential(nn.Module):
@@ -700,8 +709,17 @@ class HierarchicalPatchModel(nn.Module):
         super().__init__()
         if gnn_jk_mode not in ("last", "max", "cat"):
             raise ValueError("Only last, max or cat jumping knowledge mode is supported.")
-        if node_embedding_dim != C or node_hidden_dim != C:
-            raise NotImplementedError(f"the HIP path is built for node_embedding_dim = node_hidden_dim = {C}")
+        if node_embedding_dim != C:
+            raise NotImplementedError(f"the HIP path is built for node_embedding_dim = {C} (node-feature packing, models.py:498-537)")
+        if not (1 <= node_hidden_dim <= C):
+            raise NotImplementedError(f"node_hidden_dim must be in [1, {C}]")
+        # Widths other than configs/default.yml's 128 / 32 -- the reference's signature defaults are node_hidden_dim = 64,
+        # classifier_hidden_dim = 16 (models.py:286-301) -- take a COMPATIBILITY route: GCNConv on the 128-channel kernels with
+        # zero padding, BatchNorm / Dropout / activation / heads as the torch modules they are; none of the fused kernels.
+        self._narrow = node_hidden_dim != C or classifier_hidden_dim != 32
+        if self._narrow and use_coordinate_graph:
+            raise NotImplementedError("use_coordinate_graph needs node_hidden_dim = 128 and classifier_hidden_dim = 32 "
+                                      "(the coordinate rows are resampled from 128-channel node rows)")
         self.gnn_layers = nn.ModuleList()
         self.node_coordinate_mlp = nn.ModuleList()
         for i in range(num_gnn_layers):
@@ -980,7 +998,7 @@ class HierarchicalPatchModel(nn.Module):
             node_coords = node_coords.reshape(B, 4, -1)
         else:
             node_coords = None
-        fused = (not self.training) and (not torch.is_grad_enabled() or not node_feats.requires_grad)
+        fused = (not self.training) and (not torch.is_grad_enabled() or not node_feats.requires_grad) and not self._narrow
         fused = fused and self.layer_output_hook is None and not any(
             p.requires_grad and torch.is_grad_enabled() for p in self.parameters())
         # JumpingKnowledge('max') stays on the fused path as a running maximum written by the layer kernels
@@ -1005,7 +1023,7 @@ class HierarchicalPatchModel(nn.Module):
                     and self.num_output_channels == 4 and self.classifier_hidden_dim == 32)
         jkb = self._jk_buffers(graph, gb, node_feats) if jk_fused else None
         train_kids = (None, None)
-        if self.training and not fused and all(self._layer_cfg_static_ok(i) for i in range(self.num_gnn_layers)):
+        if self.training and not fused and not self._narrow and all(self._layer_cfg_static_ok(i) for i in range(self.num_gnn_layers)):
             train_kids = self._train_kidsums(graph, gb)
         for i in range(self.num_gnn_layers):
             x_in = hidden[i]
@@ -1034,7 +1052,7 @@ class HierarchicalPatchModel(nn.Module):
                                                       bn.running_var, cfg, *head_params)
                 finish()
                 return out.squeeze(1), None
-            elif self.training:
+            elif self.training and not self._narrow:
                 tk = train_kids if not self.use_coordinate_graph else (None, None)      # (the explicit coordinate update rewrites rows)
                 h = self._layer_train(i, x_in, graph, gb, (tk[(i + 1) & 1] if i > 0 else None,
                                                            tk[i & 1] if i < self.num_gnn_layers - 1 else None))
@@ -1058,7 +1076,7 @@ class HierarchicalPatchModel(nn.Module):
             if self.training and self._stacked_heads_ok():
                 out = self._classifier_train(h, B, n, n_conn, n_valid)
             else:
-                hv = h.view(B, n, C)[:, n_conn:n_conn + n_valid, :].reshape(B * n_valid, C)
+                hv = h.view(B, n, h.shape[1])[:, n_conn:n_conn + n_valid, :].reshape(B * n_valid, h.shape[1])
                 out = torch.cat([clf(hv) for clf in self.node_classifiers], dim=1)
         if self.use_coordinate_graph:
             node_coords = node_coords.reshape(B * 4, -1)
@@ -1066,8 +1084,9 @@ class HierarchicalPatchModel(nn.Module):
 
     def _act_in_heads_ok(self) -> bool:
         """Train mode without the coordinate graph: may the last layer + the heads run as _LastLayerHeadsTrainFn?"""
-        return (not self.use_coordinate_graph and self.layer_output_hook is None and self.jk is None and self._stacked_heads_ok()
-                and self._layer_cfg_static_ok(self.num_gnn_layers - 1) and os.environ.get("EG_ACT_HEADS", "1") != "0")
+        return (not self._narrow and not self.use_coordinate_graph and self.layer_output_hook is None and self.jk is None
+                and self._stacked_heads_ok() and self._layer_cfg_static_ok(self.num_gnn_layers - 1)
+                and os.environ.get("EG_ACT_HEADS", "1") != "0")
 
     # ---- the 4 classifier heads in train mode as ONE stacked network ----------------------------------------
     def _stacked_heads_ok(self) -> bool:
@@ -1076,7 +1095,7 @@ class HierarchicalPatchModel(nn.Module):
         plain_bn = all(m.training and m.affine and m.track_running_stats and m.momentum is not None and
                        m.momentum == ref.momentum and m.eps == ref.eps for md in mods for m in (md["1"], md["5"]))
         drops_on = all(m.training for md in mods for m in (md["3"], md["7"]))
-        return (self.num_output_channels == 4 and self.classifier_hidden_dim == 32 and self.node_embedding_dim == C
+        return (not self._narrow and self.num_output_channels == 4 and self.classifier_hidden_dim == 32 and self.node_embedding_dim == C
                 and plain_bn and drops_on and os.environ.get("EG_STACKED_HEADS", "1") != "0")
 
     def _classifier_train_cfg(self):

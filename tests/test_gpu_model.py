@@ -198,3 +198,37 @@ def test_cfg3_main_only_full_batch_32():
 def test_cfg5_448_full_batch_8():
     """BASELINE configs[4]: 448x448, 8 aux levels, 8 frames per GPU (N = 288,084 per frame, 1.18 GB of node features)."""
     _full_size_properties(448, 8, 8)
+
+
+@pytest.mark.parametrize("frame,naux,batch,hidden,cls_hidden", [(16, 3, 2, 64, 16), (64, 6, 1, 64, 16), (16, 3, 2, 96, 32), (16, 3, 2, 128, 16)])
+def test_signature_default_widths_take_the_compatibility_route(frame, naux, batch, hidden, cls_hidden):
+    """The reference's SIGNATURE defaults are node_hidden_dim = 64, classifier_hidden_dim = 16 (models.py:286-301; default.yml and
+    every BASELINE config use 128 / 32, which is what the fused kernels are built for).  Such a model is constructed with the
+    reference's parameter shapes (same state_dict) and runs GCNConv on the 128-channel kernels with zero padding, everything
+    else as the torch modules it is: eval logits and one train step (p = 0) against the oracle."""
+    hip, ref = model_pair(frame, naux, 3, seed=23, node_hidden_dim=hidden, classifier_hidden_dim=cls_hidden)
+    assert hip.gnn_layers[0].module_0.lin.weight.shape == (hidden, 128) and hip.node_classifiers[0][0].weight.shape == (cls_hidden, hidden)
+    assert set(hip.state_dict()) == set(ref.state_dict())
+    topo, ei, nt, bi = graph_tensors(frame, naux, batch)
+    frames = synthetic_frames(batch, 128, frame, 5)
+    with torch.no_grad():
+        want, _ = ref(x=frames, edge_index=ei, node_type=nt, batch_idx=bi)
+        got, _ = hip(x=frames.to(DEV), edge_index=ei.to(DEV), node_type=nt.to(DEV), batch_idx=bi.to(DEV))
+    assert got.shape == want.shape and (got.cpu() - want).abs().max() < TOL
+    assert torch.equal(O.landmark_argmax(got.cpu(), batch, frame), O.landmark_argmax(want, batch, frame))
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    hip.train(); ref.train()
+    want, _ = ref(x=frames, edge_index=ei, node_type=nt, batch_idx=bi)
+    got, _ = hip(x=frames.to(DEV), edge_index=ei.to(DEV), node_type=nt.to(DEV), batch_idx=bi.to(DEV))
+    assert (got.detach().cpu() - want.detach()).abs().max() < 2e-4
+    (want ** 2).mean().backward(); (got ** 2).mean().backward()
+    rg = dict(ref.named_parameters())
+    for name, p in hip.named_parameters():
+        g = rg[name].grad
+        assert p.grad is not None and p.grad.shape == g.shape, name
+        assert (p.grad.cpu() - g).abs().max() < 5e-3 * g.abs().max() + 1e-6, name
+    with pytest.raises(NotImplementedError):
+        model_pair(frame, naux, 3, coord=True, node_hidden_dim=64)
+

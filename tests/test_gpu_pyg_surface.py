@@ -99,9 +99,21 @@ def test_gcnconv_alone_matches_dense_fp64():
         got = conv(x.to(DEV), ei.to(DEV))
     assert (got.cpu().double() - want).abs().max() < 2e-5
     with pytest.raises(NotImplementedError):
-        egnn.GCNConv(128, 64)
+        egnn.GCNConv(128, 256)                              # (wider than the kernels' 128-channel rows)
     with pytest.raises(NotImplementedError):
         egnn.GCNConv(128, 128, improved=True)
+    # narrower layers -- the reference's signature defaults are 128 -> 64 -> 64 -- run zero-padded on the same kernels
+    for cin, cout in ((128, 64), (64, 64), (40, 100)):
+        narrow = egnn.GCNConv(cin, cout)
+        fill_state_dict(narrow, seed=cin + cout)
+        xn = synthetic_node_feats(topo.num_nodes, 128, seed=9)[:, :cin].contiguous()
+        want = O.gcn_conv_dense64(xn, ei, narrow.lin.weight.detach(), narrow.bias.detach())
+        narrow = narrow.to(DEV)
+        xg = xn.to(DEV).requires_grad_(True)
+        got = narrow(xg, ei.to(DEV))
+        assert got.shape == (topo.num_nodes, cout) and (got.detach().cpu().double() - want).abs().max() < 2e-5
+        got.sum().backward()
+        assert xg.grad.shape == xn.shape and narrow.lin.weight.grad.shape == (cout, cin) and narrow.bias.grad.shape == (cout,)
 
 
 @pytest.mark.parametrize("frame,naux,batch", [(16, 3, 2), (64, 6, 2)])
