@@ -25,6 +25,8 @@
 
 namespace eg {
 
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
 constexpr int H1 = 128;             // 4 heads x 32
 constexpr int H2 = 64;              // 4 heads x 16
 constexpr int LDZ = H2 + 4;         // LDS row stride of a [64][64] tile
@@ -691,12 +693,17 @@ struct FirstBwdArgs {
     const float *lz, *lmean, *linvstd, *lgamma, *lbeta;      // the layer's z [batch * stride, 128] and BatchNorm vectors
     ActArgs la;                                              // its (relu, p, seed)
     float* partial_lsums;                                    // [blocks][2][128]
+    unsigned bytes_c, bytes_m;                               // sizes of the compact [rows,128] / unfiltered [batch * stride,128] arrays
+    int direct;                                              // both below 2 GB: buffer accesses off whole-array descriptors
 };
 
+#ifndef FB_ABL
+#define FB_ABL 0            // timing-only ablations (bits): 1 no weight-gradient product, 2 no dh product; direct form also: 4 no dz1 arithmetic,
+#endif                      // 8 no dh store, 16 no LDS tile writes, 32 no row loads, 64 no layer sums
 // The two roles run separate instantiations of the tile loop (so that neither carries the other's persistent registers: the
 // [32 x 128] accumulators of the weight gradient / the W1 slice); both execute the same two workgroup barriers per tile.
 template <bool GEMM2, bool SUMS>
-__device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* s_x, float* s_o, const float* s_c, int wave) {
+__device__ inline void first_bwd_role_flat(const FirstBwdArgs& a, float* s_g, float* s_x, float* s_o, const float* s_c, int wave) {
     const int tid = threadIdx.x, lane_k = tid & 63;
     const int c4 = (tid & 31) * 4;
     float wreg[GEMM2 ? 64 : 1];                   // waves 4..7: W1[64 kh + s][32 (wave - 4) + i] (the transposed slice)
@@ -784,9 +791,6 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
         }
         __syncthreads();                          // tile in LDS; s_o of the tile before has been stored
         if (t + gridDim.x < n_tiles) issue(t + gridDim.x);
-#ifndef FB_ABL
-#define FB_ABL 0            // timing-only ablations: 1 no weight-gradient product, 2 no dh product, 3 neither
-#endif
         if constexpr (!GEMM2) {
             const int i = lane & 31, kh = lane >> 5;
             if (!(FB_ABL & 1))
@@ -870,7 +874,219 @@ __device__ inline void first_bwd_role(const FirstBwdArgs& a, float* s_g, float* 
     }
 }
 
-template <bool SUMS>
+// DIRECT form (the arrays below 2 GB each -- batch 32 at 224/7 has 1.2 GB -- else the flat-address form above).
+// Every vector instruction of a tile serialises with the SIMD's MFMAs (running the two roles half a period apart, so
+// that each SIMD always had one wave in its chain and one wave on the tile's other work, changed nothing:
+// profiles/r05_heads_bwd_stagger_ab.txt), so what the tile costs beside its 256 MFMAs per SIMD is its instruction COUNT.  Here the
+// 16 row loads and 4 row stores of a tile are buffer accesses off whole-array descriptors: the lane's part of the offset is one
+// VGPR per row group for the lifetime of the workgroup, the tile's part an SGPR; rows past the end read as zero and their stores
+// are dropped (no per-row bounds test, no zero-initialised prefetch registers), no 64-bit address arithmetic; the one tile per
+// frame that straddles a frame boundary adds the gap to the offsets of its later rows.  The layer's z rows (SUMS) are loaded
+// row group by row group in the store phase, each right behind the last use of the current tile's (no second register set).
+// Same arithmetic per element, same accumulation order: the same bits as the flat form.
+template <bool GEMM2, bool SUMS>
+__device__ inline void first_bwd_role_direct(const FirstBwdArgs& a, float* s_g, float* s_x, float* s_o, const float* s_c, int wave) {
+    const int tid = threadIdx.x, lane_k = tid & 63;
+    const int c4 = (tid & 31) * 4;
+    float wreg[GEMM2 ? 64 : 1];                   // waves 4..7: W1[64 kh + s][32 (wave - 4) + i] (the transposed slice)
+    f32x16 acc[GEMM2 ? 1 : 4];                    // waves 0..3: dW1[32 wave + m][32 jb + n]
+    if constexpr (GEMM2) load_w_slice(a.W1, wave - 4, lane_k, 1, wreg);
+    else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+    }
+    const int n_tiles = (int)((a.rows + TILE - 1) / TILE);
+    const int rows = (int)a.rows;                 // (< 2^22 rows: the arrays are below 2 GB)
+    f32x4 pd[4], pz[4], px[4];
+    f32x4 pl[SUMS ? 4 : 1];
+    f32x4 lsg = {0.f, 0.f, 0.f, 0.f}, lsx = lsg;
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dh1), 0, (int)a.bytes_c, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z1), 0, (int)a.bytes_c, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h), 0, (int)a.bytes_m, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SUMS ? a.lz : a.h), 0, (int)a.bytes_m, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, (int)a.bytes_m, 0x00020000);
+    const int rl0 = tid >> 5;                     // this thread's rows of a tile: rl0 + 16 q
+    const int voff0 = rl0 * (C * 4) + c4 * 4;     // ... their byte offsets: voff0 + q * QB
+    constexpr int QB = 16 * C * 4;
+    const int gap = (a.xm.stride - a.xm.n_valid) * (C * 4);
+    // tile t: compact rows 64 t ..; its first row is row in0 of frame f0's kept rows (a 32-bit division on the scalar unit)
+    struct Tile { int soff_c, soff_m, brk; };     // byte offsets of the tile's first row (compact / unfiltered); rows >= brk lie in the next frame
+    auto tile_of = [&](int t) -> Tile {
+        const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane(t * TILE);
+        const unsigned f0 = r0 / (unsigned)a.xm.n_valid;
+        const int in0 = (int)(r0 - f0 * (unsigned)a.xm.n_valid);
+        return Tile{(int)r0 * (C * 4), ((int)f0 * a.xm.stride + a.xm.lo + in0) * (C * 4), a.xm.n_valid - in0};
+    };
+    // offset of row group q in the unfiltered arrays (a tile that straddles a frame boundary -- one per frame -- skips the gap)
+    auto vm = [&](const Tile& T, int q) -> int {
+        const int v = voff0 + q * QB;
+        return T.brk >= TILE ? v : (rl0 + 16 * q >= T.brk ? v + gap : v);
+    };
+    auto issue = [&](const Tile& T) {
+        if (FB_ABL & 32) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pd[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, voff0 + q * QB, T.soff_c, 0));
+            pz[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, voff0 + q * QB, T.soff_c, 0));
+            px[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, vm(T, q), T.soff_m, 0));
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) {
+        const Tile T = tile_of(blockIdx.x);
+        issue(T);
+        if (SUMS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pl[SUMS ? q : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_l, vm(T, q), T.soff_m, 0));
+        }
+    }
+#ifdef FB_STAMP              // (diagnostic build: cycles per phase, summed over the workgroup's tiles, printed by two waves of workgroup 0)
+    unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0};
+#define FB_T0 unsigned long long t_prev_ = __builtin_readcyclecounter();
+#define FB_MARK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_readcyclecounter(); st[k] += now_ - t_prev_; t_prev_ = now_; } while (0)
+#define FB_MARK_NOWAIT(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); st[k] += now_ - t_prev_; t_prev_ = now_; } while (0)
+#else
+#define FB_T0
+#define FB_MARK(k) do {} while (0)
+#define FB_MARK_NOWAIT(k) do {} while (0)
+#endif
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
+        FB_T0
+        FB_MARK(0);                               // wait for the prefetched rows
+        const bool ragged = (t + 1) * TILE > rows;            // the array's last tile: rows past the end must not reach the sums
+        {
+            const f32x4 mn = *reinterpret_cast<const f32x4*>(s_c + 0 * H1 + c4), is = *reinterpret_cast<const f32x4*>(s_c + 1 * H1 + c4);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(s_c + 2 * H1 + c4), be = *reinterpret_cast<const f32x4*>(s_c + 3 * H1 + c4);
+            const f32x4 mg = *reinterpret_cast<const f32x4*>(s_c + 4 * H1 + c4), mgx = *reinterpret_cast<const f32x4*>(s_c + 5 * H1 + c4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rl = rl0 + 16 * q;
+                f32x4 vg;
+                f32x4 d = pd[q];
+                if (FB_ABL & 4) vg = d + pz[q];
+                else if (a.masked) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float xh = (pz[q][u] - mn[u]) * is[u];
+                        vg[u] = ga[u] * is[u] * (d[u] - mg[u] - xh * mgx[u]);
+                    }
+                } else {
+                    if (a.d1.p > 0.f) d *= keep_scale4(a.d1.seed, (unsigned long long)(t * TILE + rl) * C + c4, a.d1.p, a.d1.inv_keep);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float xh = (pz[q][u] - mn[u]) * is[u];
+                        const float v = xh * ga[u] + be[u];
+                        const float g = v > 0.f ? d[u] : 0.f;
+                        vg[u] = ga[u] * is[u] * (g - mg[u] - xh * mgx[u]);
+                    }
+                }
+                if (ragged && t * TILE + rl >= rows) vg = f32x4{0.f, 0.f, 0.f, 0.f};      // (as the flat form: a missing row is a zero row)
+                if (!(FB_ABL & 16)) {
+                    *reinterpret_cast<f32x4*>(&s_g[rl * LDA + c4]) = vg;
+                    *reinterpret_cast<f32x4*>(&s_x[rl * LDA + c4]) = px[q];
+                } else asm volatile("" :: "v"(vg.x), "v"(vg.y), "v"(vg.z), "v"(vg.w), "v"(px[q].x), "v"(px[q].y), "v"(px[q].z), "v"(px[q].w));
+            }
+        }
+        __syncthreads();                          // tile in LDS; s_o of the tile before has been stored
+        const bool more = t + (int)gridDim.x < n_tiles;      // (the loads in FRONT of this barrier instead: 2.40 -> 2.42 ms, profiles/r05_heads_bwd_ablations.txt)
+        Tile Tn{0, 0, TILE};
+        if (more) { Tn = tile_of(t + gridDim.x); issue(Tn); }
+        FB_MARK_NOWAIT(3);                        // issue
+        if constexpr (!GEMM2) {
+            const int i = lane & 31, kh = lane >> 5;
+            if (!(FB_ABL & 1))
+#pragma unroll 4
+            for (int s = 0; s < TILE / 2; ++s) {
+                const int r = 2 * s + kh;
+                const float av = s_g[r * LDA + 32 * wave + i];
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb)
+                    acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_x[r * LDA + 32 * jb + i], acc[jb], 0, 0, 0);
+            }
+        } else {
+            const int j = lane & 31, hh = lane >> 5, w = wave - 4;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x16 o;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] = 0.f;
+                if (!(FB_ABL & 2)) mfma_rowblock(s_g, 32 * rb, lane, wreg, o);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(&s_o[(32 * rb + j) * LDA + 32 * w + 4 * hh + 8 * g]) = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+            }
+        }
+        FB_MARK_NOWAIT(4);                        // products
+        __syncthreads();                          // products done: s_g / s_x may be refilled, s_o is complete
+        FB_MARK_NOWAIT(5);                        // barrier 2
+        {
+            const Tile T = tile_of(t);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rl = rl0 + 16 * q;
+                const int vo = vm(T, q);
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(&s_o[rl * LDA + c4]);
+                if (!(FB_ABL & 8)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dv), rs_o, vo, T.soff_m, 0);
+                if (SUMS && !(FB_ABL & 64) && !(ragged && t * TILE + rl >= rows)) {     // k_bn_bwd_partial's expression per element (train.hip), on the row just written
+                    const f32x4 lm = *reinterpret_cast<const f32x4*>(s_c + 6 * H1 + c4), li = *reinterpret_cast<const f32x4*>(s_c + 7 * H1 + c4);
+                    const f32x4 lg = *reinterpret_cast<const f32x4*>(s_c + 8 * H1 + c4), lb = *reinterpret_cast<const f32x4*>(s_c + 9 * H1 + c4);
+                    f32x4 g = dv;
+                    if (a.la.p > 0.f) g *= keep_scale4(a.la.seed, (unsigned long long)(((unsigned)T.soff_m + (unsigned)vo) >> 2), a.la.p, a.la.inv_keep);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float xh = (pl[SUMS ? q : 0][u] - lm[u]) * li[u];
+                        const float v = xh * lg[u] + lb[u];
+                        float ge = g[u];
+                        if (a.la.relu) ge = v > 0.f ? ge : 0.f;
+                        lsg[u] += ge;
+                        lsx[u] += ge * xh;
+                    }
+                }
+                asm volatile("s_nop 1" :: "v"(dv.x), "v"(dv.y), "v"(dv.z), "v"(dv.w) : "memory");       // (store data: DESIGN 5.26)
+                if (SUMS && more) pl[SUMS ? q : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_l, vm(Tn, q), Tn.soff_m, 0));
+            }
+        }
+        FB_MARK_NOWAIT(6);                        // store phase
+    }
+#ifdef FB_STAMP
+    if (blockIdx.x == 7 && (tid & 63) == 0 && (wave == 0 || wave == 4 || wave == 3))
+        printf("wave %d tiles %d  wait-loads %llu build %llu bar1 %llu issue %llu products %llu bar2 %llu store %llu  (cycles per tile)\n", wave,
+               (n_tiles - 7 + (int)gridDim.x - 1) / (int)gridDim.x, st[0] * (unsigned long long)gridDim.x / n_tiles, st[1] * (unsigned long long)gridDim.x / n_tiles,
+               st[2] * (unsigned long long)gridDim.x / n_tiles, st[3] * (unsigned long long)gridDim.x / n_tiles, st[4] * (unsigned long long)gridDim.x / n_tiles,
+               st[5] * (unsigned long long)gridDim.x / n_tiles, st[6] * (unsigned long long)gridDim.x / n_tiles);
+#endif
+    if constexpr (SUMS) {                         // the 16 threads that share a channel group (both roles), in a fixed order
+        __syncthreads();
+        float* red = s_g;                         // [16][2][128]
+        const int rg = tid >> 5;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { red[(rg * 2 + 0) * H1 + c4 + u] = lsg[u]; red[(rg * 2 + 1) * H1 + c4 + u] = lsx[u]; }
+        __syncthreads();
+        if (tid < 2 * H1) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k * 2 * H1 + tid];
+            a.partial_lsums[(size_t)blockIdx.x * 2 * H1 + tid] = t;
+        }
+        __syncthreads();
+    }
+    if constexpr (!GEMM2) {
+        const int i = lane_k & 31, kh = lane_k >> 5;
+        float* p = a.partial_dw1 + (size_t)blockIdx.x * C * C;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                p[(size_t)(32 * wave + m) * C + 32 * jb + i] = acc[jb][e];
+            }
+    }
+}
+
+template <bool SUMS, bool DIRECT>
 __global__ __launch_bounds__(512) void k_cls_first_bwd(const FirstBwdArgs a, const ClsBn bn1, const float* __restrict__ beta1) {
     extern __shared__ __attribute__((aligned(16))) float fb_smem[];
     float* s_g = fb_smem;                         // [64][LDA]  dz1 tile
@@ -894,8 +1110,13 @@ __global__ __launch_bounds__(512) void k_cls_first_bwd(const FirstBwdArgs a, con
         }
     }
     __syncthreads();
-    if (wave < 4) first_bwd_role<false, SUMS>(a, s_g, s_x, s_o, s_c, wave);
-    else first_bwd_role<true, SUMS>(a, s_g, s_x, s_o, s_c, wave);
+    if constexpr (DIRECT) {
+        if (wave < 4) first_bwd_role_direct<false, SUMS>(a, s_g, s_x, s_o, s_c, wave);
+        else first_bwd_role_direct<true, SUMS>(a, s_g, s_x, s_o, s_c, wave);
+    } else {
+        if (wave < 4) first_bwd_role_flat<false, SUMS>(a, s_g, s_x, s_o, s_c, wave);
+        else first_bwd_role_flat<true, SUMS>(a, s_g, s_x, s_o, s_c, wave);
+    }
 }
 
 __global__ void k_zero_rows(float* __restrict__ x, int batch, int stride, int lo, int n_valid) {
@@ -1087,8 +1308,10 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
             int dev = 0;
             EG_HIP_TRY(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-                EG_HIP_TRY(hipFuncSetAttribute((const void*)k_cls_first_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                EG_HIP_TRY(hipFuncSetAttribute((const void*)k_cls_first_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                EG_HIP_TRY(hipFuncSetAttribute((const void*)k_cls_first_bwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                EG_HIP_TRY(hipFuncSetAttribute((const void*)k_cls_first_bwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                EG_HIP_TRY(hipFuncSetAttribute((const void*)k_cls_first_bwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                EG_HIP_TRY(hipFuncSetAttribute((const void*)k_cls_first_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
             }
         }
@@ -1097,15 +1320,22 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
         float* slabs = (float*)((char*)shared + eg_workspace_bytes() - (size_t)FB_BLOCKS * C * C * sizeof(float));
         const size_t lds = (size_t)(3 * TILE * LDA + 10 * H1) * sizeof(float);
         FirstBwdArgs fa{dh1_scratch, z1, h, P->w1, (const double*)tot_bn1, rows, xm, d1, dh, slabs, masked ? 1 : 0};
+        {
+            static const bool direct_ok = !(getenv("EG_FB_DIRECT") && atoi(getenv("EG_FB_DIRECT")) == 0);      // (0: flat addresses for every tile)
+            const long long bc = rows * (C * 4), bm = (long long)batch * n_per_frame * (C * 4);
+            fa.direct = direct_ok && bc < (1ll << 31) - (1ll << 20) && bm < (1ll << 31) - (1ll << 20);   // (32-bit offsets incl. a tile's overhang)
+            fa.bytes_c = fa.direct ? (unsigned)bc : 0u;
+            fa.bytes_m = fa.direct ? (unsigned)bm : 0u;
+        }
         if (ls) {
             fa.lz = ls->z; fa.lmean = ls->bn; fa.linvstd = ls->bn + C; fa.lgamma = ls->gamma; fa.lbeta = ls->beta;
             fa.la.rows = (long long)batch * n_per_frame; fa.la.relu = ls->relu; fa.la.p = ls->p;
             fa.la.inv_keep = ls->p > 0.f ? 1.0f / (1.0f - ls->p) : 1.0f; fa.la.seed = ls->seed;
             fa.partial_lsums = partial_bn1;                                       // (reduced into tot_bn1 already)
-            hipLaunchKernelGGL(k_cls_first_bwd<true>, dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
+            hipLaunchKernelGGL((fa.direct ? k_cls_first_bwd<true, true> : k_cls_first_bwd<true, false>), dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
             hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)partial_bn1, nf, 2 * H1, ls->sums);
         } else {
-            hipLaunchKernelGGL(k_cls_first_bwd<false>, dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
+            hipLaunchKernelGGL((fa.direct ? k_cls_first_bwd<false, true> : k_cls_first_bwd<false, false>), dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
         }
         hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nf, grads);
         EG_HIP_TRY(hipGetLastError());
