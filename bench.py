@@ -178,7 +178,7 @@ def infer_workload(frame, naux, layers, main_only, B, device, rank, hip_graph=Tr
     return model, kw, topo, feats, edge_index, step
 
 
-def train_workload(frame, naux, layers, B, device, world, rank, force_collective=False, bucket_kb=0):
+def train_workload(frame, naux, layers, B, device, world, rank, force_collective=False, bucket_kb=0, capturable=False):
     """forward + losses + backward + gradient all-reduce + Adam on the stack's parameters,
     node features [B*N,128] resident in HBM, B frames per GPU (32 in BASELINE's cfg4), coordinate graph on."""
     import numpy as np
@@ -203,9 +203,9 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
             "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux), "coordinate": engine.MSE(1)}
     params = list(model.parameters())
     try:                                   # one launch for the whole update instead of a dozen multi-tensor ones (same arithmetic)
-        opt = torch.optim.Adam(params, lr=1e-4, fused=os.environ.get("EG_BENCH_FUSED_ADAM", "1") != "0")
+        opt = torch.optim.Adam(params, lr=1e-4, fused=os.environ.get("EG_BENCH_FUSED_ADAM", "1") != "0", capturable=capturable)
     except (RuntimeError, TypeError):
-        opt = torch.optim.Adam(params, lr=1e-4)
+        opt = torch.optim.Adam(params, lr=1e-4, capturable=capturable)
     reducer = None
     if world > 1 or force_collective:
         broadcast_parameters(model)
@@ -225,7 +225,12 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
         opt.step()
         return loss
 
+    def loss_fn():                         # (what engine.GraphedTrainStep captures: the same step without the optimizer calls)
+        preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0.clone())
+        return sum(engine.compute_loss(crit, preds, y, coord_preds, coord_y, valid, B).values())
+
     step.reducer = reducer
+    step.graphed = (lambda warmup=2: engine.GraphedTrainStep(loss_fn, opt, warmup=warmup)) if capturable and reducer is None else None
     return step, topo
 
 
@@ -364,6 +369,12 @@ def main_train(args, world, rank, device, dist_info):
                 out["roofline"] = train_layer_roofline(B, topo, device, args.layers, step)
             except Exception as ex:
                 out["roofline"] = {"error": repr(ex)}
+        if world == 1 and step.reducer is None:
+            del step
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["hip_graph_replay"] = graphed_train_ms(args, device, B, n=max(8, min(args.steps, 50)))
         emit(out)
 
 
@@ -667,7 +678,34 @@ def train_entry(args, device, B, what, roofline=False):
         out = {"workload": what, "error": repr(ex)}
     gc.collect()
     torch.cuda.empty_cache()
+    if "error" not in out:
+        out["hip_graph_replay"] = graphed_train_ms(args, device, B)
     return out
+
+
+def graphed_train_ms(args, device, B, n=8):
+    """The same training step as ONE HIP graph (echoglad_amd.engine.GraphedTrainStep: forward, criteria, backward and a capturable
+    fused Adam captured once; the graph's first node bumps the device's dropout epoch, so every replay draws fresh masks)."""
+    import gc
+    import torch
+    try:
+        step, _ = train_workload(224, 7, args.layers, B, device, 1, 0, capturable=True)
+        g = step.graphed(2)
+        for _ in range(2):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            g()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        res = {"ms_per_step": round(ms, 3), "frames_s": round(B / (ms * 1e-3), 1), "final_loss": float(g.outputs[0])}
+        del g, step
+    except Exception as ex:
+        res = {"error": repr(ex)}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 def other_configs(args, device):

@@ -15,7 +15,7 @@ LIB_PATH = Path(os.environ.get("ECHOGLAD_LIB", _PKG / "lib" / "libechoglad_hip.s
 HEADER_PATH = _PKG.parent / "include" / "echoglad_hip.h"
 
 EG_OK, EG_ERR_ARG, EG_ERR_UNSUPPORTED, EG_ERR_HIP = 0, -1, -2, -3
-ABI_VERSION = 133          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
+ABI_VERSION = 134          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
 
 _lib: Optional[ct.CDLL] = None
 
@@ -50,6 +50,9 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_graph_deg_inv_sqrt": (_i, [_p, _p, _p]),
     "eg_edge_hash": (_i, [_p, _i64, _p, _p]),
     "eg_debug_xcc": (_i, [_p, _i, _p]),
+    "eg_dropout_epoch_add": (_i, [ct.c_uint64, _p]),
+    "eg_dropout_epoch_set": (_i, [ct.c_uint64, _p]),
+    "eg_debug_dropout_epoch": (_i, [ct.POINTER(ct.c_uint64)]),
     "eg_debug_layer_timing_begin": (_i, [_i]),
     "eg_debug_layer_timing_end": (_i, [ct.POINTER(ct.c_float), ct.POINTER(ct.c_int), _i]),
     "eg_debug_phase_cycles": (_i, [_p, ct.POINTER(ct.c_uint64), _i]),

@@ -19,7 +19,13 @@ struct ActTileArgs {
     int relu;
     float p, inv_keep;
     unsigned long long seed;
+    const unsigned long long* epoch;
 };
+__device__ inline ActTileArgs resolved(const ActTileArgs& a) {
+    ActTileArgs r = a;
+    r.seed = a.seed + epoch_now(a.epoch);
+    return r;
+}
 
 __device__ inline f32x4 act4(const f32x4& z, const f32x4& sc, const f32x4& sh, const ActTileArgs& a, unsigned long long idx) {
     f32x4 v = z * sc + sh;                          // (the same expression as k_bn_act_fwd / the backward kernels: DESIGN 5.13)
@@ -133,7 +139,8 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd_tiles(const float* __restric
                                                           const float* __restrict__ shift, const float* __restrict__ residual,
                                                           float* __restrict__ out, float* __restrict__ kout,
                                                           const SegDesc* __restrict__ segs, const float* __restrict__ patsq,
-                                                          const ActTileArgs a) {
+                                                          const ActTileArgs a_) {
+    const ActTileArgs a = resolved(a_);
     const int lane = threadIdx.x & 63, p = wave_id();
     const int tile = blockIdx.x;
     const int frame = tile / a.tiles_per_frame, t_in = tile - frame * a.tiles_per_frame;
@@ -149,7 +156,8 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd_tiles_p(const float* __restr
                                                             const float* __restrict__ shift, const float* __restrict__ residual,
                                                             float* __restrict__ out, float* __restrict__ kout,
                                                             const SegDesc* __restrict__ segs, const float* __restrict__ patsq,
-                                                            const ActTileArgs a) {
+                                                            const ActTileArgs a_) {
+    const ActTileArgs a = resolved(a_);
     const int lane_k = threadIdx.x & 63;
     const long long units = (long long)a.tiles_per_frame * a.batch * 4;
     const long long stride = (long long)gridDim.x * 4;
@@ -187,7 +195,7 @@ int eg_launch_bn_act_tiles(const eg_graph* g, int batch, const float* z, const f
     if ((long long)g->n_nodes * (C * 4) >= (1ll << 31)) return EG_ERR_UNSUPPORTED;          // per-frame buffer descriptors
     ActTileArgs a{};
     a.n_per_frame = (int)g->n_nodes; a.tiles_per_frame = g->n_tiles; a.batch = batch; a.kid_rows = g->kid_rows;
-    a.relu = relu; a.p = dropout_p; a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f; a.seed = seed;
+    a.relu = relu; a.p = dropout_p; a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f; a.seed = seed; a.epoch = eg_epoch_ptr();
     const long long n_tiles = (long long)g->n_tiles * batch;
     if (n_tiles <= 0) return EG_OK;
     if (n_tiles >= (1ll << 31)) return eg::set_error(EG_ERR_ARG, "too many tiles");

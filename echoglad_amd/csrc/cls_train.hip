@@ -40,7 +40,13 @@ struct ClsBn {                      // per-channel vectors of one BatchNorm laye
 struct ClsDrop {
     float p, inv_keep;
     unsigned long long seed;
+    const unsigned long long* epoch;       // (train_common.h: seed + epoch is what the kernels hash with)
 };
+__device__ inline ClsDrop resolved(const ClsDrop& d) {
+    ClsDrop r = d;
+    r.seed = d.seed + epoch_now(d.epoch);
+    return r;
+}
 
 // ---- z1 = x[in rows] W^T (+ bias) -> out[out rows]  (+ column sums of the result) ---------------------------------
 // 8 waves, 64-row tiles that never straddle a frame; wave w owns output channels 16w..16w+15 (W slice in 32 VGPRs).
@@ -62,7 +68,9 @@ struct LinAct {
 template <bool STATS, bool ACT>
 __global__ __launch_bounds__(512, 4) void k_lin128_map(const float* __restrict__ x, const float* __restrict__ W,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       float* __restrict__ partial, const LinMapDims a, const LinAct act) {
+                                                       float* __restrict__ partial, const LinMapDims a, const LinAct act_) {
+    LinAct act = act_;
+    act.a = resolved(act_.a);
     __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA + 4];
     const int tid = threadIdx.x, lane_k = tid & 63, wave = wave_id();
     float wreg[32];
@@ -176,7 +184,9 @@ __global__ __launch_bounds__(512, 4) void k_lin128_map(const float* __restrict__
 // Same tiles per workgroup, same MFMA chain per output block, same per-thread sums as k_lin128_map: the results are the bits
 // eg_bn_act_fwd + eg_classifier_train_fwd give.
 __global__ __launch_bounds__(256, 2) void k_act_lin128(const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out,
-                                                       float* __restrict__ partial, const LinMapDims a, const LinAct act) {
+                                                       float* __restrict__ partial, const LinMapDims a, const LinAct act_) {
+    LinAct act = act_;
+    act.a = resolved(act_.a);
     __shared__ __attribute__((aligned(16))) float s_a[TILE * LDA + 4];
     const int tid = threadIdx.x, lane_k = tid & 63, wave = wave_id();
     float wreg0[32], wreg1[32];
@@ -296,8 +306,9 @@ __device__ inline f32x4 hidden_act4(const f32x4& z, const f32x4& scale, const f3
 
 // ---- forward, second layers: z2 = h1 W2^T + b2 (block diagonal: head = wave), column sums of z2 -----------------------
 __global__ __launch_bounds__(CT_THREADS) void k_cls_mid_fwd(const float* __restrict__ z1, long long rows, const float* __restrict__ w2,
-                                                            const float* __restrict__ b2, const ClsBn bn1, const ClsDrop d1,
+                                                            const float* __restrict__ b2, const ClsBn bn1, const ClsDrop d1_,
                                                             float* __restrict__ z2, float* __restrict__ partial) {
+    const ClsDrop d1 = resolved(d1_);
     __shared__ __attribute__((aligned(16))) float s_h[TILE * LDA];
     __shared__ __attribute__((aligned(16))) float s_z[TILE * LDZ];
     const int tid = threadIdx.x, lane = tid & 63, head = wave_id();
@@ -384,9 +395,10 @@ __global__ __launch_bounds__(CT_THREADS) void k_cls_mid_fwd(const float* __restr
 }
 
 // ---- forward, third layers: one thread per (row, head) -----------------------------------------------------------------
-__global__ __launch_bounds__(CT_THREADS) void k_cls_out_fwd(const float* __restrict__ z2, long long rows, const ClsBn bn2, const ClsDrop d2,
+__global__ __launch_bounds__(CT_THREADS) void k_cls_out_fwd(const float* __restrict__ z2, long long rows, const ClsBn bn2, const ClsDrop d2_,
                                                             const float* __restrict__ w3, const float* __restrict__ b3, int sigmoid,
                                                             float* __restrict__ logits) {
+    const ClsDrop d2 = resolved(d2_);
     const long long n = rows * 4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int head = (int)(i & 3);
@@ -413,8 +425,9 @@ __global__ __launch_bounds__(CT_THREADS) void k_cls_out_fwd(const float* __restr
 // partial layout per block: [3][64] + [4]
 constexpr int OUT_SUMS = 3 * H2 + 4;
 __global__ __launch_bounds__(CT_THREADS) void k_cls_out_bwd_sums(const float* __restrict__ dlogits, const float* __restrict__ z2, long long rows,
-                                                                 const ClsBn bn2, const ClsDrop d2, const float* __restrict__ w3,
+                                                                 const ClsBn bn2, const ClsDrop d2_, const float* __restrict__ w3,
                                                                  float* __restrict__ partial) {
+    const ClsDrop d2 = resolved(d2_);
     __shared__ float red[4][CT_THREADS / 4][17];            // [head][thread of the head][channel]
     const int tid = threadIdx.x, head = tid & 3;
     float mean[16], istd[16], scl[16], sft[16], w3v[16];
@@ -487,11 +500,12 @@ __global__ __launch_bounds__(CT_THREADS) void k_cls_out_bwd_sums(const float* __
 // forms it anyway for its sums), so that k_cls_first_bwd need not regenerate the dropout / ReLU mask per element.
 template <bool MASKED>
 __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const float* __restrict__ dlogits, const float* __restrict__ z2,
-                                                            const float* __restrict__ z1, long long rows, const ClsBn bn1, const ClsDrop d1,
-                                                            const ClsBn bn2, const ClsDrop d2, const float* __restrict__ w2,
+                                                            const float* __restrict__ z1, long long rows, const ClsBn bn1, const ClsDrop d1_,
+                                                            const ClsBn bn2, const ClsDrop d2_, const float* __restrict__ w2,
                                                             const float* __restrict__ w3, const double* __restrict__ tot,
                                                             float* __restrict__ dh1, float* __restrict__ partial_dw2,
                                                             float* __restrict__ partial_bn1) {
+    const ClsDrop d1 = resolved(d1_), d2 = resolved(d2_);
     __shared__ __attribute__((aligned(16))) float s_h[TILE * LDA];      // h1 tile, then the dh1 tile
     __shared__ __attribute__((aligned(16))) float s_dz[TILE * LDZ];
     __shared__ float s_c[3][H2];                                          // a2 = gamma2 invstd2, mean g2, mean g2 xhat2
@@ -1087,7 +1101,10 @@ __device__ inline void first_bwd_role_direct(const FirstBwdArgs& a, float* s_g, 
 }
 
 template <bool SUMS, bool DIRECT>
-__global__ __launch_bounds__(512) void k_cls_first_bwd(const FirstBwdArgs a, const ClsBn bn1, const float* __restrict__ beta1) {
+__global__ __launch_bounds__(512) void k_cls_first_bwd(const FirstBwdArgs a_, const ClsBn bn1, const float* __restrict__ beta1) {
+    FirstBwdArgs a = a_;
+    a.d1 = resolved(a_.d1);
+    if (SUMS) a.la = resolved(a_.la);
     extern __shared__ __attribute__((aligned(16))) float fb_smem[];
     float* s_g = fb_smem;                         // [64][LDA]  dz1 tile
     float* s_x = fb_smem + TILE * LDA;            // [64][LDA]  h tile (valid rows)
@@ -1210,7 +1227,7 @@ static int classifier_train_fwd(const float* h, const LinAct* act, int batch, in
     // ---- second layers + BatchNorm1d(64) statistics
     float* bn2p = bn + 4 * H1;
     const ClsBn bn1{bn + 0 * H1, bn + 1 * H1, bn + 2 * H1, bn + 3 * H1, P->gamma1};
-    const ClsDrop d1{P->p1, P->p1 > 0.f ? 1.0f / (1.0f - P->p1) : 1.0f, P->seed1};
+    const ClsDrop d1{P->p1, P->p1 > 0.f ? 1.0f / (1.0f - P->p1) : 1.0f, P->seed1, eg_epoch_ptr()};
     const int g2 = grid_for(rows, TILE, 768);
     hipLaunchKernelGGL(k_cls_mid_fwd, dim3(g2), dim3(CT_THREADS), 0, stream, z1, rows, P->w2, P->b2, bn1, d1, z2, partial);
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4), dim3(RED_F32_THREADS), 0, stream, partial, g2, 128, totals + 256);
@@ -1219,7 +1236,7 @@ static int classifier_train_fwd(const float* h, const LinAct* act, int batch, in
     hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, stream, f2);
     // ---- third layers
     const ClsBn bn2{bn2p + 0 * H2, bn2p + 1 * H2, bn2p + 2 * H2, bn2p + 3 * H2, P->gamma2};
-    const ClsDrop d2{P->p2, P->p2 > 0.f ? 1.0f / (1.0f - P->p2) : 1.0f, P->seed2};
+    const ClsDrop d2{P->p2, P->p2 > 0.f ? 1.0f / (1.0f - P->p2) : 1.0f, P->seed2, eg_epoch_ptr()};
     hipLaunchKernelGGL(k_cls_out_fwd, dim3(grid_for(rows * 4, CT_THREADS, 65536)), dim3(CT_THREADS), 0, stream, z2, rows, bn2, d2,
                        P->w3, P->b3, sigmoid, logits);
     EG_HIP_TRY(hipGetLastError());
@@ -1243,7 +1260,7 @@ int eg_classifier_train_fwd_act(const float* z, const float* layer_bn, const flo
     LinAct act{};
     act.z = z; act.scale = layer_bn + 2 * C; act.shift = layer_bn + 3 * C; act.residual = residual; act.h = h;
     act.a.rows = (long long)batch * n_per_frame; act.a.relu = relu; act.a.p = dropout_p;
-    act.a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f; act.a.seed = seed;
+    act.a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f; act.a.seed = seed; act.a.epoch = eg_epoch_ptr();
     return classifier_train_fwd(nullptr, &act, batch, n_per_frame, row_lo, n_valid, P, workspace, z1, z2, bn, sigmoid, logits, stream);
 }
 
@@ -1278,8 +1295,8 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
     const float* bn2p = bn + 4 * H1;
     const ClsBn bn1{bn + 0 * H1, bn + 1 * H1, bn + 2 * H1, bn + 3 * H1, P->gamma1};
     const ClsBn bn2{bn2p + 0 * H2, bn2p + 1 * H2, bn2p + 2 * H2, bn2p + 3 * H2, P->gamma2};
-    const ClsDrop d1{P->p1, P->p1 > 0.f ? 1.0f / (1.0f - P->p1) : 1.0f, P->seed1};
-    const ClsDrop d2{P->p2, P->p2 > 0.f ? 1.0f / (1.0f - P->p2) : 1.0f, P->seed2};
+    const ClsDrop d1{P->p1, P->p1 > 0.f ? 1.0f / (1.0f - P->p1) : 1.0f, P->seed1, eg_epoch_ptr()};
+    const ClsDrop d2{P->p2, P->p2 > 0.f ? 1.0f / (1.0f - P->p2) : 1.0f, P->seed2, eg_epoch_ptr()};
     // ---- third layers: sums
     const int ga = grid_for(rows * 4, CT_THREADS * 8, CT_MAX_BLOCKS);
     hipLaunchKernelGGL(k_cls_out_bwd_sums, dim3(ga), dim3(CT_THREADS), 0, stream, dlogits, z2, rows, bn2, d2, P->w3, partial);
@@ -1330,7 +1347,7 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
         if (ls) {
             fa.lz = ls->z; fa.lmean = ls->bn; fa.linvstd = ls->bn + C; fa.lgamma = ls->gamma; fa.lbeta = ls->beta;
             fa.la.rows = (long long)batch * n_per_frame; fa.la.relu = ls->relu; fa.la.p = ls->p;
-            fa.la.inv_keep = ls->p > 0.f ? 1.0f / (1.0f - ls->p) : 1.0f; fa.la.seed = ls->seed;
+            fa.la.inv_keep = ls->p > 0.f ? 1.0f / (1.0f - ls->p) : 1.0f; fa.la.seed = ls->seed; fa.la.epoch = eg_epoch_ptr();
             fa.partial_lsums = partial_bn1;                                       // (reduced into tot_bn1 already)
             hipLaunchKernelGGL((fa.direct ? k_cls_first_bwd<true, true> : k_cls_first_bwd<true, false>), dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
             hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)partial_bn1, nf, 2 * H1, ls->sums);

@@ -265,6 +265,8 @@ struct eg_graph {
     mutable std::atomic<void*> only_stream;      // the one stream this handle has launched on so far ...
     mutable std::atomic<unsigned char> multi_stream;   // ... until a second one shows up: from then on every launch records its event
     mutable std::atomic<unsigned char> any_launch;
+    hipEvent_t era_event;                         // recorded on only_stream at the moment a second stream shows up: behind it lie all
+    mutable std::atomic<unsigned char> era_recorded;   // launches that carry no event of their own (slot_used == 2)
 
     // the slice of the queue ring for one launch on `stream` (graph.hip); EG_OK / EG_ERR_UNSUPPORTED / EG_ERR_HIP
     int acquire_queue_slice(hipStream_t stream, int** slice, int* slot) const;

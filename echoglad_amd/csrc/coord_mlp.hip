@@ -28,6 +28,7 @@ struct CoordMlpW {
     const float *w1, *b1, *gamma1, *beta1, *w2, *b2, *gamma2, *beta2, *w3, *b3;
     float p1, ik1, p2, ik2;
     unsigned long long seed1, seed2;
+    const unsigned long long* epoch;                // (train_common.h: seed + epoch is what the kernels hash with)
 };
 
 struct CoordMlpFwd {
@@ -160,7 +161,17 @@ __device__ inline void bn_setup(const float* __restrict__ z, int rows, int train
     __syncthreads();
 }
 
-__global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd a) {
+__device__ inline CoordMlpW resolved(const CoordMlpW& w) {
+    CoordMlpW r = w;
+    const unsigned long long e = epoch_now(w.epoch);
+    r.seed1 = w.seed1 + e;
+    r.seed2 = w.seed2 + e;
+    return r;
+}
+
+__global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd a_) {
+    CoordMlpFwd a = a_;
+    a.w = resolved(a_.w);
     __shared__ __attribute__((aligned(16))) float s_in[CM_TILE * CM_LDI];       // input tile, later the h1 tile
     __shared__ float s_w1[CM_H1 * CM_LDW1], s_w2[CM_H2 * CM_LDW2], s_w3[CM_OUT * CM_H2];
     __shared__ float s_red[CM_THREADS], s_mean[CM_H1], s_var[CM_H1], s_sc1[CM_H1], s_sh1[CM_H1], s_sc2[CM_H2], s_sh2[CM_H2];
@@ -226,7 +237,9 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd 
     }
 }
 
-__global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd a) {
+__global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd a_) {
+    CoordMlpBwd a = a_;
+    a.w = resolved(a_.w);
     __shared__ __attribute__((aligned(16))) float s_in[CM_TILE * CM_LDI];       // input tile; before that h1 | keep1 | xhat1 tiles
     __shared__ float s_w1[CM_H1 * CM_LDW1], s_w2[CM_H2 * CM_LDW2], s_w3[CM_OUT * CM_H2];
     __shared__ float s_dz[CM_TILE * CM_LDH];                                    // dz2 tile [64][17], later dz1 tile [64][33]
@@ -428,6 +441,7 @@ static CoordMlpW weights_of(const eg_cls_train_params* P, bool train) {
     w.ik2 = w.p2 > 0.f ? 1.0f / (1.0f - w.p2) : 1.0f;
     w.seed1 = P->seed1;
     w.seed2 = P->seed2;
+    w.epoch = eg_epoch_ptr();
     return w;
 }
 

@@ -63,11 +63,36 @@ int eg_graph::acquire_queue_slice(hipStream_t stream, int** slice, int* slot) co
     // a handle that has only ever launched on ONE stream needs no events (its launches are ordered); the moment a second stream
     // shows up every launch records one.  Slices last used before that moment carry none: their stream is queried as a whole.
     if (!any_launch.exchange(1, std::memory_order_acq_rel)) only_stream.store((void*)stream, std::memory_order_release);
-    else if (!multi_stream.load(std::memory_order_acquire) && only_stream.load(std::memory_order_acquire) != (void*)stream)
+    // A capturing stream queries nothing (a query of another stream is not a capturable call, and the answer would describe the
+    // moment of the capture, not of a replay): a captured launch is ordered with the handle's other users by the CALLER (header).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (any_launch.load(std::memory_order_acquire) && !multi_stream.load(std::memory_order_acquire) &&
+        only_stream.load(std::memory_order_acquire) != (void*)stream) {
+        // A second stream shows up.  The launches so far carry no events.  If their stream is idle NOW they are all done and their
+        // slices are simply free; otherwise ONE event recorded on it now lies behind all of them.  (Querying that stream as a
+        // whole at every later reuse, as before, answers "not ready" for the legacy default stream whenever torch has parked a
+        // cross-stream wait on it: a train step warmed up on a side stream after eager steps on the default stream was refused.)
+        hipStream_t old = (hipStream_t)only_stream.load(std::memory_order_acquire);
+        if (cap == hipStreamCaptureStatusNone) {
+            if (hipStreamQuery(old) == hipSuccess) {
+                for (int i = 0; i < eg::QUEUE_SLOTS; ++i) {
+                    unsigned char two = 2;
+                    slot_used[i].compare_exchange_strong(two, 0, std::memory_order_acq_rel);
+                }
+            } else {
+                (void)hipGetLastError();
+                if (era_event && hipEventRecord(era_event, old) == hipSuccess) era_recorded.store(1, std::memory_order_release);
+                else (void)hipGetLastError();
+            }
+        }
         multi_stream.store(1, std::memory_order_release);
+    }
     const unsigned char used = slot_used[s].load(std::memory_order_acquire);
-    if (used && slot_stream[s].load(std::memory_order_acquire) != (void*)stream) {
-        const hipError_t q = used == 1 ? hipEventQuery(slot_event[s]) : hipStreamQuery((hipStream_t)slot_stream[s].load(std::memory_order_acquire));
+    if (cap == hipStreamCaptureStatusNone && used && slot_stream[s].load(std::memory_order_acquire) != (void*)stream) {
+        const hipError_t q = used == 1 ? hipEventQuery(slot_event[s])
+                             : (era_recorded.load(std::memory_order_acquire) ? hipEventQuery(era_event)
+                                                                             : hipStreamQuery((hipStream_t)slot_stream[s].load(std::memory_order_acquire)));
         if (q == hipErrorNotReady) {
             (void)hipGetLastError();
             return eg::set_error(EG_ERR_UNSUPPORTED, "more than 64 launches of this graph handle are in flight on different streams: "
@@ -97,6 +122,7 @@ namespace eg {
 static int create_slot_events(eg_graph* g) {
     for (int i = 0; i < QUEUE_SLOTS; ++i)
         if (hipEventCreateWithFlags(&g->slot_event[i], hipEventDisableTiming) != hipSuccess) return EG_ERR_HIP;
+    if (hipEventCreateWithFlags(&g->era_event, hipEventDisableTiming) != hipSuccess) return EG_ERR_HIP;
     return EG_OK;
 }
 
@@ -857,6 +883,7 @@ int eg_graph_destroy(eg_graph* g) {
     if (g->walk_counters) (void)hipFree(g->walk_counters);
     for (int i = 0; i < eg::QUEUE_SLOTS; ++i)
         if (g->slot_event[i]) (void)hipEventDestroy(g->slot_event[i]);
+    if (g->era_event) (void)hipEventDestroy(g->era_event);
     if (g->rowptr) (void)hipFree(g->rowptr);
     if (g->colidx) (void)hipFree(g->colidx);
     if (g->conn_table) (void)hipFree(g->conn_table);

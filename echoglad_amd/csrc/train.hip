@@ -9,6 +9,8 @@
 // pass), so results are bitwise reproducible run to run: no float atomics anywhere.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "train_common.h"
 
 namespace eg {
@@ -131,7 +133,8 @@ __global__ void k_stats_final(const double* __restrict__ totals, long long rows,
 // stream are in flight per lane before the first use.
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ z, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ residual,
-                                                    float* __restrict__ out, const ActArgs a) {
+                                                    float* __restrict__ out, const ActArgs a_) {
+    const ActArgs a = resolved(a_);
     const long long n4 = a.rows * (C / 4);
     const long long stride = (long long)gridDim.x * blockDim.x;
     // (stride is a multiple of 32 float4 = one row: a thread always works on the same 4 channels)
@@ -183,7 +186,8 @@ __device__ inline f32x2 act_grad2(const float* __restrict__ dy, const float* __r
 __global__ __launch_bounds__(RED_THREADS) void k_bn_bwd_partial(const float* __restrict__ dy, const float* __restrict__ z,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                double* __restrict__ partial, const ActArgs a) {
+                                                                double* __restrict__ partial, const ActArgs a_) {
+    const ActArgs a = resolved(a_);
     __shared__ double s_red[8][2][C];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, q = lane & 31;
     const int c4 = 4 * q;
@@ -237,7 +241,8 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_presum(const double* __restrict
                                                         const float* __restrict__ z, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const RowMap m, int batch,
-                                                        double* __restrict__ totals, const ActArgs a) {
+                                                        double* __restrict__ totals, const ActArgs a_) {
+    const ActArgs a = resolved(a_);
     __shared__ double s_red[8][2][C];
     const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
     const int extra = m.stride - m.n_valid;                                    // rows per frame outside the range
@@ -277,7 +282,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const double* __restrict__ totals, float* __restrict__ dz,
-                                                      const ActArgs a) {
+                                                      const ActArgs a_) {
+    const ActArgs a = resolved(a_);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double inv_n = 1.0 / (double)a.rows;
     const f32x2 mg = {(float)(totals[2 * lane] * inv_n), (float)(totals[2 * lane + 1] * inv_n)};             // mean of g
@@ -381,7 +387,8 @@ __global__ __launch_bounds__(256, 3) void k_bn_bwd_apply_dw(const float* __restr
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const double* __restrict__ totals, float* __restrict__ dz,
-                                                         float* __restrict__ partial, const ActArgs a, const RowMap xm) {
+                                                         float* __restrict__ partial, const ActArgs a_, const RowMap xm) {
+    const ActArgs a = resolved(a_);
     __shared__ __attribute__((aligned(16))) float s_g[DW_ROWS * C];
     __shared__ __attribute__((aligned(16))) float s_x[DW_ROWS * C];
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
@@ -532,9 +539,53 @@ int eg_launch_dweight(const float* g, const float* x, long long rows, const eg::
     return EG_OK;
 }
 
+// ---- dropout epoch: one 64-bit word per device that every mask-generating kernel adds to its seed (train_common.h) -----------
+namespace eg {
+__global__ void k_epoch_update(unsigned long long* __restrict__ e, unsigned long long v, int add) { *e = add ? *e + v : v; }
+
+static std::mutex epoch_mu;
+static unsigned long long* epoch_dev[64];
+
+const unsigned long long* eg_epoch_ptr() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(epoch_mu);
+    if (!epoch_dev[dev]) {                                   // (first train-mode launch on this device; never inside a stream capture:
+        unsigned long long* p = nullptr;                     //  a warm-up step in front of the capture has been here)
+        if (hipMalloc((void**)&p, sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(p, 0, sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+        epoch_dev[dev] = p;
+    }
+    return epoch_dev[dev];
+}
+}  // namespace eg
+
+static int epoch_update(uint64_t v, int add, eg_stream_t stream) {
+    unsigned long long* e = const_cast<unsigned long long*>(eg_epoch_ptr());
+    if (!e) return set_error(EG_ERR_HIP, "the dropout epoch word could not be allocated (first use inside a stream capture?)");
+    hipLaunchKernelGGL(k_epoch_update, dim3(1), dim3(1), 0, (hipStream_t)stream, e, (unsigned long long)v, add);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+extern "C" {
+int eg_dropout_epoch_add(uint64_t delta, eg_stream_t stream) { return epoch_update(delta, 1, stream); }
+int eg_dropout_epoch_set(uint64_t value, eg_stream_t stream) { return epoch_update(value, 0, stream); }
+int eg_debug_dropout_epoch(uint64_t* out_host) {
+    if (!out_host) return set_error(EG_ERR_ARG, "NULL argument");
+    const unsigned long long* e = eg_epoch_ptr();
+    if (!e) return set_error(EG_ERR_HIP, "the dropout epoch word could not be allocated");
+    EG_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    EG_HIP_TRY(hipMemcpy(&v, e, sizeof(v), hipMemcpyDeviceToHost));
+    *out_host = v;
+    return EG_OK;
+}
+}
+
 static ActArgs make_act(int64_t rows, int relu, float p, uint64_t seed) {
     ActArgs a{};
-    a.rows = rows; a.relu = relu; a.p = p; a.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    a.rows = rows; a.relu = relu; a.p = p; a.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed; a.epoch = eg_epoch_ptr();
     return a;
 }
 

@@ -42,13 +42,26 @@ __device__ inline f32x2 keep_scale2(unsigned long long seed, unsigned long long 
     return f32x2{keep_field(w, u, thr, inv_keep), keep_field(w, u + 1, thr, inv_keep)};
 }
 
+// The seed a kernel hashes with is  seed (the caller's, a kernel argument) + EPOCH (one 64-bit word per device, read from
+// device memory at the top of every kernel that applies or regenerates a mask; 0 unless eg_dropout_epoch_* moved it).  A train
+// step captured into a HIP graph freezes its kernel arguments -- the epoch word, bumped by a node of the graph itself, is what
+// gives every replay fresh masks (echoglad_amd/engine.py GraphedTrainStep).  Host side: train.hip.
+const unsigned long long* eg_epoch_ptr();            // this device's epoch word (allocated and zeroed at first use; NULL on failure)
+
 // arguments of the BN affine + dropout + ReLU (+ residual) activation
 struct ActArgs {
     long long rows;
     int relu;
     float p, inv_keep;
     unsigned long long seed;
+    const unsigned long long* epoch;                 // (host: make_act / the launchers; device: resolved() at the top of the kernel)
 };
+__device__ inline unsigned long long epoch_now(const unsigned long long* epoch) { return epoch ? *epoch : 0ull; }
+__device__ inline ActArgs resolved(const ActArgs& a) {
+    ActArgs r = a;
+    r.seed = a.seed + epoch_now(a.epoch);
+    return r;
+}
 
 // non-temporal 16-B load of a streaming pass (every operand is read once)
 __device__ inline f32x4 ldnt4(const float* p) {

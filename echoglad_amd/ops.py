@@ -136,6 +136,23 @@ class Graph:
 LAUNCH_KINDS = ("symmetric", "ps_plain", "ps_train_fwd", "ps_dx", "ps_cls")      # EG_LAUNCH_* of include/echoglad_hip.h
 
 
+def dropout_epoch_add(delta: int = 1) -> None:
+    """eg_dropout_epoch_add on the current stream: every mask generated by a later launch hashes with seed + (epoch += delta).
+    Capturable -- the first node of engine.GraphedTrainStep's graph."""
+    _lib.check(_lib.load().eg_dropout_epoch_add(int(delta) & 0xFFFFFFFFFFFFFFFF, _stream()), "eg_dropout_epoch_add")
+
+
+def dropout_epoch_set(value: int) -> None:
+    _lib.check(_lib.load().eg_dropout_epoch_set(int(value) & 0xFFFFFFFFFFFFFFFF, _stream()), "eg_dropout_epoch_set")
+
+
+def dropout_epoch() -> int:
+    """The device's dropout epoch (synchronises; tests)."""
+    out = ct.c_uint64(0)
+    _lib.check(_lib.load().eg_debug_dropout_epoch(ct.byref(out)), "eg_debug_dropout_epoch")
+    return int(out.value)
+
+
 class layer_timing:
     """Context manager over eg_debug_layer_timing_begin / _end: HIP events around every fused-layer kernel launch issued inside
     the block (up to `max_launches`), wherever it is issued from (autograd nodes included).  After the block, ``.launches`` is a

@@ -35,7 +35,7 @@
  *     launch (none before that: a single stream orders its launches), and a launch that would reuse a slice whose last
  *     user is still in flight on ANOTHER stream returns EG_ERR_UNSUPPORTED
  *     instead of sharing live counters with it (use one handle per stream, or
- *     synchronise).  Launches recorded into a HIP graph carry no event: a
+ *     synchronise).  Launches recorded into a HIP graph carry no event and query none: a
  *     captured launch keeps its slice for every replay, so replays of such a
  *     graph and more than 64 eager launches of the same handle on other
  *     streams must not overlap.  Connection-node handles own a scratch sized
@@ -67,8 +67,9 @@ extern "C" {
  * the new calls with shifted arguments).  130: eg_topo_create with the reference builder's full flag set, jk_in inside
  * eg_gcn_layer_cls_fwd, eg_graph_set_precision removed (round 3); train-forward child sums, fused heads backward, the
  * 64-slice queue ring refuses instead of corrupting (round 4).  131: eg_classifier_train_fwd_act.
- * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_*, eg_elm_reduce, eg_coord_mlp_*_rows, eg_bilinear4_*_rows (round 5). */
-#define EG_ABI_VERSION 133
+ * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_*, eg_elm_reduce, eg_coord_mlp_*_rows, eg_bilinear4_*_rows (round 5).
+ * 134: eg_dropout_epoch_add / _set, eg_debug_dropout_epoch (round 5: a whole train step as one HIP graph). */
+#define EG_ABI_VERSION 134
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
 
@@ -243,6 +244,19 @@ int eg_dweight128(const float* g, const float* x, int64_t rows, void* workspace,
 
 /* BatchNorm1d(128) batch statistics over ALL rows: mean[128], biased variance var[128] (models.py:333) */
 int eg_bn_stats(const float* x, int64_t rows, void* workspace, float* mean, float* var, eg_stream_t stream);
+
+/* Dropout epoch.  Every Dropout site below takes its seed as an ARGUMENT (the mask is a pure function of (seed, element index), so
+ * forward and backward kernels regenerate it and nothing is stored).  A train step captured into a HIP graph freezes its kernel
+ * arguments; what the kernels hash with is therefore  seed + EPOCH, EPOCH = one 64-bit word per device in device memory, read
+ * at the top of every kernel that applies or regenerates a mask, 0 until one of these calls moves it.  eg_dropout_epoch_add is a
+ * one-thread kernel on `stream` (capturable: a graph that starts with it draws fresh masks at every replay; the forward and
+ * backward kernels of one step see the same value because they are ordered behind it); eg_dropout_epoch_set the same with an
+ * absolute value (an eager step under epoch k reproduces replay k of a graph captured under epoch 0 with the same seeds).
+ * The word is allocated at the first train-mode launch (or the first of these calls) on a device -- never inside a capture.
+ * eg_debug_dropout_epoch synchronises the device and reads the word (tests). */
+int eg_dropout_epoch_add(uint64_t delta, eg_stream_t stream);
+int eg_dropout_epoch_set(uint64_t value, eg_stream_t stream);
+int eg_debug_dropout_epoch(uint64_t* out_host);
 
 /* out = relu?(dropout_p(z * scale + shift)) + residual ; dropout keeps element e iff hash(seed, e) >= p and
  * scales by 1/(1-p) (nn.Dropout semantics; the mask is a pure function of (seed, element index)).

@@ -91,3 +91,81 @@ def test_training_reduces_the_loss_and_eval_step_feeds_the_evaluator():
         # degenerate synthetic labels (two landmarks on one pixel) give inf / nan percentages in the reference too
         assert np.isclose(float(v), float(want[k]), rtol=1e-4, atol=1e-4, equal_nan=True), (k, float(v), float(want[k]))
     assert set(ls) == {"bce", "elm"}
+
+
+@pytest.mark.parametrize("frame,naux,coord,p", [(32, 4, True, 0.5), (16, 3, False, 0.5), (32, 4, True, 0.0)])
+def test_graphed_train_step_replays_equal_eager_steps_under_the_same_epoch(frame, naux, coord, p):
+    """engine.GraphedTrainStep: the whole step (embedder, model, three criteria, backward, Adam) as ONE HIP graph.  Replay k must be
+    the eager step that draws the same host seeds and runs under dropout epoch k -- bit for bit: same kernels, same arguments but
+    the epoch word the graph's first node bumps.  With p = 0.5 consecutive replays must also differ from each other's masks
+    (the epoch does reach the kernels), and the epoch must have advanced by one per replay."""
+    import copy
+    from echoglad_amd import ops
+    B, warm, replays = 2, 2, 3
+
+    def build():
+        hip, _, emb_hip, _, ds = _setup(frame, naux, coord, 11)
+        for m in hip.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = p
+        hip.train()
+        batch = data.to_device(data.collate([ds[i] for i in range(B)], ds.topology), DEV)
+        crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1), "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux)}
+        if coord:
+            crit["coordinate"] = engine.MSE(1)
+        params = list(hip.parameters()) + list(emb_hip.parameters())
+        opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+        model = {"embedder": emb_hip, "landmark": hip}
+        coords0 = batch.node_coords.clone() if coord else None
+
+        def loss_fn():
+            if coord:
+                batch.node_coords = coords0.clone()                      # (the model updates the landmark guesses it is given)
+            preds, coord_preds = engine.forward_batch(model, batch, coord)
+            ls = engine.compute_loss(crit, preds, batch.y, coord_preds, batch.node_coord_y if coord else None, batch.valid_labels, B)
+            return sum(ls.values()), preds
+        return hip, emb_hip, opt, loss_fn, params
+
+    ops.dropout_epoch_set(0)
+    # --- the graph: `warm` eager steps, then the capture (which draws the seeds every replay reuses), then `replays` replays
+    torch.manual_seed(123)
+    hip_g, emb_g, opt_g, loss_g, params_g = build()
+    torch.manual_seed(77)
+    step = engine.GraphedTrainStep(loss_g, opt_g, warmup=warm)
+    e0 = ops.dropout_epoch()                                              # (the capture itself executes nothing)
+    losses_g, preds_g = [], []
+    for _ in range(replays):
+        out = step()
+        losses_g.append(float(out[0]))
+        preds_g.append(out[1].clone())
+    assert ops.dropout_epoch() == e0 + replays and step.replays == replays
+    # --- the same thing eagerly: `warm` steps, then `replays` steps that all start from the host RNG state the capture started from
+    ops.dropout_epoch_set(e0)
+    torch.manual_seed(123)
+    hip_e, emb_e, opt_e, loss_e, params_e = build()
+    torch.manual_seed(77)
+
+    def eager():
+        out = loss_e()
+        opt_e.zero_grad(set_to_none=True)
+        out[0].backward()
+        opt_e.step()
+        return out
+    for _ in range(warm):
+        eager()
+    rng = torch.get_rng_state()
+    for k in range(replays):
+        torch.set_rng_state(rng)
+        ops.dropout_epoch_set(e0 + k + 1)
+        out = eager()
+        assert float(out[0].detach()) == losses_g[k], (k, float(out[0].detach()), losses_g[k])
+        assert torch.equal(out[1].detach(), preds_g[k]), k
+    for a, b in zip(params_g, params_e):
+        assert torch.equal(a.detach(), b.detach())
+    for (na, ba), (nb, bb) in zip(hip_g.named_buffers(), hip_e.named_buffers()):
+        assert na == nb and torch.equal(ba, bb), na
+    if p > 0:
+        assert len(set(losses_g)) == replays, losses_g                  # fresh masks at every replay
+    ops.dropout_epoch_set(0)
+    with pytest.raises(ValueError):
+        engine.GraphedTrainStep(loss_e, torch.optim.Adam(params_e, lr=1e-3), warmup=1)      # (not capturable)
