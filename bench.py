@@ -64,6 +64,7 @@ def parse():
     p.add_argument("--bucket-kb", type=int, default=0,
                    help="train mode: size of a gradient all-reduce bucket in KiB (0: the reducer's default, max(total / 2, 64 KiB) "
                         "capped at 8 MiB); the first multi-GPU run can sweep it")
+    p.add_argument("--no-graph-replay", action="store_true", help="--mode train: skip the HIP-graph replay of the step (A/B scripts)")
     p.add_argument("--mode", choices=["infer", "train"], default="infer",
                    help="infer (default): BASELINE configs[1], the metric's configuration.  train: one full training "
                         "step of the GNN stack on configs[3] (coordinate graph; SURVEY 8d), reported under its own metric name")
@@ -369,7 +370,7 @@ def main_train(args, world, rank, device, dist_info):
                 out["roofline"] = train_layer_roofline(B, topo, device, args.layers, step)
             except Exception as ex:
                 out["roofline"] = {"error": repr(ex)}
-        if world == 1 and step.reducer is None:
+        if world == 1 and step.reducer is None and not args.no_graph_replay:
             del step
             import gc
             gc.collect()

@@ -567,7 +567,11 @@ __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const f
 #pragma unroll
                     for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
                     if (d1.p > 0.f) {
+#ifdef EG_ABL_HASH_MID        // (timing-only)
+                        const f32x4 kk = f32x4{d1.inv_keep, 0.f, d1.inv_keep, 0.f};
+#else
                         const f32x4 kk = keep_scale4(d1.seed, (unsigned long long)(row0 + r) * H1 + c4, d1.p, d1.inv_keep);
+#endif
                         v *= kk;
 #pragma unroll
                         for (int u = 0; u < 4; ++u) keep1 |= (kk[u] != 0.f ? 1u : 0u) << (4 * it + u);
@@ -588,8 +592,12 @@ __global__ __launch_bounds__(CT_THREADS, MID_BWD_WGS) void k_cls_mid_bwd(const f
                 const f32x4 mn = *reinterpret_cast<const f32x4*>(bn2.mean + c4), is = *reinterpret_cast<const f32x4*>(bn2.invstd + c4);
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(bn2.scale + c4), sh = *reinterpret_cast<const f32x4*>(bn2.shift + c4);
                 const f32x4 ww = *reinterpret_cast<const f32x4*>(w3 + c4);
+#ifdef EG_ABL_HASH_MID
+                const f32x4 kk = f32x4{d2.inv_keep, 0.f, d2.inv_keep, 0.f}; (void)row;
+#else
                 const f32x4 kk = d2.p > 0.f ? keep_scale4(d2.seed, (unsigned long long)row * H2 + c4, d2.p, d2.inv_keep)
                                             : f32x4{1.f, 1.f, 1.f, 1.f};
+#endif
                 float ov[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -1048,7 +1056,11 @@ __device__ inline void first_bwd_role_direct(const FirstBwdArgs& a, float* s_g, 
                     const f32x4 lm = *reinterpret_cast<const f32x4*>(s_c + 6 * H1 + c4), li = *reinterpret_cast<const f32x4*>(s_c + 7 * H1 + c4);
                     const f32x4 lg = *reinterpret_cast<const f32x4*>(s_c + 8 * H1 + c4), lb = *reinterpret_cast<const f32x4*>(s_c + 9 * H1 + c4);
                     f32x4 g = dv;
+#ifdef EG_ABL_HASH_FIRST      // (timing-only)
+                    g *= a.la.inv_keep;
+#else
                     if (a.la.p > 0.f) g *= keep_scale4(a.la.seed, (unsigned long long)(((unsigned)T.soff_m + (unsigned)vo) >> 2), a.la.p, a.la.inv_keep);
+#endif
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float xh = (pl[SUMS ? q : 0][u] - lm[u]) * li[u];

@@ -473,7 +473,11 @@ __global__ __launch_bounds__(256, 3) void k_bn_bwd_apply_dw(const float* __restr
 #endif
                 const f32x4 zz = pz[q];
                 f32x4 d = pd[q];
+#ifdef EG_ABL_HASH_APPLY      // (timing-only: what would stored keep-bits be worth in this kernel?)
+                d *= a.inv_keep; (void)off;
+#else
                 if (a.p > 0.f) d *= keep_scale4(a.seed, (unsigned long long)off, a.p, a.inv_keep);
+#endif
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float xh = (zz[u] - mn[u]) * is[u];
