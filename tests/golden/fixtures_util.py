@@ -47,3 +47,39 @@ def gcn_known_answer():
     out[:, 1] = torch.tensor([-1.20710678, -2.26776695, -2.20710678, -4.0, -5.32842712, -6.0], dtype=torch.float64)
     deg_inv_sqrt = torch.tensor([0.70710678, 0.5, 0.70710678, 1.0, 0.70710678, 1.0], dtype=torch.float64)
     return ei, x, w, b, out, deg_inv_sqrt
+
+
+def gcn_closed_form_families(n: int, seed: int = 0):
+    """Graph families on which GCNConv (PyG 2.0.2 gcn_norm: one self loop per node, degree by target, d^-1/2 on both ends) has a
+    CLOSED FORM that can be written down without running any aggregation code -- further anchors of the operator's semantics
+    beside the hand-computed 6-node case above (PyG's own source is absent from /root/reference).  -> [(name, edge_index,
+    A_hat as a function (x fp64 [n, c]) -> fp64 [n, c])]:
+      complete graph K_n (both directions of every pair): deg + 1 = n everywhere       -> every row = column mean of x
+      cycle C_n (i <-> i + 1 mod n): deg + 1 = 3                                       -> (x[i-1] + x[i] + x[i+1]) / 3
+      star S_n (centre 0 <-> leaves): deg + 1 = n at the centre, 2 at a leaf           -> centre: x0 / n + sum(leaves) / sqrt(2 n),
+                                                                                           leaf j: x_j / 2 + x0 / sqrt(2 n)"""
+    import math
+    idx = torch.arange(n, dtype=torch.int64)
+    src, dst = torch.meshgrid(idx, idx, indexing="ij")
+    off = src != dst
+    complete = torch.stack([src[off], dst[off]])
+    nxt = (idx + 1) % n
+    cycle = torch.stack([torch.cat([idx, nxt]), torch.cat([nxt, idx])])
+    leaves = idx[1:]
+    zeros = torch.zeros_like(leaves)
+    star = torch.stack([torch.cat([zeros, leaves]), torch.cat([leaves, zeros])])
+    g = torch.Generator().manual_seed(seed)                       # the edge ORDER must not matter: shuffle every list
+    out = []
+
+    def shuffled(ei):
+        return ei[:, torch.randperm(ei.shape[1], generator=g)]
+
+    out.append(("complete", shuffled(complete), lambda x: x.mean(dim=0, keepdim=True).expand_as(x).clone()))
+    out.append(("cycle", shuffled(cycle), lambda x: (torch.roll(x, 1, 0) + x + torch.roll(x, -1, 0)) / 3.0))
+
+    def star_fn(x):
+        y = x / 2.0 + x[0:1] / math.sqrt(2.0 * n)
+        y[0] = x[0] / n + x[1:].sum(dim=0) / math.sqrt(2.0 * n)
+        return y
+    out.append(("star", shuffled(star), star_fn))
+    return out

@@ -109,6 +109,40 @@ def test_gcn_conv_literal_known_answer_on_the_csr_kernel():
     assert (got2.cpu().double() - want).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("n", [3, 7, 64, 130, 1000])
+def test_gcn_conv_closed_form_families_on_the_csr_kernels(n):
+    """Complete graph, cycle, star (fixtures_util.gcn_closed_form_families: A_hat written down in closed form, no aggregation
+    code involved) through eg_csr_create + the fused layer kernel, the aggregation kernel, nn.GCNConv -- and, 2 frames batched,
+    the same graph repeated per frame.  n = 130 / 1000: several 64-row tiles, rows of degree n - 1 next to rows of degree 1."""
+    from fixtures_util import gcn_closed_form_families
+    from echoglad_amd import nn as egnn
+    rs = np.random.RandomState(n)
+    x = torch.from_numpy(rs.standard_normal((n, 128)).astype(np.float32))
+    w = torch.from_numpy(rs.uniform(-0.2, 0.2, (128, 128)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(128).astype(np.float32))
+    tol = 2e-5 * max(1.0, float(n) ** 0.5 / 8)
+    for name, ei, a_hat in gcn_closed_form_families(n, seed=n):
+        if name == "complete" and n > 200:
+            continue                                                  # (10^6 edges of K_1000: nothing a smaller K_n does not show)
+        want = a_hat(x.double() @ w.double().t()) + b.double()
+        g = ops.Graph.csr(ei.to(DEV), n)
+        got = ops.gcn_layer_fwd(g, 1, x.to(DEV), w.to(DEV), None, b.to(DEV), None, False)
+        assert (got.cpu().double() - want).abs().max() < tol, name
+        agg = ops.gcn_aggregate(g, 1, x.to(DEV)).cpu().double()
+        assert (agg - a_hat(x.double())).abs().max() < tol, name
+        conv = egnn.GCNConv(128, 128)
+        with torch.no_grad():
+            conv.lin.weight.copy_(w); conv.bias.copy_(b)
+        conv = conv.to(DEV)
+        with torch.no_grad():
+            got2 = conv(x.to(DEV), ei.to(DEV))
+        assert (got2.cpu().double() - want).abs().max() < tol, name
+        x2 = torch.cat([x, -2.0 * x])                               # two frames on one handle: frame 1 = -2 x frame 0
+        got3 = ops.gcn_layer_fwd(g, 2, x2.to(DEV), w.to(DEV), None, None, None, False).cpu().double()
+        base = a_hat(x.double() @ w.double().t())
+        assert (got3[:n] - base).abs().max() < tol and (got3[n:] + 2.0 * base).abs().max() < 2 * tol, name
+
+
 @pytest.mark.parametrize("rows", [1, 31, 32, 33, 64, 65, 200, 4116])
 @pytest.mark.parametrize("transpose", [False, True])
 def test_linear128(rows, transpose):

@@ -92,6 +92,21 @@ def test_gcn_conv_literal_known_answer():
     assert (deg.pow(-0.5) - dis).abs().max() < 1e-7
 
 
+@pytest.mark.parametrize("n", [3, 7, 64, 130])
+def test_gcn_conv_closed_form_families(n):
+    """Complete graph, cycle, star: A_hat has a closed form (fixtures_util.gcn_closed_form_families) -- both restatements of
+    GCNConv must reproduce it, with a random weight and bias applied on top (out = A_hat (x W^T) + b)."""
+    from fixtures_util import gcn_closed_form_families
+    rs = np.random.RandomState(n)
+    x = torch.from_numpy(rs.standard_normal((n, 128)).astype(np.float32))
+    w = torch.from_numpy(rs.uniform(-0.2, 0.2, (128, 128)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(128).astype(np.float32))
+    for name, ei, a_hat in gcn_closed_form_families(n, seed=n):
+        want = a_hat(x.double() @ w.double().t()) + b.double()
+        assert (O.gcn_conv_dense64(x, ei, w, b) - want).abs().max() < 1e-12, name
+        assert (O.gcn_conv_sparse(x, ei, w, b).double() - want).abs().max() < 2e-5, name
+
+
 def test_dense_and_sparse_agree_on_multigraphs():
     rs = np.random.RandomState(0)
     n, e = 40, 300                                     # dense enough that many (src, dst) pairs repeat

@@ -34,7 +34,7 @@ for step in "$@"; do
       # trace:train|infer   kernel sequence of one step (start, duration, gap in front) from a rocprofv3 --kernel-trace of bench.py
       rm -rf /tmp/trace_$tag
       if [ "$rest" == "train" ]; then
-        timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_$tag -- python3 bench.py --mode train --batch ${EG_B:-32} --steps 5 --warmup 2 --no-other-configs > gpurun_out/${tag}_trace_run.log 2>&1
+        timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_$tag -- python3 bench.py --mode train --batch ${EG_B:-32} --steps 5 --warmup 2 --no-other-configs --no-graph-replay > gpurun_out/${tag}_trace_run.log 2>&1
         python3 tools/trace_seq.py $(find /tmp/trace_$tag -name "*kernel_trace.csv" | head -1) > gpurun_out/${tag}_trace_train.txt 2>&1
         python3 tools/trace_gaps.py $(find /tmp/trace_$tag -name "*kernel_trace.csv" | head -1) >> gpurun_out/${tag}_trace_train.txt 2>&1
         tail -5 gpurun_out/${tag}_trace_train.txt
@@ -47,7 +47,7 @@ for step in "$@"; do
       # pmc:<counter>,<counter>,...[:train]  one rocprofv3 --pmc pass over the default bench command (or the training step), per-kernel means
       IFS=: read -r ctrs mode <<< "$rest"
       cmd="bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --repeats 0"
-      [ "$mode" == "train" ] && cmd="bench.py --mode train --batch 32 --steps 5 --warmup 2 --no-other-configs"
+      [ "$mode" == "train" ] && cmd="bench.py --mode train --batch 32 --steps 5 --warmup 2 --no-other-configs --no-graph-replay"
       rm -rf /tmp/pmc_$tag
       timeout 600 rocprofv3 --pmc ${ctrs//,/ } --output-format csv -d /tmp/pmc_$tag -- python3 $cmd > gpurun_out/${tag}_pmc_run.log 2>&1
       python3 - <<PY > gpurun_out/${tag}_pmc_${ctrs%%,*}.txt

@@ -7,7 +7,7 @@ B=${2:-32}
 OUT=$PWD/gpurun_out/profiles
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="bench.py --mode train --batch $B --steps 5 --warmup 2 --no-other-configs"   # STEPS below = 2 warm-up + 5 timed + 5 on the rank's own clock
+CMD="bench.py --mode train --batch $B --steps 5 --warmup 2 --no-other-configs --no-graph-replay"   # STEPS below = 2 warm-up + 5 timed + 5 on the rank's own clock
 rm -rf /tmp/prof_train_pmc
 for pmc in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" GRBM_GUI_ACTIVE; do
   n=$(echo $pmc | tr ' ' '_')

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 B=${1:-32}
 STEPS=5; WARM=2
 rm -rf /tmp/prof_train
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -- python3 bench.py --mode train --batch $B --steps $STEPS --warmup $WARM --no-other-configs > gpurun_out/train_prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -- python3 bench.py --mode train --batch $B --steps $STEPS --warmup $WARM --no-other-configs --no-graph-replay > gpurun_out/train_prof.log 2>&1
 f=$(find /tmp/prof_train -name "*kernel_stats.csv" | head -1)
 mkdir -p gpurun_out/profiles
 cp $f gpurun_out/profiles/train_kernel_stats.csv
