@@ -93,7 +93,7 @@ def test_training_reduces_the_loss_and_eval_step_feeds_the_evaluator():
     assert set(ls) == {"bce", "elm"}
 
 
-@pytest.mark.parametrize("frame,naux,coord,p", [(32, 4, True, 0.5), (16, 3, False, 0.5), (32, 4, True, 0.0)])
+@pytest.mark.parametrize("frame,naux,coord,p", [(32, 4, True, 0.5), (16, 3, False, 0.5), (32, 4, True, 0.0), (224, 7, True, 0.5)])
 def test_graphed_train_step_replays_equal_eager_steps_under_the_same_epoch(frame, naux, coord, p):
     """engine.GraphedTrainStep: the whole step (embedder, model, three criteria, backward, Adam) as ONE HIP graph.  Replay k must be
     the eager step that draws the same host seeds and runs under dropout epoch k -- bit for bit: same kernels, same arguments but
