@@ -60,6 +60,20 @@ __device__ inline int ps_static_tile(int ord, int n_tiles) {
 #define PSTAMP_FLUSH(base) do {} while (0)
 #endif
 
+// EG_PROBE_SITE / EG_PROBE_N (experiment): N extra vector instructions (v_mov on two scratch registers) at ONE place of the
+// tile loop -- how many cycles does an instruction COST there?  (1 producer: behind the load issue; 2 producer: behind the main
+// stage, in front of the child sums / LDS stores; 3 producer: end of the tile; 4 consumer: top of the tile; 5 consumer: end of
+// the tile, in front of the barrier)
+#ifdef EG_PROBE_SITE
+#ifndef EG_PROBE_N
+#define EG_PROBE_N 64
+#endif
+#define EG_PROBE(site) do { if ((site) == EG_PROBE_SITE) { int pa_ = lane, pb_ = lane; _Pragma("unroll") for (int i_ = 0; i_ < EG_PROBE_N / 2; ++i_) { \
+    asm volatile("v_mov_b32 %0, %0" : "+v"(pa_)); asm volatile("v_mov_b32 %0, %0" : "+v"(pb_)); } asm volatile("" :: "v"(pa_), "v"(pb_)); } } while (0)
+#else
+#define EG_PROBE(site) do {} while (0)
+#endif
+
 // frame = tile / tiles_per_frame (the divisor is loop-invariant: the compiler keeps its reciprocal, a division is ~16 scalar
 // instructions).  EG_FRAME_HINT: try the last frame first (consecutive tiles of a queue mostly lie in one frame).
 __device__ inline int frame_of(int tile, int tiles_per_frame, int& hint) {
@@ -247,6 +261,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             asm volatile("" : "+v"(lane));
             const int cd = s_cd[(k & 1) * 32 + (lane & 31)];
             PSTAMP(3);
+            EG_PROBE(4);
             float* s_a = s_a0 + (k & 1) * TILE * LDA;
             float* s_x = s_x0 + (k & 1) * TILE * LDA;
 #ifdef EG_ABL_HOT          // timing-only ablation: every frame's tiles read and write FRAME 0 (36.9 MB in, as much out: served by L2 / the
@@ -583,6 +598,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
 #pragma unroll
                 for (int b4 = 0; b4 < 4; ++b4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[b4]), lrsrc, lvoff[b4], 0, 0);
             }
+            EG_PROBE(5);
             PSTAMP(1);
             __syncthreads();                               // barrier k+1: buffer (k+1)&1 is full, buffer k&1 is free
             PSTAMP(2);
@@ -695,6 +711,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
 #endif
                 __builtin_amdgcn_sched_barrier(0);                  // every load of both segments is issued above this line
                 PSTAMP(PS_ISSUE);
+                EG_PROBE(1);
                 const float* wqa = s_pat + sd0.pat * PATQ + 32 * (lane >> 5);      // this lane's weights (LDS, quad layout)
                 const float* wqb = s_pat + sd1.pat * PATQ + 32 * (lane >> 5);
                 float* s_t = (s_x && !RSEP) ? s_x : s_a;            // where the segments' own rows pass through LDS
@@ -728,6 +745,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                 pin_acc4(acc1);                                     // the 40 main-stage registers are dead from here on
                 __builtin_amdgcn_sched_barrier(0);
                 PSTAMP(PS_MAIN);
+                EG_PROBE(2);
                 if (use_kin) {
                     segp_kidsum_add(KS, wqa, wqb, acc0, acc1);
                 } else if (sd0.aux & 1) {                           // uniform: aux level, children pulled as rows
@@ -774,6 +792,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     }
                 }
             }
+            EG_PROBE(3);
             PSTAMP(2);
         };
         int dv_next = 0;

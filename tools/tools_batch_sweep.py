@@ -23,7 +23,7 @@ for B in (1, 2, 4, 8, 16, 32):
     gc.collect(); torch.cuda.empty_cache()
 b = (rows[-1][1] - rows[0][1]) / (rows[-1][0] - rows[0][0])
 print(f"# least fixed cost: t(B) ~ {rows[0][1] - b:.3f} ms + {b:.4f} ms * B  (from B = 1 and B = 32)")
-print("# training step, 224x224 / 7 aux levels + coordinate graph, dropout 0.5, 3 losses, fused Adam (ms per step; host issue time)")
+print("# training step, 224x224 / 7 aux levels + coordinate graph, dropout 0.5, 3 losses, fused Adam (ms per step; host issue time | engine.GraphedTrainStep)")
 for B in (1, 2, 4, 8, 16, 32):
     step, topo = bench.train_workload(224, 7, 3, B, dev, 1, 0)
     for _ in range(5):
@@ -36,6 +36,8 @@ for B in (1, 2, 4, 8, 16, 32):
     t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
-    print(f"B = {B:2d}: {1e3 * t_all / n:7.3f} ms   host issue {1e3 * t_issue / n:6.3f} ms   {B / (t_all / n):7.0f} frames/s", flush=True)
     del step
     gc.collect(); torch.cuda.empty_cache()
+    g = bench.graphed_train_ms(bench.argparse.Namespace(layers=3), dev, B, n=30)          # the same step replayed from ONE HIP graph
+    print(f"B = {B:2d}: {1e3 * t_all / n:7.3f} ms   host issue {1e3 * t_issue / n:6.3f} ms   {B / (t_all / n):7.0f} frames/s"
+          f"   | HIP-graph replay {g.get('ms_per_step', float('nan')):7.3f} ms   {g.get('frames_s', float('nan')):7.0f} frames/s", flush=True)

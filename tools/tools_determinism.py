@@ -94,6 +94,38 @@ def soak_train(reps):
     return bad
 
 
+def soak_graphed(replays, runs=3):
+    """engine.GraphedTrainStep on configs[3] at batch 32 (bench.py's training workload, capturable fused Adam): `runs` independent
+    captures from the same initial state and host seed, `replays` replays each -- loss of the last replay and every parameter must
+    come out bit-identical (the graph's epoch node gives replay k the masks of epoch k in every run)."""
+    import gc
+    import hashlib
+    import bench
+    dev = torch.device("cuda", 0)
+    digests = []
+    for _ in range(runs):
+        ops.dropout_epoch_set(0)
+        torch.manual_seed(1234)
+        step, _ = bench.train_workload(224, 7, 3, 32, dev, 1, 0, capturable=True)
+        torch.manual_seed(99)
+        g = step.graphed(1)
+        for _ in range(replays):
+            out = g()
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        h.update(out[0].detach().cpu().numpy().tobytes())
+        for q in g.optimizer.param_groups[0]["params"]:
+            h.update(q.detach().cpu().numpy().tobytes())
+        digests.append(h.hexdigest()[:16])
+        del g, step
+        gc.collect(); torch.cuda.empty_cache()
+    ops.dropout_epoch_set(0)
+    bad = sum(d != digests[0] for d in digests[1:])
+    print(f"graphed train step 224/7+coord B=32: {runs} captures x {replays} replays (+ 1 eager warm-up step each), digests {digests}: "
+          f"{bad} of {runs - 1} runs differ from the first")
+    return bad
+
+
 if __name__ == "__main__":
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     total = 0
@@ -106,4 +138,5 @@ if __name__ == "__main__":
         total += soak(224, 7, 8, mode, max(reps // 2, 2), diag=True, conn=True)
     total += soak_csr(reps)
     total += soak_train(max(reps // 10, 3))
+    total += soak_graphed(max(reps // 10, 3))
     sys.exit(1 if total else 0)
