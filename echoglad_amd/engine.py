@@ -79,59 +79,76 @@ def train_step(model: Dict[str, torch.nn.Module], batch, criterion: Dict[str, ob
 class GraphedTrainStep:
     """One WHOLE training step -- forward, criteria, backward, optimizer update (engine.py:239-273 of the reference) -- captured
     once into a HIP graph and replayed: ~130 kernel launches per step leave the host as one.  At the reference's own batch size
-    (configs/default.yml:27, ``batch_size: 1``) an eager step is bound by the host's launch rate (2.4 - 2.9 ms for 1.0 ms of GPU
-    work); at batch 32 the GPU is the bound and a replay saves the gaps between launches.
+    (configs/default.yml:27, ``batch_size: 1``) an eager step is bound by the host's launch rate (2.4 - 3.4 ms for 1.0 ms of GPU
+    work); at batch 32 the GPU is the bound and a replay changes nothing.
 
     ``loss_fn()`` -> loss, or (loss, *tensors to keep): it must read its inputs from tensors that stay where they are (write a new
-    batch INTO them before calling the step) and must not synchronise with the host.  ``optimizer`` has to be capturable
-    (``torch.optim.Adam(..., capturable=True)``; ``fused=True`` as well for one launch).  Dropout: the seeds a train-mode forward
+    batch INTO them before calling the step) and must not synchronise with the host.  Dropout: the seeds a train-mode forward
     draws on the host are frozen into the graph's kernel arguments, so the graph's first node bumps the device's dropout EPOCH
     (include/echoglad_hip.h: the kernels hash with seed + epoch) -- every replay draws fresh masks, its forward and backward see
     the same ones.  BatchNorm running statistics, ``num_batches_tracked`` and the optimizer's step count live on the device and
     advance with every replay.
 
-    ``warmup`` eager steps run first (on the capture stream, as torch.cuda.graph asks): they allocate every workspace, topology
-    handle and the epoch word outside the capture -- and they ARE training steps.  Data-parallel gradient averaging is not part of
-    the graph: use ``train_step`` with a ``GradientAllReducer`` when the world has more than one rank."""
+    Single rank (``reducer`` None): the optimizer update is part of the graph, so ``optimizer`` has to be capturable
+    (``torch.optim.Adam(..., capturable=True)``; ``fused=True`` as well for one launch).
+    Data parallel (``reducer`` = a ``parallel.GradientAllReducer`` WITHOUT attached hooks): the graph holds forward + backward
+    only; every call replays it, averages the gradients over the ranks with the reducer's hook-less ``allreduce()`` (a handful of
+    RCCL collectives on ~280 KB: they are not captured) and runs ``optimizer.step()`` eagerly -- any optimizer will do.  The
+    overlap of the collectives with backward that ``train_step`` + ``attach_hooks()`` gives is traded for the launch-free step:
+    the trade pays where the step is host-bound (small per-rank batches), not at batch 32.
 
-    def __init__(self, loss_fn, optimizer, warmup: int = 3):
+    ``warmup`` eager steps run first (on the capture stream, as torch.cuda.graph asks): they allocate every workspace, topology
+    handle and the epoch word outside the capture -- and they ARE training steps."""
+
+    def __init__(self, loss_fn, optimizer, warmup: int = 3, reducer: Optional[GradientAllReducer] = None):
         from . import ops
         if warmup < 1:
             raise ValueError("at least one eager warm-up step is needed (workspaces and handles are created by it)")
-        for group in optimizer.param_groups:
-            if not group.get("capturable", False):
-                raise ValueError("GraphedTrainStep needs a capturable optimizer (e.g. torch.optim.Adam(params, capturable=True))")
-        self.loss_fn, self.optimizer = loss_fn, optimizer
+        if reducer is None:
+            for group in optimizer.param_groups:
+                if not group.get("capturable", False):
+                    raise ValueError("GraphedTrainStep needs a capturable optimizer (e.g. torch.optim.Adam(params, capturable=True))")
+        elif getattr(reducer, "_hooks", None):
+            raise ValueError("GraphedTrainStep drives the reducer itself: pass a GradientAllReducer without attach_hooks() "
+                             "(collectives fired from inside backward cannot be part of the captured graph)")
+        self.loss_fn, self.optimizer, self.reducer = loss_fn, optimizer, reducer
         self.replays = 0
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             for _ in range(warmup):
-                self._step(ops, eager=True)
+                self.optimizer.zero_grad(set_to_none=True)
+                self._forward_backward(ops, bump=False)
+                self._update()
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph, stream=stream):
-            self.outputs = self._step(ops, eager=False)
-        self.replays = 0
+            self.outputs = self._forward_backward(ops, bump=True)
+            if reducer is None:
+                self.optimizer.step()
 
-    def _step(self, ops, eager: bool):
-        if not eager:
+    def _forward_backward(self, ops, bump: bool):
+        if bump:
             ops.dropout_epoch_add(1)
         out = self.loss_fn()
         loss = out[0] if isinstance(out, (tuple, list)) else out
-        if eager:
-            self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        self.optimizer.step()
         if isinstance(out, (tuple, list)):
             return tuple(t.detach() for t in out)
         return (loss.detach(),)
 
+    def _update(self):
+        if self.reducer is not None:
+            self.reducer.allreduce()
+        self.optimizer.step()
+
     def __call__(self):
         """Replay the step; returns the graph's static output tensors (loss first), valid until the next replay."""
         self.graph.replay()
+        if self.reducer is not None:
+            self._update()
         self.replays += 1
         return self.outputs
 

@@ -105,8 +105,102 @@ def _main():
     dist.destroy_process_group()
 
 
+def _main_graphed():
+    """Child process of test_graphed_train_step_in_its_data_parallel_form...: engine.GraphedTrainStep with a reducer on a one-rank
+    RCCL group (graph = forward + backward; hook-less all-reduce and an ordinary Adam step outside it) against the same steps
+    taken eagerly under the same dropout epochs."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from fixtures_util import initial_coords, synthetic_node_feats
+    from gpu_util import DEV, graph_tensors, model_pair
+    from echoglad_amd import engine, ops
+    from echoglad_amd.parallel import GradientAllReducer
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    frame, naux, B, warm, replays = 32, 4, 3, 2, 3
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+    x = synthetic_node_feats(B * topo.num_nodes, 128, seed=41).to(DEV)
+    eid = ei.to(DEV)
+    coords0 = initial_coords(B, frame).to(DEV)
+
+    def build():
+        hip, _ = model_pair(frame, naux, 3, coord=True, seed=23)
+        hip.train()
+        params = list(hip.parameters())
+        opt = torch.optim.Adam(params, lr=1e-3)                     # (NOT capturable: the update stays outside the graph)
+        red = GradientAllReducer(params, bucket_bytes=32 << 10, force_collective=True)
+
+        def loss_fn():
+            logits, coords = hip.forward_nodes(x, eid, B, coords0.clone())
+            return (logits ** 2).mean() + (coords ** 2).mean() * 1e-3, logits
+        return hip, params, opt, red, loss_fn
+
+    ops.dropout_epoch_set(0)
+    hip_g, params_g, opt_g, red_g, loss_g = build()
+    torch.manual_seed(77)
+    step = engine.GraphedTrainStep(loss_g, opt_g, warmup=warm, reducer=red_g)
+    e0 = ops.dropout_epoch()
+    losses_g = [float(step()[0]) for _ in range(replays)]
+    hooked_refused = False
+    try:
+        engine.GraphedTrainStep(loss_g, opt_g, warmup=1, reducer=GradientAllReducer(params_g, force_collective=True).attach_hooks())
+    except ValueError:
+        hooked_refused = True
+    ops.dropout_epoch_set(e0)
+    hip_e, params_e, opt_e, red_e, loss_e = build()
+    torch.manual_seed(77)
+
+    def eager():
+        opt_e.zero_grad(set_to_none=True)
+        out = loss_e()
+        out[0].backward()
+        red_e.allreduce()
+        opt_e.step()
+        return float(out[0].detach())
+    for _ in range(warm):
+        eager()
+    rng = torch.get_rng_state()
+    losses_e = []
+    for k in range(replays):
+        torch.set_rng_state(rng)
+        ops.dropout_epoch_set(e0 + k + 1)
+        losses_e.append(eager())
+    torch.cuda.synchronize()
+    same = all(torch.equal(a.detach(), b.detach()) for a, b in zip(params_g, params_e))
+    print(json.dumps({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "buckets": len(red_g._buckets),
+                      "collectives_issued": red_g.collectives_issued, "steps": warm + replays, "losses_equal": losses_g == losses_e,
+                      "params_bit_identical": bool(same), "replays_differ": len(set(losses_g)) == replays,
+                      "hooked_reducer_refused": hooked_refused, "epoch_advanced": ops.dropout_epoch() - e0}))
+    ops.dropout_epoch_set(0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_train_step_in_its_data_parallel_form_on_rccl_world_1():
+    """engine.GraphedTrainStep(reducer=...): the captured graph holds forward + backward, the gradient all-reduce (RCCL, hook-less)
+    and the optimizer step follow every replay eagerly.  On a one-rank "nccl" group: bit-identical to the eager steps under the same
+    dropout epochs, one collective per bucket and step, a reducer with attached hooks is refused."""
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "graphed"], capture_output=True, text=True, timeout=600, env=_child_env())
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d["buckets"] >= 2
+    assert d["collectives_issued"] == d["buckets"] * d["steps"]
+    assert d["losses_equal"] is True and d["params_bit_identical"] is True and d["replays_differ"] is True
+    assert d["hooked_reducer_refused"] is True and d["epoch_advanced"] == 3
+
+
 if __name__ == "__main__":
-    _main()
+    _main_graphed() if sys.argv[1:] == ["graphed"] else _main()
 
 
 def test_default_bench_takes_the_training_leg_on_every_rank():
