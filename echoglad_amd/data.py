@@ -134,3 +134,18 @@ def to_device(batch, device):
         if torch.is_tensor(v):
             setattr(batch, k, v.to(device, non_blocking=True))
     return batch
+
+
+def copy_batch_(dst, src):
+    """Writes every tensor attribute of the collated batch ``src`` INTO the tensors of ``dst`` (same shapes; ``dst`` typically on
+    the device, ``src`` fresh from ``collate``): what a captured training step (``engine.GraphedTrainStep``) needs -- its graph
+    reads the tensors it was captured with, so a new batch has to arrive in place.  Returns ``dst``."""
+    for k, v in vars(src).items():
+        if not torch.is_tensor(v):
+            continue
+        d = getattr(dst, k, None)
+        if not torch.is_tensor(d) or d.shape != v.shape:
+            raise ValueError(f"batch attribute {k!r}: {None if d is None else tuple(d.shape)} in the static batch, {tuple(v.shape)} in the new one "
+                             "(a captured step takes batches of ONE shape)")
+        d.copy_(v, non_blocking=True)
+    return dst

@@ -84,3 +84,21 @@ def test_unet_variant_example_registers_the_references_state_dict(golden_dir):
         maps = m.eval().decoder_maps(torch.zeros(1, 4, 224, 224))
     assert [tuple(t.shape[1:]) for t in maps] == [(512, 2, 2), (256, 4, 4), (128, 8, 8), (64, 16, 16), (32, 32, 32), (16, 64, 64),
                                                   (8, 128, 128), (4, 224, 224)]
+
+
+def test_copy_batch_writes_into_the_static_tensors():
+    """data.copy_batch_: a new collated batch arrives IN PLACE (what a captured training step reads), shapes must agree."""
+    np.random.seed(3)
+    ds = data.SyntheticEchoDataset(num_aux_graphs=3, frame_size=16, use_coordinate_graph=True)
+    a = data.collate([ds[0], ds[1]], ds.topology)
+    b = data.collate([ds[2], ds[3]], ds.topology)
+    ptrs = {k: v.data_ptr() for k, v in vars(a).items() if torch.is_tensor(v)}
+    assert not torch.equal(a.x, b.x)
+    out = data.copy_batch_(a, b)
+    assert out is a and all(getattr(a, k).data_ptr() == p for k, p in ptrs.items())
+    for k, v in vars(b).items():
+        if torch.is_tensor(v):
+            assert torch.equal(getattr(a, k), v), k
+    c = data.collate([ds[0]], ds.topology)
+    with pytest.raises(ValueError):
+        data.copy_batch_(a, c)
