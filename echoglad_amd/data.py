@@ -114,12 +114,25 @@ def collate(samples: Sequence, topology: Optional[HierTopology] = None):
     out.x = torch.cat([s.x for s in samples], dim=0)
     out.y = torch.cat([s.y for s in samples], dim=0)
     out.valid_labels = torch.cat([s.valid_labels for s in samples], dim=0)
-    out.node_type = torch.cat([s.node_type for s in samples], dim=0)
     if topology is not None:
-        out.edge_index = torch.from_numpy(topology.batched_edge_index(B))
+        # what depends on (topology, B) only is built once and handed out again AS THE SAME TENSORS: the model resolves an
+        # edge_index it has seen before by identity (no digest pass), and to_device() below moves such a tensor once per device
+        const = topology.__dict__.setdefault("_collate_const", {})
+        hit = const.get(B)
+        if hit is None or hit[3] is not samples[0].node_type:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")                       # (a read-only numpy array behind a tensor nobody writes to)
+                ei = torch.from_numpy(topology.batched_edge_index(B))
+            hit = (ei, torch.arange(B).repeat_interleave(n), torch.cat([s.node_type for s in samples], dim=0), samples[0].node_type)
+            while len(const) >= 4:
+                const.pop(next(iter(const)))
+            const[B] = hit
+        out.edge_index, out.batch, out.node_type = hit[0], hit[1], hit[2]
     else:
+        out.node_type = torch.cat([s.node_type for s in samples], dim=0)
         out.edge_index = torch.cat([s.edge_index + i * n for i, s in enumerate(samples)], dim=1)
-    out.batch = torch.arange(B).repeat_interleave(n)
+        out.batch = torch.arange(B).repeat_interleave(n)
     if hasattr(samples[0], "node_coords"):
         out.node_coords = torch.cat([s.node_coords for s in samples], dim=0)
         out.node_coord_y = torch.cat([s.node_coord_y for s in samples], dim=0)
@@ -128,10 +141,25 @@ def collate(samples: Sequence, topology: Optional[HierTopology] = None):
     return out
 
 
+_CONST_ON_DEVICE = {}       # (id of a collate() constant, device) -> (the CPU tensor, its device copy): one host-to-device copy per device
+
+
 def to_device(batch, device):
-    """Moves every tensor attribute of a collated batch."""
+    """Moves every tensor attribute of a collated batch.  The tensors collate() hands out again for every batch of a (topology,
+    batch size) -- edge_index (55 MB at 224/7, batch 8), batch, node_type -- are moved ONCE per device and the same device tensors
+    come back afterwards: nothing to copy, and the model recognises the edge_index by identity."""
+    device = torch.device(device)
     for k, v in vars(batch).items():
-        if torch.is_tensor(v):
+        if not torch.is_tensor(v):
+            continue
+        if k in ("edge_index", "batch", "node_type") and v.device != device:
+            hit = _CONST_ON_DEVICE.get((id(v), str(device)))
+            if hit is None or hit[0] is not v:
+                while len(_CONST_ON_DEVICE) >= 16:
+                    _CONST_ON_DEVICE.pop(next(iter(_CONST_ON_DEVICE)))
+                hit = _CONST_ON_DEVICE[(id(v), str(device))] = (v, v.to(device))
+            setattr(batch, k, hit[1])
+        else:
             setattr(batch, k, v.to(device, non_blocking=True))
     return batch
 

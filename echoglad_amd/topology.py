@@ -235,10 +235,21 @@ class HierTopology:
 
     # --------------------------------------------------------- batched forms
     def batched_edge_index(self, batch: int) -> np.ndarray:
-        """Disjoint union of ``batch`` frames: per-frame node offset N (PyG collate)."""
+        """Disjoint union of ``batch`` frames: per-frame node offset N (PyG collate).  The array of a batch size is built once and
+        handed out again (read-only: 0.4 s of numpy at 224/7, batch 8 -- per training step if it were rebuilt in every collate);
+        the four most recent batch sizes are kept."""
+        cache = self.__dict__.setdefault("_batched_ei", {})
+        hit = cache.get(batch)
+        if hit is not None:
+            return hit
         e = self.edge_index()
         off = (np.arange(batch, dtype=np.int64) * self.num_nodes)[:, None, None]
-        return np.ascontiguousarray((e[None] + off).transpose(1, 0, 2).reshape(2, -1))
+        out = np.ascontiguousarray((e[None] + off).transpose(1, 0, 2).reshape(2, -1))
+        out.setflags(write=False)
+        while len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+        cache[batch] = out
+        return out
 
     def level_table(self) -> np.ndarray:
         """int32 [n_levels, 2] = (base, side) for aux levels then the main grid."""

@@ -102,3 +102,25 @@ def test_copy_batch_writes_into_the_static_tensors():
     c = data.collate([ds[0]], ds.topology)
     with pytest.raises(ValueError):
         data.copy_batch_(a, c)
+
+
+def test_collate_hands_out_the_constant_tensors_of_a_topology_again():
+    """collate(..., topology): edge_index / batch / node_type depend on (topology, batch size) only -- built once, the SAME tensors
+    for every later batch (the model resolves a known edge_index by identity; to_device moves it once per device), equal to what a
+    fresh build gives; another batch size gets its own."""
+    np.random.seed(4)
+    ds = data.SyntheticEchoDataset(num_aux_graphs=3, frame_size=16)
+    a = data.collate([ds[0], ds[1]], ds.topology)
+    b = data.collate([ds[2], ds[3]], ds.topology)
+    assert a.edge_index is b.edge_index and a.batch is b.batch and a.node_type is b.node_type
+    n = ds.topology.num_nodes
+    want = torch.cat([ds.edge_index, ds.edge_index + n], dim=1)
+    assert torch.equal(a.edge_index, want) and torch.equal(a.batch, torch.arange(2).repeat_interleave(n))
+    assert torch.equal(a.node_type, torch.cat([ds.node_type, ds.node_type]))
+    c = data.collate([ds[0], ds[1], ds[2]], ds.topology)
+    assert c.edge_index is not a.edge_index and c.edge_index.shape[1] == 3 * ds.edge_index.shape[1]
+    assert ds.topology.batched_edge_index(2) is ds.topology.batched_edge_index(2)
+    plain = data.collate([ds[0], ds[1]])                                   # without the topology: PyG's shifted copies, same values
+    assert torch.equal(plain.edge_index, a.edge_index) and torch.equal(plain.node_type, a.node_type)
+    moved = data.to_device(data.collate([ds[0], ds[1]], ds.topology), "cpu")
+    assert moved.edge_index is a.edge_index                                # (already there: nothing to move)

@@ -173,3 +173,15 @@ def test_graphed_train_step_replays_equal_eager_steps_under_the_same_epoch(frame
     ops.dropout_epoch_set(0)
     with pytest.raises(ValueError):
         engine.GraphedTrainStep(loss_e, torch.optim.Adam(params_e, lr=1e-3), warmup=1)      # (not capturable)
+
+
+def test_to_device_moves_the_constant_tensors_of_a_topology_once():
+    """data.collate + data.to_device: edge_index / batch / node_type of a (topology, batch size) are the SAME device tensors for every
+    batch (one host-to-device copy per device; the model resolves the edge_index by identity), the per-sample tensors are fresh."""
+    _, _, _, _, ds = _setup(16, 3, False, 9)
+    a = data.to_device(data.collate([ds[0], ds[1]], ds.topology), DEV)
+    b = data.to_device(data.collate([ds[2], ds[3]], ds.topology), DEV)
+    assert a.edge_index is b.edge_index and a.batch is b.batch and a.node_type is b.node_type and a.edge_index.is_cuda
+    assert a.x is not b.x and a.x.is_cuda and not torch.equal(a.x, b.x)
+    n = ds.topology.num_nodes
+    assert torch.equal(a.edge_index.cpu(), torch.cat([ds.edge_index, ds.edge_index + n], dim=1))
