@@ -64,6 +64,16 @@ def parse():
     p.add_argument("--bucket-kb", type=int, default=0,
                    help="train mode: size of a gradient all-reduce bucket in KiB (0: the reducer's default, max(total / 2, 64 KiB) "
                         "capped at 8 MiB); the first multi-GPU run can sweep it")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                   help="process-group backend at world > 1: nccl (= RCCL over xGMI, the production path) or gloo (collectives through "
+                        "the host: the way to run world > 1 on ONE GPU together with --share-device, RCCL refuses duplicate devices)")
+    p.add_argument("--share-device", action="store_true",
+                   help="every rank uses cuda:0 (world > 1 on a single-GPU box: the N>1 code path -- shard seeds, digests, gradient hooks "
+                        "on a side stream, the all-ranks training leg -- on real kernels; says nothing about RCCL or xGMI)")
+    p.add_argument("--details", choices=["file", "stderr", "inline"], default="file",
+                   help="where everything beyond the headline goes (other_configs, before / after the path, notes): a JSON file "
+                        "(--details-path), one JSON line on stderr, or inline in the stdout line (the pre-round-6 format)")
+    p.add_argument("--details-path", default=os.path.join("gpurun_out", "bench_details.json"))
     p.add_argument("--no-graph-replay", action="store_true", help="--mode train: skip the HIP-graph replay of the step (A/B scripts)")
     p.add_argument("--mode", choices=["infer", "train"], default="infer",
                    help="infer (default): BASELINE configs[1], the metric's configuration.  train: one full training "
@@ -124,7 +134,8 @@ def spawn_ranks(n: int) -> int:
             procs.remove(p)
             if rc != 0:
                 worst = worst or rc
-                deadline = deadline or time.time() + 30.0        # a dead rank would leave the others in a collective forever
+                # a dead rank would leave the others in a collective (or the rendezvous) forever
+                deadline = deadline or time.time() + float(os.environ.get("EG_BENCH_KILL_AFTER", "30"))
         if deadline is not None and time.time() > deadline:
             for p in procs:
                 p.kill()
@@ -376,7 +387,7 @@ def main_train(args, world, rank, device, dist_info):
             gc.collect()
             torch.cuda.empty_cache()
             out["hip_graph_replay"] = graphed_train_ms(args, device, B, n=max(8, min(args.steps, 50)))
-        emit(out)
+        emit(out)               # (--mode train is a tool's command, not the driver's: one inline line)
 
 
 def train_leg_all_ranks(args, world, rank, device):
@@ -423,6 +434,10 @@ def train_leg_all_ranks(args, world, rank, device):
         torch.cuda.synchronize()
         own.append(1e3 * (time.perf_counter() - t0))
     wait_ms = red.collective_wait_ms()
+    red.trace = []                                       # one traced step: which buckets left from inside backward, in which order
+    step()
+    torch.cuda.synchronize()
+    tr, red.trace = red.trace, None
     red.detach_hooks()                                   # same buckets, issued from finish(): nothing overlaps the backward
     for _ in range(2):
         step()
@@ -430,7 +445,9 @@ def train_leg_all_ranks(args, world, rank, device):
     elapsed_after, _ = timed_loop(step, K, world, device)
     wait_after = red.collective_wait_ms()
     mine = {"rank": rank, "ms_per_step_alone": round(min(own), 3), "ms_in_finish_behind_collectives": None if wait_ms is None else round(wait_ms, 4),
-            "ms_in_finish_collectives_after_backward": None if wait_after is None else round(wait_after, 4)}
+            "ms_in_finish_collectives_after_backward": None if wait_after is None else round(wait_after, 4),
+            "bucket_fire_order": [b for b, _, _ in tr], "buckets_fired_inside_backward": sum(1 for _, h, _ in tr if h),
+            "collectives_on_side_stream": bool(tr) and all(sd for _, _, sd in tr), "final_loss": float(loss.detach())}
     per_rank = [mine]
     if world > 1:
         per_rank = [None] * world
@@ -490,7 +507,8 @@ def cpu_baseline(args, kw, state_dict):
             times.append(time.perf_counter() - t0)
         out, _ = ref.forward_nodes(feats, ei, nt, B)
     best = min(times)
-    return {"value": round(B / best, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(B / best, 3), "unit": "frames/s", "cores": cores, "kind": "port", "sample_batch": B,
+            "sample_short": f"{B} frames of the workload, min of {len(times)} runs",
             "sample": f"{B} frames of the same workload (F={args.frame}, naux={args.naux}, L={args.layers}), "
                       f"min of {len(times)} runs after warm-up, torch CPU fp32, {cores} threads "
                       f"(fastest of the probed thread counts {sorted(probe)} on {avail} host cores)"}, out, feats, ei
@@ -629,11 +647,15 @@ def pyg_surface_entry(args, device, B=8):
             per_step = (graph.layer_launches - l0, graph.ps_launches - p0)
             ms = time_steps(step, iters=20, warm=5)
             ms_layers = time_steps(layers_only, iters=20, warm=3)
+            forced = os.environ.get("EG_SEQ_FUSED")              # (a caller's / knob matrix's own setting survives this entry)
             os.environ["EG_SEQ_FUSED"] = "0"
             try:
                 ms_unfused = time_steps(step, iters=10, warm=3)
             finally:
-                del os.environ["EG_SEQ_FUSED"]
+                if forced is None:
+                    del os.environ["EG_SEQ_FUSED"]
+                else:
+                    os.environ["EG_SEQ_FUSED"] = forced
             same = float((got - model.forward_nodes(feats, ei, B)[0]).abs().max())
         sb, sf = stack_work(topo, args.layers)
         fps = B / (ms * 1e-3)
@@ -643,6 +665,8 @@ def pyg_surface_entry(args, device, B=8):
                "launches": {"fused_layer_launches_per_step": per_step[0], "of_them_producer_consumer": per_step[1],
                             "torch": f"{args.layers} residual adds, 1 row gather, 4 heads x (3 Linear + 2 BatchNorm1d + 2 ReLU) + cat"},
                "stencil_handle": bool(graph.structured), "max_abs_diff_vs_route_A": same}
+        if forced == "0":
+            out["note"] = "EG_SEQ_FUSED=0 was set for the whole run: ms_per_step and the launch counts are the module-by-module route too"
         del model, feats, ei
     except Exception as ex:
         out = {"workload": what, "error": repr(ex)}
@@ -709,6 +733,57 @@ def graphed_train_ms(args, device, B, n=8):
     return res
 
 
+def documented_graphed_loop_ms(args, device, B=1, n=24):
+    """INTEGRATION.md section E as written, timed: frames -> embedder (1x1 conv) -> model(x=...) -> three criteria -> backward ->
+    Adam as ONE HIP graph over a static collated batch, every step preceded by ``data.copy_batch_(static, next batch)`` with
+    batches fresh from ``collate`` on the host (pageable memory, as a DataLoader hands them over).  What graphed_train_ms leaves out:
+    the node-feature packing in front of the stack and the per-step host-to-device copies of x / y / valid_labels."""
+    import gc
+    import torch
+    try:
+        from echoglad_amd import data, engine, losses
+        frame, naux = 224, 7
+        model = build_model(model_kwargs(frame, naux, args.layers, coord=True), device, train=True)
+        emb = torch.nn.Conv2d(1, C, kernel_size=1).to(device)
+        ds = data.SyntheticEchoDataset(num_aux_graphs=naux, frame_size=frame, use_coordinate_graph=True)
+        host = [data.collate([ds[i * B + j] for j in range(B)], ds.topology) for i in range(4)]
+        import copy
+        static = data.to_device(copy.copy(host[0]), device)
+        crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1), "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux),
+                "coordinate": engine.MSE(1)}
+        params = list(model.parameters()) + list(emb.parameters())
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=True)
+        md = {"embedder": emb, "landmark": model}
+        coords0 = static.node_coords.clone()
+
+        def loss_fn():
+            static.node_coords = coords0.clone()
+            preds, cp = engine.forward_batch(md, static, True)
+            return sum(engine.compute_loss(crit, preds, static.y, cp, static.node_coord_y, static.valid_labels, B).values())
+
+        step = engine.GraphedTrainStep(loss_fn, opt, warmup=2)
+        v0 = static.edge_index._version
+        for k in range(3):
+            data.copy_batch_(static, host[k % 4]); step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n):
+            data.copy_batch_(static, host[k % 4])
+            out = step()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        res = {"ms_per_step": round(ms, 3), "frames_s": round(B / (ms * 1e-3), 1), "final_loss": float(out[0]),
+               "edge_index_untouched": static.edge_index._version == v0,
+               "what": "INTEGRATION.md E: copy_batch_(static, fresh host batch) + one graph launch per step (embedder, packing, stack, "
+                       "3 criteria, backward, fused Adam)"}
+        del step, model, emb, static, host
+    except Exception as ex:
+        res = {"error": repr(ex)}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def other_configs(args, device):
     """The BASELINE configs the metric is not quoted on, timed like the headline (HIP-graph replay, inputs in HBM);
     reported beside it, never inside `value`.  (What each entry is: DESIGN.md section 4; the strings here stay short so that the
@@ -757,6 +832,7 @@ def other_configs(args, device):
     torch.cuda.empty_cache()
     out["cfg4_train"] = train_entry(args, device, 32, "configs[3]: 224/7 + coordinate graph, batch 32 per GPU, one train step", roofline=True)
     out["cfg4_train_b1"] = train_entry(args, device, 1, "configs[3] shape at batch 1 (default.yml:27), one train step")
+    out["cfg4_train_b1"]["documented_graphed_loop"] = documented_graphed_loop_ms(args, device)
     return out
 
 
@@ -767,6 +843,8 @@ def main():
         sys.exit(spawn_ranks(args.gpus))
 
     guard_stdout()                       # from here on only emit() reaches the real stdout
+    import warnings
+    warnings.filterwarnings("ignore", message="The given NumPy array is not writable")      # (cached read-only edge lists, only read)
     import numpy as np  # noqa: F401
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -774,8 +852,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if os.environ.get("EG_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        raise SystemExit(3)               # (test hook: one rank dies before the rendezvous; the parent must report it)
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist_info = {"world_size": 1, "backend": None, "allreduce_check": None}
     use_dist = world > 1 or (args.force_collective and args.mode == "train") or (args.train_leg and args.mode == "infer")
     if use_dist:
@@ -790,11 +871,16 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         import datetime
         # (a bounded timeout: a collective that never completes must end the run with an error, not hold a node for ten minutes)
-        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))          # "nccl" IS RCCL on ROCm
+        if args.share_device and args.backend == "nccl" and world > 1:
+            raise SystemExit("--share-device needs --backend gloo: RCCL refuses two ranks on one device")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))      # "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))      # (CUDA tensors are reduced through the host)
         one = torch.ones(1, device=device)
         dist.all_reduce(one)
         dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                     "allreduce_check": float(one.item()) == float(world)}
+                     "allreduce_check": float(one.item()) == float(world), "share_device": bool(args.share_device)}
         if not dist_info["allreduce_check"]:
             raise SystemExit(f"rank {rank}: all-reduce of ones over {world} ranks gave {float(one.item())}")
     if args.gpus != world and rank == 0:
@@ -833,6 +919,16 @@ def main_infer(args, world, rank, device, dist_info):
     elapsed, out = timed_loop(step, args.steps, world, device)          # THE timed region: exactly K steps
     frames_per_s = world * B * args.steps / elapsed
     rep = [1e3 * timed_loop(step, args.steps, world, device)[0] / args.steps for _ in range(max(args.repeats, 0))]
+    # the same step launched eagerly from Python (4 launches + queue resets per step), timed the same way: what a caller without
+    # enable_hip_graph() gets
+    eager_ms = None
+    if not args.no_hip_graph:
+        model.use_hip_graph = False                  # (the captured graph stays where it is)
+        for _ in range(max(args.warmup, 3)):
+            step()
+        eager_ms = 1e3 * timed_loop(step, args.steps, world, device)[0] / args.steps
+        model.use_hip_graph = True
+        out = step()
 
     # ---- every rank's logits for ITS shard must be what one GPU alone computes for the same frames (frames are seeded by global
     # rank index; the kernels are bitwise deterministic): rank 0 recomputes every other shard and compares digests
@@ -946,12 +1042,16 @@ def main_infer(args, world, rank, device, dist_info):
     result = {
         "metric": "echo frames/sec through full GNN stack (224x224 default hier-graph); MAE parity",
         "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1] default.yml: {args.frame}x{args.frame} frame, "
                                f"{'main grid only' if args.main_only else str(args.naux) + ' aux levels'}, "
                                f"num_gnn_layers={args.layers}, batch={B} per GPU, eval mode, "
                                "node features [B*N,128] in HBM -> logits [B*N_valid,4] in HBM",
+                   "workload_short": f"configs[1] default.yml: {args.frame}x{args.frame}, "
+                                     f"{'main grid only' if args.main_only else str(args.naux) + ' aux levels'}, L={args.layers}, "
+                                     f"batch {B}/GPU, eval",
                    "nodes_per_frame": N, "directed_edges_per_frame": e_dir, "global_batch": B * world,
                    "parallelism": f"dp{world} (batch-sharded frames, no data-path collective)",
                    "launch": "eager" if args.no_hip_graph else "hipGraph replay of the step's kernels",
@@ -1011,16 +1111,30 @@ def main_infer(args, world, rank, device, dist_info):
                 from echoglad_amd.examples import UNetNodeFeatureModel
                 um = UNetNodeFeatureModel(**kw).to(device).eval()
                 fr = torch.randn(B, 4, args.frame, args.frame, device=device)
+                frs = [torch.randn(B, 4, args.frame, args.frame, device=device) for _ in range(3)]
                 with torch.no_grad():
                     e2e = time_steps(lambda: um(x=fr, edge_index=edge_index), 10, 3)
                     front = time_steps(lambda: um.decoder_maps(fr), 10, 3)
                     mp = um.decoder_maps(fr)
                     tail = time_steps(lambda: um.pack_node_features_linear(mp, list(um.linears), B), 10, 3)
+                    # ... and through model(x=...) with enable_hip_graph(True): the tail writes the model's static node-feature
+                    # buffer, the stack replays ONE captured graph for every new batch of frames (3 different frame tensors in turn)
+                    um.enable_hip_graph(True)
+                    turn = [0]
+
+                    def replayed():
+                        turn[0] += 1
+                        return um(x=frs[turn[0] % 3], edge_index=edge_index)
+
+                    e2e_replay = time_steps(replayed, 12, 3)
+                    captures = um.hip_graph_captures
                 result["before_path"]["end_to_end"] = {
                     "frame_to_logits_ms": round(e2e, 4), "frames_s": round(B / (e2e * 1e-3), 1), "unet_front_end_ms": round(front, 4),
                     "tail_1x1conv_relu_pack_ms": round(tail, 4),
+                    "frame_to_logits_ms_stack_replayed": round(e2e_replay, 4), "stack_graph_captures": captures,
                     "note": "context only (SURVEY 8d): UNet encoder / decoder on stock PyTorch-ROCm (MIOpen), not part of the hot path; "
-                            "eager launches, batch " + str(B)}
+                            "eager launches, batch " + str(B) + "; _stack_replayed: model(x=new frames) with enable_hip_graph(True)"}
+                del frs
                 del um, fr, mp
         result["after_path"] = {"landmark_decode_ms": round(time_steps(lambda: EV.decode_landmarks(lg, B, args.frame, yl, vl), 20, 3), 4),
                                 "losses_fwd_bwd_ms": round(time_steps(loss_step, 20, 3), 4),
@@ -1044,7 +1158,77 @@ def main_infer(args, world, rank, device, dist_info):
         result["other_configs"] = other_configs(args, device)
     if train_leg is not None:
         result.setdefault("other_configs", {})[f"cfg4_train_dp{world}"] = train_leg
-    emit(result)
+    emit_with_details(args, result)
+
+
+def _short(text, n):
+    return text if len(text) <= n else text[:n - 1] + "~"
+
+
+def headline_of(result: dict, details_where: str) -> dict:
+    """The stdout line: the contract's keys + roofline + cpu_baseline + parity + the summary numbers of the other BASELINE
+    configs, short enough (<= ~1.5 KB) that the last 2000 characters of the run's output hold the WHOLE object.  Everything
+    else (per-config entries, notes, before / after the path, per-rank diagnostics) goes to `details`."""
+    h = {k: result[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "eager_ms_per_step",
+                                "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in result}
+    cfg = result.get("config", {})
+    h["config"] = {"workload": cfg.get("workload_short") or _short(cfg.get("workload", ""), 96), "global_batch": cfg.get("global_batch"),
+                   "parallelism": cfg.get("parallelism", "").split(" ")[0], "launch": " ".join(cfg.get("launch", "").split(" ")[:2])}
+    rf = result.get("roofline", {})
+    h["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")}
+    if isinstance(rf.get("hbm"), dict):
+        h["roofline"]["hbm_frac"] = rf["hbm"].get("frac")
+    h["stack_mfma_frac"], h["stack_hbm_frac"] = result.get("stack_mfma_frac"), result.get("stack_hbm_frac")
+    if "cpu_baseline" in result:
+        cb = result["cpu_baseline"]
+        h["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "sample_batch": cb.get("sample_batch"),
+                             "sample": cb.get("sample_short") or _short(cb["sample"], 40)}
+    if "parity" in result:
+        h["parity"] = dict(result["parity"], max_abs_err_vs_oracle=float(f"{result['parity']['max_abs_err_vs_oracle']:.3e}"))
+    rp = result.get("repeats")
+    h["repeats"] = None if not rp else dict(rp["ms_per_step"], n=rp["n"])
+    d = result.get("distributed") or {}
+    h["distributed"] = {k: d[k] for k in ("world_size", "backend", "share_device", "shard_digests_equal_single_rank") if k in d}
+    oc = result.get("other_configs") or {}
+    t = oc.get("cfg4_train")
+    if isinstance(t, dict) and "ms_per_step" in t:
+        h["cfg4_train"] = {"ms_per_step": t["ms_per_step"], "mfma_frac": t.get("mfma_frac"), "hbm_frac": t.get("hbm_frac"),
+                           "traffic_bytes_per_step": t.get("traffic_bytes_per_step"),
+                           "algorithmic_bytes_per_step": t.get("algorithmic_bytes_per_step")}
+    brief = {}
+    for k, v in oc.items():
+        if isinstance(v, dict) and k not in ("cfg4_train", "cfg2_diagonal", "cfg2_connection_nodes"):
+            brief[k] = v.get("ms_per_step", "error" if "error" in v else None)
+            if k.startswith("cfg4_train_b1") and isinstance(v.get("hip_graph_replay"), dict):
+                brief[k + "_replayed"] = v["hip_graph_replay"].get("ms_per_step")
+    if brief:
+        h["other_ms_per_step"] = brief
+    h["details"] = details_where
+    return h
+
+
+def emit_with_details(args, result: dict) -> None:
+    """stdout: the headline line.  The full result: --details file (default: gpurun_out/bench_details.json, which gpurun merges
+    back; a short pointer on stderr), stderr (one JSON line, written BEFORE the stdout line), or inline (one long stdout line)."""
+    if args.details == "inline":
+        emit(result)
+        return
+    where = "stderr"
+    if args.details == "file":
+        path = args.details_path if os.path.isabs(args.details_path) else os.path.join(ROOT, args.details_path)
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(result, f)
+            where = os.path.relpath(path, ROOT)
+        except OSError as ex:
+            where = "stderr"
+            print(f"bench.py: cannot write {path} ({ex!r}); details follow on stderr", file=sys.stderr)
+    if where == "stderr":
+        sys.stderr.write(json.dumps({"bench_details": result}) + "\n")
+        sys.stderr.flush()
+    emit(headline_of(result, where))
 
 
 if __name__ == "__main__":

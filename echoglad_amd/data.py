@@ -11,6 +11,7 @@ valid_labels, node_coord_y, pix2mm_x, pix2mm_y for the losses / evaluators.
 from __future__ import annotations
 
 import types
+import weakref
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -128,6 +129,8 @@ def collate(samples: Sequence, topology: Optional[HierTopology] = None):
             while len(const) >= 4:
                 const.pop(next(iter(const)))
             const[B] = hit
+            for t in hit[:3]:
+                _COLLATE_CONSTS[id(t)] = weakref.ref(t)
         out.edge_index, out.batch, out.node_type = hit[0], hit[1], hit[2]
     else:
         out.node_type = torch.cat([s.node_type for s in samples], dim=0)
@@ -141,7 +144,20 @@ def collate(samples: Sequence, topology: Optional[HierTopology] = None):
     return out
 
 
+_COLLATE_CONSTS = {}        # id -> weak reference of every tensor collate(samples, topology) hands out again for later batches
 _CONST_ON_DEVICE = {}       # (id of a collate() constant, device) -> (the CPU tensor, its device copy): one host-to-device copy per device
+_GRAPH_CONST_ATTRS = ("edge_index", "batch", "node_type")
+
+
+def _is_collate_const(t) -> bool:
+    ref = _COLLATE_CONSTS.get(id(t))
+    if ref is None:
+        return False
+    if ref() is t:
+        return True
+    if ref() is None:
+        del _COLLATE_CONSTS[id(t)]
+    return False
 
 
 def to_device(batch, device):
@@ -152,7 +168,9 @@ def to_device(batch, device):
     for k, v in vars(batch).items():
         if not torch.is_tensor(v):
             continue
-        if k in ("edge_index", "batch", "node_type") and v.device != device:
+        if k in _GRAPH_CONST_ATTRS and v.device != device and _is_collate_const(v):
+            # (only tensors collate() registered: a fresh edge_index per batch -- collate without a topology, batches unpickled
+            # from DataLoader workers -- could never hit again and would only pin copies here)
             hit = _CONST_ON_DEVICE.get((id(v), str(device)))
             if hit is None or hit[0] is not v:
                 while len(_CONST_ON_DEVICE) >= 16:
@@ -167,7 +185,15 @@ def to_device(batch, device):
 def copy_batch_(dst, src):
     """Writes every tensor attribute of the collated batch ``src`` INTO the tensors of ``dst`` (same shapes; ``dst`` typically on
     the device, ``src`` fresh from ``collate``): what a captured training step (``engine.GraphedTrainStep``) needs -- its graph
-    reads the tensors it was captured with, so a new batch has to arrive in place.  Returns ``dst``."""
+    reads the tensors it was captured with, so a new batch has to arrive in place.  Returns ``dst``.
+
+    The graph tensors (``edge_index``, ``batch``, ``node_type``) are NOT copied: a captured step runs on the topology handle it
+    was captured with, whatever is written into the edge_index later (and a pageable 7 - 55 MB host-to-device copy per step
+    would synchronise a step whose point is ~1 ms of GPU work behind one launch).  When ``src`` carries the collate() constant
+    that ``dst``'s tensor was moved from (or ``dst``'s tensor itself) there is nothing to do; any other tensor is compared with
+    the static one ONCE per static batch and attribute (equal: later batches are taken on trust by shape; different: ValueError
+    -- a captured step takes batches of ONE topology)."""
+    verified = dst.__dict__.setdefault("_graph_consts_verified", set())
     for k, v in vars(src).items():
         if not torch.is_tensor(v):
             continue
@@ -175,5 +201,17 @@ def copy_batch_(dst, src):
         if not torch.is_tensor(d) or d.shape != v.shape:
             raise ValueError(f"batch attribute {k!r}: {None if d is None else tuple(d.shape)} in the static batch, {tuple(v.shape)} in the new one "
                              "(a captured step takes batches of ONE shape)")
+        if k in _GRAPH_CONST_ATTRS:
+            if v is d:
+                continue
+            hit = _CONST_ON_DEVICE.get((id(v), str(d.device)))
+            if hit is not None and hit[0] is v and hit[1] is d:
+                continue
+            if k not in verified:
+                if not torch.equal(d, v.to(d.device)):
+                    raise ValueError(f"batch attribute {k!r} differs from the static batch's: a captured step takes batches of ONE "
+                                     "topology (capture a new step for another graph)")
+                verified.add(k)
+            continue
         d.copy_(v, non_blocking=True)
     return dst

@@ -762,6 +762,8 @@ class HierarchicalPatchModel(nn.Module):
         self._resolver = GraphResolver(self.topology_spec)
         self._fold_cache: Dict[str, tuple] = {}
         self._hip_graphs: Dict[tuple, tuple] = {}
+        self._static_feats: Dict[tuple, torch.Tensor] = {}
+        self.hip_graph_captures = 0
         self.use_hip_graph = False
         # eval path: layer i leaves the child sums of its output in a side buffer for layer i+1
         # (eg_gcn_layer_fwd_chain); EG_CHAIN=0 runs every layer on its own
@@ -779,12 +781,42 @@ class HierarchicalPatchModel(nn.Module):
 
     def enable_hip_graph(self, flag: bool = True) -> "HierarchicalPatchModel":
         """Inference only: capture the kernel sequence of ``forward_nodes`` (3 fused layers + classifier
-        + queue resets) into a HIP graph the first time a given input buffer is seen and replay it on
-        later calls with the same buffers (same data_ptr / shape / weights).  The returned logits
-        tensor is owned by the graph and overwritten by the next replay."""
+        + queue resets) into a HIP graph and replay it on later calls.
+
+        Through ``forward()`` -- ``model(x=frames, edge_index=...)`` / ``model(data_batch)``, the calls engine.py:251-255,
+        :394-398 make -- the node-feature packing in front of the stack (``pack_node_features`` / ``_linear``) writes into ONE static
+        ``[B*N,128]`` buffer per (batch size, device), so every new batch of frames replays the SAME captured graph: the key
+        is (that buffer's address, B, the resolved graph handle, parameter versions), never the identity of an input tensor.
+        ``forward_nodes`` on a caller-owned buffer is captured once per buffer address (the buffer is kept alive by the entry).
+        The returned logits tensor -- and, through ``forward()``, the node features -- are owned by the model and overwritten by
+        the next call.  ``hip_graph_captures`` counts captures (a test asserts 1 over many batches)."""
         self.use_hip_graph = bool(flag)
         self._hip_graphs.clear()
+        self._static_feats.clear()
         return self
+
+    def _static_node_feats(self, B: int, inputs) -> Optional[torch.Tensor]:
+        """The static node-feature buffer ``forward()``'s packing writes into when the call will take the replayed route
+        (eval, nothing wants a gradient, no coordinate graph / narrow widths / hook), else None."""
+        if not self.use_hip_graph or self.training or self._narrow or self.use_coordinate_graph or self.layer_output_hook is not None:
+            return None
+        if torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in inputs) or
+                                        any(p.requires_grad for p in self.parameters())):
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        dev = inputs[0].device
+        if dev.type != "cuda":
+            return None
+        n = self._row_ranges()[0]
+        key = (B, n, dev)
+        buf = self._static_feats.get(key)
+        if buf is None:
+            if len(self._static_feats) >= 4:               # (entries of _hip_graphs keep the buffers their graphs read alive)
+                self._static_feats.clear()
+            buf = torch.empty(B * n, C, dtype=torch.float32, device=dev)
+            self._static_feats[key] = buf
+        return buf
 
     # ---- static row ranges (replace the reference's node_type host syncs, models.py:447,456,473,485)
     def _row_ranges(self):
@@ -1009,7 +1041,8 @@ class HierarchicalPatchModel(nn.Module):
         fused = fused and (self.jk is None or jk_fused)
         if not fused and self._train_coord_fused_ok(node_coords):
             return self._forward_train_coord_fused(node_feats, graph, gb, B, node_coords)
-        if fused and self.use_hip_graph and not self.use_coordinate_graph and not torch.cuda.is_current_stream_capturing():
+        if fused and self.use_hip_graph and not self.use_coordinate_graph and node_feats.is_contiguous() \
+                and not torch.cuda.is_current_stream_capturing():
             return self._forward_nodes_graphed(node_feats, edge_index, B), None
         hidden = [node_feats.contiguous()]
         kid = (None, None)
@@ -1156,10 +1189,15 @@ class HierarchicalPatchModel(nn.Module):
         return hit[1], hit[2]
 
     def _forward_nodes_graphed(self, node_feats, edge_index, B):
-        key = (id(node_feats), node_feats.data_ptr(), tuple(node_feats.shape), id(edge_index), edge_index._version, B,
+        # keyed on what the captured kernels actually point at: the input buffer's ADDRESS (the entry holds a reference to the
+        # tensor it was captured on, so that address cannot be handed to anybody else while the entry lives: another tensor
+        # object with the same data_ptr is a view of the same storage), the graph handle the edge_index resolves to (an equal
+        # edge_index in a fresh tensor replays too), and the parameter versions -- not on the identity of either input tensor
+        graph, gb = self._resolver.resolve(edge_index, node_feats.shape[0])
+        key = (node_feats.data_ptr(), tuple(node_feats.shape), node_feats.device, id(graph), gb, B,
                tuple(_versions(l) for l in self.gnn_layers), tuple(_versions(c) for c in self.node_classifiers))
         hit = self._hip_graphs.get(key)
-        if hit is not None and (hit[2] is not node_feats or hit[3] is not edge_index):
+        if hit is not None and hit[4][0] is not graph:
             hit = None
         if hit is None:
             was = self.use_hip_graph
@@ -1175,14 +1213,14 @@ class HierarchicalPatchModel(nn.Module):
                     out, _ = self.forward_nodes(node_feats, edge_index, B)
             finally:
                 self.use_hip_graph = was
+            self.hip_graph_captures += 1
             if len(self._hip_graphs) > 8:
                 self._hip_graphs.clear()
-            # everything the captured kernels point at stays alive with the entry: the input tensors, the graph handle,
+            # everything the captured kernels point at stays alive with the entry: the input buffer, the graph handle,
             # the child-sum side buffers and the folded / packed parameters (their caches may evict independently)
-            graph, gb = self._resolver.resolve(edge_index, node_feats.shape[0])
             keep = (graph, self._kidsum.get((id(graph), gb)), self._kidsum.get(("jk", id(graph), gb, tuple(node_feats.shape))),
                     self._fold_cache.get("layers"), self._fold_cache.get("cls"))
-            hit = (g, out, node_feats, edge_index, keep)
+            hit = (g, out, node_feats, None, keep)
             self._hip_graphs[key] = hit
         hit[0].replay()
         return hit[1]
@@ -1208,7 +1246,8 @@ class HierarchicalPatchModel(nn.Module):
         B = int(num_samples_per_batch)
         n, n_conn, _, main_base, coord_base = self._row_ranges()
         fs = self.frame_size
-        feats = ops.pack_levels([m.float() for m in level_maps], B, n, n_conn)
+        maps = [m.float() for m in level_maps]
+        feats = ops.pack_levels(maps, B, n, n_conn, out=self._static_node_feats(B, maps + [connection_embed]))
         if n_conn:
             feats = feats.clone() if feats.requires_grad else feats
             feats.view(B, n, C)[:, :n_conn, :] = connection_embed
@@ -1226,8 +1265,10 @@ class HierarchicalPatchModel(nn.Module):
         B = int(num_samples_per_batch)
         n, n_conn, _, main_base, coord_base = self._row_ranges()
         fs = self.frame_size
-        feats = ops.conv1x1_relu_pack_levels([f.float() for f in features], [m.weight for m in linears],
-                                             [m.bias for m in linears], B, n, n_conn)
+        fl = [f.float() for f in features]
+        ws, bs = [m.weight for m in linears], [m.bias for m in linears]
+        feats = ops.conv1x1_relu_pack_levels(fl, ws, bs, B, n, n_conn,
+                                             out=self._static_node_feats(B, fl + ws + bs + [connection_embed]))
         if n_conn:
             feats = feats.clone() if feats.requires_grad else feats
             feats.view(B, n, C)[:, :n_conn, :] = connection_embed

@@ -913,9 +913,29 @@ class _PackLevelsFn(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
-def pack_levels(maps, batch: int, n_rows: int, row_offset: int = 0) -> torch.Tensor:
+def _pack_out(out: torch.Tensor, inputs, batch: int, n_rows: int, row_offset: int, used: int) -> torch.Tensor:
+    """``out=`` of the packing calls: the caller's [batch * n_rows, 128] buffer is written in place (a static node-feature
+    buffer that a captured HIP graph reads: nn.HierarchicalPatchModel.enable_hip_graph).  No autograd through it."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in inputs):
+        raise RuntimeError("pack into out= is not differentiable: call it under torch.no_grad() or without out=")
+    _check_rows(out, "out", batch * n_rows)
+    if row_offset > 0 or used < n_rows:              # rows no level covers (connection / coordinate nodes) read as zero, as without out=
+        v = out.view(batch, n_rows, C)
+        if row_offset > 0:
+            v[:, :row_offset].zero_()
+        if row_offset + used < n_rows:
+            v[:, row_offset + used:].zero_()
+    return out
+
+
+def pack_levels(maps, batch: int, n_rows: int, row_offset: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """NCHW level maps [batch,128,p,p] (coarse to fine) -> node-major [batch * n_rows, 128]; level l lands at rows
-    row_offset + sum_{k<l} p_k^2 of every frame.  Differentiable w.r.t. the maps."""
+    row_offset + sum_{k<l} p_k^2 of every frame.  Differentiable w.r.t. the maps (not with ``out=``: written in place)."""
+    if out is not None:
+        maps = [m.contiguous() for m in maps]
+        _pack_out(out, maps, int(batch), int(n_rows), int(row_offset), sum(int(m.shape[2]) ** 2 for m in maps))
+        _pack_call("eg_pack_levels", maps, out, int(batch), int(n_rows), int(row_offset))
+        return out
     return _PackLevelsFn.apply(int(batch), int(n_rows), int(row_offset), *maps)
 
 
@@ -989,8 +1009,17 @@ class _ConvReluPackFn(torch.autograd.Function):
         return (None, None, None, None, *gf, *gw, *gb)
 
 
-def conv1x1_relu_pack_levels(feats, weights, biases, batch: int, n_rows: int, row_offset: int = 0) -> torch.Tensor:
+def conv1x1_relu_pack_levels(feats, weights, biases, batch: int, n_rows: int, row_offset: int = 0,
+                             out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """relu(Conv2d(C_l, 128, 1)(feats[l])) for every level (coarse to fine), written node-major [batch * n_rows, 128] like
-    `pack_levels` (models.py:707-710 + :726-756 in one launch).  Differentiable w.r.t. features, weights and biases."""
+    `pack_levels` (models.py:707-710 + :726-756 in one launch).  Differentiable w.r.t. features, weights and biases (not with
+    ``out=``: written in place)."""
     n = len(feats)
+    if out is not None:
+        feats = [f.contiguous() for f in feats]
+        weights = [w.detach().contiguous() for w in weights]
+        biases = [b.detach().contiguous() if b is not None else None for b in biases]
+        _pack_out(out, list(feats), int(batch), int(n_rows), int(row_offset), sum(int(f.shape[2]) ** 2 for f in feats))
+        _conv_pack_call(feats, weights, biases, out, int(batch), int(n_rows), int(row_offset))
+        return out
     return _ConvReluPackFn.apply(int(batch), int(n_rows), int(row_offset), n, *feats, *weights, *biases)

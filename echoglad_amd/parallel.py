@@ -116,6 +116,10 @@ class GradientAllReducer:
         self.profile = False
         self._wait_events: List[tuple] = []
         self.finish_calls = 0
+        # optional trace of one or more steps (set to a list): one entry per bucket launch --
+        # (bucket index, fired from a gradient hook inside backward?, issued on the side stream?)
+        self.trace: Optional[list] = None
+        self._in_hook = False
 
     # ---- plumbing -----------------------------------------------------------------------------------------------
     def _buffer(self) -> torch.Tensor:
@@ -142,8 +146,12 @@ class GradientAllReducer:
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         self._buckets[self._where[id(p)]].ready += 1
         # every complete bucket at the head of the line goes out; a complete bucket behind an incomplete one waits
-        while self._next < len(self._buckets) and self._buckets[self._next].ready >= len(self._buckets[self._next].params):
-            self._launch(self._buckets[self._next])
+        self._in_hook = True
+        try:
+            while self._next < len(self._buckets) and self._buckets[self._next].ready >= len(self._buckets[self._next].params):
+                self._launch(self._buckets[self._next])
+        finally:
+            self._in_hook = False
 
     def _flush(self) -> None:
         while self._next < len(self._buckets):
@@ -168,7 +176,10 @@ class GradientAllReducer:
         assert self._buckets[self._next] is b, "buckets leave in index order"
         b.launched = True
         self._next += 1
-        if self._world() > 1 or (self.force_collective and dist.is_initialized()):
+        collective = self._world() > 1 or (self.force_collective and dist.is_initialized())
+        if self.trace is not None:
+            self.trace.append((self._next - 1, self._in_hook, bool(collective and flat.is_cuda)))
+        if collective:
             self.collectives_issued += 1
             if flat.is_cuda:
                 if self._side is None:

@@ -70,7 +70,29 @@ def test_bench_line_contract():
     assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
-    assert d["repeats"]["n"] == 2 and d["repeats"]["ms_per_step"]["min"] <= d["repeats"]["ms_per_step"]["max"]
+    assert d["repeats"]["n"] == 2 and d["repeats"]["min"] <= d["repeats"]["max"]
+    assert d["eager_ms_per_step"] > 0 and "replay" in d["config"]["launch"]
+    assert len(lines[0]) <= 1600 and os.path.exists(os.path.join(ROOT, d["details"]))
+    full = json.load(open(os.path.join(ROOT, d["details"])))
+    assert full["value"] == d["value"] and "avg_launch_timing" in full["roofline"]
+
+
+def test_headline_of_a_full_result_fits_the_drivers_tail_window():
+    """The driver keeps the last 2000 characters of the run's output: the stdout line must fit there as a WHOLE JSON object
+    with the numbers a reader needs (round 5's line was 7 KB and arrived truncated)."""
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    full["eager_ms_per_step"] = 0.8312
+    full["cpu_baseline"]["sample_batch"] = 2
+    h = b.headline_of(full, "gpurun_out/bench_details.json")
+    line = json.dumps(h)
+    assert len(line) <= 1536, len(line)          # 1.5 KB
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "eager_ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "cfg4_train"):
+        assert key in h, key
+    assert h["roofline"]["frac"] == full["roofline"]["frac"] and h["roofline"]["traffic"] == full["roofline"]["traffic"]
+    assert h["cfg4_train"]["traffic_bytes_per_step"] == full["other_configs"]["cfg4_train"]["traffic_bytes_per_step"]
+    assert h["cpu_baseline"]["sample_batch"] == 2 and h["other_ms_per_step"]["cfg2_b1"] > 0
 
 
 def test_only_the_result_line_reaches_stdout():

@@ -104,6 +104,50 @@ def test_copy_batch_writes_into_the_static_tensors():
         data.copy_batch_(a, c)
 
 
+def test_copy_batch_never_copies_the_graph_tensors():
+    """A captured step runs on the topology handle it was captured with: edge_index / batch / node_type are not copied (a
+    pageable host-to-device copy of 7 - 55 MB per step otherwise, and a version bump that defeats the identity resolution) --
+    the collate() constant the static tensor was moved from is recognised by identity, a fresh equal tensor is compared once, a
+    different graph is refused instead of silently running on the old one."""
+    np.random.seed(5)
+    ds = data.SyntheticEchoDataset(num_aux_graphs=3, frame_size=16)
+    static = data.collate([ds[0], ds[1]], ds.topology)
+    static.edge_index, static.batch, static.node_type = static.edge_index.clone(), static.batch.clone(), static.node_type.clone()
+    v0 = (static.edge_index._version, static.batch._version, static.node_type._version)
+    calls = []
+    orig = torch.equal
+    try:
+        torch.equal = lambda a, b: (calls.append(1), orig(a, b))[1]
+        for k in (2, 4):
+            data.copy_batch_(static, data.collate([ds[k], ds[k + 1]]))              # fresh (equal) graph tensors every time
+    finally:
+        torch.equal = orig
+    assert len(calls) == 3                                                            # compared once per attribute, not per step
+    assert (static.edge_index._version, static.batch._version, static.node_type._version) == v0
+    other = data.collate([ds[0], ds[1]])
+    other.edge_index = other.edge_index.flip(0)
+    fresh = data.collate([ds[0], ds[1]], ds.topology)
+    fresh.edge_index, fresh.batch, fresh.node_type = fresh.edge_index.clone(), fresh.batch.clone(), fresh.node_type.clone()
+    with pytest.raises(ValueError, match="ONE\\s+topology"):
+        data.copy_batch_(fresh, other)
+
+
+def test_to_device_caches_only_what_collate_registered():
+    np.random.seed(6)
+    ds = data.SyntheticEchoDataset(num_aux_graphs=3, frame_size=16)
+    before = len(data._CONST_ON_DEVICE)
+    plain = data.collate([ds[0], ds[1]])                                              # fresh graph tensors: never cached
+    data.to_device(plain, "meta")
+    assert len(data._CONST_ON_DEVICE) == before and plain.edge_index.device.type == "meta"
+    const = data.collate([ds[0], ds[1]], ds.topology)
+    cpu_ei = const.edge_index
+    data.to_device(const, "meta")
+    again = data.to_device(data.collate([ds[2], ds[3]], ds.topology), "meta")
+    assert len(data._CONST_ON_DEVICE) == before + 3 and again.edge_index is const.edge_index and data._is_collate_const(cpu_ei)
+    for k in [k for k in data._CONST_ON_DEVICE if k[1] == "meta"]:
+        del data._CONST_ON_DEVICE[k]
+
+
 def test_collate_hands_out_the_constant_tensors_of_a_topology_again():
     """collate(..., topology): edge_index / batch / node_type depend on (topology, batch size) only -- built once, the SAME tensors
     for every later batch (the model resolves a known edge_index by identity; to_device moves it once per device), equal to what a

@@ -185,3 +185,45 @@ def test_to_device_moves_the_constant_tensors_of_a_topology_once():
     assert a.x is not b.x and a.x.is_cuda and not torch.equal(a.x, b.x)
     n = ds.topology.num_nodes
     assert torch.equal(a.edge_index.cpu(), torch.cat([ds.edge_index, ds.edge_index + n], dim=1))
+
+
+def test_documented_graphed_loop_takes_new_batches_without_touching_the_graph_tensors():
+    """``copy_batch_(static, batch); step()``.  New frames / labels arrive in place and reach the replay (the
+    loss follows the batch), while edge_index / batch / node_type are neither copied (no version bump, no pageable host-to-device
+    copy per step) nor silently replaced: another graph is refused."""
+    import copy
+    B, frame, naux = 2, 32, 4
+    hip, _, emb_hip, _, ds = _setup(frame, naux, True, 13)
+    for m in hip.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    hip.train()
+    for q in emb_hip.parameters():
+        q.requires_grad_(False)
+    host = [data.collate([ds[2 * i], ds[2 * i + 1]], ds.topology) for i in range(3)]
+    static = data.to_device(copy.copy(host[0]), DEV)
+    crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1), "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux),
+            "coordinate": engine.MSE(1)}
+    opt = torch.optim.Adam(list(hip.parameters()), lr=0.0, capturable=True)         # lr 0: the loss is a function of the batch alone
+    model = {"embedder": emb_hip, "landmark": hip}
+    coords0 = static.node_coords.clone()
+
+    def loss_fn():
+        static.node_coords = coords0.clone()
+        preds, cp = engine.forward_batch(model, static, True)
+        return sum(engine.compute_loss(crit, preds, static.y, cp, static.node_coord_y, static.valid_labels, B).values())
+
+    step = engine.GraphedTrainStep(loss_fn, opt, warmup=1)
+    ei, v0 = static.edge_index, static.edge_index._version
+    seen = []
+    for k in (1, 2, 1):
+        data.copy_batch_(static, host[k])
+        seen.append(float(step()[0]))
+        assert torch.equal(static.x.cpu(), host[k].x) and torch.equal(static.y.cpu(), host[k].y)
+    assert static.edge_index is ei and ei._version == v0
+    assert seen[0] != seen[1] and seen[0] == seen[2]             # the replay reads the new batch; same batch, same loss (p = 0, lr = 0)
+    other = data.collate([ds[0], ds[1]])                         # fresh tensors with another graph in them
+    other.edge_index = other.edge_index.flip(0).contiguous()
+    fresh_static = data.to_device(copy.copy(data.collate([ds[0], ds[1]])), DEV)
+    with pytest.raises(ValueError):
+        data.copy_batch_(fresh_static, other)

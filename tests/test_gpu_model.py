@@ -232,3 +232,52 @@ def test_signature_default_widths_take_the_compatibility_route(frame, naux, batc
     with pytest.raises(NotImplementedError):
         model_pair(frame, naux, 3, coord=True, node_hidden_dim=64)
 
+
+
+@pytest.mark.parametrize("frame,naux,batch,conn", [(64, 6, 2, False), (224, 7, 1, False), (32, 4, 2, True)])
+def test_hip_graph_replay_is_reached_through_forward_with_new_frames_every_call(frame, naux, batch, conn):
+    """engine.py:251-255 / :394-398 call ``model(x=frames, edge_index=...)`` with NEW frames (and, from a DataLoader, a new
+    edge_index tensor of the same content) every step.  With enable_hip_graph(True) the packing in front of the stack writes into
+    the model's static node-feature buffer and every call replays ONE captured graph: 5 different frame tensors + a fresh copy of
+    the edge_index -> exactly 1 capture, every output bit-equal to the eager forward of the same frames; ``model(data_batch)``
+    takes the same route; a parameter update captures again (the folded parameters changed) and follows it."""
+    hip, ref = model_pair(frame, naux, 3, seed=31, use_connection_nodes=conn)
+    topo, ei, nt, bi = graph_tensors(frame, naux, batch, conn=conn)
+    ei_d, nt_d, bi_d = ei.to(DEV), nt.to(DEV), bi.to(DEV)
+    frames = [synthetic_frames(batch, 128, frame, 40 + k).to(DEV) for k in range(5)]
+    with torch.no_grad():
+        eager = [hip(x=f, edge_index=ei_d, node_type=nt_d, batch_idx=bi_d)[0].clone() for f in frames]
+        want, _ = ref(x=frames[2].cpu(), edge_index=ei, node_type=nt, batch_idx=bi)
+    assert (eager[2].cpu() - want).abs().max() < TOL
+    hip.enable_hip_graph(True)
+    assert hip.hip_graph_captures == 0
+    with torch.no_grad():
+        for k, f in enumerate(frames):
+            e = ei_d if k % 2 == 0 else ei_d.clone()             # (a fresh tensor with the same edges resolves to the same handle)
+            got = hip(x=f, edge_index=e, node_type=nt_d, batch_idx=bi_d)[0]
+            assert torch.equal(got, eager[k]), k
+        assert hip.hip_graph_captures == 1
+
+        class _Batch:
+            pass
+        db = _Batch()
+        db.x, db.edge_index, db.batch, db.node_type = frames[3], ei_d, bi_d, nt_d
+        assert torch.equal(hip(db)[0], eager[3]) and hip.hip_graph_captures == 1
+        # the caller's own buffer through forward_nodes: captured once per buffer ADDRESS, whatever tensor object wraps it
+        feats = hip.create_node_pixels(frames[1], batch).clone()
+        a = hip.forward_nodes(feats, ei_d, batch)[0].clone()
+        b = hip.forward_nodes(feats.view(-1, 128), ei_d.clone(), batch)[0].clone()
+        assert torch.equal(a, eager[1]) and torch.equal(b, eager[1]) and hip.hip_graph_captures == 2
+        # new weights: the next call follows them (one more capture), bit-equal to eager again
+        hip.gnn_layers[0].module_0.lin.weight.mul_(1.5)
+        got = hip(x=frames[4], edge_index=ei_d, node_type=nt_d, batch_idx=bi_d)[0].clone()
+        assert hip.hip_graph_captures == 3
+        hip.enable_hip_graph(False)
+        assert torch.equal(got, hip(x=frames[4], edge_index=ei_d, node_type=nt_d, batch_idx=bi_d)[0])
+    # a call that wants gradients never lands in the static buffer
+    hip.enable_hip_graph(True)
+    n0 = hip.hip_graph_captures
+    x = frames[0].clone().requires_grad_(True)
+    out, _ = hip(x=x, edge_index=ei_d, node_type=nt_d, batch_idx=bi_d)
+    out.sum().backward()
+    assert x.grad is not None and hip.hip_graph_captures == n0

@@ -155,13 +155,15 @@ def test_two_rank_gradients_match_single_process(tmp_path, mode):
 
 def test_bench_starts_its_own_ranks_and_propagates_failure():
     """`python bench.py --gpus 2` without WORLD_SIZE starts 2 rank processes itself (before any GPU call in the parent).
-    In this container there is no GPU, so both ranks refuse to run and the parent must exit non-zero."""
+    In this container there is no GPU, so both ranks refuse to run and the parent must exit non-zero.  With a GPU the same
+    parent / child structure runs for real: tests/test_gpu_parallel.py::test_world_2_on_one_gpu_... (two ranks on one device over
+    gloo) and ::test_world_2_parent_exits_with_the_worst_rank_code."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     if torch.cuda.is_available():
-        pytest.skip("exercised for real by the GPU runs")
+        pytest.skip("with a GPU: tests/test_gpu_parallel.py::test_world_2_* run the same parent with real ranks")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
