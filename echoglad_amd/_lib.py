@@ -15,7 +15,7 @@ LIB_PATH = Path(os.environ.get("ECHOGLAD_LIB", _PKG / "lib" / "libechoglad_hip.s
 HEADER_PATH = _PKG.parent / "include" / "echoglad_hip.h"
 
 EG_OK, EG_ERR_ARG, EG_ERR_UNSUPPORTED, EG_ERR_HIP = 0, -1, -2, -3
-ABI_VERSION = 134          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
+ABI_VERSION = 135          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
 
 _lib: Optional[ct.CDLL] = None
 
@@ -34,6 +34,18 @@ class ClsTrainParams(ct.Structure):
 _f = ct.c_float
 _u64 = ct.c_uint64
 _pp = ct.POINTER(ClsTrainParams)
+
+
+class LowerSums(ct.Structure):
+    """eg_lower_sums: the layer below the one whose dX launch takes its BatchNorm-backward sums (eg_gcn_layer_bwd_lower)."""
+    _fields_ = [("z", _p), ("bn", _p), ("relu", _i), ("dropout_p", _f), ("seed", _u64), ("row_hi", _i64), ("tile_scratch", _p),
+                ("sums_out", _p)]
+
+
+class GivenSums(ct.Structure):
+    """eg_given_sums: sums of THIS layer that somebody else has taken already (+ the bilinear backward's later additions)."""
+    _fields_ = [("sums", _p), ("frames", _i), ("row_lo", _i64), ("n_valid", _i64), ("taps", _p)]
+
 
 # name -> (restype, argtypes); must list every symbol the header declares
 SIGNATURES: Dict[str, tuple] = {
@@ -83,6 +95,9 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_classifier_bwd_sums": (_i, [_p, _p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _u64, _p, _p]),
     "eg_gcn_layer_bwd_presummed": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _f, _u64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i,
                                         _i64, _i64, _p]),
+    "eg_gcn_layer_bwd_lower": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _f, _u64, _i, _p, _p, _p, _p, _p, _p, _p,
+                                    ct.POINTER(GivenSums), ct.POINTER(LowerSums), _p]),
+    "eg_bilinear4_bwd_rows_sums": (_i, [_p, _i64, _p, _p, _i, _i, _i64, _i64, _i, _p, _p, ct.POINTER(LowerSums), _p, _p]),
     "eg_coord_mlp_fwd": (_i, [_p, _p, _i, _pp, _i, _i, _p, _p, _p, _p, _p, _p]),
     "eg_coord_mlp_bwd": (_i, [_p, _p, _p, _i, _pp, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "eg_coord_mlp_fwd_rows": (_i, [_p, _i64, _p, _p, _i, _pp, _i, _i, _p, _p, _p, _p, _p, _p]),

@@ -1195,7 +1195,8 @@ using namespace eg;
 int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, int relu, float dropout_p, unsigned long long seed, void* workspace, float* dz,
                      float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream,
-                     const double* presum = nullptr, const eg::RowMap* presum_rows = nullptr, int presum_frames = 0);
+                     const double* presum = nullptr, const eg::RowMap* presum_rows = nullptr, int presum_frames = 0,
+                     const float* presum_taps = nullptr);
 
 extern "C" {
 

@@ -296,6 +296,24 @@ struct ClsArgs {
     int row_lo, n_valid;        // the heads' node-type filter: rows [row_lo, row_lo + n_valid) of a frame have a logits row (logits is [batch * n_valid, 4])
 };
 }  // namespace eg
+namespace eg {
+// dX launch that ALSO takes the BatchNorm-backward sums of the layer BELOW (k_gcn_layer_ps MODE 3): its output rows are that
+// layer's dy, so  sum g  and  sum g * z  (g = dy * dropout keep * ReLU gate of the lower layer's activation) are accumulated where
+// the finished rows pass through the consumers' registers on their way out, one [2][128] float partial per TILE (fixed order
+// inside a tile, tiles summed in index order afterwards: the same bits whoever wins a queue).  Rows >= row_hi of a frame (the
+// coordinate nodes: the coordinate update's backward rewrites them afterwards) are left out.
+struct LowerSums {
+    const float* z;                 // the lower layer's pre-BatchNorm rows [batch * n, 128]
+    const float* scale;             // its BatchNorm forward scale / shift (bn + 2 * 128, bn + 3 * 128 of eg_gcn_layer_train_fwd)
+    const float* shift;
+    int relu;
+    float p, inv_keep;
+    unsigned long long seed;
+    const unsigned long long* epoch;
+    int row_hi;
+    float* tile_partial;            // [batch * tiles_per_frame][2][128]
+};
+}  // namespace eg
 // symmetric 8-wave layer kernel (gcn_layer.hip) for any handle; agg_out (nullable) receives the aggregated rows A_hat x,
 // stats_partial (nullable) per-workgroup column sums of out and out^2 as float [*grid_out][2][128]
 int eg_launch_layer_sym(const eg_graph* g, int batch, const float* x, const float* W, const float* scale, const float* shift,
@@ -304,4 +322,5 @@ int eg_launch_layer_sym(const eg_graph* g, int batch, const float* x, const floa
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
                        const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream, const float* jk_in = nullptr,
-                       float* jk_out = nullptr, float* agg_out = nullptr, float* stats_partial = nullptr, int* grid_out = nullptr);
+                       float* jk_out = nullptr, float* agg_out = nullptr, float* stats_partial = nullptr, int* grid_out = nullptr,
+                       const eg::LowerSums* lower = nullptr);

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "seg_wide.h"
+#include "train_common.h"
 
 namespace eg {
 
@@ -35,6 +36,7 @@ struct PsDims {
     const float* conn;
     int conn_stride, conn_agg, conn_scaled, n_conn;
     int self_reset;    // the last workgroup out zeroes the launch's slice of the queue ring (no memset in front of the next user)
+    LowerSums lower;   // MODE 3: the BatchNorm-backward sums of the layer below, taken from the rows this launch writes (common.h)
 };
 
 // Static walk: blockIdx % 8 labels the chunk of the tile order (round-robin dispatch puts those workgroups on one XCD: a
@@ -144,7 +146,8 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                                                                 int* __restrict__ counters, const PsDims a, const ClsArgs ca,
                                                                 const int* __restrict__ rowptr, const int* __restrict__ colidx) {
     constexpr bool TRAIN = MODE == 1;                 // train forward: aggregated rows kept, BatchNorm sums, static walk
-    constexpr bool RSEP = MODE == 2;                  // the residual is a tensor of its own (a.res: the backward's dX = (A_hat dz) W + dy)
+    constexpr bool RSEP = MODE >= 2;                  // the residual is a tensor of its own (a.res: the backward's dX = (A_hat dz) W + dy)
+    constexpr bool SUMS = MODE == 3;                  // ... and the rows written are the lower layer's dy: its BatchNorm-backward sums leave per tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_a0 = smem;                               // [2][TILE * LDA]  aggregated tiles
     float* s_x0 = smem + 2 * TILE * LDA;              // [2][TILE * LDA]  raw self rows (residual); then the output tile
@@ -247,6 +250,14 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
         f32x16 csum, csq;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { csum[i] = 0.f; csq[i] = 0.f; }
+        // SUMS: this lane's 4 channels in the store phase are 32 wave + 4 (lane & 7) + {0..3} for every row it touches
+        f32x4 lsc = {0.f, 0.f, 0.f, 0.f}, lsh = lsc;
+        unsigned long long lseed = 0;
+        if (SUMS) {
+            lsc = *reinterpret_cast<const f32x4*>(a.lower.scale + 32 * wave + 4 * (lane_k & 7));
+            lsh = *reinterpret_cast<const f32x4*>(a.lower.shift + 32 * wave + 4 * (lane_k & 7));
+            lseed = a.lower.seed + epoch_now(a.lower.epoch);
+        }
         __syncthreads();                                   // tile 0 is in buffer 0
         int frame_hint = 0;
         PSTAMP_INIT;
@@ -275,6 +286,21 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             for (int i = 0; i < 8; ++i) {
                 seg_first[i] = __builtin_amdgcn_readlane(cd, 4 * i);
                 seg_cnt[i] = __builtin_amdgcn_readlane(cd, 4 * i + 1);
+            }
+            // SUMS: the lower layer's z rows of the tile, in the store phase's layout (8 lanes per row), issued here -- a whole tile of
+            // matrix work in front of their use, inside ONE iteration (the compiler counts the stores issued behind them: no drain)
+            f32x4 zr[8];
+            f32x4 ls1 = {0.f, 0.f, 0.f, 0.f}, lt1 = ls1;
+            if (SUMS) {
+                const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(a.lower.z) + (size_t)frame * a.n_per_frame * C, 0, a.n_per_frame * (C * 4), 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int last = seg_cnt[i] - 1;
+                    const int u = (lane >> 3) < last ? (lane >> 3) : last;        // (absent segment: u = -1, out of range, reads 0)
+                    zr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        zrsrc, u * (C * 4) + (32 * wave + 4 * (lane & 7)) * 4, seg_first[i] * (C * 4), 0));
+                }
             }
             // Child sums of the OUTPUT for the next layer (kout): lane -> (parent q = (lane >> 3) + 8 i, 16-B chunk lane & 7);
             // the parent's four children are rows 2 pr, 2 pr + 1, columns 2 pc, 2 pc + 1 of this patch.
@@ -420,6 +446,24 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     }
                 }
             };
+            auto lower_sums = [&](int i0) {                 // SUMS: rows of segments i0 .. i0+3 as they sit in o[] (dy of the lower layer)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int node = seg_first[i0 + e] + u8;
+                    const bool live = u8 < seg_cnt[i0 + e] && node < a.lower.row_hi;      // not a repeated / absent row, not a coordinate node
+                    f32x4 g = o[e];
+                    if (a.lower.p > 0.f)
+                        g *= keep_scale4(lseed, ((unsigned long long)frame * a.n_per_frame + node) * C + 32 * wave + c4, a.lower.p, a.lower.inv_keep);
+                    const f32x4 zz = zr[i0 + e];
+                    const f32x4 v = zz * lsc + lsh;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float ge = (live && (!a.lower.relu || v[u] > 0.f)) ? g[u] : 0.f;
+                        ls1[u] += ge;
+                        lt1[u] += ge * zz[u];
+                    }
+                }
+            };
             auto store_segments = [&]() {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -438,7 +482,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             auto between = [&](int c) {
                 if (c < 2) { finish_group(acc0, 0, 2 * c); finish_group(acc0, 0, 2 * c + 1); }
                 else if (!CLS && c == 2) read_segments(0);
-                else if (!CLS) { store_segments(); kout_half(0); }
+                else if (!CLS) { store_segments(); if (SUMS) lower_sums(0); kout_half(0); }
                 else if (c == 2) {                      // CLS: the residual rows of the second block, into the registers the first one has left
 #pragma unroll
                     for (int g = 0; g < 4; ++g) res[0][g] = *reinterpret_cast<const f32x4*>(s_x + (32 + j) * LDA + 32 * wave + 4 * h + 8 * g);
@@ -451,7 +495,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             if (!CLS) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
-                read_segments(0); store_segments(); kout_half(0);
+                read_segments(0); store_segments(); if (SUMS) lower_sums(0); kout_half(0);
             } else {
                 between(0); between(1); between(2);
             }
@@ -467,7 +511,7 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             acc0[0] += wreg[0] + s_a[lane]; acc1[0] += wreg[63];
 #pragma unroll
             for (int g = 0; g < 4; ++g) finish_group(acc0, 0, g);
-            if (!CLS) { read_segments(0); store_segments(); kout_half(0); }
+            if (!CLS) { read_segments(0); store_segments(); if (SUMS) lower_sums(0); kout_half(0); }
 #endif
             PSTAMP(0);
 #ifdef EG_STAMP3                  // finer consumer stamp: the first EG_STAMP3 groups of the exposed epilogue count as "loop"
@@ -483,6 +527,21 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
             if (!CLS) {
                 read_segments(4);
                 store_segments();
+                if (SUMS) {
+                    lower_sums(4);
+                    // over the 8 rows a wave instruction covers (lane bits 3..5), fixed order; lanes 0..7 hold the tile's sums of
+                    // channels 32 wave + 4 lane .. + 3
+#pragma unroll
+                    for (int m = 8; m < 64; m <<= 1) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { ls1[u] += __shfl_xor(ls1[u], m); lt1[u] += __shfl_xor(lt1[u], m); }
+                    }
+                    if (lane < 8) {
+                        float* tp = a.lower.tile_partial + (size_t)t_cur * 2 * C + 32 * wave + 4 * lane;
+                        *reinterpret_cast<f32x4*>(tp) = ls1;
+                        *reinterpret_cast<f32x4*>(tp + C) = lt1;
+                    }
+                }
                 kout_half(1);
             } else {
                 // ---- classifier heads on the finished tile (all 128 channels of it are needed: the four consumer waves
@@ -856,8 +915,11 @@ int eg_launch_conn_prepass(const eg_graph* g, int batch, const float* x, int slo
 int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float* W, const float* scale,
                        const float* shift, const float* residual, int relu, int transpose_w, float* out,
                        const float* kin, float* kout, const eg::ClsArgs* cls, hipStream_t stream, const float* jk_in, float* jk_out,
-                       float* agg_out, float* stats_partial, int* grid_out) {
+                       float* agg_out, float* stats_partial, int* grid_out, const eg::LowerSums* lower) {
     if (!g || g->kind != GRAPH_TOPO) return EG_ERR_UNSUPPORTED;
+    if (lower && !(residual != nullptr && residual != x)) return set_error(EG_ERR_ARG, "the lower layer's sums go with the dX launch (a residual tensor of its own)");
+    if (lower && (!lower->z || !lower->scale || !lower->shift || !lower->tile_partial || lower->row_hi < 1))
+        return set_error(EG_ERR_ARG, "incomplete LowerSums");
     const bool train = stats_partial != nullptr;
     const bool rsep = residual != nullptr && residual != x;       // a residual tensor of its own: MODE 2, plain calls only
     if (rsep && (train || kin || kout || cls || jk_in || jk_out)) return EG_ERR_UNSUPPORTED;
@@ -883,6 +945,7 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     a.kid_rows = g->kid_rows; a.n_pats = g->n_pats;
     a.agg_out = agg_out; a.stats_partial = stats_partial; a.static_walk = train ? 1 : 0;
     a.res = rsep ? residual : nullptr;
+    if (lower) a.lower = *lower;
     const long long n_tiles = (long long)a.tiles_per_frame * batch;
     if (n_tiles <= 0) return EG_OK;
     const size_t lds = (size_t)(PS_LDS_PAT + g->n_pats * PATQ + (cls ? 4 * C : 0)) * sizeof(float);      // (graph.hip checks the same sum)
@@ -896,7 +959,8 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
                                      (const void*)k_gcn_layer_ps<false, true>, (const void*)k_gcn_layer_ps<true, true>,
                                      (const void*)k_gcn_layer_ps<false, false, 1>, (const void*)k_gcn_layer_ps<false, false, 2>,
                                      (const void*)k_gcn_layer_ps<false, false, 0, true>, (const void*)k_gcn_layer_ps<true, false, 0, true>,
-                                     (const void*)k_gcn_layer_ps<false, false, 1, true>, (const void*)k_gcn_layer_ps<false, false, 2, true>};
+                                     (const void*)k_gcn_layer_ps<false, false, 1, true>, (const void*)k_gcn_layer_ps<false, false, 2, true>,
+                                     (const void*)k_gcn_layer_ps<false, false, 3>, (const void*)k_gcn_layer_ps<false, false, 3, true>};
             for (const void* f : kernels) EG_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
@@ -946,10 +1010,12 @@ int eg_launch_layer_ps(const eg_graph* g, int batch, const float* x, const float
     eg::LaunchTimer timer(train ? EG_LAUNCH_PS_TRAIN_FWD : rsep ? EG_LAUNCH_PS_DX : cls ? EG_LAUNCH_PS_CLS : EG_LAUNCH_PS_PLAIN, stream);
     if (diag) {
         if (train) launch(k_gcn_layer_ps<false, false, 1, true>);
+        else if (rsep && lower) launch(k_gcn_layer_ps<false, false, 3, true>);
         else if (rsep) launch(k_gcn_layer_ps<false, false, 2, true>);
         else if (cls) launch(k_gcn_layer_ps<true, false, 0, true>);
         else launch(k_gcn_layer_ps<false, false, 0, true>);
     } else if (train) launch(k_gcn_layer_ps<false, false, 1>);
+    else if (rsep && lower) launch(k_gcn_layer_ps<false, false, 3>);
     else if (rsep) launch(k_gcn_layer_ps<false, false, 2>);
     else if (cls) { if (jk) launch(k_gcn_layer_ps<true, true>); else launch(k_gcn_layer_ps<true, false>); }
     else { if (jk) launch(k_gcn_layer_ps<false, true>); else launch(k_gcn_layer_ps<false, false>); }

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_presum(const double* __restrict
                                                         const float* __restrict__ z, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const RowMap m, int batch,
-                                                        double* __restrict__ totals, const ActArgs a_) {
+                                                        double* __restrict__ totals, const ActArgs a_, const float* __restrict__ taps) {
     const ActArgs a = resolved(a_);
     __shared__ double s_red[8][2][C];
     const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
@@ -269,8 +269,41 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_presum(const double* __restrict
         double t = presum[grp * C + c];
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += s_red[k][grp][c];
+        if (taps)                                  // what the bilinear backward added inside the summed range afterwards, frame by frame
+            for (int f = 0; f < batch; ++f) t += (double)taps[((size_t)f * 2 + grp) * C + c];
         totals[grp * C + c] = t;
     }
+}
+
+// ---- the lower layer's sums from the dX launch's per-tile partials (gcn_layer_ps.hip MODE 3): float [n_tiles][2][128] ->
+// stage 1: one workgroup per (32 columns, chunk of tiles): double [chunks][256];  stage 2: chunks in ascending order, and
+// sum g * z  ->  sum g * xhat = invstd * (sum g * z - mean * sum g).  Fixed order throughout.
+constexpr int TILE_SUM_CHUNKS = 64;
+__global__ __launch_bounds__(RED_F32_THREADS) void k_tile_sums_stage1(const float* __restrict__ partial, int n_tiles, int per,
+                                                                      double* __restrict__ out) {
+    __shared__ double red[RED_F32_THREADS];
+    const int t = threadIdx.x, col = blockIdx.x * 32 + (t & 31), sl = t >> 5;
+    const int lo = blockIdx.y * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    double s = 0.0;
+#pragma unroll 4
+    for (int b = lo + sl; b < hi; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * 2 * C + col];
+    red[t] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = RED_F32_THREADS / 64; st > 0; st >>= 1) {
+        if (sl < st) red[t] += red[t + 32 * st];
+        __syncthreads();
+    }
+    if (sl == 0) out[(size_t)blockIdx.y * 2 * C + col] = red[t];
+}
+__global__ void k_tile_sums_stage2(const double* __restrict__ chunks, int n_chunks, const float* __restrict__ mean,
+                                   const float* __restrict__ invstd, double* __restrict__ sums) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, t1 = 0.0;
+    for (int k = 0; k < n_chunks; ++k) { s1 += chunks[(size_t)k * 2 * C + c]; t1 += chunks[(size_t)k * 2 * C + C + c]; }
+    sums[c] = s1;
+    sums[C + c] = (double)invstd[c] * (t1 - (double)mean[c] * s1);
 }
 
 __global__ void k_bn_bwd_final(const double* __restrict__ totals, float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -598,7 +631,7 @@ static ActArgs make_act(int64_t rows, int relu, float p, uint64_t seed) {
 int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, int relu, float dropout_p, unsigned long long seed, void* workspace, float* dz,
                      float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream,
-                     const double* presum, const eg::RowMap* presum_rows, int presum_batch) {
+                     const double* presum, const eg::RowMap* presum_rows, int presum_batch, const float* presum_taps) {
     if (!dy || !z || !mean || !invstd || !gamma || !beta || !workspace || !dgamma || !dbeta || rows < 1)
         return set_error(EG_ERR_ARG, "bad argument");
     if (!dz && !(dw && x)) return set_error(EG_ERR_ARG, "dz may only be NULL when the fused weight gradient is computed");
@@ -609,7 +642,7 @@ int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const floa
     double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
     if (presum) {          // the sums over most rows exist: add the few rows they leave out
         hipLaunchKernelGGL(k_bn_bwd_presum, dim3(1), dim3(1024), 0, stream, presum, dy, z, mean, invstd, gamma, beta, *presum_rows,
-                           presum_batch, totals, a);
+                           presum_batch, totals, a, presum_taps);
     } else {
         hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nb), dim3(RED_THREADS), 0, stream, dy, z, mean, invstd, gamma, beta, partial, a);
         hipLaunchKernelGGL(k_reduce_partials<2>, dim3(2 * C / 8), dim3(256), 0, stream, partial, nb, totals);
@@ -685,7 +718,7 @@ int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* me
                   const float* gamma, const float* beta, int relu, float dropout_p, uint64_t seed, void* workspace,
                   float* dz, float* dgamma, float* dbeta, eg_stream_t stream) {
     return eg_launch_bn_bwd(dy, z, rows, mean, invstd, gamma, beta, relu, dropout_p, seed, workspace, dz, dgamma, dbeta, nullptr,
-                            nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0);
+                            nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0, nullptr);
 }
 
 int eg_dweight128(const float* g, const float* x, int64_t rows, void* workspace, float* dw, eg_stream_t stream) {
@@ -744,23 +777,50 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
 static int gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
                          const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
                          int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
-                         float* dbeta, const double* presum, const RowMap* presum_rows, int presum_frames, eg_stream_t stream_) {
+                         float* dbeta, const double* presum, const RowMap* presum_rows, int presum_frames, eg_stream_t stream_,
+                         const float* presum_taps = nullptr, const eg_lower_sums* lower = nullptr) {
     if (!g_bwd || !dy || !z || !W || !gamma || !beta || !bn || !workspace || !dgamma || !dbeta)
         return set_error(EG_ERR_ARG, "NULL argument");
+    static const bool train_ps_on = !(getenv("EG_TRAIN_PS") && atoi(getenv("EG_TRAIN_PS")) == 0);
+    if (lower) {
+        // decided before anything is launched: the by-product exists only on the producer / consumer kernel's dX launch
+        if (!lower->z || !lower->bn || !lower->tile_scratch || !lower->sums_out || lower->row_hi < 1 || lower->row_hi > g_bwd->n_nodes)
+            return set_error(EG_ERR_ARG, "incomplete eg_lower_sums");
+        if (lower->dropout_p < 0.f || lower->dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+        if (!dx || !residual || !train_ps_on || g_bwd->kind != GRAPH_TOPO) return EG_ERR_UNSUPPORTED;
+        if (lower->dropout_p > 0.f && !eg_epoch_ptr()) return set_error(EG_ERR_HIP, "the dropout epoch word could not be allocated");
+    }
     if (!dz_scratch && (dx || !dw)) return set_error(EG_ERR_ARG, "dz_scratch may only be NULL when dx is not wanted and dw is");
     if (dw && !agg) return set_error(EG_ERR_ARG, "dW needs the aggregated input kept by eg_gcn_layer_train_fwd");
     hipStream_t stream = (hipStream_t)stream_;
     const long long rows = (long long)g_bwd->n_nodes * batch;
     int rc = eg_launch_bn_bwd(dy, z, rows, bn, bn + C, gamma, beta, relu, dropout_p, seed, workspace, dz_scratch, dgamma, dbeta,
-                              dw ? agg : nullptr, nullptr, dw, stream, presum, presum_rows, presum_frames);
+                              dw ? agg : nullptr, nullptr, dw, stream, presum, presum_rows, presum_frames, presum_taps);
     if (rc != EG_OK) return rc;
     if (dx) {
         // dX = (A_hat dz) W + dy: the producer / consumer kernel with the residual as a tensor of its own (implicit topologies)
-        static const bool train_ps = !(getenv("EG_TRAIN_PS") && atoi(getenv("EG_TRAIN_PS")) == 0);
+        const bool train_ps = train_ps_on;
         rc = EG_ERR_UNSUPPORTED;
-        if (train_ps && residual)
+        if (lower) {
+            const LowerSums ls{lower->z, lower->bn + 2 * C, lower->bn + 3 * C, lower->relu, lower->dropout_p,
+                               lower->dropout_p > 0.f ? 1.0f / (1.0f - lower->dropout_p) : 1.0f, (unsigned long long)lower->seed,
+                               eg_epoch_ptr(), (int)lower->row_hi, lower->tile_scratch};
+            rc = eg_launch_layer_ps(g_bwd, batch, dz_scratch, W, nullptr, nullptr, dy, 0, 1, dx, nullptr, nullptr, nullptr, stream,
+                                    nullptr, nullptr, nullptr, nullptr, nullptr, &ls);
+            if (rc == EG_ERR_UNSUPPORTED) return set_error(EG_ERR_HIP, "the dX launch with the lower layer's sums was refused after the layer's own passes had run");
+            if (rc != EG_OK) return public_rc(rc);
+            const int n_tiles = g_bwd->n_tiles * batch;
+            const int chunks = n_tiles < TILE_SUM_CHUNKS ? n_tiles : TILE_SUM_CHUNKS;
+            const int per = (n_tiles + chunks - 1) / chunks;
+            double* chunk_sums = (double*)workspace;             // (the reduction area of the workspace: this layer's own passes are done with it)
+            hipLaunchKernelGGL(k_tile_sums_stage1, dim3(2 * C / 32, chunks), dim3(RED_F32_THREADS), 0, stream, (const float*)lower->tile_scratch,
+                               n_tiles, per, chunk_sums);
+            hipLaunchKernelGGL(k_tile_sums_stage2, dim3(1), dim3(128), 0, stream, (const double*)chunk_sums, chunks, lower->bn, lower->bn + C,
+                               lower->sums_out);
+            EG_HIP_TRY(hipGetLastError());
+        } else if (train_ps && residual)
             rc = eg_launch_layer_ps(g_bwd, batch, dz_scratch, W, nullptr, nullptr, dy, 0, 1, dx, nullptr, nullptr, nullptr, stream);
-        if (rc == EG_ERR_UNSUPPORTED)
+        if (rc == EG_ERR_UNSUPPORTED && !lower)
             rc = eg_launch_layer_sym(g_bwd, batch, dz_scratch, W, nullptr, nullptr, residual ? dy : nullptr, 0, 1, dx, nullptr, nullptr,
                                      nullptr, stream);
         if (rc != EG_OK) return public_rc(rc);
@@ -789,6 +849,25 @@ int eg_gcn_layer_bwd_presummed(const eg_graph* g_bwd, int batch, const float* dy
     // (frames, not `batch`, counts the row ranges: a CSR handle of a whole batch has batch == 1)
     return gcn_layer_bwd(g_bwd, batch, dy, z, agg, W, gamma, beta, bn, relu, dropout_p, seed, residual, workspace, dz_scratch, dx, dw,
                          db, dgamma, dbeta, dy_sums, &m, frames, stream);
+}
+
+
+int eg_gcn_layer_bwd_lower(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
+                           const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
+                           int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
+                           float* dbeta, const eg_given_sums* given, const eg_lower_sums* lower, eg_stream_t stream) {
+    if (!g_bwd) return set_error(EG_ERR_ARG, "NULL argument");
+    RowMap m{0, 0, 0};
+    if (given) {
+        if (!given->sums || given->frames < 1 || (long long)g_bwd->n_nodes * batch % given->frames != 0)
+            return set_error(EG_ERR_ARG, "given sums: frames must divide the layer's rows");
+        const long long n_per_frame = (long long)g_bwd->n_nodes * batch / given->frames;
+        if (given->row_lo < 0 || given->n_valid < 1 || given->row_lo + given->n_valid > n_per_frame) return set_error(EG_ERR_ARG, "bad row range");
+        m = RowMap{(int)given->n_valid, (int)n_per_frame, (int)given->row_lo};
+    }
+    return gcn_layer_bwd(g_bwd, batch, dy, z, agg, W, gamma, beta, bn, relu, dropout_p, seed, residual, workspace, dz_scratch, dx, dw,
+                         db, dgamma, dbeta, given ? given->sums : nullptr, given ? &m : nullptr, given ? given->frames : 0, stream,
+                         given ? given->taps : nullptr, lower);
 }
 
 }  // extern "C"

@@ -161,6 +161,38 @@ class _GCNConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+# ---- BatchNorm-backward sums handed DOWN the stack (round 6) --------------------------------------------------------------------
+# dx of layer i + 1 is dy of layer i: the dX launch takes layer i's sums where the rows leave it (ops.gcn_layer_bwd(lower=)), and
+# the node of layer i picks them up here instead of running its own sums pass over dy and z.  Keyed by what the tensor IS -- address,
+# shape, version -- never by a Python identity that autograd may not preserve: an entry is written right before the producing node
+# returns dx and popped by the first backward that receives a tensor with that address AND version (autograd accumulating another
+# gradient into dx bumps the version: the sums would be stale, the entry is ignored and the layer takes its own).  The model clears
+# the table at every train-mode forward, so an entry never outlives the backward pass of its own step.
+_SUMS_DOWN: Dict[tuple, tuple] = {}
+
+
+def _sums_key(t: torch.Tensor) -> tuple:
+    return (t.data_ptr(), tuple(t.shape), t.device, t._version)
+
+
+def _hand_down(dx: torch.Tensor, sums, frames: int, row_hi: int, taps=None) -> None:
+    if len(_SUMS_DOWN) > 8:
+        _SUMS_DOWN.clear()
+    _SUMS_DOWN[_sums_key(dx)] = (sums, frames, 0, row_hi, taps)
+
+
+def _handed_down(dy: torch.Tensor):
+    return _SUMS_DOWN.pop(_sums_key(dy), None) if _SUMS_DOWN else None
+
+
+def _lower_of(box, dims_row_hi):
+    """(z, bn, relu, p, seed, row_hi) of the layer below from the box its forward filled, or None."""
+    if not box:
+        return None
+    z, bn, relu, p, seed = box
+    return z, bn, relu, p, seed, dims_row_hi
+
+
 def _bn_step(bn: nn.BatchNorm1d, pending: Optional[list] = None):
     """What nn.BatchNorm1d.forward decides before calling F.batch_norm: (use batch statistics?, update factor | None).
     Counts the batch in ``num_batches_tracked``; ``momentum=None`` is the cumulative moving average.  ``pending``: a list that
@@ -187,25 +219,40 @@ class _LayerTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, graph, batch, relu, p, momentum, eps, seed,
-                residual, kid=(None, None)):
+                residual, kid=(None, None), down=None):
+        """down = (box this layer fills for the layer above | None, box of the layer below | None, row_hi): the hand-down of the
+        BatchNorm-backward sums (_SUMS_DOWN)."""
         x = x.contiguous()
         need_w = weight.requires_grad
         out, z, agg, bn = ops.gcn_layer_train_fwd(graph, batch, x, weight.contiguous(), bias.contiguous(), gamma.contiguous(),
                                                   beta.contiguous(), running_mean, running_var, momentum, eps, relu, p, seed,
                                                   residual, want_agg=need_w, kidsum_in=kid[0], kidsum_out=kid[1])
+        mine, below, row_hi = down if down is not None else (None, None, 0)
+        if mine is not None:
+            mine[:] = [z, bn, relu, p, seed]
+        lower = _lower_of(below, row_hi)
+        ctx.lower = None if lower is None else lower[2:]
         ctx.save_for_backward(z, agg if agg is not None else z.new_zeros(0), weight.detach().contiguous(),
-                              gamma.detach().contiguous(), beta.detach().contiguous(), bn)
+                              gamma.detach().contiguous(), beta.detach().contiguous(), bn, *(lower[:2] if lower is not None else ()))
         ctx.cfg = (graph, batch, relu, p, seed, residual, need_w)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        z, agg, weight, gamma, beta, bn = ctx.saved_tensors
+        z, agg, weight, gamma, beta, bn, *lz = ctx.saved_tensors
         graph, batch, relu, p, seed, residual, had_agg = ctx.cfg
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and had_agg, ctx.needs_input_grad[2]
-        dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dy.contiguous(), z, agg if had_agg else None, weight, gamma,
-                                                      beta, bn, relu, p, seed, residual, need_x, need_w)
-        return (dx, dw, db if need_b else None, dgamma, dbeta) + (None,) * 11
+        given = _handed_down(dy)
+        dy = dy.contiguous()
+        if ctx.lower is not None and need_x and residual:
+            dx, dw, db, dgamma, dbeta, lsums = ops.gcn_layer_bwd(graph.bwd, batch, dy, z, agg if had_agg else None, weight, gamma,
+                                                                 beta, bn, relu, p, seed, residual, True, need_w, dy_sums=given,
+                                                                 lower=(lz[0], lz[1]) + ctx.lower)
+            _hand_down(dx, lsums, batch, ctx.lower[3])
+        else:
+            dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dy, z, agg if had_agg else None, weight, gamma,
+                                                          beta, bn, relu, p, seed, residual, need_x, need_w, dy_sums=given)
+        return (dx, dw, db if need_b else None, dgamma, dbeta) + (None,) * 12
 
 
 # ---- the coordinate-graph update (models.py:438-473) as part of the node that CONSUMES the layer output -------------------------
@@ -235,22 +282,28 @@ def _coord_update_fwd(h, coords_prev, dims, mlp_cfg, mlp_params, want_backward=T
     return new, (lm, flat, saved, {k: v for k, v in P.items() if not k.startswith("running")})
 
 
-def _coord_update_bwd(dx, dcoords_new, h, new, lm, flat, saved, P, dims, need_dprev, sampled_rows_used=True):
+def _coord_update_bwd(dx, dcoords_new, h, new, lm, flat, saved, P, dims, need_dprev, sampled_rows_used=True, lower=None):
     """dx: gradient w.r.t. the tensor AFTER the overwrite, a buffer the caller has just allocated; turned IN PLACE into the
-    gradient w.r.t. the tensor BEFORE it.  -> (dcoords_prev [4B,2] | None, packed MLP gradients)."""
+    gradient w.r.t. the tensor BEFORE it.  -> (dcoords_prev [4B,2] | None, packed MLP gradients, taps | None).
+    lower: dx is the dy of a layer whose BatchNorm-backward sums were taken before this call (ops.gcn_layer_bwd(lower=)): the sums
+    of what the 16 taps per frame add are returned as taps [B,2,128]."""
     B, n, main_base, frame, coord_base = dims
     total = dcoords_new
+    taps = None
     if sampled_rows_used:
         # the sampled rows' gradient is read where it lies (the coordinate rows of dx), 16 taps per frame go into dx's main-grid
         # rows; the coordinate rows themselves are overwritten below (their old values were overwritten in the forward)
-        dbil = ops.bilinear4_bwd(None, h, new, B, n, main_base, frame, dh=dx, want_dcoords=True, dout_rows=(dx, n, coord_base))
+        dbil = ops.bilinear4_bwd(None, h, new, B, n, main_base, frame, dh=dx, want_dcoords=True, dout_rows=(dx, n, coord_base),
+                                 lower=lower)
+        if lower is not None:
+            dbil, taps = dbil
         total = dbil if total is None else total + dbil
     if total is None:
         total = torch.zeros(B * 4, 2, dtype=torch.float32, device=dx.device)
     # d lm goes straight into the coordinate rows: they fed the MLP and nothing else (= when their samples were used, += otherwise)
     _, dprev, g = ops.coord_mlp_bwd(total.contiguous().view(B * 4, 2), lm, flat, B, P, frame, saved, True, need_dprev,
                                     out_rows=(dx, n, coord_base), accumulate=not sampled_rows_used)
-    return dprev, g
+    return dprev, g, taps
 
 
 def _mlp_grads(g):
@@ -263,32 +316,45 @@ def _mlp_grads(g):
 class _CoordLayerTrainFn(torch.autograd.Function):
     """Coordinate update of layer i - 1 (on this node's input) + train-mode layer i:
         (h_prev [B*N,128], coords_prev [B,4,2]) -> (out, coords [B,4,2]).
-    ``cfg`` = (graph, batch, relu, p, momentum, eps, seed, residual, dims, mlp_cfg, kid); params = the 10 tensors of
-    node_coordinate_mlp[i - 1] in _HEAD_PARAM_IDX order."""
+    ``cfg`` = (graph, batch, relu, p, momentum, eps, seed, residual, dims, mlp_cfg, kid, down); params = the 10 tensors of
+    node_coordinate_mlp[i - 1] in _HEAD_PARAM_IDX order.  ``down`` as in _LayerTrainFn."""
 
     @staticmethod
     def forward(ctx, h_prev, coords_prev, weight, bias, gamma, beta, running_mean, running_var, cfg, *mlp_params):
-        graph, batch, relu, p, momentum, eps, seed, residual, dims, mlp_cfg, kid = cfg
+        graph, batch, relu, p, momentum, eps, seed, residual, dims, mlp_cfg, kid, down = cfg
         new, (lm, flat, saved, P) = _coord_update_fwd(h_prev, coords_prev, dims, mlp_cfg, mlp_params)
         need_w = weight.requires_grad
         out, z, agg, bn = ops.gcn_layer_train_fwd(graph, batch, h_prev, weight.contiguous(), bias.contiguous(), gamma.contiguous(),
                                                   beta.contiguous(), running_mean, running_var, momentum, eps, relu, p, seed,
                                                   residual, want_agg=need_w, kidsum_in=kid[0], kidsum_out=kid[1])
+        mine, below, row_hi = down if down is not None else (None, None, 0)
+        if mine is not None:
+            mine[:] = [z, bn, relu, p, seed]
+        lower = _lower_of(below, row_hi)
+        ctx.lower = None if lower is None else lower[2:]
+        ctx.n_lower = 0 if lower is None else 2
         ctx.save_for_backward(z, agg if agg is not None else z.new_zeros(0), weight.detach().contiguous(),
-                              gamma.detach().contiguous(), beta.detach().contiguous(), bn, h_prev, new, lm, flat, *saved)
+                              gamma.detach().contiguous(), beta.detach().contiguous(), bn, h_prev, new, lm, flat,
+                              *(lower[:2] if lower is not None else ()), *saved)
         ctx.cfg = (graph, batch, relu, p, seed, residual, need_w, dims, P)
         return out, new.view(dims[0], 4, 2).clone()      # (a tensor of its own: `new` is saved for the backward; dims[0] = frames; `batch` = copies of the handle's graph: 1 for a CSR of the whole batch)
 
     @staticmethod
     def backward(ctx, dy, dcoords):
         z, agg, weight, gamma, beta, bn, h_prev, new, lm, flat, *saved = ctx.saved_tensors
+        lz, saved = saved[:ctx.n_lower], saved[ctx.n_lower:]
         graph, batch, relu, p, seed, residual, had_agg, dims, P = ctx.cfg
         need_w, need_b = ctx.needs_input_grad[2] and had_agg, ctx.needs_input_grad[3]
-        dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dy.contiguous(), z, agg if had_agg else None, weight, gamma,
-                                                      beta, bn, relu, p, seed, residual, True, need_w)
+        given = _handed_down(dy)
+        lower = (lz[0], lz[1]) + ctx.lower if (ctx.lower is not None and residual) else None
+        res = ops.gcn_layer_bwd(graph.bwd, batch, dy.contiguous(), z, agg if had_agg else None, weight, gamma,
+                                beta, bn, relu, p, seed, residual, True, need_w, dy_sums=given, lower=lower)
+        dx, dw, db, dgamma, dbeta = res[:5]
         B = dims[0]
-        dprev, g = _coord_update_bwd(dx, None if dcoords is None else dcoords.reshape(B * 4, 2), h_prev, new, lm, flat,
-                                     tuple(saved), P, dims, ctx.needs_input_grad[1])
+        dprev, g, taps = _coord_update_bwd(dx, None if dcoords is None else dcoords.reshape(B * 4, 2), h_prev, new, lm, flat,
+                                           tuple(saved), P, dims, ctx.needs_input_grad[1], lower=lower)
+        if lower is not None:
+            _hand_down(dx, res[5], batch, lower[5], taps)
         return (dx, None if dprev is None else dprev.view(B, 4, 2), dw, db if need_b else None, dgamma, dbeta, None, None,
                 None) + _mlp_grads(g)
 
@@ -394,8 +460,8 @@ class _CoordClassifierTrainFn(torch.autograd.Function):
         if sigmoid:
             dl = dl * y * (1.0 - y)
         dh, g = ops.classifier_bwd(dl, h, batch, n, row_lo, n_valid, ctx.P, z1, z2, bn, True)
-        dprev, gm = _coord_update_bwd(dh, None if dcoords is None else dcoords.reshape(batch * 4, 2), h, new, lm, flat, tuple(saved),
-                                      Pm, coord_dims, ctx.needs_input_grad[1], sampled_rows_used=False)
+        dprev, gm, _ = _coord_update_bwd(dh, None if dcoords is None else dcoords.reshape(batch * 4, 2), h, new, lm, flat, tuple(saved),
+                                         Pm, coord_dims, ctx.needs_input_grad[1], sampled_rows_used=False)
         return (dh, None if dprev is None else dprev.view(batch, 4, 2), None, None, None, None, None) + _mlp_grads(gm) + \
             _unstack_head_grads(g)
 
@@ -407,11 +473,13 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
     With the coordinate graph the node also carries the update in front of the layer (of layer L - 2, on h_prev; absent when
     L = 1) and the one behind it (of layer L - 1, on h), exactly as _CoordLayerTrainFn / _CoordClassifierTrainFn do.
     cfg = (graph, batch, relu, p, momentum, eps, seed, residual, kid_in, dims5, sigmoid, cls_cfg, coord_dims | None,
-           mlp_prev_cfg | None, mlp_cfg | None); params = [10 tensors of the MLP in front] + [10 of the MLP behind] + 40 head tensors."""
+           mlp_prev_cfg | None, mlp_cfg | None[, down]); params = [10 tensors of the MLP in front] + [10 of the MLP behind] + 40 head
+    tensors.  ``down`` = (None, box of the layer below | None, row_hi) as in _LayerTrainFn."""
 
     @staticmethod
     def forward(ctx, h_prev, coords_prev, weight, bias, gamma, beta, running_mean, running_var, cfg, *params):
-        (graph, batch, relu, p, momentum, eps, seed, residual, kid_in, dims5, sigmoid, cls_cfg, cdims, mlp_prev_cfg, mlp_cfg) = cfg
+        down = cfg[15] if len(cfg) > 15 else None
+        (graph, batch, relu, p, momentum, eps, seed, residual, kid_in, dims5, sigmoid, cls_cfg, cdims, mlp_prev_cfg, mlp_cfg) = cfg[:15]
         has_coord, has_prev = mlp_cfg is not None, mlp_prev_cfg is not None
         k0 = 10 if has_prev else 0
         k1 = k0 + (10 if has_coord else 0)
@@ -440,6 +508,10 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
         if has_prev:
             saved += [coords_mid, st_prev[0], st_prev[1], *st_prev[2]]
         ctx.n_saved2 = len(st[2]) if has_coord else 0
+        lower = _lower_of(down[1], down[2]) if down is not None else None
+        ctx.lower = None if lower is None else lower[2:]
+        if lower is not None:
+            saved += [lower[0], lower[1]]                 # (at the END: z and bn of the layer below)
         ctx.save_for_backward(*saved)
         return logits, (new.view(B, 4, 2).clone() if has_coord else None)
 
@@ -447,6 +519,9 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
     def backward(ctx, dy, dcoords):
         (graph, batch, relu, p, seed, residual, had_agg, dims5, sigmoid, cdims, has_coord, has_prev, Pm, Pm_prev) = ctx.cfg
         z, agg, weight, gamma, beta, bn, h_prev, h, z1, z2, cbn, y, *rest = ctx.saved_tensors
+        lower = None
+        if ctx.lower is not None:
+            lower, rest = (rest[-2], rest[-1]) + ctx.lower, rest[:-2]
         B, n, row_lo, n_valid = dims5
         if dy is None:
             dy = torch.zeros(B * n_valid, 4, dtype=torch.float32, device=h.device)
@@ -467,17 +542,23 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
             new, lm, flat = rest[0], rest[1], rest[2]
             saved2 = tuple(rest[3:3 + ctx.n_saved2])
             rest = rest[3 + ctx.n_saved2:]
-            dmid, gm = _coord_update_bwd(dh, None if dcoords is None else dcoords.reshape(B * 4, 2), h, new, lm, flat, saved2, Pm,
-                                         cdims, has_prev or ctx.needs_input_grad[1], sampled_rows_used=False)
+            dmid, gm, _ = _coord_update_bwd(dh, None if dcoords is None else dcoords.reshape(B * 4, 2), h, new, lm, flat, saved2, Pm,
+                                            cdims, has_prev or ctx.needs_input_grad[1], sampled_rows_used=False)
         need_x = has_prev or ctx.needs_input_grad[0]
         need_w, need_b = ctx.needs_input_grad[2] and had_agg, ctx.needs_input_grad[3]
-        dx, dw, db, dgamma, dbeta = ops.gcn_layer_bwd(graph.bwd, batch, dh, z, agg if had_agg else None, weight, gamma, beta, bn,
-                                                      relu, p, seed, residual, need_x, need_w, dy_sums=presum)
+        if not (need_x and residual):
+            lower = None
+        res = ops.gcn_layer_bwd(graph.bwd, batch, dh, z, agg if had_agg else None, weight, gamma, beta, bn,
+                                relu, p, seed, residual, need_x, need_w, dy_sums=presum, lower=lower)
+        dx, dw, db, dgamma, dbeta = res[:5]
         dprev = dmid
+        taps = None
         if has_prev:
             new1, lm1, flat1 = rest[0], rest[1], rest[2]
-            dprev, gm_prev = _coord_update_bwd(dx, dmid, h_prev, new1, lm1, flat1, tuple(rest[3:]), Pm_prev, cdims,
-                                               ctx.needs_input_grad[1])
+            dprev, gm_prev, taps = _coord_update_bwd(dx, dmid, h_prev, new1, lm1, flat1, tuple(rest[3:]), Pm_prev, cdims,
+                                                     ctx.needs_input_grad[1], lower=lower)
+        if lower is not None:
+            _hand_down(dx, res[5], batch, lower[5], taps)
         out = (dx if ctx.needs_input_grad[0] else None, None if dprev is None else dprev.view(B, 4, 2), dw,
                db if need_b else None, dgamma, dbeta, None, None, None)
         if has_prev:
@@ -634,7 +715,7 @@ class Sequential(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0          # host RNG, like the model's own route
             _, momentum = _bn_step(bn)
             return _LayerTrainFn.apply(x, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                       graph, batch, relu, p, momentum, bn.eps, seed, False, (None, None))
+                                       graph, batch, relu, p, momentum, bn.eps, seed, False, (None, None), None)
         return None
 
     def forward(self, x, edge_index):
@@ -873,7 +954,7 @@ class HierarchicalPatchModel(nn.Module):
             self.dropout_seed_hook("gnn", layer, (seed,))
         return conv, bn, i < self.num_gnn_layers - 1, p, seed
 
-    def _layer_train(self, i: int, x_in: torch.Tensor, graph: ops.Graph, gb: int, kid=(None, None)):
+    def _layer_train(self, i: int, x_in: torch.Tensor, graph: ops.Graph, gb: int, kid=(None, None), down=None):
         cfg = self._layer_cfg(i)
         if cfg is None:
             # a frozen (eval-mode) BatchNorm / Dropout inside a training model: GCNConv kernel + the torch modules
@@ -882,7 +963,16 @@ class HierarchicalPatchModel(nn.Module):
         conv, bn, relu, p, seed = cfg
         _, momentum = _bn_step(bn)
         return _LayerTrainFn.apply(x_in, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                   graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid)
+                                   graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid, down)
+
+    def _sums_down_boxes(self, graph: ops.Graph):
+        """One box per layer for the hand-down of the BatchNorm-backward sums (layer i's forward fills box i, the node of layer
+        i + 1 reads it and its dX launch takes layer i's sums: _SUMS_DOWN), or None where that launch is not the producer /
+        consumer kernel's.  EG_SUMS_DOWN=0: every layer takes its own sums (the round-5 step; A/B and fallback)."""
+        _SUMS_DOWN.clear()
+        if not (self.residual and ops.lower_sums_supported(graph.bwd) and os.environ.get("EG_SUMS_DOWN", "1") != "0"):
+            return None
+        return [[] for _ in range(self.num_gnn_layers)]
 
     # ---- coordinate-graph update (models.py:438-473), explicit form ------------------------------------------------------
     def _coordinate_update(self, i: int, h: torch.Tensor, node_coords: torch.Tensor, batch: int):
@@ -975,6 +1065,8 @@ class HierarchicalPatchModel(nn.Module):
         kids = self._train_kidsums(graph, gb)
         h, coords = x0.contiguous(), node_coords
         L = self.num_gnn_layers
+        boxes = self._sums_down_boxes(graph)
+        down_of = (lambda i: None) if boxes is None else (lambda i: (boxes[i] if i < L - 1 else None, boxes[i - 1] if i > 0 else None, coord_base))
         counters = []                      # num_batches_tracked of every BatchNorm of the step: bumped together by finish(counters)
         act_in_heads = os.environ.get("EG_ACT_HEADS", "1") != "0"      # the last layer's activation pass inside the heads' first kernel
         for i in range(L):
@@ -986,7 +1078,7 @@ class HierarchicalPatchModel(nn.Module):
                 mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i], counters)
                 cls_cfg, head_params, finish = self._classifier_train_cfg()
                 cfg = (graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid[0], (B, n, n_conn, n_valid),
-                       self.output_activation == "sigmoid", cls_cfg, dims, mlp_prev_cfg, mlp_cfg)
+                       self.output_activation == "sigmoid", cls_cfg, dims, mlp_prev_cfg, mlp_cfg, down_of(i))
                 logits, coords = _LastLayerHeadsTrainFn.apply(h, coords, conv.lin.weight, conv.bias, bn.weight, bn.bias,
                                                               bn.running_mean, bn.running_var, cfg, *mlp_prev, *mlp_params,
                                                               *head_params)
@@ -994,10 +1086,10 @@ class HierarchicalPatchModel(nn.Module):
                 return logits.squeeze(1), coords.reshape(B * 4, -1)
             if i == 0:
                 h = _LayerTrainFn.apply(h, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                        graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid)
+                                        graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), kid, down_of(i))
             else:
                 mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[i - 1], counters)
-                cfg = (graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), dims, mlp_cfg, kid)
+                cfg = (graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), dims, mlp_cfg, kid, down_of(i))
                 h, coords = _CoordLayerTrainFn.apply(h, coords, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                                      bn.running_var, cfg, *mlp_params)
         mlp_cfg, mlp_params = self._coord_mlp_train_cfg(self.node_coordinate_mlp[self.num_gnn_layers - 1], counters)
@@ -1056,8 +1148,15 @@ class HierarchicalPatchModel(nn.Module):
                     and self.num_output_channels == 4 and self.classifier_hidden_dim == 32)
         jkb = self._jk_buffers(graph, gb, node_feats) if jk_fused else None
         train_kids = (None, None)
+        boxes = None
         if self.training and not fused and not self._narrow and all(self._layer_cfg_static_ok(i) for i in range(self.num_gnn_layers)):
             train_kids = self._train_kidsums(graph, gb)
+            # (nothing but the next layer may consume a layer's output: a hook, JumpingKnowledge or the explicit coordinate update
+            # would put other gradients or row patches between the dX launch and the layer below)
+            if not self.use_coordinate_graph and self.layer_output_hook is None and self.jk is None:
+                boxes = self._sums_down_boxes(graph)
+        L_ = self.num_gnn_layers
+        down_of = (lambda i: None) if boxes is None else (lambda i: (boxes[i] if i < L_ - 1 else None, boxes[i - 1] if i > 0 else None, n))
         for i in range(self.num_gnn_layers):
             x_in = hidden[i]
             if fused:
@@ -1080,7 +1179,7 @@ class HierarchicalPatchModel(nn.Module):
                 _, momentum = _bn_step(bn)
                 cls_cfg, head_params, finish = self._classifier_train_cfg()
                 cfg = (graph, gb, relu, p, momentum, bn.eps, seed, bool(self.residual), train_kids[(i + 1) & 1] if i > 0 else None,
-                       (B, n, n_conn, n_valid), self.output_activation == "sigmoid", cls_cfg, None, None, None)
+                       (B, n, n_conn, n_valid), self.output_activation == "sigmoid", cls_cfg, None, None, None, down_of(i))
                 out, _ = _LastLayerHeadsTrainFn.apply(x_in, None, conv.lin.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                                       bn.running_var, cfg, *head_params)
                 finish()
@@ -1088,7 +1187,7 @@ class HierarchicalPatchModel(nn.Module):
             elif self.training and not self._narrow:
                 tk = train_kids if not self.use_coordinate_graph else (None, None)      # (the explicit coordinate update rewrites rows)
                 h = self._layer_train(i, x_in, graph, gb, (tk[(i + 1) & 1] if i > 0 else None,
-                                                           tk[i & 1] if i < self.num_gnn_layers - 1 else None))
+                                                           tk[i & 1] if i < self.num_gnn_layers - 1 else None), down_of(i))
             else:
                 h = self.gnn_layers[i].forward_graph(x_in, graph, gb)
                 if self.residual and h.shape[1] == x_in.shape[1]:

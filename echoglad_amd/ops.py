@@ -59,6 +59,7 @@ class Graph:
         self.device = device
         # rows per frame of a child-sum side buffer (chained layers); 0 = not available for this handle
         self.kidsum_rows = int(_lib.load().eg_graph_kidsum_rows(handle)) if structured else 0
+        self.num_tiles = int(_lib.load().eg_graph_num_tiles(handle))          # 64-row work tiles per frame
         # a closed-form topology with 'grid-diagonal' levels: stencil in the producer/consumer kernel, per-frame CSR elsewhere
         self.hybrid = False
         self.num_conn = 0           # connection nodes at the head of every frame (rows the heads' node-type filter drops)
@@ -441,13 +442,69 @@ def gcn_layer_train_fwd(graph: Graph, batch: int, x, weight, bias, gamma, beta, 
     return out, z, agg, bn
 
 
+_tile_scratch = {}
+
+
+def _lower_scratch(graph: Graph, batch: int, device) -> torch.Tensor:
+    """[tiles, 2, 128] floats for the per-tile partials of eg_gcn_layer_bwd_lower (one buffer per device, stream and size)."""
+    n = graph.num_tiles * batch * 2 * C
+    key = (torch.device(device), torch.cuda.current_stream().cuda_stream)
+    buf = _tile_scratch.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _tile_scratch[key] = torch.empty(n, dtype=torch.float32, device=device)
+    return buf
+
+
+def lower_sums_supported(graph_bwd: Graph) -> bool:
+    """May the dX launch on this handle also take the BatchNorm-backward sums of the layer below (eg_gcn_layer_bwd_lower)?"""
+    return bool(graph_bwd.structured) and os.environ.get("EG_TRAIN_PS", "1") != "0"
+
+
 def gcn_layer_bwd(graph_bwd: Graph, batch: int, dy, z, agg, weight, gamma, beta, bn, relu: bool, dropout_p: float, seed: int,
-                  residual: bool, need_dx: bool, need_dw: bool, dy_sums=None):
-    """-> (dx | None, dw | None, db | None (zeros), dgamma, dbeta).
-    dy_sums = (sums [256] float64, frames, row_lo, n_valid) from classifier_bwd(..., layer=...): the BatchNorm-backward sums over
-    those rows of every frame are given, the layer's own sums pass only adds the other rows (eg_gcn_layer_bwd_presummed)."""
+                  residual: bool, need_dx: bool, need_dw: bool, dy_sums=None, lower=None):
+    """-> (dx | None, dw | None, db | None (zeros), dgamma, dbeta)   [+ lower_sums when ``lower`` is given].
+    dy_sums = (sums [256] float64, frames, row_lo, n_valid[, taps]) from classifier_bwd(..., layer=...) or from the dX launch of
+    the layer above (``lower``): the BatchNorm-backward sums over those rows of every frame are given, the layer's own sums pass
+    only adds the other rows (eg_gcn_layer_bwd_presummed / _lower); taps [frames, 2, 128]: bilinear4_bwd(..., lower=)'s sums.
+    lower = (z, bn, relu, dropout_p, seed, row_hi) of the layer BELOW: the dX launch takes its BatchNorm-backward sums over rows
+    [0, row_hi) of every frame from the rows it writes (eg_gcn_layer_bwd_lower) -> 6th result, float64 [256]."""
     rows = graph_bwd.num_nodes * batch
     _check_rows(dy, "dy", rows)
+    if lower is not None:
+        if not (need_dx and residual and lower_sums_supported(graph_bwd)):
+            raise RuntimeError("lower sums go with the producer / consumer kernel's dX launch (ops.lower_sums_supported, need_dx, residual)")
+        lz, lbn, lrelu, lp, lseed, row_hi = lower
+        _check_rows(lz, "lower z", rows)
+        if lbn.numel() != 4 * C or not lbn.is_cuda or not lbn.is_contiguous() or lbn.dtype != torch.float32:
+            raise RuntimeError("lower bn must be the [4,128] float32 tensor of gcn_layer_train_fwd")
+        dz = torch.empty_like(dy)
+        dx = torch.empty_like(dy)
+        dw = torch.empty(C, C, dtype=torch.float32, device=dy.device) if need_dw else None
+        small = torch.empty(3, C, dtype=torch.float32, device=dy.device)
+        lsums = torch.empty(2 * C, dtype=torch.float64, device=dy.device)
+        ls = _lib.LowerSums(_ptr(lz), _ptr(lbn), int(lrelu), float(lp), int(lseed) & 0xFFFFFFFFFFFFFFFF, int(row_hi),
+                            _ptr(_lower_scratch(graph_bwd, batch, dy.device)), _ptr(lsums))
+        gs = None
+        if dy_sums is not None:
+            gs = _given_sums(dy_sums)
+        _lib.check(_lib.load().eg_gcn_layer_bwd_lower(
+            graph_bwd._h, batch, _ptr(dy), _ptr(z), _ptr(agg), _ptr(weight), _ptr(gamma), _ptr(beta), _ptr(bn), int(relu),
+            float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(residual), _ptr(_workspace(dy.device)), _ptr(dz), _ptr(dx), _ptr(dw),
+            _ptr(small[0]), _ptr(small[1]), _ptr(small[2]), ct.byref(gs) if gs is not None else None, ct.byref(ls), _stream()),
+            "eg_gcn_layer_bwd_lower")
+        return dx, dw, small[0], small[1], small[2], lsums
+    if dy_sums is not None and len(dy_sums) > 4 and dy_sums[4] is not None:
+        # sums with the bilinear backward's later additions: the struct form without a lower layer
+        dz = torch.empty_like(dy) if (need_dx or not need_dw) else None
+        dx = torch.empty_like(dy) if need_dx else None
+        dw = torch.empty(C, C, dtype=torch.float32, device=dy.device) if need_dw else None
+        small = torch.empty(3, C, dtype=torch.float32, device=dy.device)
+        gs = _given_sums(dy_sums)
+        _lib.check(_lib.load().eg_gcn_layer_bwd_lower(
+            graph_bwd._h, batch, _ptr(dy), _ptr(z), _ptr(agg), _ptr(weight), _ptr(gamma), _ptr(beta), _ptr(bn), int(relu),
+            float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(residual), _ptr(_workspace(dy.device)), _ptr(dz), _ptr(dx), _ptr(dw),
+            _ptr(small[0]), _ptr(small[1]), _ptr(small[2]), ct.byref(gs), None, _stream()), "eg_gcn_layer_bwd_lower")
+        return dx, dw, small[0], small[1], small[2]
     dz = torch.empty_like(dy) if (need_dx or not need_dw) else None       # dW alone comes out of the fused apply pass
     dx = torch.empty_like(dy) if need_dx else None
     dw = torch.empty(C, C, dtype=torch.float32, device=dy.device) if need_dw else None
@@ -458,12 +515,24 @@ def gcn_layer_bwd(graph_bwd: Graph, batch: int, dy, z, agg, weight, gamma, beta,
     if dy_sums is None:
         _lib.check(_lib.load().eg_gcn_layer_bwd(*common, _stream()), "eg_gcn_layer_bwd")
     else:
-        sums, frames, row_lo, n_valid = dy_sums
+        sums, frames, row_lo, n_valid = dy_sums[:4]
         if sums.dtype != torch.float64 or sums.numel() != 2 * C or not sums.is_cuda or not sums.is_contiguous():
             raise RuntimeError("dy_sums must be a contiguous CUDA float64 tensor of 256 elements")
         _lib.check(_lib.load().eg_gcn_layer_bwd_presummed(*common, _ptr(sums), int(frames), int(row_lo), int(n_valid), _stream()),
                    "eg_gcn_layer_bwd_presummed")
     return dx, dw, small[0], small[1], small[2]
+
+
+def _given_sums(dy_sums) -> "_lib.GivenSums":
+    sums, frames, row_lo, n_valid = dy_sums[:4]
+    taps = dy_sums[4] if len(dy_sums) > 4 else None
+    if sums.dtype != torch.float64 or sums.numel() != 2 * C or not sums.is_cuda or not sums.is_contiguous():
+        raise RuntimeError("dy_sums must be a contiguous CUDA float64 tensor of 256 elements")
+    if taps is not None and (taps.dtype != torch.float32 or taps.numel() != int(frames) * 2 * C or not taps.is_cuda or not taps.is_contiguous()):
+        raise RuntimeError("taps must be a contiguous CUDA float32 tensor [frames, 2, 128]")
+    gs = _lib.GivenSums(_ptr(sums), int(frames), int(row_lo), int(n_valid), _ptr(taps))
+    gs._keep = (sums, taps)
+    return gs
 
 
 CLS_GRADS_FLOATS = 19076
@@ -668,11 +737,26 @@ def bilinear4_fwd(h, coords, batch, n_per_frame, main_base, frame, points=4, out
     return out
 
 
-def bilinear4_bwd(dout, h, coords, batch, n_per_frame, main_base, frame, dh=None, want_dcoords=True, points=4, dout_rows=None):
-    """dout_rows = (src, n_per_frame, row0): the samples' gradient is read from rows row0 .. of every frame of src (dout is None)."""
+def bilinear4_bwd(dout, h, coords, batch, n_per_frame, main_base, frame, dh=None, want_dcoords=True, points=4, dout_rows=None,
+                  lower=None):
+    """dout_rows = (src, n_per_frame, row0): the samples' gradient is read from rows row0 .. of every frame of src (dout is None).
+    lower = (z, bn, relu, dropout_p, seed, ...) of the layer whose dy ``dh`` is, when that layer's BatchNorm-backward sums were taken
+    before this call (gcn_layer_bwd(..., lower=)): -> (dcoords, taps [batch, 2, 128]), the sums of what is added here."""
     _check_rows(h, "h", batch * n_per_frame)
     _check_coords(coords, batch, points)
     dcoords = torch.empty(batch * points, 2, dtype=torch.float32, device=h.device) if want_dcoords else None
+    if lower is not None:
+        if dout_rows is None or dh is None:
+            raise RuntimeError("tap sums go with the in-place form (dout_rows, dh)")
+        lz, lbn, lrelu, lp, lseed = lower[:5]
+        _check_rows(lz, "lower z", batch * n_per_frame)
+        taps = torch.empty(batch, 2, C, dtype=torch.float32, device=h.device)
+        ls = _lib.LowerSums(_ptr(lz), _ptr(lbn), int(lrelu), float(lp), int(lseed) & 0xFFFFFFFFFFFFFFFF, 0, None, None)
+        ptr, stride = _frame_rows_ptr(dout_rows[0], batch, dout_rows[1], dout_rows[2])
+        _lib.check(_lib.load().eg_bilinear4_bwd_rows_sums(ptr, stride, _ptr(h), _ptr(coords), batch, points, n_per_frame, main_base, frame,
+                                                          _ptr(dh), _ptr(dcoords), ct.byref(ls), _ptr(taps), _stream()),
+                   "eg_bilinear4_bwd_rows_sums")
+        return dcoords, taps
     if dout_rows is not None:
         ptr, stride = _frame_rows_ptr(dout_rows[0], batch, dout_rows[1], dout_rows[2])
         _lib.check(_lib.load().eg_bilinear4_bwd_rows(ptr, stride, _ptr(h), _ptr(coords), batch, points, n_per_frame, main_base, frame,

@@ -69,7 +69,7 @@ extern "C" {
  * 64-slice queue ring refuses instead of corrupting (round 4).  131: eg_classifier_train_fwd_act.
  * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_*, eg_elm_reduce, eg_coord_mlp_*_rows, eg_bilinear4_*_rows (round 5).
  * 134: eg_dropout_epoch_add / _set, eg_debug_dropout_epoch (round 5: a whole train step as one HIP graph). */
-#define EG_ABI_VERSION 134
+#define EG_ABI_VERSION 135
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
 
@@ -367,6 +367,44 @@ int eg_gcn_layer_bwd_presummed(const eg_graph* g_bwd, int batch, const float* dy
                                int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
                                float* dbeta, const double* dy_sums, int frames, int64_t row_lo, int64_t n_valid, eg_stream_t stream);
 
+/* ---- the BatchNorm-backward sums of the layer BELOW, taken by the dX launch that writes its dy (round 6) ----------------------
+ * dx of layer i + 1 IS dy of layer i, so layer i's sums  sum g, sum g * xhat  (g = dy * dropout keep * ReLU gate of layer i's
+ * activation, src/core/models.py:333-335 backwards) can be taken where the finished dx rows leave the layer kernel instead of by a
+ * pass of their own over dy and z (0.40 ms and 2.4 GB per layer at batch 32).  eg_gcn_layer_bwd_lower is eg_gcn_layer_bwd /
+ * eg_gcn_layer_bwd_presummed (given != NULL) with that by-product:
+ *   lower->z, lower->bn            layer i's pre-BatchNorm rows and {mean, invstd, scale, shift} (eg_gcn_layer_train_fwd)
+ *   lower->relu, dropout_p, seed   its activation, as given to eg_gcn_layer_train_fwd
+ *   lower->row_hi                  rows [0, row_hi) of every frame are summed (the coordinate nodes behind them are rewritten by the
+ *                                  coordinate update's backward afterwards; the consumer of the sums adds them: given->row_lo = 0,
+ *                                  given->n_valid = row_hi)
+ *   lower->tile_scratch            eg_graph_num_tiles(g_bwd) * batch * 256 floats: one partial per tile (tiles are summed in
+ *                                  index order afterwards: bit-reproducible under the dynamic tile queues)
+ *   lower->sums_out                [2][128] doubles, the `sums` of a later eg_gcn_layer_bwd_lower(given) / _presummed call
+ * given->taps (nullable): [given->frames][2][128] floats from eg_bilinear4_bwd_rows_sums -- what the bilinear backward added to
+ * rows inside the summed range AFTER the sums were taken (the sums are linear in dy: the additions' own sums are simply added).
+ * EG_ERR_UNSUPPORTED (nothing launched) when the dX launch is not the producer / consumer kernel's (CSR handles, dx NULL,
+ * residual 0): call eg_gcn_layer_bwd and let the lower layer take its own sums. */
+typedef struct eg_lower_sums {
+    const float* z;
+    const float* bn;
+    int relu;
+    float dropout_p;
+    uint64_t seed;
+    int64_t row_hi;
+    float* tile_scratch;
+    double* sums_out;
+} eg_lower_sums;
+typedef struct eg_given_sums {
+    const double* sums;
+    int frames;
+    int64_t row_lo, n_valid;
+    const float* taps;
+} eg_given_sums;
+int eg_gcn_layer_bwd_lower(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
+                           const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
+                           int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,
+                           float* dbeta, const eg_given_sums* given, const eg_lower_sums* lower, eg_stream_t stream);
+
 /* ---- coordinate-graph landmark update (src/core/models.py:438-453) -----------------------------------
  * For the 4 landmark rows of every frame (R = 4 * batch rows):
  *   shape_feats[(f,j), 2k+d] = coords[f,k,d] - coords[f,j,d]                                   (models.py:441-444)
@@ -413,6 +451,12 @@ int eg_bilinear4_fwd_rows(const float* h, const float* coords, int batch, int po
                           int frame, float* out, int64_t out_frame_stride, eg_stream_t stream);
 int eg_bilinear4_bwd_rows(const float* dout, int64_t dout_frame_stride, const float* h, const float* coords, int batch, int points,
                           int64_t n_per_frame, int64_t main_base, int frame, float* dh, float* dcoords, eg_stream_t stream);
+/* ... and, when dh is the dy of a layer whose BatchNorm-backward sums were taken BEFORE this call (eg_gcn_layer_bwd_lower), the
+ * sums of what is added here: tap_sums [batch][2][128] floats = per frame  sum add * mask, sum add * mask * xhat  over its taps
+ * (lower->z, bn, relu, dropout_p, seed describe that layer; the other fields are not used). */
+int eg_bilinear4_bwd_rows_sums(const float* dout, int64_t dout_frame_stride, const float* h, const float* coords, int batch, int points,
+                               int64_t n_per_frame, int64_t main_base, int frame, float* dh, float* dcoords,
+                               const eg_lower_sums* lower, float* tap_sums, eg_stream_t stream);
 
 /* ---- losses on the logits and landmark decode (the steps right after the hot path) ---------------------
  * Reference: src/core/criterion.py:13-27 (WeightedBCEWithLogitsLoss), :93-151 (ExpectedLandmarkMSE),

@@ -970,3 +970,57 @@ def test_whole_train_step_with_dropout_against_the_oracle_under_the_kernels_mask
     plain.train()
     other, _ = plain.forward_nodes(feats, ei, nt, B, c0.clone())
     assert (other.detach() - w32).abs().max() > 100 * (got.detach().cpu() - w32).abs().max()
+
+
+@pytest.mark.parametrize("frame,naux,coord,conn,B,p", [(32, 4, True, False, 3, 0.5), (64, 6, False, False, 2, 0.5), (224, 7, True, False, 2, 0.5),
+                                                       (30, 3, True, False, 3, 0.3), (32, 4, False, True, 2, 0.5), (64, 6, True, False, 2, 0.0)])
+def test_batchnorm_backward_sums_handed_down_by_the_dx_launch(monkeypatch, frame, naux, coord, conn, B, p):
+    """dx of layer i + 1 is dy of layer i: the dX launch (k_gcn_layer_ps MODE 3) takes layer i's BatchNorm-backward sums where the
+    rows leave it -- per tile, fixed order -- the coordinate update's backward adds the sums of its 16 taps per frame, and layers
+    1 and 2 of the step run WITHOUT a sums pass of their own (src/core/models.py:333-335 backwards).  Against EG_SUMS_DOWN=0 (every
+    layer sums its own dy and z in fp64): the same forward bit for bit, every gradient to the rounding of an fp32 partial sum, and
+    the step is bit-reproducible run to run (the partials do not depend on who wins a tile queue)."""
+    from echoglad_amd import nn as egnn, ops
+    hip, _ = model_pair(frame, naux, 3, coord=coord, seed=47, use_connection_nodes=conn)
+    for m in hip.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = p
+    hip.train()
+    topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=coord, conn=conn)
+    x = synthetic_node_feats(B * topo.num_nodes, 128, seed=3).to(DEV)
+    coords0 = initial_coords(B, frame).to(DEV) if coord else None
+    state = {k: v.clone() for k, v in hip.state_dict().items()}
+    calls = []
+    orig = ops.gcn_layer_bwd
+
+    def spy(*a, **kw):
+        calls.append((kw.get("dy_sums") is not None, kw.get("lower") is not None))
+        return orig(*a, **kw)
+    monkeypatch.setattr(ops, "gcn_layer_bwd", spy)
+    res = {}
+    for knob in ("1", "0", "1b"):
+        monkeypatch.setenv("EG_SUMS_DOWN", knob[0])
+        hip.load_state_dict(state)
+        for q in hip.parameters():
+            q.grad = None
+        torch.manual_seed(99)
+        calls.clear()
+        got, gc = hip.forward_nodes(x, ei.to(DEV), B, None if coords0 is None else coords0.clone())
+        ((got ** 2).mean() + (0 if gc is None else (gc ** 2).mean() * 1e-3)).backward()
+        res[knob] = (got.detach().clone(), None if gc is None else gc.detach().clone(),
+                     {k: q.grad.clone() for k, q in hip.named_parameters()}, list(calls))
+        assert not egnn._SUMS_DOWN, "every handed-down entry was consumed"
+    # backward order: layer 3, 2, 1.  (given sums?, hands sums down?)
+    given3 = res["1"][3][0][0]                                   # (layer 3's sums come from the heads' backward where that route applies)
+    assert res["1"][3] == [(given3, True), (True, True), (True, False)], res["1"][3]
+    assert res["0"][3] == [(given3, False), (False, False), (False, False)], res["0"][3]
+    a, b, a2 = res["1"], res["0"], res["1b"]
+    assert torch.equal(a[0], b[0]) and (not coord or torch.equal(a[1], b[1]))
+    worst = 0.0
+    for k in a[2]:
+        scale = float(b[2][k].abs().max())
+        err = float((a[2][k] - b[2][k]).abs().max())
+        assert err <= 2e-4 * scale + 1e-8, (k, err, scale)
+        worst = max(worst, err / (scale + 1e-30))
+        assert torch.equal(a[2][k], a2[2][k]), k                # bit-reproducible
+    print(f"sums handed down vs own sums pass: worst relative gradient difference {worst:.2e}")
