@@ -1233,20 +1233,18 @@ static int classifier_train_fwd(const float* h, const LinAct* act, int batch, in
     if (act && act4) hipLaunchKernelGGL(k_act_lin128, dim3(g1), dim3(256), 0, stream, P->w1, P->b1, z1, partial, d, *act);
     else if (act) hipLaunchKernelGGL((k_lin128_map<true, true>), dim3(g1), dim3(512), 0, stream, (const float*)nullptr, P->w1, P->b1, z1, partial, d, *act);
     else hipLaunchKernelGGL((k_lin128_map<true, false>), dim3(g1), dim3(512), 0, stream, h, P->w1, P->b1, z1, partial, d, LinAct{});
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(8), dim3(RED_F32_THREADS), 0, stream, partial, g1, 256, totals);
     BnFinalize f1{totals, rows, H1, P->gamma1, P->beta1, P->eps1, P->momentum1, P->running_mean1, P->running_var1,
                   bn + 0 * H1, bn + 1 * H1, bn + 2 * H1, bn + 3 * H1};
-    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(128), 0, stream, f1);
+    hipLaunchKernelGGL(k_bn_reduce_finalize, dim3(H1 / 16), dim3(RED_F32_THREADS), 0, stream, (const float*)partial, g1, f1);
     // ---- second layers + BatchNorm1d(64) statistics
     float* bn2p = bn + 4 * H1;
     const ClsBn bn1{bn + 0 * H1, bn + 1 * H1, bn + 2 * H1, bn + 3 * H1, P->gamma1};
     const ClsDrop d1{P->p1, P->p1 > 0.f ? 1.0f / (1.0f - P->p1) : 1.0f, P->seed1, eg_epoch_ptr()};
     const int g2 = grid_for(rows, TILE, 768);
     hipLaunchKernelGGL(k_cls_mid_fwd, dim3(g2), dim3(CT_THREADS), 0, stream, z1, rows, P->w2, P->b2, bn1, d1, z2, partial);
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4), dim3(RED_F32_THREADS), 0, stream, partial, g2, 128, totals + 256);
     BnFinalize f2{totals + 256, rows, H2, P->gamma2, P->beta2, P->eps2, P->momentum2, P->running_mean2, P->running_var2,
                   bn2p + 0 * H2, bn2p + 1 * H2, bn2p + 2 * H2, bn2p + 3 * H2};
-    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, stream, f2);
+    hipLaunchKernelGGL(k_bn_reduce_finalize, dim3(H2 / 16), dim3(RED_F32_THREADS), 0, stream, (const float*)partial, g2, f2);
     // ---- third layers
     const ClsBn bn2{bn2p + 0 * H2, bn2p + 1 * H2, bn2p + 2 * H2, bn2p + 3 * H2, P->gamma2};
     const ClsDrop d2{P->p2, P->p2 > 0.f ? 1.0f / (1.0f - P->p2) : 1.0f, P->seed2, eg_epoch_ptr()};

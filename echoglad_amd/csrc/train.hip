@@ -62,11 +62,16 @@ __global__ __launch_bounds__(RED_F32_THREADS) void k_reduce_f32_partials(const f
     if (sl == 0 && col < n) totals[col] = red[t];
 }
 
+__device__ inline void bn_finalize_channel(const BnFinalize& a, int c, double sum, double sumsq);
 __global__ void k_bn_finalize(const BnFinalize a) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.cc) return;
-    const double m = a.totals[c] / (double)a.rows;
-    double v = a.totals[a.cc + c] / (double)a.rows - m * m;
+    bn_finalize_channel(a, c, a.totals[c], a.totals[a.cc + c]);
+}
+
+__device__ inline void bn_finalize_channel(const BnFinalize& a, int c, double sum, double sumsq) {
+    const double m = sum / (double)a.rows;
+    double v = sumsq / (double)a.rows - m * m;
     v = v > 0.0 ? v : 0.0;
     const float is = (float)(1.0 / sqrt(v + (double)a.eps));
     const float sc = a.gamma[c] * is;
@@ -79,6 +84,24 @@ __global__ void k_bn_finalize(const BnFinalize a) {
         a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
         a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
     }
+}
+
+__global__ __launch_bounds__(RED_F32_THREADS) void k_bn_reduce_finalize(const float* __restrict__ partial, int nblocks, const BnFinalize a) {
+    __shared__ double red[RED_F32_THREADS];
+    const int t = threadIdx.x, j = t & 31, sl = t >> 5;
+    const int c = blockIdx.x * 16 + (j & 15);                     // channel; j >> 4: 0 = sum, 1 = sum of squares
+    const int col = (j >> 4) * a.cc + c, n = 2 * a.cc;
+    double s = 0.0;
+    if (c < a.cc)
+        for (int b = sl; b < nblocks; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * n + col];
+    red[t] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = RED_F32_THREADS / 64; st > 0; st >>= 1) {
+        if (sl < st) red[t] += red[t + 32 * st];
+        __syncthreads();
+    }
+    if (t < 16 && c < a.cc) bn_finalize_channel(a, c, red[t], red[t + 16]);
 }
 
 // stage 2: fixed-order sum over the workgroup partials -> totals[NQ][C] (double, first NQ*C of the workspace tail)
@@ -241,7 +264,8 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_presum(const double* __restrict
                                                         const float* __restrict__ z, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const RowMap m, int batch,
-                                                        double* __restrict__ totals, const ActArgs a_, const float* __restrict__ taps) {
+                                                        double* __restrict__ totals, const ActArgs a_, const float* __restrict__ taps,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const ActArgs a = resolved(a_);
     __shared__ double s_red[8][2][C];
     const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
@@ -262,6 +286,12 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_presum(const double* __restrict
         sg += (double)g;
         sx += (double)(g * xh);
     }
+    if (taps) {                                    // what the bilinear backward added inside the summed range afterwards: frames
+        for (int f = grp; f < batch; f += 8) {     // f = grp, grp + 8, ... in ascending order per group, the groups in order below
+            sg += (double)taps[((size_t)f * 2 + 0) * C + c];
+            sx += (double)taps[((size_t)f * 2 + 1) * C + c];
+        }
+    }
     s_red[grp][0][c] = sg;
     s_red[grp][1][c] = sx;
     __syncthreads();
@@ -269,9 +299,9 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_presum(const double* __restrict
         double t = presum[grp * C + c];
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += s_red[k][grp][c];
-        if (taps)                                  // what the bilinear backward added inside the summed range afterwards, frame by frame
-            for (int f = 0; f < batch; ++f) t += (double)taps[((size_t)f * 2 + grp) * C + c];
         totals[grp * C + c] = t;
+        if (grp == 0) dbeta[c] = (float)t;         // (k_bn_bwd_final's job, here: one launch fewer)
+        else dgamma[c] = (float)t;
     }
 }
 
@@ -296,14 +326,23 @@ __global__ __launch_bounds__(RED_F32_THREADS) void k_tile_sums_stage1(const floa
     }
     if (sl == 0) out[(size_t)blockIdx.y * 2 * C + col] = red[t];
 }
-__global__ void k_tile_sums_stage2(const double* __restrict__ chunks, int n_chunks, const float* __restrict__ mean,
-                                   const float* __restrict__ invstd, double* __restrict__ sums) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(1024) void k_tile_sums_stage2(const double* __restrict__ chunks, int n_chunks, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, double* __restrict__ sums) {
+    __shared__ double red[8][2][C];
+    const int c = threadIdx.x & 127, sl = threadIdx.x >> 7;       // 8 slices of the chunk list, each in ascending order
     double s1 = 0.0, t1 = 0.0;
-    for (int k = 0; k < n_chunks; ++k) { s1 += chunks[(size_t)k * 2 * C + c]; t1 += chunks[(size_t)k * 2 * C + C + c]; }
-    sums[c] = s1;
-    sums[C + c] = (double)invstd[c] * (t1 - (double)mean[c] * s1);
+#pragma unroll 4
+    for (int k = sl; k < n_chunks; k += 8) { s1 += chunks[(size_t)k * 2 * C + c]; t1 += chunks[(size_t)k * 2 * C + C + c]; }
+    red[sl][0][c] = s1;
+    red[sl][1][c] = t1;
+    __syncthreads();
+    if (sl == 0) {
+        s1 = 0.0; t1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1 += red[k][0][c]; t1 += red[k][1][c]; }
+        sums[c] = s1;
+        sums[C + c] = (double)invstd[c] * (t1 - (double)mean[c] * s1);
+    }
 }
 
 __global__ void k_bn_bwd_final(const double* __restrict__ totals, float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -642,12 +681,12 @@ int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const floa
     double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
     if (presum) {          // the sums over most rows exist: add the few rows they leave out
         hipLaunchKernelGGL(k_bn_bwd_presum, dim3(1), dim3(1024), 0, stream, presum, dy, z, mean, invstd, gamma, beta, *presum_rows,
-                           presum_batch, totals, a, presum_taps);
+                           presum_batch, totals, a, presum_taps, dgamma, dbeta);
     } else {
         hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nb), dim3(RED_THREADS), 0, stream, dy, z, mean, invstd, gamma, beta, partial, a);
         hipLaunchKernelGGL(k_reduce_partials<2>, dim3(2 * C / 8), dim3(256), 0, stream, partial, nb, totals);
+        hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(128), 0, stream, totals, dgamma, dbeta);
     }
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(128), 0, stream, totals, dgamma, dbeta);
     if (dw && x) {
         long long nt = (rows + DW_ROWS - 1) / DW_ROWS;
         const int nd = (int)(nt < DW_BLOCKS ? nt : DW_BLOCKS);
@@ -759,9 +798,8 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
     if (rc == EG_ERR_UNSUPPORTED) rc = eg_launch_layer_sym(g, batch, x, W, nullptr, bias, nullptr, 0, 0, z, agg, partial, &grid, stream);
     if (rc != EG_OK) return public_rc(rc);
     const long long rows = (long long)g->n_nodes * batch;
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * C / 32), dim3(RED_F32_THREADS), 0, stream, partial, grid, 2 * C, totals);
     BnFinalize f{totals, rows, C, gamma, beta, eps, momentum, running_mean, running_var, bn, bn + C, bn + 2 * C, bn + 3 * C};
-    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(128), 0, stream, f);
+    hipLaunchKernelGGL(k_bn_reduce_finalize, dim3(C / 16), dim3(RED_F32_THREADS), 0, stream, (const float*)partial, grid, f);
     EG_HIP_TRY(hipGetLastError());
     if (!out) return EG_OK;                       // z, agg and the batch statistics only
     // the activation pass in tile order leaves the child sums of `out` behind for the next layer's train forward
@@ -815,7 +853,7 @@ static int gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, cons
             double* chunk_sums = (double*)workspace;             // (the reduction area of the workspace: this layer's own passes are done with it)
             hipLaunchKernelGGL(k_tile_sums_stage1, dim3(2 * C / 32, chunks), dim3(RED_F32_THREADS), 0, stream, (const float*)lower->tile_scratch,
                                n_tiles, per, chunk_sums);
-            hipLaunchKernelGGL(k_tile_sums_stage2, dim3(1), dim3(128), 0, stream, (const double*)chunk_sums, chunks, lower->bn, lower->bn + C,
+            hipLaunchKernelGGL(k_tile_sums_stage2, dim3(1), dim3(1024), 0, stream, (const double*)chunk_sums, chunks, lower->bn, lower->bn + C,
                                lower->sums_out);
             EG_HIP_TRY(hipGetLastError());
         } else if (train_ps && residual)

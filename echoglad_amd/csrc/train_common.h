@@ -99,5 +99,9 @@ struct BnFinalize {
     float *mean, *invstd, *scale, *shift;
 };
 __global__ void k_bn_finalize(const BnFinalize a);
+// ... with the fixed-order reduction of the per-workgroup partials float [nblocks][2 * cc] in front of it, in ONE launch of
+// cc / 16 workgroups (RED_F32_THREADS threads: 16 columns x {sum, sum of squares} x 32 slices of the partial list; the same
+// summation order as k_reduce_f32_partials, so the same bits).  a.totals is not read.
+__global__ void k_bn_reduce_finalize(const float* __restrict__ partial, int nblocks, const BnFinalize a);
 
 }  // namespace eg
