@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 from echoglad_amd import ops, _lib
 from echoglad_amd.synthetic import synthetic_node_feats
-B = 8
+B = int(os.environ.get("EG_STAMP_B", "8"))
 g = ops.Graph.topo(224, 7)
 x = synthetic_node_feats(B * g.num_nodes, 128, 1).cuda()
 w = (synthetic_node_feats(128, 128, 2) * 0.1).cuda()
@@ -44,6 +44,9 @@ tiles = 1128 * B
 print(f"waves(counted)={waves} tiles={tiles}")
 if v[10]:
     print(f"in-kernel clock = {v[9] / v[10] * 0.1:.3f} GHz  (shader cycles / 100-MHz ticks around the tile loop, stamp build)")
+    n_wg = min(256, tiles)
+    print(f"tile loop per workgroup: {v[10] / n_wg * 0.01:.1f} us mean ({v[9] / n_wg:.0f} cycles; {tiles / n_wg:.2f} tiles per workgroup, "
+          f"{v[9] / max(tiles, 1):.0f} cycles per tile incl. pipeline fill / drain)")
 wgs = 256 if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else waves / 8
 waves = wgs * 4 if (os.environ.get("EG_LAYER_IMPL", "0") != "0" or form) else waves
 for n, c in zip(names, v[:8]):
