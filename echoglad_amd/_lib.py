@@ -109,6 +109,8 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_pack_levels": (_i, [ct.POINTER(_p), ct.POINTER(_i), _i, _i, _i64, _i64, _p, _p]),
     "eg_conv1x1_relu_pack_levels": (_i, [ct.POINTER(_p), ct.POINTER(_p), ct.POINTER(_p), ct.POINTER(_i), ct.POINTER(_i), _i, _i,
                                          _i64, _i64, _p, _p]),
+    "eg_avg_pool_pyramid_fwd": (_i, [_p, _i64, _i, ct.POINTER(_i), _i, ct.POINTER(_p), _p]),
+    "eg_avg_pool_pyramid_bwd": (_i, [ct.POINTER(_p), _p, _i64, _i, ct.POINTER(_i), _i, _p, _p]),
     "eg_unpack_levels": (_i, [_p, ct.POINTER(_p), ct.POINTER(_i), _i, _i, _i64, _i64, _p]),
     "eg_heatmap_workspace_bytes": (ct.c_size_t, [_i, ct.POINTER(_i), _i]),
     "eg_heatmap_expect_fwd": (_i, [_p, _p, _p, _i, _i64, ct.POINTER(_i), ct.POINTER(_i), _i, _p, _p, _p, _p, _p, _p, _p]),

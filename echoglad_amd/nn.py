@@ -1328,14 +1328,32 @@ class HierarchicalPatchModel(nn.Module):
     def create_node_pixels(self, echo_frames: torch.Tensor, num_samples_per_batch: int, node_coords=None):
         """models.py:498-537: average-pooled pyramid of the frame embedding + the frame itself, node-major."""
         B = int(num_samples_per_batch)
-        maps = []
-        if not self.use_main_graph_only:
-            maps = [F.adaptive_avg_pool2d(echo_frames, output_size=(2 ** g, 2 ** g)) for g in range(1, self.num_aux_graphs + 1)]
-        maps.append(echo_frames)
         conn = None
         if self.use_connection_nodes and not self.use_main_graph_only:
             conn = echo_frames.mean(dim=(2, 3)).unsqueeze(1).expand(B, self.num_aux_graphs + 1, C)
+        sides = [] if self.use_main_graph_only else [2 ** g for g in range(1, self.num_aux_graphs + 1)]
+        if sides and echo_frames.shape[1] == C and ops.pyramid_supported(echo_frames, sides) and os.environ.get("EG_POOL_PYRAMID", "1") != "0":
+            # the pooled pyramid and the packing as ONE autograd node, two launches each way (eg_avg_pool_pyramid_*, eg_pack_levels):
+            # torch's adaptive_avg_pool2d is a launch per level (219 us each at 224 x 224, batch 1) and, backwards, a launch of float
+            # atomics per level (254 us each) -- 3.3 ms of a batch-1 training step whose GNN stack takes 1 ms
+            n, n_conn, _, main_base, coord_base = self._row_ranges()
+            x = echo_frames.float()
+            feats = ops.pyramid_pack(x, sides, B, n, n_conn, out=self._static_node_feats(B, [x, conn]))
+            return self._finish_node_features(feats, B, node_coords, conn)
+        maps = [F.adaptive_avg_pool2d(echo_frames, output_size=(p, p)) for p in sides]
+        maps.append(echo_frames)
         return self.pack_node_features(maps, B, node_coords, conn)
+
+    def _finish_node_features(self, feats, B, node_coords, connection_embed):
+        """Connection-node rows and coordinate-node samples on top of the packed levels (models.py:524-533)."""
+        n, n_conn, _, main_base, coord_base = self._row_ranges()
+        if n_conn:
+            feats = feats.clone() if feats.requires_grad else feats
+            feats.view(B, n, C)[:, :n_conn, :] = connection_embed
+        if self.use_coordinate_graph and not self.use_main_graph_only:
+            new = ops.bilinear4(feats, node_coords.reshape(B, 4, 2).contiguous(), B, n, main_base, self.frame_size)
+            feats = ops.scatter_coord_rows(feats, new, B, n, coord_base)
+        return feats
 
     def pack_node_features(self, level_maps, num_samples_per_batch: int, node_coords=None, connection_embed=None):
         """The tail every create_node_pixels variant of the reference shares (models.py:511-537, :603-636, :726-756):
@@ -1347,13 +1365,7 @@ class HierarchicalPatchModel(nn.Module):
         fs = self.frame_size
         maps = [m.float() for m in level_maps]
         feats = ops.pack_levels(maps, B, n, n_conn, out=self._static_node_feats(B, maps + [connection_embed]))
-        if n_conn:
-            feats = feats.clone() if feats.requires_grad else feats
-            feats.view(B, n, C)[:, :n_conn, :] = connection_embed
-        if self.use_coordinate_graph and not self.use_main_graph_only:
-            new = ops.bilinear4(feats, node_coords.reshape(B, 4, 2).contiguous(), B, n, main_base, fs)
-            feats = ops.scatter_coord_rows(feats, new, B, n, coord_base)
-        return feats
+        return self._finish_node_features(feats, B, node_coords, connection_embed)
 
     def pack_node_features_linear(self, features, linears, num_samples_per_batch: int, node_coords=None, connection_embed=None):
         """The UNet variant's whole tail (models.py:707-756): ``F.relu(self.linears[i](features[i]))`` for every level (1x1
@@ -1368,13 +1380,7 @@ class HierarchicalPatchModel(nn.Module):
         ws, bs = [m.weight for m in linears], [m.bias for m in linears]
         feats = ops.conv1x1_relu_pack_levels(fl, ws, bs, B, n, n_conn,
                                              out=self._static_node_feats(B, fl + ws + bs + [connection_embed]))
-        if n_conn:
-            feats = feats.clone() if feats.requires_grad else feats
-            feats.view(B, n, C)[:, :n_conn, :] = connection_embed
-        if self.use_coordinate_graph and not self.use_main_graph_only:
-            new = ops.bilinear4(feats, node_coords.reshape(B, 4, 2).contiguous(), B, n, main_base, fs)
-            feats = ops.scatter_coord_rows(feats, new, B, n, coord_base)
-        return feats
+        return self._finish_node_features(feats, B, node_coords, connection_embed)
 
     def forward(self, data_batch=None, x=None, node_coords=None, edge_index=None, node_type=None, batch_idx=None):
         if data_batch is not None:

@@ -956,6 +956,97 @@ def bce_logits(logits, labels, valid=None, ones_weight: float = 1.0) -> torch.Te
 
 
 # ---------------------------------------------------------------------------
+# average-pool pyramid (pool.hip) + node-feature packing (pack.hip)
+# ---------------------------------------------------------------------------
+def pyramid_supported(x: torch.Tensor, sides) -> bool:
+    """eg_avg_pool_pyramid_* cover square float32 CUDA planes up to 512 x 512 and strictly ascending sides <= the frame."""
+    sides = list(sides)
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] <= 512 and
+            1 <= len(sides) <= 16 and all(1 <= a < b for a, b in zip(sides, sides[1:])) and sides[-1] <= x.shape[2] and sides[0] >= 1)
+
+
+def _pool_fwd(x: torch.Tensor, sides):
+    B, Cn, Fr, _ = x.shape
+    maps = [torch.empty(B, Cn, p, p, dtype=torch.float32, device=x.device) for p in sides]
+    n = len(sides)
+    _lib.check(_lib.load().eg_avg_pool_pyramid_fwd(_ptr(x), B * Cn, Fr, (ct.c_int * n)(*sides), n,
+                                                   (ct.c_void_p * n)(*[m.data_ptr() for m in maps]), _stream()), "eg_avg_pool_pyramid_fwd")
+    return maps
+
+
+def _pool_bwd(grads, frame_grad, sides, shape, device):
+    B, Cn, Fr, _ = shape
+    n = len(sides)
+    dx = torch.empty(shape, dtype=torch.float32, device=device)
+    ptrs = (ct.c_void_p * n)(*[(g.data_ptr() if g is not None else None) for g in grads])
+    _lib.check(_lib.load().eg_avg_pool_pyramid_bwd(ptrs, _ptr(frame_grad), B * Cn, Fr, (ct.c_int * n)(*sides), n, _ptr(dx), _stream()),
+               "eg_avg_pool_pyramid_bwd")
+    return dx
+
+
+class _AvgPoolPyramidFn(torch.autograd.Function):
+    """[B, C, F, F] -> tuple of F.adaptive_avg_pool2d(x, p) for every side p, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, *sides):
+        x = x.contiguous()
+        ctx.meta = (tuple(sides), tuple(x.shape), x.device)
+        return tuple(_pool_fwd(x, list(sides)))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        sides, shape, device = ctx.meta
+        gs = [g.contiguous() if g is not None else None for g in grads]
+        return (_pool_bwd(gs, None, list(sides), shape, device),) + (None,) * len(sides)
+
+
+def avg_pool_pyramid(x: torch.Tensor, sides):
+    """[F.adaptive_avg_pool2d(x, (p, p)) for p in sides] (strictly ascending) in one launch; differentiable w.r.t. x."""
+    if not pyramid_supported(x, sides):
+        raise RuntimeError("avg_pool_pyramid: square float32 CUDA planes up to 512 x 512, strictly ascending sides <= the frame")
+    return list(_AvgPoolPyramidFn.apply(x, *[int(p) for p in sides]))
+
+
+class _PyramidPackFn(torch.autograd.Function):
+    """create_node_pixels of the base model (models.py:511-523) as ONE autograd node: pooled pyramid of the frame embedding +
+    the frame itself -> node-major rows.  Forward: eg_avg_pool_pyramid_fwd + eg_pack_levels; backward: eg_unpack_levels +
+    eg_avg_pool_pyramid_bwd (the frame's own rows are added there: no second [B,128,F,F] gradient for autograd to sum)."""
+
+    @staticmethod
+    def forward(ctx, x, batch, n_rows, row_offset, out, *sides):
+        x = x.contiguous()
+        sides = list(sides)
+        maps = _pool_fwd(x, sides) + [x]
+        used = sum(int(m.shape[2]) ** 2 for m in maps)
+        if out is not None:
+            nodes = _pack_out(out, [], batch, n_rows, row_offset, used)
+        else:
+            alloc = torch.empty if (row_offset == 0 and used == n_rows) else torch.zeros
+            nodes = alloc(batch * n_rows, C, dtype=torch.float32, device=x.device)
+        _pack_call("eg_pack_levels", maps, nodes, batch, n_rows, row_offset)
+        ctx.meta = (batch, n_rows, row_offset, sides, tuple(x.shape))
+        if out is not None:
+            ctx.mark_dirty(out)
+        return nodes
+
+    @staticmethod
+    def backward(ctx, d_nodes):
+        batch, n_rows, row_offset, sides, shape = ctx.meta
+        grads = [torch.empty(shape[0], shape[1], p, p, dtype=torch.float32, device=d_nodes.device) for p in sides]
+        g_frame = torch.empty(shape, dtype=torch.float32, device=d_nodes.device)
+        _pack_call("eg_unpack_levels", grads + [g_frame], d_nodes.contiguous(), batch, n_rows, row_offset)
+        return (_pool_bwd(grads, g_frame, sides, shape, d_nodes.device),) + (None,) * (4 + len(sides))
+
+
+def pyramid_pack(x: torch.Tensor, sides, batch: int, n_rows: int, row_offset: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Pooled pyramid (sides ascending) of x [batch,128,F,F] + x itself, packed node-major [batch * n_rows, 128] like
+    ``pack_levels([adaptive_avg_pool2d(x, p) ...] + [x])``.  Differentiable w.r.t. x (not with ``out=``: written in place)."""
+    if out is not None and torch.is_grad_enabled() and x.requires_grad:
+        raise RuntimeError("pyramid_pack into out= is not differentiable: call it under torch.no_grad() or without out=")
+    return _PyramidPackFn.apply(x, int(batch), int(n_rows), int(row_offset), out, *[int(p) for p in sides])
+
+
+# ---------------------------------------------------------------------------
 # node-feature packing (pack.hip)
 # ---------------------------------------------------------------------------
 def _pack_call(fn_name, maps, nodes, batch, n_rows, row_offset):

@@ -512,6 +512,19 @@ int eg_conv1x1_relu_pack_levels(const float* const* level_feats, const float* co
                                 const float* const* level_biases, const int* level_channels, const int* level_side,
                                 int n_levels, int batch, int64_t n_rows, int64_t row_offset, float* nodes, eg_stream_t stream);
 
+/* ---- average-pool pyramid of the frame embedding: the head of create_node_pixels (src/core/models.py:511-521) -------------
+ * eg_avg_pool_pyramid_fwd: level_maps[l] [planes, side_l, side_l] = F.adaptive_avg_pool2d(x [planes, frame, frame], side_l)
+ *   for every level in ONE launch (planes = batch * channels; level_side strictly ascending, coarse to fine, as the node rows are
+ *   laid out; window (i, j) = rows [floor(i F / p), ceil((i + 1) F / p)) x the same columns).
+ * eg_avg_pool_pyramid_bwd: dx [planes, frame, frame] = frame_grad (nullable: the gradient that reaches the frame as the finest
+ *   level of the node array) + the pooling's gradient, sum over levels and over the windows containing a pixel of
+ *   level_grads[l][window] / area(window) (level_grads[l] NULL: none) -- a gather, no atomics: bit-reproducible (torch's
+ *   atomic_adaptive_average_gradinput is not).  Frames up to 512 x 512. */
+int eg_avg_pool_pyramid_fwd(const float* x, int64_t planes, int frame, const int* level_side, int n_levels, float* const* level_maps,
+                            eg_stream_t stream);
+int eg_avg_pool_pyramid_bwd(const float* const* level_grads, const float* frame_grad, int64_t planes, int frame, const int* level_side,
+                            int n_levels, float* dx, eg_stream_t stream);
+
 
 #ifdef __cplusplus
 }

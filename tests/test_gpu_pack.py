@@ -139,3 +139,56 @@ def test_unet_variant_example_end_to_end(frame, naux, coord):
     missing = [k for k, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
     assert not missing, missing
     assert float(model.linears[0].weight.grad.abs().max()) > 0 and float(model.down_convs[0].conv1.weight.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("frame,sides,batch,chans", [(224, [2, 4, 8, 16, 32, 64, 128], 2, 128), (64, [2, 4, 8, 16, 32, 64], 2, 128),
+                                                      (30, [2, 4, 8], 3, 128), (31, [2, 4, 8, 16], 2, 8), (448, [2, 4, 8, 16, 32, 64, 128, 256], 1, 4),
+                                                      (16, [3, 5, 16], 2, 16), (256, [2, 4, 8, 16, 32, 64, 128], 1, 16), (8, [2], 1, 128)])
+def test_avg_pool_pyramid_is_adaptive_avg_pool2d_for_every_level(frame, sides, batch, chans):
+    """models.py:511-521: F.adaptive_avg_pool2d(frame, (2^g, 2^g)) for every aux level -- all levels in one launch
+    (eg_avg_pool_pyramid_fwd: exact block means of a coarser level taken as the mean of 2 x 2 finer ones, everything else summed
+    window by window) against torch's own op on the CPU in float64, and the gradient (a gather, no atomics) against torch's
+    autograd; odd frames, sides that do not divide the frame, a side equal to the frame."""
+    rs = np.random.RandomState(frame + len(sides))
+    x_cpu = torch.from_numpy(rs.standard_normal((batch, chans, frame, frame))).requires_grad_(True)          # float64
+    want = [torch.nn.functional.adaptive_avg_pool2d(x_cpu, (p, p)) for p in sides]
+    x = x_cpu.detach().float().to(DEV).requires_grad_(True)
+    got = ops.avg_pool_pyramid(x, sides)
+    for g, w, p in zip(got, want, sides):
+        assert g.shape == w.shape
+        assert float((g.detach().cpu().double() - w.detach()).abs().max()) < 2e-6, p
+    ws = [torch.from_numpy(rs.standard_normal(tuple(w.shape))) for w in want]
+    sum((w * k).sum() for w, k in zip(want, ws)).backward()
+    sum((g * k.float().to(DEV)).sum() for g, k in zip(got, ws)).backward()
+    assert float((x.grad.cpu().double() - x_cpu.grad).abs().max()) < 1e-5
+    # bit-reproducible (torch's CUDA backward adds with float atomics)
+    x2 = x.detach().clone().requires_grad_(True)
+    sum((g * k.float().to(DEV)).sum() for g, k in zip(ops.avg_pool_pyramid(x2, sides), ws)).backward()
+    assert torch.equal(x2.grad, x.grad)
+    # a level without a gradient
+    x3 = x.detach().clone().requires_grad_(True)
+    ops.avg_pool_pyramid(x3, sides)[0].sum().backward()
+    x_cpu.grad = None
+    torch.nn.functional.adaptive_avg_pool2d(x_cpu, (sides[0], sides[0])).sum().backward()
+    assert float((x3.grad.cpu().double() - x_cpu.grad).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("frame,naux,coord,conn,batch", [(224, 7, True, False, 2), (64, 6, False, True, 2), (30, 3, False, False, 3), (32, 4, True, True, 2)])
+def test_create_node_pixels_with_the_fused_pyramid_equals_the_torch_pools(monkeypatch, frame, naux, coord, conn, batch):
+    """create_node_pixels (models.py:498-537) through eg_avg_pool_pyramid_* + eg_pack_levels as one autograd node against the
+    route with torch's adaptive_avg_pool2d per level (EG_POOL_PYRAMID=0): node features to 2e-6, the gradient w.r.t. the frames to
+    1e-5 of its largest entry."""
+    hip, _ = model_pair(frame, naux, 2, coord=coord, seed=3, use_connection_nodes=conn)
+    frames = synthetic_frames(batch, 128, frame, 9).to(DEV)
+    coords = initial_coords(batch, frame).to(DEV).reshape(batch, 4, 2) if coord else None
+    w = synthetic_frames(1, 1, 64, 3).reshape(-1)[:128].to(DEV)
+    res = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("EG_POOL_PYRAMID", knob)
+        x = frames.clone().requires_grad_(True)
+        feats = hip.create_node_pixels(x, batch, coords)
+        (feats * w).sum().backward()
+        res[knob] = (feats.detach().clone(), x.grad.clone())
+    assert res["1"][0].shape == res["0"][0].shape
+    assert float((res["1"][0] - res["0"][0]).abs().max()) < 2e-6
+    assert float((res["1"][1] - res["0"][1]).abs().max()) < 1e-5 * float(res["0"][1].abs().max())
