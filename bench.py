@@ -229,7 +229,7 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
     def step():
         preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0.clone())
         ls = engine.compute_loss(crit, preds, y, coord_preds, coord_y, valid, B)
-        loss = sum(ls.values())
+        loss = engine.total_loss(ls)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         if reducer is not None:
@@ -239,7 +239,7 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
 
     def loss_fn():                         # (what engine.GraphedTrainStep captures: the same step without the optimizer calls)
         preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0.clone())
-        return sum(engine.compute_loss(crit, preds, y, coord_preds, coord_y, valid, B).values())
+        return engine.total_loss(engine.compute_loss(crit, preds, y, coord_preds, coord_y, valid, B))
 
     step.reducer = reducer
     step.graphed = (lambda warmup=2: engine.GraphedTrainStep(loss_fn, opt, warmup=warmup)) if capturable and reducer is None else None
@@ -759,7 +759,7 @@ def documented_graphed_loop_ms(args, device, B=1, n=24):
         def loss_fn():
             static.node_coords = coords0.clone()
             preds, cp = engine.forward_batch(md, static, True)
-            return sum(engine.compute_loss(crit, preds, static.y, cp, static.node_coord_y, static.valid_labels, B).values())
+            return engine.total_loss(engine.compute_loss(crit, preds, static.y, cp, static.node_coord_y, static.valid_labels, B))
 
         step = engine.GraphedTrainStep(loss_fn, opt, warmup=2)
         v0 = static.edge_index._version

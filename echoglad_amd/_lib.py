@@ -115,6 +115,11 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_heatmap_workspace_bytes": (ct.c_size_t, [_i, ct.POINTER(_i), _i]),
     "eg_heatmap_expect_fwd": (_i, [_p, _p, _p, _i, _i64, ct.POINTER(_i), ct.POINTER(_i), _i, _p, _p, _p, _p, _p, _p, _p]),
     "eg_heatmap_expect_bwd": (_i, [_p, _p, _p, _p, _i, _i64, ct.POINTER(_i), ct.POINTER(_i), _i, _p, _p]),
+    "eg_criteria_workspace_bytes": (ct.c_size_t, [_i, ct.POINTER(_i), _i]),
+    "eg_criteria_fwd": (_i, [_p, _p, _p, _i, _i64, ct.POINTER(_i), ct.POINTER(_i), _i, _p, _f, _f, _f, _p, _p, _i64, _f, _p, _p, _p, _p,
+                             _p, _p, _p, _p, _p, _p, _p]),
+    "eg_criteria_bwd": (_i, [_p, _p, _p, _i, _i64, ct.POINTER(_i), ct.POINTER(_i), _i, _f, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p,
+                             _p, _p, _p]),
     "eg_elm_reduce": (_i, [_p, _p, _p, _p, _i, _i, ct.c_float, _p, _p, _p]),
     "eg_bce_logits_fwd": (_i, [_p, _p, _p, _i64, ct.c_float, _p, _p, _p]),
     "eg_bce_logits_bwd": (_i, [_p, _p, _p, _i64, ct.c_float, _p, _p, _p]),

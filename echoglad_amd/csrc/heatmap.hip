@@ -309,6 +309,127 @@ __global__ __launch_bounds__(128) void k_elm_reduce(const float* __restrict__ ex
     }
 }
 
+
+// ---- the three criteria of a training step as ONE node (engine.py:582-600 + criterion.py:13-27, :36-48, :93-151) -----------------
+// forward: k_bce_partial + k_hm_partial + k_hm_final + k_criteria_final (4 launches); backward: k_criteria_bwd (1 launch).  As
+// separate autograd nodes with torch's glue around them the same arithmetic was ~33 launches of ~5 us each -- a sixth of a
+// batch-1 training step captured into a HIP graph.
+struct CriteriaFinal {
+    const float *expect, *gt, *vmean, *inv_side;
+    int batch, n_levels;
+    float w_elm;
+    float* d_expect;
+    const double* bce_part;
+    int bce_blocks;
+    float w_bce;
+    const float *coord_pred, *coord_y;      // nullable: no coordinate criterion
+    int n_coord;
+    float w_coord;
+    float* d_coord;                         // [n_coord] = w_coord * 2 (pred - y) / n_coord
+    float *total, *bce, *elm, *coord;       // one float each
+    float* bce_scale;                       // w_bce / sum(valid): what every element of the BCE gradient is multiplied by
+};
+
+__global__ __launch_bounds__(128) void k_criteria_final(const CriteriaFinal a) {
+    __shared__ double s_part[128];
+    __shared__ double s_bce[2][128];
+    __shared__ double s_coord[128];
+    const int t = threadIdx.x, n = a.n_levels * 8;
+    // ExpectedLandmarkMSE (k_elm_reduce's arithmetic)
+    double part = 0.0;
+    if (t < n) {
+        const int l = t >> 3, c = (t >> 1) & 3;
+        float nv = 0.f;
+        for (int b = 0; b < a.batch; ++b) nv += a.vmean[((size_t)b * a.n_levels + l) * 4 + c];
+        if (nv == 0.f) nv = 1.f;
+        const float is = a.inv_side[l];
+        for (int b = 0; b < a.batch; ++b) {
+            const size_t i = (size_t)b * n + t;
+            const float diff = (a.expect[i] - a.gt[i]) * is;
+            const float wv = a.vmean[((size_t)b * a.n_levels + l) * 4 + c] / nv;
+            part += (double)(diff * diff * wv);
+            a.d_expect[i] = 2.0f * a.w_elm * diff * wv * is;
+        }
+    }
+    s_part[t] = part;
+    // weighted BCE: the partials of k_bce_partial, thread t sums partials t, t + 128, ... in ascending order
+    double ba = 0.0, bv = 0.0;
+    for (int k = t; k < a.bce_blocks; k += 128) { ba += a.bce_part[2 * k]; bv += a.bce_part[2 * k + 1]; }
+    s_bce[0][t] = ba;
+    s_bce[1][t] = bv;
+    // coordinate MSE (mean over all elements) and its gradient
+    double cs = 0.0;
+    if (a.coord_pred) {
+        const float inv_n = 1.0f / (float)a.n_coord;
+        for (int i = t; i < a.n_coord; i += 128) {
+            const float d = a.coord_pred[i] - a.coord_y[i];
+            cs += (double)(d * d);
+            a.d_coord[i] = a.w_coord * 2.0f * d * inv_n;
+        }
+    }
+    s_coord[t] = cs;
+    __syncthreads();
+    if (t == 0) {
+        double elm = 0.0, A = 0.0, V = 0.0, cc = 0.0;
+        for (int k = 0; k < n; ++k) elm += s_part[k];
+        for (int k = 0; k < 128; ++k) { A += s_bce[0][k]; V += s_bce[1][k]; cc += s_coord[k]; }
+        const float f_elm = (float)(elm * (double)a.w_elm);
+        const float f_bce = a.w_bce * (float)(A / V);
+        const float f_coord = a.coord_pred ? a.w_coord * (float)(cc / (double)a.n_coord) : 0.f;
+        *a.elm = f_elm;
+        *a.bce = f_bce;
+        if (a.coord) *a.coord = f_coord;
+        *a.total = (f_bce + f_elm) + f_coord;
+        *a.bce_scale = a.w_bce / (float)V;
+    }
+}
+
+struct CriteriaBwd {
+    const float *logits, *labels, *valid;    // valid nullable (= 1)
+    const float *expect, *stats, *d_expect;
+    const float* bce_scale;
+    float ones_weight;
+    const float *g_total, *g_bce, *g_elm, *g_coord;      // upstream gradients (device scalars), each nullable
+    const float* d_coord;
+    int n_coord;
+    float* d_logits;
+    float* d_coord_out;                      // nullable
+};
+
+__global__ __launch_bounds__(HM_THREADS) void k_criteria_bwd(const CriteriaBwd a, const HmLevels L) {
+    const float gt = a.g_total ? *a.g_total : 0.f;
+    const float s_bce = (gt + (a.g_bce ? *a.g_bce : 0.f)) * a.bce_scale[0];
+    const float s_elm = gt + (a.g_elm ? *a.g_elm : 0.f);
+    const long long t = (long long)blockIdx.x * HM_THREADS + threadIdx.x;
+    if (a.d_coord_out && t < a.n_coord) a.d_coord_out[t] = (gt + (a.g_coord ? *a.g_coord : 0.f)) * a.d_coord[t];
+    if (t >= (long long)L.batch * L.n_rows) return;
+    const int b = (int)(t / L.n_rows), r = (int)(t - (long long)b * L.n_rows);
+    int l = -1;
+    for (int k = 0; k < L.n_levels; ++k) if (r >= L.start[k] && r < L.start[k] + L.side[k] * L.side[k]) l = k;
+    const float4 x = *reinterpret_cast<const float4*>(a.logits + (size_t)t * 4);
+    const float4 y = *reinterpret_cast<const float4*>(a.labels + (size_t)t * 4);
+    const float4 v = a.valid ? *reinterpret_cast<const float4*>(a.valid + (size_t)t * 4) : float4{1.f, 1.f, 1.f, 1.f};
+    const float xv[4] = {x.x, x.y, x.z, x.w}, yv[4] = {y.x, y.y, y.z, y.w}, vv[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float w = (a.ones_weight > 1.0f && yv[c] == 1.0f) ? a.ones_weight : 1.0f;
+        const float sg = 1.0f / (1.0f + expf(-xv[c]));
+        o[c] = (sg - yv[c]) * w * vv[c] * s_bce;
+    }
+    if (l >= 0) {
+        const int rr = r - L.start[l], side = L.side[l];
+        const float h = (float)(rr / side), w = (float)(rr - (rr / side) * side);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const size_t q = (((size_t)b * L.n_levels + l) * 4 + c) * 2;
+            const float p = expf(xv[c] - a.stats[q]) / a.stats[q + 1];
+            o[c] += s_elm * (p * ((h - a.expect[q]) * a.d_expect[q] + (w - a.expect[q + 1]) * a.d_expect[q + 1]));
+        }
+    }
+    *reinterpret_cast<float4*>(a.d_logits + (size_t)t * 4) = float4{o[0], o[1], o[2], o[3]};
+}
+
 }  // namespace eg
 
 using namespace eg;
@@ -385,6 +506,69 @@ int eg_elm_reduce(const float* expect, const float* gt, const float* vmean, cons
     if (!expect || !gt || !vmean || !inv_side || !loss || !d_expect || batch < 1 || n_levels < 1 || n_levels > 16)
         return set_error(EG_ERR_ARG, "bad argument");
     hipLaunchKernelGGL(k_elm_reduce, dim3(1), dim3(128), 0, (hipStream_t)stream, expect, gt, vmean, inv_side, batch, n_levels, weight, loss, d_expect);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+size_t eg_criteria_workspace_bytes(int batch, const int* level_side, int n_levels) {
+    if (batch < 1 || !level_side || n_levels < 1 || n_levels > HM_MAX_LEVELS) return 0;
+    size_t chunks = 0;
+    for (int l = 0; l < n_levels; ++l) chunks += ((size_t)level_side[l] * level_side[l] + HM_CHUNK - 1) / HM_CHUNK;
+    return (size_t)batch * chunks * 4 * HM_REC * sizeof(double) + (size_t)BCE_BLOCKS * 2 * sizeof(double) +
+           (size_t)batch * n_levels * 12 * sizeof(float);           // + gt [B,L,4,2] and vmean [B,L,4]
+}
+
+int eg_criteria_fwd(const float* logits, const float* labels, const float* valid, int batch, int64_t n_rows, const int* level_start,
+                    const int* level_side, int n_levels, const float* inv_side, float bce_ones_weight, float w_bce, float w_elm,
+                    const float* coord_pred, const float* coord_y, int64_t n_coord, float w_coord, void* workspace, float* expect,
+                    float* stats, float* d_expect, float* d_coord, float* bce_scale, float* total, float* bce, float* elm, float* coord,
+                    eg_stream_t stream) {
+    if (!logits || !labels || !valid || !inv_side || !workspace || !expect || !stats || !d_expect || !bce_scale || !total || !bce || !elm)
+        return set_error(EG_ERR_ARG, "NULL argument");
+    if ((coord_pred != nullptr) != (coord_y != nullptr) || (coord_pred && (!d_coord || !coord || n_coord < 1 || n_coord >= (1 << 30))))
+        return set_error(EG_ERR_ARG, "the coordinate criterion needs predictions, targets, d_coord and coord");
+    if (((uintptr_t)logits | (uintptr_t)labels | (uintptr_t)valid) & 15) return set_error(EG_ERR_ARG, "logits / labels / valid must be 16-byte aligned");
+    HmLevels L{};
+    int rc = fill_levels(batch, n_rows, level_start, level_side, n_levels, L);
+    if (rc != EG_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    double* hm_part = (double*)workspace;
+    double* bce_part = hm_part + (size_t)batch * L.total_chunks * 4 * HM_REC;
+    const long long n = (long long)batch * n_rows * 4;
+    long long blocks = ((n >> 2) + 2 * HM_THREADS - 1) / (2 * HM_THREADS);
+    if (blocks < 1) blocks = 1;
+    if (blocks > BCE_BLOCKS) blocks = BCE_BLOCKS;
+    hipLaunchKernelGGL(k_bce_partial, dim3((unsigned)blocks), dim3(HM_THREADS), 0, s, logits, labels, valid, n, bce_ones_weight, bce_part);
+    // gt / vmean of the heat maps live behind the expectations' statistics in `stats`'s sibling buffers: the caller's d_expect doubles
+    // as scratch for neither -- they are written into the tail of the workspace the final kernel reads them from
+    float* gt = (float*)(bce_part + (size_t)BCE_BLOCKS * 2);
+    float* vmean = gt + (size_t)batch * n_levels * 8;
+    hipLaunchKernelGGL(k_hm_partial, dim3((unsigned)(batch * L.total_chunks)), dim3(HM_THREADS), 0, s, logits, labels, valid, hm_part, L);
+    const int n_out = batch * n_levels * 4;
+    hipLaunchKernelGGL(k_hm_final, dim3((unsigned)((n_out + 63) / 64)), dim3(64), 0, s, (const double*)hm_part, expect, stats,
+                       (int64_t*)nullptr, gt, vmean, L);
+    CriteriaFinal a{expect, gt, vmean, inv_side, batch, n_levels, w_elm, d_expect, bce_part, (int)blocks, w_bce, coord_pred, coord_y,
+                    (int)n_coord, w_coord, d_coord, total, bce, elm, coord, bce_scale};
+    hipLaunchKernelGGL(k_criteria_final, dim3(1), dim3(128), 0, s, a);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_criteria_bwd(const float* logits, const float* labels, const float* valid, int batch, int64_t n_rows, const int* level_start,
+                    const int* level_side, int n_levels, float bce_ones_weight, const float* expect, const float* stats,
+                    const float* d_expect, const float* bce_scale, const float* d_coord, int64_t n_coord, const float* g_total,
+                    const float* g_bce, const float* g_elm, const float* g_coord, float* d_logits, float* d_coord_out,
+                    eg_stream_t stream) {
+    if (!logits || !labels || !expect || !stats || !d_expect || !bce_scale || !d_logits) return set_error(EG_ERR_ARG, "NULL argument");
+    if (d_coord_out && (!d_coord || n_coord < 1)) return set_error(EG_ERR_ARG, "d_coord_out needs d_coord");
+    HmLevels L{};
+    int rc = fill_levels(batch, n_rows, level_start, level_side, n_levels, L);
+    if (rc != EG_OK) return rc;
+    const long long n = (long long)batch * n_rows;
+    if (d_coord_out && n_coord > n) return set_error(EG_ERR_ARG, "more coordinate elements than logit rows");
+    const CriteriaBwd a{logits, labels, valid, expect, stats, d_expect, bce_scale, bce_ones_weight, g_total, g_bce, g_elm, g_coord,
+                        d_coord, (int)n_coord, d_logits, d_coord_out};
+    hipLaunchKernelGGL(k_criteria_bwd, dim3((unsigned)((n + HM_THREADS - 1) / HM_THREADS)), dim3(HM_THREADS), 0, (hipStream_t)stream, a, L);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

@@ -36,6 +36,11 @@ def compute_loss(criterion: Dict[str, object], node_landmark_preds, node_landmar
                  valid_labels, batch_size: int, num_output_channels: int = 4) -> Dict[str, torch.Tensor]:
     """engine.py:582-600: the 'coordinate' criterion sees the coordinate predictions, every other one the logits
     reshaped to [B, nodes, channels]."""
+    if num_output_channels == 4:
+        from .losses import fused_criteria
+        fused = fused_criteria(criterion, node_landmark_preds, node_landmark_y, valid_labels, node_coord_preds, node_coord_y, batch_size)
+        if fused is not None:                # one autograd node, 5 launches; ``.total`` is the sum out of the same node
+            return fused
     losses = {}
     preds = node_landmark_preds.view(batch_size, -1, num_output_channels)
     y = node_landmark_y.view(batch_size, -1, num_output_channels)
@@ -45,6 +50,12 @@ def compute_loss(criterion: Dict[str, object], node_landmark_preds, node_landmar
         else:
             losses[name] = crit.compute(preds, y, valid_labels)
     return losses
+
+
+def total_loss(losses) -> torch.Tensor:
+    """engine.py:271: the sum of the criteria -- straight out of the fused node when compute_loss used it."""
+    total = getattr(losses, "total", None)
+    return total if total is not None else sum(losses.values())
 
 
 def forward_batch(model: Dict[str, torch.nn.Module], batch, use_coordinate_graph: bool):
@@ -63,7 +74,7 @@ def train_step(model: Dict[str, torch.nn.Module], batch, criterion: Dict[str, ob
     preds, coord_preds = forward_batch(model, batch, use_coordinate_graph)
     coord_y = batch.node_coord_y if use_coordinate_graph else None
     losses = compute_loss(criterion, preds, batch.y, coord_preds, coord_y, batch.valid_labels, batch_size)
-    loss = sum(losses.values())
+    loss = total_loss(losses)
     optimizer.zero_grad()
     loss.backward()                 # with reducer.attach_hooks(): the buckets' all-reduces are issued from inside backward
     if reducer is not None:

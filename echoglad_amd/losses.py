@@ -86,3 +86,42 @@ class _ElmReduceFn(torch.autograd.Function):
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
         return d * g, None, None, None, None
+
+
+class LossDict(dict):
+    """``engine.compute_loss``'s result when the criteria ran as one node: the reference's ``{name: loss}`` dictionary
+    (engine.py:582-600) plus ``total`` = their sum as it comes out of the same node (``sum(d.values())`` gives the same value and
+    gradients through three more autograd nodes and a handful of tiny launches)."""
+    total: torch.Tensor
+
+
+def fused_criteria(criterion: dict, preds, y, valid, coord_preds, coord_y, batch_size: int):
+    """The criteria of engine.py:582-600 as ONE autograd node (ops.landmark_criteria) when they are exactly the configured set --
+    a WeightedBCEWithLogitsLoss and an ExpectedLandmarkMSE on the logits and optionally ``engine.MSE`` under the name
+    'coordinate' -- else None (the caller computes them one by one).  EG_FUSED_CRITERIA=0: always one by one."""
+    import os
+    if os.environ.get("EG_FUSED_CRITERIA", "1") == "0":
+        return None
+    bce = [(k, c) for k, c in criterion.items() if isinstance(c, WeightedBCEWithLogitsLoss)]
+    elm = [(k, c) for k, c in criterion.items() if isinstance(c, ExpectedLandmarkMSE)]
+    rest = [k for k, c in criterion.items() if not isinstance(c, (WeightedBCEWithLogitsLoss, ExpectedLandmarkMSE))]
+    if len(bce) != 1 or len(elm) != 1 or any(k != "coordinate" for k in rest):
+        return None
+    coord = criterion.get("coordinate")
+    if coord is not None and (type(coord).__name__ != "MSE" or coord_preds is None or coord_y is None):
+        return None
+    if valid is None or not preds.is_cuda or elm[0][1].batch_size != batch_size:
+        return None
+    (kb, cb), (ke, ce) = bce[0], elm[0]
+    x, yy, vv = _rows4(preds), _rows4(y), _rows4(valid)
+    inv_side = ce._side.get(x.device)
+    if inv_side is None:
+        inv_side = ce._side[x.device] = (1.0 / torch.tensor(ce.grid_sizes, dtype=torch.float32, device=x.device)).contiguous()
+    total, vb, ve, vc = ops.landmark_criteria(x, yy, vv, batch_size, ce.levels, inv_side, cb.ones_weight, cb.loss_weight, ce.loss_weight,
+                                              coord_preds if coord is not None else None, coord_y if coord is not None else None,
+                                              coord.loss_weight if coord is not None else 1.0)
+    out = LossDict()
+    for k in criterion:                      # the caller's order
+        out[k] = vb if k == kb else (ve if k == ke else vc)
+    out.total = total
+    return out

@@ -955,6 +955,66 @@ def bce_logits(logits, labels, valid=None, ones_weight: float = 1.0) -> torch.Te
     return _BCELogitsFn.apply(logits, labels, valid, float(ones_weight))
 
 
+class _CriteriaFn(torch.autograd.Function):
+    """WeightedBCEWithLogitsLoss + ExpectedLandmarkMSE (+ MSE on the landmark coordinates) of one training step as ONE autograd
+    node over eg_criteria_fwd / eg_criteria_bwd: (logits [B*n,4], coord_pred [R,2] | None) -> (total, bce, elm, coord | None),
+    every output a 0-d tensor that can be backpropagated on its own or summed (engine.py:582-600, :271)."""
+
+    @staticmethod
+    def forward(ctx, logits, coord_pred, labels, valid, coord_y, batch, levels, inv_side, ones_weight, w_bce, w_elm, w_coord):
+        dev = logits.device
+        n_rows = logits.shape[0] // batch
+        start, side, n = _level_arrays(levels)
+        lib = _lib.load()
+        ws = _hm_workspace(dev, int(lib.eg_criteria_workspace_bytes(batch, side, n)))
+        expect = torch.empty(batch, n, 4, 2, dtype=torch.float32, device=dev)
+        stats = torch.empty_like(expect)
+        d_expect = torch.empty_like(expect)
+        has_coord = coord_pred is not None
+        cp = coord_pred.contiguous() if has_coord else None
+        cy = coord_y.to(torch.float32).contiguous() if has_coord else None
+        d_coord = torch.empty_like(cp) if has_coord else None
+        bce_scale = torch.empty(1, dtype=torch.float32, device=dev)
+        total, vb, ve = (torch.empty((), dtype=torch.float32, device=dev) for _ in range(3))
+        vc = torch.empty((), dtype=torch.float32, device=dev) if has_coord else None
+        _lib.check(lib.eg_criteria_fwd(_ptr(logits), _ptr(labels), _ptr(valid), batch, n_rows, start, side, n, _ptr(inv_side),
+                                       ct.c_float(ones_weight), ct.c_float(w_bce), ct.c_float(w_elm), _ptr(cp), _ptr(cy),
+                                       cp.numel() if has_coord else 0, ct.c_float(w_coord), _ptr(ws), _ptr(expect), _ptr(stats),
+                                       _ptr(d_expect), _ptr(d_coord), _ptr(bce_scale), _ptr(total), _ptr(vb), _ptr(ve), _ptr(vc),
+                                       _stream()), "eg_criteria_fwd")
+        ctx.meta = (batch, levels, ones_weight, has_coord)
+        ctx.save_for_backward(logits, labels, valid, expect, stats, d_expect, bce_scale, d_coord if has_coord else logits.new_zeros(0))
+        ctx.set_materialize_grads(False)
+        return total, vb, ve, vc
+
+    @staticmethod
+    def backward(ctx, g_total, g_bce, g_elm, g_coord):
+        logits, labels, valid, expect, stats, d_expect, bce_scale, d_coord = ctx.saved_tensors
+        batch, levels, ones_weight, has_coord = ctx.meta
+        start, side, n = _level_arrays(levels)
+        gs = [None if g is None else g.to(torch.float32).reshape(1).contiguous() for g in (g_total, g_bce, g_elm, g_coord)]
+        d_logits = torch.empty_like(logits)
+        want_coord = has_coord and ctx.needs_input_grad[1]
+        d_coord_out = torch.empty_like(d_coord) if want_coord else None
+        _lib.check(_lib.load().eg_criteria_bwd(_ptr(logits), _ptr(labels), _ptr(valid), batch, logits.shape[0] // batch, start, side, n,
+                                               ct.c_float(ones_weight), _ptr(expect), _ptr(stats), _ptr(d_expect), _ptr(bce_scale),
+                                               _ptr(d_coord) if want_coord else None, d_coord.numel() if want_coord else 0,
+                                               _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), _ptr(d_logits), _ptr(d_coord_out),
+                                               _stream()), "eg_criteria_bwd")
+        return (d_logits, d_coord_out) + (None,) * 10
+
+
+def landmark_criteria(logits, labels, valid, batch: int, levels, inv_side, ones_weight: float, w_bce: float, w_elm: float,
+                      coord_pred=None, coord_y=None, w_coord: float = 1.0):
+    """-> (total, bce, elm, coord | None): the step's criteria as one autograd node (5 launches forward + backward)."""
+    for name, t in (("logits", logits), ("labels", labels), ("valid", valid)):
+        _check_logits(t, name, logits.shape[0])
+    if any(t.data_ptr() % 16 for t in (logits, labels, valid)):
+        logits, labels, valid = (t if t.data_ptr() % 16 == 0 else t.clone() for t in (logits, labels, valid))
+    return _CriteriaFn.apply(logits, coord_pred, labels, valid, coord_y, int(batch), levels, inv_side, float(ones_weight), float(w_bce),
+                             float(w_elm), float(w_coord))
+
+
 # ---------------------------------------------------------------------------
 # average-pool pyramid (pool.hip) + node-feature packing (pack.hip)
 # ---------------------------------------------------------------------------

@@ -493,6 +493,26 @@ int eg_bce_logits_fwd(const float* logits, const float* labels, const float* val
 int eg_bce_logits_bwd(const float* logits, const float* labels, const float* valid, int64_t n, float ones_weight,
                       const float* scale_dev, float* d_logits, eg_stream_t stream);
 
+/* ---- the criteria of a training step as ONE node (src/engine.py:582-600: the sum of WeightedBCEWithLogitsLoss, ExpectedLandmarkMSE
+ * and, with the coordinate graph, MSE on the landmark coordinates -- criterion.py:13-27, :36-48, :93-151).
+ * eg_criteria_fwd (4 launches): *bce = w_bce * sum(w bce(x, y) valid) / sum(valid); *elm = eg_elm_reduce's loss with weight w_elm;
+ *   *coord = w_coord * mean((coord_pred - coord_y)^2) over n_coord elements (coord_pred NULL: no such criterion, *coord untouched);
+ *   *total = their sum.  Kept for the backward: expect, stats [batch,n_levels,4,2], d_expect (= d elm / d expect), d_coord [n_coord]
+ *   (= d coord / d coord_pred), bce_scale [1].  inv_side: DEVICE [n_levels] = 1 / level side.  workspace: eg_criteria_workspace_bytes().
+ * eg_criteria_bwd (1 launch): d_logits = (g_total + g_bce) * d bce / d logits + (g_total + g_elm) * d elm / d logits,
+ *   d_coord_out (nullable) = (g_total + g_coord) * d_coord;  g_*: upstream gradients as DEVICE scalars, each nullable (= 0). */
+size_t eg_criteria_workspace_bytes(int batch, const int* level_side, int n_levels);
+int eg_criteria_fwd(const float* logits, const float* labels, const float* valid, int batch, int64_t n_rows, const int* level_start,
+                    const int* level_side, int n_levels, const float* inv_side, float bce_ones_weight, float w_bce, float w_elm,
+                    const float* coord_pred, const float* coord_y, int64_t n_coord, float w_coord, void* workspace, float* expect,
+                    float* stats, float* d_expect, float* d_coord, float* bce_scale, float* total, float* bce, float* elm, float* coord,
+                    eg_stream_t stream);
+int eg_criteria_bwd(const float* logits, const float* labels, const float* valid, int batch, int64_t n_rows, const int* level_start,
+                    const int* level_side, int n_levels, float bce_ones_weight, const float* expect, const float* stats,
+                    const float* d_expect, const float* bce_scale, const float* d_coord, int64_t n_coord, const float* g_total,
+                    const float* g_bce, const float* g_elm, const float* g_coord, float* d_logits, float* d_coord_out,
+                    eg_stream_t stream);
+
 /* ---- node-feature packing (the step right before the hot path) -------------------------------------------
  * Reference: the per-sample loops at the tail of create_node_pixels (src/core/models.py:498-537, :590-636,
  * :707-756): map[i].permute(1, 2, 0).reshape(-1, 128) of every level, concatenated per frame.

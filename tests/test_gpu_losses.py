@@ -128,3 +128,55 @@ def test_bce_accepts_contiguous_views_at_odd_offsets():
     got_view = ops.bce_logits(xv, y, v, 9000.0)
     got_view.backward()
     assert torch.equal(got.detach(), got_view.detach()) and xv.grad is not None and torch.isfinite(xv.grad).all()
+
+
+@pytest.mark.parametrize("frame,naux,B,coord", [(32, 4, 2, True), (224, 7, 1, True), (16, 3, 3, False)])
+def test_fused_criteria_node_equals_the_criteria_one_by_one(monkeypatch, frame, naux, B, coord):
+    """engine.compute_loss (src/engine.py:582-600): WeightedBCEWithLogitsLoss + ExpectedLandmarkMSE (+ MSE on the landmark
+    coordinates) as ONE autograd node over eg_criteria_fwd / eg_criteria_bwd against the three criteria computed one by one
+    (EG_FUSED_CRITERIA=0: the route the CPU oracles pin in this file): every value, the total, and the gradients w.r.t. the logits
+    and the coordinates -- through ``.total``, through ``sum(values)`` and through one component alone."""
+    from echoglad_amd import engine, losses
+    rs = np.random.RandomState(frame + B)
+    lv = losses.level_grids(frame, naux)
+    n = lv[-1][0] + lv[-1][1] ** 2
+    logits = torch.from_numpy(rs.standard_normal((B * n, 4)).astype(np.float32) * 2).to(DEV)
+    y = torch.zeros(B, n, 4)
+    for b in range(B):
+        for c in range(4):
+            for st, s in lv:
+                y[b, st + rs.randint(0, s * s), c] = 1.0
+    y = y.reshape(B * n, 4).to(DEV)
+    valid = torch.from_numpy((rs.uniform(size=(B * n, 4)) > 0.1).astype(np.float32)).to(DEV)
+    cp = torch.from_numpy(rs.uniform(0, frame - 1, (B * 4, 2)).astype(np.float32)).to(DEV)
+    cy = torch.from_numpy(rs.uniform(0, frame - 1, (B * 4, 2)).astype(np.float32)).to(DEV)
+    crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1), "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux)}
+    if coord:
+        crit["coordinate"] = engine.MSE(0.5)
+
+    def run(knob, how):
+        monkeypatch.setenv("EG_FUSED_CRITERIA", knob)
+        x = logits.clone().requires_grad_(True)
+        c = cp.clone().requires_grad_(True)
+        ls = engine.compute_loss(crit, x, y, c if coord else None, cy if coord else None, valid, B)
+        assert isinstance(ls, losses.LossDict) == (knob == "1") and list(ls) == list(crit)
+        if how == "total":
+            loss = engine.total_loss(ls)
+        elif how == "sum":
+            loss = sum(ls.values())
+        else:
+            loss = ls["elm"] * 3.0
+        loss.backward()
+        return {k: float(v) for k, v in ls.items()}, float(loss), x.grad.clone(), (c.grad.clone() if (coord and c.grad is not None) else None)
+
+    for how in ("total", "sum", "elm"):
+        va, la, ga, ca = run("1", how)
+        vb, lb, gb, cb = run("0", how)
+        for k in va:
+            assert abs(va[k] - vb[k]) <= 2e-6 * abs(vb[k]) + 1e-7, (how, k, va[k], vb[k])
+        assert abs(la - lb) <= 2e-6 * abs(lb) + 1e-7
+        assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max()) + 1e-12, how
+        if coord and how != "elm":
+            assert float((ca - cb).abs().max()) <= 2e-6 * float(cb.abs().max())
+        if how == "elm":
+            assert ca is None or float(ca.abs().max()) == 0.0

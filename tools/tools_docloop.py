@@ -33,7 +33,7 @@ coords0 = static.node_coords.clone()
 def loss_fn():
     static.node_coords = coords0.clone()
     preds, cp = engine.forward_batch(md, static, True)
-    return sum(engine.compute_loss(crit, preds, static.y, cp, static.node_coord_y, static.valid_labels, B).values())
+    return engine.total_loss(engine.compute_loss(crit, preds, static.y, cp, static.node_coord_y, static.valid_labels, B))
 
 
 step = engine.GraphedTrainStep(loss_fn, opt, warmup=2)
