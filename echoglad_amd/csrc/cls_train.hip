@@ -1196,7 +1196,7 @@ int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const floa
                      const float* beta, int relu, float dropout_p, unsigned long long seed, void* workspace, float* dz,
                      float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream,
                      const double* presum = nullptr, const eg::RowMap* presum_rows = nullptr, int presum_frames = 0,
-                     const float* presum_taps = nullptr);
+                     const float* presum_taps = nullptr, float* db_zero = nullptr);
 
 extern "C" {
 

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_presum(const double* __restrict
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const RowMap m, int batch,
                                                         double* __restrict__ totals, const ActArgs a_, const float* __restrict__ taps,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db) {
     const ActArgs a = resolved(a_);
     __shared__ double s_red[8][2][C];
     const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_presum(const double* __restrict
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += s_red[k][grp][c];
         totals[grp * C + c] = t;
-        if (grp == 0) dbeta[c] = (float)t;         // (k_bn_bwd_final's job, here: one launch fewer)
+        if (grp == 0) { dbeta[c] = (float)t; if (db) db[c] = 0.f; }     // (k_bn_bwd_final's job, and the bias gradient's memset, here)
         else dgamma[c] = (float)t;
     }
 }
@@ -345,9 +345,9 @@ __global__ __launch_bounds__(1024) void k_tile_sums_stage2(const double* __restr
     }
 }
 
-__global__ void k_bn_bwd_final(const double* __restrict__ totals, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void k_bn_bwd_final(const double* __restrict__ totals, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db) {
     const int c = threadIdx.x;
-    if (c < C) { dbeta[c] = (float)totals[c]; dgamma[c] = (float)totals[C + c]; }
+    if (c < C) { dbeta[c] = (float)totals[c]; dgamma[c] = (float)totals[C + c]; if (db) db[c] = 0.f; }
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ z,
@@ -670,7 +670,7 @@ static ActArgs make_act(int64_t rows, int relu, float p, uint64_t seed) {
 int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, int relu, float dropout_p, unsigned long long seed, void* workspace, float* dz,
                      float* dgamma, float* dbeta, const float* x, const eg::RowMap* xmap, float* dw, hipStream_t stream,
-                     const double* presum, const eg::RowMap* presum_rows, int presum_batch, const float* presum_taps) {
+                     const double* presum, const eg::RowMap* presum_rows, int presum_batch, const float* presum_taps, float* db_zero) {
     if (!dy || !z || !mean || !invstd || !gamma || !beta || !workspace || !dgamma || !dbeta || rows < 1)
         return set_error(EG_ERR_ARG, "bad argument");
     if (!dz && !(dw && x)) return set_error(EG_ERR_ARG, "dz may only be NULL when the fused weight gradient is computed");
@@ -681,11 +681,11 @@ int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const floa
     double* totals = partial + (size_t)RED_BLOCKS * 2 * C;
     if (presum) {          // the sums over most rows exist: add the few rows they leave out
         hipLaunchKernelGGL(k_bn_bwd_presum, dim3(1), dim3(1024), 0, stream, presum, dy, z, mean, invstd, gamma, beta, *presum_rows,
-                           presum_batch, totals, a, presum_taps, dgamma, dbeta);
+                           presum_batch, totals, a, presum_taps, dgamma, dbeta, db_zero);
     } else {
         hipLaunchKernelGGL(k_bn_bwd_partial, dim3(nb), dim3(RED_THREADS), 0, stream, dy, z, mean, invstd, gamma, beta, partial, a);
         hipLaunchKernelGGL(k_reduce_partials<2>, dim3(2 * C / 8), dim3(256), 0, stream, partial, nb, totals);
-        hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(128), 0, stream, totals, dgamma, dbeta);
+        hipLaunchKernelGGL(k_bn_bwd_final, dim3(1), dim3(128), 0, stream, totals, dgamma, dbeta, db_zero);
     }
     if (dw && x) {
         long long nt = (rows + DW_ROWS - 1) / DW_ROWS;
@@ -757,7 +757,7 @@ int eg_bn_act_bwd(const float* dy, const float* z, int64_t rows, const float* me
                   const float* gamma, const float* beta, int relu, float dropout_p, uint64_t seed, void* workspace,
                   float* dz, float* dgamma, float* dbeta, eg_stream_t stream) {
     return eg_launch_bn_bwd(dy, z, rows, mean, invstd, gamma, beta, relu, dropout_p, seed, workspace, dz, dgamma, dbeta, nullptr,
-                            nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0, nullptr);
+                            nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 int eg_dweight128(const float* g, const float* x, int64_t rows, void* workspace, float* dw, eg_stream_t stream) {
@@ -833,7 +833,7 @@ static int gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, cons
     hipStream_t stream = (hipStream_t)stream_;
     const long long rows = (long long)g_bwd->n_nodes * batch;
     int rc = eg_launch_bn_bwd(dy, z, rows, bn, bn + C, gamma, beta, relu, dropout_p, seed, workspace, dz_scratch, dgamma, dbeta,
-                              dw ? agg : nullptr, nullptr, dw, stream, presum, presum_rows, presum_frames, presum_taps);
+                              dw ? agg : nullptr, nullptr, dw, stream, presum, presum_rows, presum_frames, presum_taps, db);
     if (rc != EG_OK) return rc;
     if (dx) {
         // dX = (A_hat dz) W + dy: the producer / consumer kernel with the residual as a tensor of its own (implicit topologies)
@@ -863,7 +863,7 @@ static int gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, cons
                                      nullptr, stream);
         if (rc != EG_OK) return public_rc(rc);
     }
-    if (db) EG_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * C, stream));     // a bias in front of a train-mode BatchNorm
+    // (db = 0 -- a bias in front of a train-mode BatchNorm -- is written by the sums' final kernel: no memset node)
     return EG_OK;
 }
 

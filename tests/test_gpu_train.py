@@ -130,7 +130,10 @@ def test_train_step_gradients_vs_oracle(frame, naux, coord):
             m.p = 0.0
     hip.train(); ref.train()
     topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=coord)
-    frames = synthetic_frames(B, 128, frame, 11)
+    # (frame seed 13: with seed 11 one pre-activation of head 0's first hidden layer sits within an ulp of the ReLU kink -- the pooled
+    #  pyramid's 1-ulp difference to torch's adaptive_avg_pool2d flips it and moves every weight gradient by 5e-3: tools/dbg_kink3.py,
+    #  DESIGN 5.13; tests pick data away from the kink)
+    frames = synthetic_frames(B, 128, frame, 13)
     coords0 = initial_coords(B, frame) if coord else None
     want, wc = ref(x=frames, node_coords=None if coords0 is None else coords0.clone(), edge_index=ei, node_type=nt,
                    batch_idx=bi)
