@@ -149,40 +149,6 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd_tiles(const float* __restric
     act_pair<KOUT>(z, scale, shift, residual, out, kout, patsq, a, frame, sd0, sd1, lane);
 }
 
-// Persistent form: a wave walks segment pairs (unit = 4 tile + p) with a grid stride; the descriptors of its NEXT pair are
-// fetched (scalar loads) while the rows of the current one are in flight, so no row load waits behind a descriptor round trip.
-template <bool KOUT>
-__global__ __launch_bounds__(256) void k_bn_act_fwd_tiles_p(const float* __restrict__ z, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, const float* __restrict__ residual,
-                                                            float* __restrict__ out, float* __restrict__ kout,
-                                                            const SegDesc* __restrict__ segs, const float* __restrict__ patsq,
-                                                            const ActTileArgs a_) {
-    const ActTileArgs a = resolved(a_);
-    const int lane_k = threadIdx.x & 63;
-    const long long units = (long long)a.tiles_per_frame * a.batch * 4;
-    const long long stride = (long long)gridDim.x * 4;
-    long long u = (long long)blockIdx.x * 4 + wave_id();
-    if (u >= units) return;
-    auto seg_index = [&](long long unit) -> int {
-        const int tile = (int)(unit >> 2), p = (int)(unit & 3);
-        const int frame = tile / a.tiles_per_frame;
-        return (tile - frame * a.tiles_per_frame) * 8 + 2 * p;
-    };
-    int si = seg_index(u);
-    SegDesc n0 = segs[si], n1 = segs[si + 1];
-    for (; u < units; u += stride) {
-        int lane = lane_k;
-        asm volatile("" : "+v"(lane));
-        const SegDesc sd0 = n0, sd1 = n1;
-        const int frame = (int)(u >> 2) / a.tiles_per_frame;
-        if (u + stride < units) {
-            si = seg_index(u + stride);
-            n0 = segs[si]; n1 = segs[si + 1];
-        }
-        act_pair<KOUT>(z, scale, shift, residual, out, kout, patsq, a, frame, sd0, sd1, lane);
-    }
-}
-
 }  // namespace eg
 
 using namespace eg;
@@ -199,15 +165,8 @@ int eg_launch_bn_act_tiles(const eg_graph* g, int batch, const float* z, const f
     const long long n_tiles = (long long)g->n_tiles * batch;
     if (n_tiles <= 0) return EG_OK;
     if (n_tiles >= (1ll << 31)) return eg::set_error(EG_ERR_ARG, "too many tiles");
-    static const int persist = getenv("EG_ACT_PERSIST") ? atoi(getenv("EG_ACT_PERSIST")) : 0;      // workgroups per CU; 0: one per tile
-    if (persist > 0) {
-        long long grid = 256ll * persist;
-        if (grid > n_tiles) grid = n_tiles;
-        if (kout) hipLaunchKernelGGL(k_bn_act_fwd_tiles_p<true>, dim3((unsigned)grid), dim3(256), 0, stream, z, scale, shift, residual, out,
-                                     kout, g->segs_dev, g->patsq_dev, a);
-        else hipLaunchKernelGGL(k_bn_act_fwd_tiles_p<false>, dim3((unsigned)grid), dim3(256), 0, stream, z, scale, shift, residual, out,
-                                kout, g->segs_dev, g->patsq_dev, a);
-    } else if (kout) hipLaunchKernelGGL(k_bn_act_fwd_tiles<true>, dim3((unsigned)n_tiles), dim3(256), 0, stream, z, scale, shift, residual, out,
+    // (one workgroup per tile; a persistent grid with descriptor prefetch measured no faster in round 4 and is gone)
+    if (kout) hipLaunchKernelGGL(k_bn_act_fwd_tiles<true>, dim3((unsigned)n_tiles), dim3(256), 0, stream, z, scale, shift, residual, out,
                                  kout, g->segs_dev, g->patsq_dev, a);
     else hipLaunchKernelGGL(k_bn_act_fwd_tiles<false>, dim3((unsigned)n_tiles), dim3(256), 0, stream, z, scale, shift, residual, out,
                             kout, g->segs_dev, g->patsq_dev, a);

@@ -1229,9 +1229,8 @@ static int classifier_train_fwd(const float* h, const LinAct* act, int batch, in
     const long long n_tiles = (long long)d.tiles_per_frame * batch;
     if (n_tiles >= (1ll << 31)) return set_error(EG_ERR_ARG, "too many row tiles");
     const int g1 = (int)(n_tiles < LIN_GRID ? n_tiles : LIN_GRID);
-    static const bool act4 = !(getenv("EG_ACT_LIN4") && atoi(getenv("EG_ACT_LIN4")) == 0);      // (0: the 8-wave form without the prefetch)
-    if (act && act4) hipLaunchKernelGGL(k_act_lin128, dim3(g1), dim3(256), 0, stream, P->w1, P->b1, z1, partial, d, *act);
-    else if (act) hipLaunchKernelGGL((k_lin128_map<true, true>), dim3(g1), dim3(512), 0, stream, (const float*)nullptr, P->w1, P->b1, z1, partial, d, *act);
+    // (round 4's 8-wave form k_lin128_map<true, true> lost every A/B against the 4-wave k_act_lin128 and is no longer reachable)
+    if (act) hipLaunchKernelGGL(k_act_lin128, dim3(g1), dim3(256), 0, stream, P->w1, P->b1, z1, partial, d, *act);
     else hipLaunchKernelGGL((k_lin128_map<true, false>), dim3(g1), dim3(512), 0, stream, h, P->w1, P->b1, z1, partial, d, LinAct{});
     BnFinalize f1{totals, rows, H1, P->gamma1, P->beta1, P->eps1, P->momentum1, P->running_mean1, P->running_var1,
                   bn + 0 * H1, bn + 1 * H1, bn + 2 * H1, bn + 3 * H1};
@@ -1284,9 +1283,8 @@ struct LayerSumsReq {               // eg_classifier_bwd_sums: the layer in fron
 };
 
 static bool first_bwd_covers(const float* dh, int batch, int64_t n_per_frame, int64_t n_valid) {
-    static const bool fused_first = !(getenv("EG_CLS_FUSED_BWD") && atoi(getenv("EG_CLS_FUSED_BWD")) == 0);
     const long long rows = (long long)batch * n_valid;
-    return dh && fused_first && n_valid >= TILE && (long long)batch * n_per_frame * C < (1ll << 32) && rows * C < (1ll << 32);
+    return dh && n_valid >= TILE && (long long)batch * n_per_frame * C < (1ll << 32) && rows * C < (1ll << 32);
 }
 
 static int classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
@@ -1318,9 +1316,8 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
     float* partial_bn1 = partial2 + (size_t)768 * (4 * 16 * 32);               // [gb][2][128]
     double* tot_bn1 = totals + 256 + 4 * 16 * 32;
     const RowMap xm{(int)n_valid, (int)n_per_frame, (int)row_lo};
-    static const bool masked_handoff = !(getenv("EG_CLS_MASKED") && atoi(getenv("EG_CLS_MASKED")) == 0);
     const bool fused = first_bwd_covers(dh, batch, n_per_frame, n_valid);
-    const bool masked = fused && masked_handoff;      // (the unfused route below applies the mask itself)
+    const bool masked = fused;                        // the masked gradient is handed over (the unfused route below applies the mask itself)
     hipLaunchKernelGGL(masked ? k_cls_mid_bwd<true> : k_cls_mid_bwd<false>, dim3(gb), dim3(CT_THREADS), 0, stream, dlogits, z2, z1, rows,
                        bn1, d1, bn2, d2, P->w2, P->w3, totals, dh1_scratch, partial2, partial_bn1);
     hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4 * 16 * 32 / 32), dim3(RED_F32_THREADS), 0, stream, partial2, gb, 4 * 16 * 32, totals + 256);
@@ -1349,9 +1346,8 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
         const size_t lds = (size_t)(3 * TILE * LDA + 10 * H1) * sizeof(float);
         FirstBwdArgs fa{dh1_scratch, z1, h, P->w1, (const double*)tot_bn1, rows, xm, d1, dh, slabs, masked ? 1 : 0};
         {
-            static const bool direct_ok = !(getenv("EG_FB_DIRECT") && atoi(getenv("EG_FB_DIRECT")) == 0);      // (0: flat addresses for every tile)
             const long long bc = rows * (C * 4), bm = (long long)batch * n_per_frame * (C * 4);
-            fa.direct = direct_ok && bc < (1ll << 31) - (1ll << 20) && bm < (1ll << 31) - (1ll << 20);   // (32-bit offsets incl. a tile's overhang)
+            fa.direct = bc < (1ll << 31) - (1ll << 20) && bm < (1ll << 31) - (1ll << 20);   // (32-bit offsets incl. a tile's overhang)
             fa.bytes_c = fa.direct ? (unsigned)bc : 0u;
             fa.bytes_m = fa.direct ? (unsigned)bm : 0u;
         }
@@ -1369,7 +1365,7 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
         EG_HIP_TRY(hipGetLastError());
         return EG_OK;
     }
-    // dh not wanted (or EG_CLS_FUSED_BWD=0, which needs one more [rows,128] scratch array: not provided any more): dW1 alone out of
+    // dh not wanted: dW1 alone out of
     // the apply + dW pass, which then writes no dz1
     float* dgamma1 = grads + 128 * 128 + 128;
     float* dbeta1 = dgamma1 + 128;

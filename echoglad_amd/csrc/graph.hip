@@ -18,6 +18,12 @@ int set_error(int code, const std::string& msg) {
     return code;
 }
 
+#ifdef EG_DEBUG_TOPO
+#define EG_DEBUG_TOPO_ON 1          // -DEG_DEBUG_TOPO: why a handle has no child-sum side buffer, on stderr
+#else
+#define EG_DEBUG_TOPO_ON 0
+#endif
+
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
@@ -25,14 +31,35 @@ static int env_int(const char* name, int dflt) {
 
 Knobs read_knobs() {
     Knobs k;
-    k.walk_mode = env_int("EG_WALK_MODE", 0);
-    k.stagger = env_int("EG_STAGGER", 0);
-    k.grid_cap = env_int("EG_GRID", 512);
+    // Two RUN-TIME knobs are left here, each selecting a fallback that has to exist anyway (include/echoglad_hip.h lists every run-time
+    // variable).  What rounds 2 - 5 tuned through the environment is a compile-time constant now (-D to experiment): the winners
+    // are the defaults and nobody lands on a losing route by accident.
     k.layer_impl = env_int("EG_LAYER_IMPL", -1);
-    k.ps_grid = env_int("EG_PS_GRID", 256);
-    k.ring_guard = env_int("EG_RING_GUARD", 1);
-    k.queue_self_reset = env_int("EG_QUEUE_SELF_RESET", 1) != 0;
     k.csr_tiles = env_int("EG_CSR_TILES", 2);
+#ifndef EG_WALK_MODE
+#define EG_WALK_MODE 0
+#endif
+#ifndef EG_STAGGER
+#define EG_STAGGER 0
+#endif
+#ifndef EG_GRID
+#define EG_GRID 512
+#endif
+#ifndef EG_PS_GRID
+#define EG_PS_GRID 256
+#endif
+#ifndef EG_RING_GUARD
+#define EG_RING_GUARD 1
+#endif
+#ifndef EG_QUEUE_SELF_RESET
+#define EG_QUEUE_SELF_RESET 1
+#endif
+    k.walk_mode = EG_WALK_MODE;
+    k.stagger = EG_STAGGER;
+    k.grid_cap = EG_GRID;
+    k.ps_grid = EG_PS_GRID;
+    k.ring_guard = EG_RING_GUARD;
+    k.queue_self_reset = EG_QUEUE_SELF_RESET != 0;
     // the static tile walk of the train forward labels chunks with blockIdx % 8 (a grid below 8 would leave chunks without
     // an owner) and its statistics partials fill at most 2048 slabs of the workspace
     if (k.ps_grid < 8) k.ps_grid = 8;
@@ -636,26 +663,26 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
                     if (r < d.plim) {
                         const int cend = c0 + sa.cnt < d.plim ? c0 + sa.cnt : d.plim;
                         npar = cend > c0 ? (cend - c0) / 2 : 0;
-                        if (cend > c0 && ((cend - c0) & 1)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: odd t=%zu tr=%d\n", t, tr); }
+                        if (cend > c0 && ((cend - c0) & 1)) { kidsum_ok = false; if (EG_DEBUG_TOPO_ON) fprintf(stderr, "kidsum off: odd t=%zu tr=%d\n", t, tr); }
                     }
                     const int par_raw = d.pbase + (d.poff + (r >> 1)) * d.pside + d.poff + (c0 >> 1);
                     // ('grid-diagonal' levels of fewer than 8 columns run node by node -- rows pulled through the CSR, children
                     //  included -- and never read the side buffer: child sums that nobody writes for THEIR rows are not missed)
                     const bool parent_slow = td.level > 0 && level_diag(td.level - 1) && T.side[td.level - 1] < 8 && d.kind == KIND_AUX;
-                    if (npar > 0 && !parent_slow && (!sa.pad0 || par_raw != sa.par0 || par_raw + npar > kid_rows)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: parent t=%zu tr=%d level=%d pad0=%d par_raw=%d par0=%d npar=%d kid_rows=%d modes %d %d\n", t, tr, td.level, sa.pad0, par_raw, sa.par0, npar, kid_rows, sa.mode, sb.mode); }
+                    if (npar > 0 && !parent_slow && (!sa.pad0 || par_raw != sa.par0 || par_raw + npar > kid_rows)) { kidsum_ok = false; if (EG_DEBUG_TOPO_ON) fprintf(stderr, "kidsum off: parent t=%zu tr=%d level=%d pad0=%d par_raw=%d par0=%d npar=%d kid_rows=%d modes %d %d\n", t, tr, td.level, sa.pad0, par_raw, sa.par0, npar, kid_rows, sa.mode, sb.mode); }
                     sa.pad1 = npar;
                     const bool kids = d.kind == KIND_AUX && ((r >= d.clo && r < d.chi) || (r + 1 >= d.clo && r + 1 < d.chi)) && c0 < d.chi && c0 + 8 > d.clo;
                     const bool self_slow = level_diag(td.level) && d.side < 8;
                     // the pair path reads runs of 8 child-sum rows from each segment's first node: they must stay inside the
                     // frame's slice of the side buffer (tiny pyramids only: a 2x2 or 4x4 level right at its end; an over-read
                     // past the LAST frame's slice left the allocation and aborted a test run once)
-                    if (kids && !self_slow && (sa.n_first + 8 > kid_rows || sb.n_first + 8 > kid_rows)) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: 8-row run past the side buffer t=%zu tr=%d\n", t, tr); }
-                    if (kids && !sa.pad0 && !self_slow) { kidsum_ok = false; if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "kidsum off: kids unpaired t=%zu tr=%d level=%d\n", t, tr, td.level); }      // a segment that would read the side buffer is not on the pair path
+                    if (kids && !self_slow && (sa.n_first + 8 > kid_rows || sb.n_first + 8 > kid_rows)) { kidsum_ok = false; if (EG_DEBUG_TOPO_ON) fprintf(stderr, "kidsum off: 8-row run past the side buffer t=%zu tr=%d\n", t, tr); }
+                    if (kids && !sa.pad0 && !self_slow) { kidsum_ok = false; if (EG_DEBUG_TOPO_ON) fprintf(stderr, "kidsum off: kids unpaired t=%zu tr=%d level=%d\n", t, tr, td.level); }      // a segment that would read the side buffer is not on the pair path
                 }
             }
         }
         if (pats.empty()) { pats.assign(128, 0.0f); pat_extra.assign(5, 0.0f); }
-        if (getenv("EG_DEBUG_TOPO")) fprintf(stderr, "topo: %zu tiles, %zu patterns, kidsum %d\n", tiles.size(), pats.size() / 128, (int)kidsum_ok);
+        if (EG_DEBUG_TOPO_ON) fprintf(stderr, "topo: %zu tiles, %zu patterns, kidsum %d\n", tiles.size(), pats.size() / 128, (int)kidsum_ok);
     }
     eg_graph* g = new eg_graph{};
     g->kind = GRAPH_TOPO;
@@ -718,7 +745,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
             }
         g->n_conn = T.n_conn;
         g->conn_chunks = (int)(table.size() / 4);
-        g->conn_cap = env_int("EG_CONN_BATCH", 8);        // frames the scratch holds at first (it grows: conn.hip)
+        g->conn_cap = 8;                                   // frames the scratch holds at first (it grows: conn.hip)
         if (g->conn_cap < 1) g->conn_cap = 1;
         const size_t per_frame = (size_t)(g->conn_chunks + 2 * T.n_conn) * C;
         if (e == hipSuccess) e = hipMalloc((void**)&g->conn_table, sizeof(int) * (table.empty() ? 4 : table.size()));

@@ -803,8 +803,7 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
     EG_HIP_TRY(hipGetLastError());
     if (!out) return EG_OK;                       // z, agg and the batch statistics only
     // the activation pass in tile order leaves the child sums of `out` behind for the next layer's train forward
-    static const bool act_tiles = getenv("EG_ACT_TILES") && atoi(getenv("EG_ACT_TILES")) != 0;      // (experiment: tile order without child sums too)
-    if (kidsum_out || act_tiles) {
+    if (kidsum_out) {
         rc = eg_launch_bn_act_tiles(g, batch, z, bn + 2 * C, bn + 3 * C, residual ? x : nullptr, relu, dropout_p, seed, out, kidsum_out, stream);
         if (rc != EG_ERR_UNSUPPORTED) return rc;
         if (kidsum_out) return set_error(EG_ERR_UNSUPPORTED, "child sums of the output: frames of 2 GB and more are not covered");

@@ -131,6 +131,26 @@ class GraphResolver:
 _SHARED_RESOLVER = GraphResolver(None)      # every stand-alone GCNConv: the layers of a stack see the same edge_index
 
 
+class Routes:
+    """Switches of the fused routes whose FALLBACK must exist anyway -- module states and shapes the fused kernels do not cover
+    (frozen sub-modules, hooks, JumpingKnowledge on irregular handles, ...) take it by themselves -- so that a test can run the
+    fallback on the inputs of the fused route and compare.  Python attributes, deliberately NOT environment variables (rounds 3 - 5
+    had one EG_* knob per route: ~20 untimed routes a user could land on by accident; the run-time variables that are left are
+    listed in include/echoglad_hip.h)."""
+    layer_sums_in_heads = True      # the last layer's BatchNorm-backward sums inside the heads' backward
+    coord_mlp_kernel = True         # node_coordinate_mlp on eg_coord_mlp_* (off: the torch modules)
+    coord_fused = True              # coordinate update folded into the consuming node (off: autograd nodes of its own)
+    act_in_heads = True             # the last layer's activation pass inside the heads' first kernel
+    train_chain = True              # child sums handed from layer to layer in the train forward
+    jk_fused = True                 # JumpingKnowledge('max') as a running maximum inside the layer kernels
+    stacked_heads = True            # the four heads as one stacked network in train mode
+    chain_layers = True             # eval: child sums handed from layer to layer (default of HierarchicalPatchModel.chain_layers)
+    fuse_classifier = True          # eval: the heads inside the last layer's kernel (default of HierarchicalPatchModel.fuse_classifier)
+
+
+ROUTES = Routes()
+
+
 # ---------------------------------------------------------------------------
 # autograd functions over the C-ABI
 # ---------------------------------------------------------------------------
@@ -531,7 +551,7 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
         # the layer's BatchNorm-backward sums over the heads' rows are taken where dh leaves the heads' backward (no separate
         # sums pass over dh and z for the layer afterwards: only the rows the filter drops are added there)
         presum = None
-        if ops.classifier_layer_sums_supported(B, n, n_valid) and os.environ.get("EG_LAYER_SUMS_IN_HEADS", "1") != "0":
+        if ops.classifier_layer_sums_supported(B, n, n_valid) and ROUTES.layer_sums_in_heads:
             dh, g, sums = ops.classifier_bwd(dl, h, B, n, row_lo, n_valid, ctx.P, z1, z2, cbn, True,
                                              layer=(z, bn, gamma, beta, relu, p, seed))
             presum = None if sums is None else (sums, B, row_lo, n_valid)
@@ -797,10 +817,9 @@ class HierarchicalPatchModel(nn.Module):
         # Widths other than configs/default.yml's 128 / 32 -- the reference's signature defaults are node_hidden_dim = 64,
         # classifier_hidden_dim = 16 (models.py:286-301) -- take a COMPATIBILITY route: GCNConv on the 128-channel kernels with
         # zero padding, BatchNorm / Dropout / activation / heads as the torch modules they are; none of the fused kernels.
+        # With the coordinate graph on that route the landmark MLP (Linear(hidden + 8, cls_hidden) ...) runs as its torch modules and the
+        # coordinate rows are resampled by eg_bilinear4_* from the node rows zero-padded to 128 channels.
         self._narrow = node_hidden_dim != C or classifier_hidden_dim != 32
-        if self._narrow and use_coordinate_graph:
-            raise NotImplementedError("use_coordinate_graph needs node_hidden_dim = 128 and classifier_hidden_dim = 32 "
-                                      "(the coordinate rows are resampled from 128-channel node rows)")
         self.gnn_layers = nn.ModuleList()
         self.node_coordinate_mlp = nn.ModuleList()
         for i in range(num_gnn_layers):
@@ -847,10 +866,10 @@ class HierarchicalPatchModel(nn.Module):
         self.hip_graph_captures = 0
         self.use_hip_graph = False
         # eval path: layer i leaves the child sums of its output in a side buffer for layer i+1
-        # (eg_gcn_layer_fwd_chain); EG_CHAIN=0 runs every layer on its own
-        self.chain_layers = os.environ.get("EG_CHAIN", "1") != "0"
-        # ... and the last layer runs the classifier heads on its output tile inside the kernel (EG_FUSE_CLS=0: separate)
-        self.fuse_classifier = os.environ.get("EG_FUSE_CLS", "1") != "0"
+        # (eg_gcn_layer_fwd_chain); False runs every layer on its own
+        self.chain_layers = bool(ROUTES.chain_layers)
+        # ... and the last layer runs the classifier heads on its output tile inside the kernel (False: separate)
+        self.fuse_classifier = bool(ROUTES.fuse_classifier)
         self._kidsum: Dict[tuple, tuple] = {}
         # optional callable (layer index, layer output incl. residual and coordinate rows) -> None, called by forward_nodes
         self.layer_output_hook = None
@@ -981,6 +1000,17 @@ class HierarchicalPatchModel(nn.Module):
         route folds the update into the node that consumes h instead (_CoordLayerTrainFn, _CoordClassifierTrainFn)."""
         n, _, _, main_base, coord_base = self._row_ranges()
         fs = self.frame_size
+        hd = h.shape[1]
+        if hd != C:
+            # the compatibility route (node_hidden_dim < 128): the torch modules on the landmark rows, the 4-tap sample on zero-padded rows
+            lm = h.view(batch, n, hd)[:, coord_base:, :].reshape(batch * 4, hd)
+            shape_feats = (node_coords.unsqueeze(1) - node_coords.unsqueeze(2)).reshape(batch * 4, 8)
+            delta = self.node_coordinate_mlp[i](torch.cat((lm, shape_feats), dim=1))
+            node_coords = torch.clamp(node_coords + delta.view(batch, 4, 2), min=0, max=fs - 1)
+            new_feats = ops.bilinear4(F.pad(h, (0, C - hd)), node_coords, batch, n, main_base, fs)[:, :hd]
+            out = h.clone()
+            out.view(batch, n, hd)[:, coord_base:coord_base + 4, :] = new_feats.reshape(batch, 4, hd)
+            return out, node_coords
         # pairwise (other - self) offsets per frame, flattened to 8 numbers per landmark (:441-444)
         lm = h.view(batch, n, C)[:, coord_base:, :].reshape(batch * 4, C).clone()
         new_coords = self._coord_mlp_kernel(self.node_coordinate_mlp[i], lm, node_coords, batch, fs)
@@ -996,7 +1026,7 @@ class HierarchicalPatchModel(nn.Module):
 
     def _coord_mlp_cfg(self, mlp: nn.Sequential):
         """(cfg, params) of node_coordinate_mlp[i] for the kernels when every sub-module is in plain train state, else None."""
-        if self.classifier_hidden_dim != 32 or self.node_embedding_dim != C or os.environ.get("EG_COORD_MLP_KERNEL", "1") == "0":
+        if self._narrow or self.node_embedding_dim != C or not ROUTES.coord_mlp_kernel:
             return None
         m = mlp._modules                       # (nn.Sequential.__getitem__ walks an islice: ~170 of them per step were 0.2 ms of host time)
         bn1, bn2, d1, d2 = m["1"], m["5"], m["3"], m["7"]
@@ -1022,8 +1052,8 @@ class HierarchicalPatchModel(nn.Module):
     def _coord_mlp_kernel(self, mlp: nn.Sequential, lm: torch.Tensor, node_coords: torch.Tensor, batch: int, frame: int):
         """models.py:441-453 on eg_coord_mlp_fwd / _bwd (one launch each way) -> new coords [B,4,2], or None when the
         module states are not ones the kernel implements."""
-        if self.classifier_hidden_dim != 32 or self.node_embedding_dim != C or node_coords.shape[-1] != 2 or node_coords.dtype != torch.float32 or \
-                os.environ.get("EG_COORD_MLP_KERNEL", "1") == "0":
+        if self._narrow or self.node_embedding_dim != C or node_coords.shape[-1] != 2 or node_coords.dtype != torch.float32 or \
+                not ROUTES.coord_mlp_kernel:
             return None
         bn1, bn2, d1, d2 = mlp[1], mlp[5], mlp[3], mlp[7]
         if not (bn1.affine and bn2.affine):
@@ -1052,7 +1082,7 @@ class HierarchicalPatchModel(nn.Module):
             return False
         if node_coords is None or node_coords.shape[-1] != 2 or node_coords.dtype != torch.float32:
             return False
-        if os.environ.get("EG_COORD_FUSED", "1") == "0" or not self._stacked_heads_ok():
+        if not ROUTES.coord_fused or not self._stacked_heads_ok():
             return False
         for l in self.gnn_layers:
             if not (l.module_1.training and l.module_1.affine and l.module_2.training):
@@ -1068,7 +1098,7 @@ class HierarchicalPatchModel(nn.Module):
         boxes = self._sums_down_boxes(graph)
         down_of = (lambda i: None) if boxes is None else (lambda i: (boxes[i] if i < L - 1 else None, boxes[i - 1] if i > 0 else None, coord_base))
         counters = []                      # num_batches_tracked of every BatchNorm of the step: bumped together by finish(counters)
-        act_in_heads = os.environ.get("EG_ACT_HEADS", "1") != "0"      # the last layer's activation pass inside the heads' first kernel
+        act_in_heads = bool(ROUTES.act_in_heads)      # the last layer's activation pass inside the heads' first kernel
         for i in range(L):
             conv, bn, relu, p, seed = self._layer_cfg(i)
             _, momentum = _bn_step(bn, counters)
@@ -1102,7 +1132,7 @@ class HierarchicalPatchModel(nn.Module):
     def _train_kidsums(self, graph: ops.Graph, gb: int):
         """Child-sum side buffers of the chained train forward (layer i leaves the child sums of its output for layer i + 1:
         eg_gcn_layer_train_fwd), or (None, None)."""
-        if graph.kidsum_rows == 0 or self.num_gnn_layers < 2 or os.environ.get("EG_TRAIN_CHAIN", "1") == "0" or \
+        if graph.kidsum_rows == 0 or self.num_gnn_layers < 2 or not ROUTES.train_chain or \
                 not ops.train_chain_supported():
             return None, None
         return self._kidsum_buffers(graph, gb)
@@ -1129,7 +1159,7 @@ class HierarchicalPatchModel(nn.Module):
         # (eg_gcn_layer_fwd_jk); where those do not cover the handle (CSR graphs, coordinate / connection nodes) the
         # layers run one by one and torch takes the maximum, as before
         jk_fused = (fused and self.jk is not None and graph.fused_classifier_ok and not self.use_coordinate_graph
-                    and not graph.hybrid and os.environ.get("EG_JK_FUSED", "1") != "0")
+                    and not graph.hybrid and ROUTES.jk_fused)
         fused = fused and (self.jk is None or jk_fused)
         if not fused and self._train_coord_fused_ok(node_coords):
             return self._forward_train_coord_fused(node_feats, graph, gb, B, node_coords)
@@ -1218,7 +1248,7 @@ class HierarchicalPatchModel(nn.Module):
         """Train mode without the coordinate graph: may the last layer + the heads run as _LastLayerHeadsTrainFn?"""
         return (not self._narrow and not self.use_coordinate_graph and self.layer_output_hook is None and self.jk is None
                 and self._stacked_heads_ok() and self._layer_cfg_static_ok(self.num_gnn_layers - 1)
-                and os.environ.get("EG_ACT_HEADS", "1") != "0")
+                and ROUTES.act_in_heads)
 
     # ---- the 4 classifier heads in train mode as ONE stacked network ----------------------------------------
     def _stacked_heads_ok(self) -> bool:
@@ -1228,7 +1258,7 @@ class HierarchicalPatchModel(nn.Module):
                        m.momentum == ref.momentum and m.eps == ref.eps for md in mods for m in (md["1"], md["5"]))
         drops_on = all(m.training for md in mods for m in (md["3"], md["7"]))
         return (not self._narrow and self.num_output_channels == 4 and self.classifier_hidden_dim == 32 and self.node_embedding_dim == C
-                and plain_bn and drops_on and os.environ.get("EG_STACKED_HEADS", "1") != "0")
+                and plain_bn and drops_on and ROUTES.stacked_heads)
 
     def _classifier_train_cfg(self):
         """(cfg, the 40 head parameters, finish()) for _ClassifierTrainFn / _CoordClassifierTrainFn.  Running statistics: the

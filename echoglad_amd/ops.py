@@ -605,7 +605,7 @@ def classifier_train_fwd_act(z, layer_bn, residual, relu: bool, dropout_p: float
 
 def classifier_layer_sums_supported(batch: int, n_per_frame: int, n_valid: int) -> bool:
     """Does eg_classifier_bwd_sums cover this shape (the fused first-layers kernel: n_valid >= 64, < 2^32 elements)?"""
-    return n_valid >= 64 and batch * n_per_frame * C < (1 << 32) and os.environ.get("EG_CLS_FUSED_BWD", "1") != "0"
+    return n_valid >= 64 and batch * n_per_frame * C < (1 << 32)
 
 
 def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_valid: int, P: dict, z1, z2, bn, need_dh: bool,

@@ -44,8 +44,22 @@
  *     the smaller ones stay allocated until eg_graph_destroy, so graphs
  *     captured at a smaller batch keep replaying correctly.  Process-wide state: the
  *     thread-local error string, and an idempotent per-device "kernel
- *     attribute set" flag.  Environment knobs (EG_*) are read once, when a
- *     handle is created, never on a launch path.
+ *     attribute set" flag.
+ *
+ *   RUN-TIME ENVIRONMENT VARIABLES -- the complete list (round 6: 7; rounds 3 - 5 had ~20, one per A/B).  Each selects a
+ *   FALLBACK route that has to exist anyway (handles, shapes and module states the default route does not cover take it by
+ *   themselves); the GPU suite runs under every one of them (tools/knob_matrix.sh).  Everything else that used to be tunable
+ *   through the environment is a compile-time constant (-D to experiment) or a Python attribute a test can flip (nn.ROUTES).
+ *     library (read once per process / handle, never on a launch path)
+ *       EG_LAYER_IMPL=0|1      plain layer calls: 0 the symmetric 8-wave kernel, 1 the producer / consumer kernel (default: by handle)
+ *       EG_CSR_TILES=0|1|2     CSR handles: 2 (default) clustered 64-node tiles with an LDS row stash, 1 consecutive rows, 0 row by row
+ *       EG_TRAIN_PS=0          training step on the symmetric kernel (what CSR handles take; no handed-down sums)
+ *     Python host side (echoglad_amd/, read at the call)
+ *       EG_SEQ_FUSED=0         torch_geometric-shaped Sequential: module by module instead of one fused launch per layer
+ *       EG_SUMS_DOWN=0         every layer takes its own BatchNorm-backward sums (no eg_gcn_layer_bwd_lower hand-down)
+ *       EG_POOL_PYRAMID=0      create_node_pixels: torch's adaptive_avg_pool2d per level instead of eg_avg_pool_pyramid_*
+ *       EG_FUSED_CRITERIA=0    engine.compute_loss: the criteria one by one instead of eg_criteria_fwd / _bwd
+ *   (bench.py's own EG_BENCH_* variables configure the benchmark, not the library.)
  */
 #ifndef ECHOGLAD_HIP_H
 #define ECHOGLAD_HIP_H
@@ -68,7 +82,8 @@ extern "C" {
  * eg_gcn_layer_cls_fwd, eg_graph_set_precision removed (round 3); train-forward child sums, fused heads backward, the
  * 64-slice queue ring refuses instead of corrupting (round 4).  131: eg_classifier_train_fwd_act.
  * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_*, eg_elm_reduce, eg_coord_mlp_*_rows, eg_bilinear4_*_rows (round 5).
- * 134: eg_dropout_epoch_add / _set, eg_debug_dropout_epoch (round 5: a whole train step as one HIP graph). */
+ * 134: eg_dropout_epoch_add / _set, eg_debug_dropout_epoch (round 5: a whole train step as one HIP graph).
+ * 135: eg_gcn_layer_bwd_lower, eg_bilinear4_bwd_rows_sums, eg_avg_pool_pyramid_fwd / _bwd, eg_criteria_* (round 6). */
 #define EG_ABI_VERSION 135
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */

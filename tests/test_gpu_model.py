@@ -229,8 +229,38 @@ def test_signature_default_widths_take_the_compatibility_route(frame, naux, batc
         g = rg[name].grad
         assert p.grad is not None and p.grad.shape == g.shape, name
         assert (p.grad.cpu() - g).abs().max() < 5e-3 * g.abs().max() + 1e-6, name
-    with pytest.raises(NotImplementedError):
-        model_pair(frame, naux, 3, coord=True, node_hidden_dim=64)
+
+
+@pytest.mark.parametrize("frame,naux,batch,hidden,cls_hidden", [(16, 3, 2, 64, 16), (32, 4, 2, 96, 32), (16, 3, 2, 128, 16)])
+def test_signature_default_widths_with_the_coordinate_graph(frame, naux, batch, hidden, cls_hidden):
+    """HierarchicalPatchModel(node_hidden_dim=64, classifier_hidden_dim=16, use_coordinate_graph=True) is a legal reference constructor
+    call (models.py:286-301, :339-351: the landmark MLP is Linear(hidden + 8, cls_hidden) ...): the compatibility route runs it as its
+    torch modules and resamples the coordinate rows with eg_bilinear4_* on zero-padded node rows -- eval logits and coordinates, and
+    one train step (p = 0) against the oracle."""
+    hip, ref = model_pair(frame, naux, 3, coord=True, seed=29, node_hidden_dim=hidden, classifier_hidden_dim=cls_hidden)
+    assert hip.node_coordinate_mlp[0][0].weight.shape == (cls_hidden, hidden + 8) and set(hip.state_dict()) == set(ref.state_dict())
+    topo, ei, nt, bi = graph_tensors(frame, naux, batch, coord=True)
+    frames = synthetic_frames(batch, 128, frame, 6)
+    c0 = initial_coords(batch, frame)
+    with torch.no_grad():
+        want, wc = ref(x=frames, node_coords=c0.clone(), edge_index=ei, node_type=nt, batch_idx=bi)
+        got, gc = hip(x=frames.to(DEV), node_coords=c0.clone().to(DEV), edge_index=ei.to(DEV), node_type=nt.to(DEV), batch_idx=bi.to(DEV))
+    assert got.shape == want.shape and (got.cpu() - want).abs().max() < TOL and (gc.cpu() - wc).abs().max() < 1e-4
+    assert torch.equal(O.landmark_argmax(got.cpu(), batch, frame), O.landmark_argmax(want, batch, frame))
+    for m in list(hip.modules()) + list(ref.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    hip.train(); ref.train()
+    want, wc = ref(x=frames, node_coords=c0.clone(), edge_index=ei, node_type=nt, batch_idx=bi)
+    got, gc = hip(x=frames.to(DEV), node_coords=c0.clone().to(DEV), edge_index=ei.to(DEV), node_type=nt.to(DEV), batch_idx=bi.to(DEV))
+    assert (got.detach().cpu() - want.detach()).abs().max() < 2e-4 and (gc.detach().cpu() - wc.detach()).abs().max() < 2e-4
+    ((want ** 2).mean() + (wc ** 2).mean() * 1e-3).backward()
+    ((got ** 2).mean() + (gc ** 2).mean() * 1e-3).backward()
+    rg = dict(ref.named_parameters())
+    for name, p in hip.named_parameters():
+        g = rg[name].grad
+        assert p.grad is not None and p.grad.shape == g.shape, name
+        assert (p.grad.cpu() - g).abs().max() < 5e-3 * g.abs().max() + 1e-6, name
 
 
 

@@ -136,14 +136,15 @@ def test_model_jumping_knowledge_max(frame, naux, batch):
     with torch.no_grad():
         fused, _ = hip.forward_nodes(feats, ei.to(DEV), batch)
     assert graph.ps_launches - before == 3
-    os.environ["EG_JK_FUSED"] = "0"
+    from echoglad_amd import nn as egnn
+    egnn.ROUTES.jk_fused = False
     try:
         before = graph.layer_launches
         with torch.no_grad():
             unfused, _ = hip.forward_nodes(feats, ei.to(DEV), batch)
         assert graph.layer_launches - before == 3      # (three plain layer launches; torch takes the maximum and the heads run separately)
     finally:
-        del os.environ["EG_JK_FUSED"]
+        egnn.ROUTES.jk_fused = True
     assert (fused - unfused).abs().max() < 2e-5
     with pytest.raises(NotImplementedError):
         model_pair(frame, naux, 3, gnn_jk_mode="cat")

@@ -573,7 +573,7 @@ def test_train_forward_chain_child_sums(frame, naux, coord, p):
 
 
 def test_chained_train_step_equals_unchained(monkeypatch):
-    """The whole training step with child sums handed from layer to layer (default) against EG_TRAIN_CHAIN=0 (every layer
+    """The whole training step with child sums handed from layer to layer (default) against nn.ROUTES.train_chain = False (every layer
     pulls its child rows): same logits, coordinates and parameter gradients up to summation order."""
     frame, naux, B, L = 64, 6, 2, 3
     for coord in (False, True):
@@ -587,8 +587,9 @@ def test_chained_train_step_equals_unchained(monkeypatch):
         coords0 = initial_coords(B, frame).to(DEV) if coord else None
         state = {k: v.clone() for k, v in hip.state_dict().items()}
         res = {}
+        from echoglad_amd import nn as egnn
         for chain in ("1", "0"):
-            monkeypatch.setenv("EG_TRAIN_CHAIN", chain)
+            monkeypatch.setattr(egnn.ROUTES, "train_chain", chain == "1")
             hip.load_state_dict(state)
             for q in hip.parameters():
                 q.grad = None
@@ -651,7 +652,7 @@ def test_heads_forward_with_the_layer_activation_folded_in(n, row_lo, n_valid, B
 
 @pytest.mark.parametrize("coord,L", [(True, 3), (False, 3), (True, 1), (False, 1)])
 def test_train_step_with_the_activation_inside_the_heads_equals_the_separate_pass(monkeypatch, coord, L):
-    """The training step with the last layer + heads as one node (default) against EG_ACT_HEADS=0 (activation pass of its own,
+    """The training step with the last layer + heads as one node (default) against nn.ROUTES.act_in_heads = False (activation pass of its own,
     two nodes): the same arithmetic in the same order -- logits, coordinates, running statistics and every gradient bit for bit,
     dropout on (frames of 32 x 32: n_valid >= 64, so the sums-in-heads route is exercised too)."""
     frame, naux, B = 32, 4, 3
@@ -663,8 +664,9 @@ def test_train_step_with_the_activation_inside_the_heads_equals_the_separate_pas
     state = {k: v.clone() for k, v in hip.state_dict().items()}
     res = {}
     for knob in ("1", "0", "sums"):
-        monkeypatch.setenv("EG_ACT_HEADS", "0" if knob == "0" else "1")
-        monkeypatch.setenv("EG_LAYER_SUMS_IN_HEADS", "1" if knob == "sums" else "0")
+        from echoglad_amd import nn as egnn
+        monkeypatch.setattr(egnn.ROUTES, "act_in_heads", knob != "0")
+        monkeypatch.setattr(egnn.ROUTES, "layer_sums_in_heads", knob == "sums")
         hip.load_state_dict(state)
         for q in hip.parameters():
             q.grad = None
