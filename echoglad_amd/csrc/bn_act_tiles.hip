@@ -159,6 +159,7 @@ int eg_launch_bn_act_tiles(const eg_graph* g, int batch, const float* z, const f
                            int relu, float dropout_p, unsigned long long seed, float* out, float* kout, hipStream_t stream) {
     if (!g || g->kind != GRAPH_TOPO || (kout && g->kid_rows == 0)) return EG_ERR_UNSUPPORTED;
     if ((long long)g->n_nodes * (C * 4) >= (1ll << 31)) return EG_ERR_UNSUPPORTED;          // per-frame buffer descriptors
+    if (int rc = eg_epoch_required(dropout_p)) return rc;
     ActTileArgs a{};
     a.n_per_frame = (int)g->n_nodes; a.tiles_per_frame = g->n_tiles; a.batch = batch; a.kid_rows = g->kid_rows;
     a.relu = relu; a.p = dropout_p; a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f; a.seed = seed; a.epoch = eg_epoch_ptr();

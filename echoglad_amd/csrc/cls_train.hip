@@ -1212,6 +1212,8 @@ size_t eg_classifier_train_workspace_bytes(void) { return CLS_WS_SHARED + eg_wor
 static int classifier_train_fwd(const float* h, const LinAct* act, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                                 const eg_cls_train_params* P, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
                                 float* logits, eg_stream_t stream_) {
+    if (P) { if (int rc_ = eg_epoch_required(P->p1 > P->p2 ? P->p1 : P->p2)) return rc_; }
+    if (act) { if (int rc_ = eg_epoch_required(act->a.p)) return rc_; }
     if (!P || !workspace || !z1 || !z2 || !bn || !logits) return set_error(EG_ERR_ARG, "NULL argument");
     if (batch < 1 || n_per_frame < 1 || row_lo < 0 || n_valid < 1 || row_lo + n_valid > n_per_frame)
         return set_error(EG_ERR_ARG, "bad row range");
@@ -1290,6 +1292,8 @@ static bool first_bwd_covers(const float* dh, int batch, int64_t n_per_frame, in
 static int classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                           const eg_cls_train_params* P, const float* z1, const float* z2, const float* bn, void* workspace,
                           float* dh1_scratch, float* dh, float* grads, const LayerSumsReq* ls, eg_stream_t stream_) {
+    if (P) { if (int rc_ = eg_epoch_required(P->p1 > P->p2 ? P->p1 : P->p2)) return rc_; }
+    if (ls) { if (int rc_ = eg_epoch_required(ls->p)) return rc_; }
     if (!dlogits || !h || !P || !z1 || !z2 || !bn || !workspace || !dh1_scratch || !grads)
         return set_error(EG_ERR_ARG, "NULL argument");
     if (batch < 1 || n_per_frame < 1 || row_lo < 0 || n_valid < 1 || row_lo + n_valid > n_per_frame)

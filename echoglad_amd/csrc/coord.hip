@@ -165,7 +165,7 @@ int eg_bilinear4_bwd_rows_sums(const float* dout, int64_t dout_frame_stride, con
                                const eg_lower_sums* lower, float* tap_sums, eg_stream_t stream) {
     if (!lower || !lower->z || !lower->bn || !tap_sums || !dh) return set_error(EG_ERR_ARG, "NULL argument");
     if (lower->dropout_p < 0.f || lower->dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
-    if (lower->dropout_p > 0.f && !eg_epoch_ptr()) return set_error(EG_ERR_HIP, "the dropout epoch word could not be allocated");
+    if (int rc = eg_epoch_required(lower->dropout_p)) return rc;
     const TapSums ts{lower->z, lower->bn, lower->relu, lower->dropout_p, lower->dropout_p > 0.f ? 1.0f / (1.0f - lower->dropout_p) : 1.0f,
                      (unsigned long long)lower->seed, eg_epoch_ptr(), tap_sums};
     return bilinear4_bwd_rows(dout, dout_frame_stride, h, coords, batch, points, n_per_frame, main_base, frame, dh, dcoords, ts, stream);

@@ -463,6 +463,7 @@ int eg_coord_mlp_fwd_rows(const float* lm, int64_t lm_frame_stride, float* lm_co
     if (!train && (!P->running_mean1 || !P->running_var1 || !P->running_mean2 || !P->running_var2))
         return set_error(EG_ERR_ARG, "eval mode needs the running statistics");
     if (!(P->p1 >= 0.f && P->p1 < 1.f && P->p2 >= 0.f && P->p2 < 1.f)) return set_error(EG_ERR_ARG, "dropout p must be in [0, 1)");
+    if (train) { if (int rc_ = eg_epoch_required(P->p1 > P->p2 ? P->p1 : P->p2)) return rc_; }
     CoordMlpFwd a{};
     a.lm = lm; a.lm_stride = lm_frame_stride; a.lm_copy = lm_copy; a.coords = coords; a.rows = 4 * batch; a.train = train ? 1 : 0;
     a.w = weights_of(P, train != 0);
@@ -485,6 +486,7 @@ int eg_coord_mlp_bwd_rows(const float* dnew_coords, const float* lm, const float
     if (!dnew_coords || !lm || !coords || !z1 || !z2 || !bn || !pre || !scratch || !grads || !params_ok(P))
         return set_error(EG_ERR_ARG, "NULL argument");
     if (batch < 1 || frame < 1 || batch > (1 << 20) || dlm_frame_stride < 4 * C) return set_error(EG_ERR_ARG, "bad batch / frame / stride");
+    if (int rc_ = eg_epoch_required(P->p1 > P->p2 ? P->p1 : P->p2)) return rc_;
     CoordMlpBwd a{};
     a.dnew = dnew_coords; a.lm = lm; a.lm_stride = 4 * C; a.coords = coords; a.pre = pre; a.z1 = z1; a.z2 = z2; a.bn = bn; a.rows = 4 * batch;
     a.w = weights_of(P, true);

@@ -18,6 +18,8 @@ int set_error(int code, const std::string& msg) {
     return code;
 }
 
+#define EG_NO_STREAM_YET ((void*)(intptr_t)-1)          // eg_graph::only_stream before the handle's first launch
+
 #ifdef EG_DEBUG_TOPO
 #define EG_DEBUG_TOPO_ON 1          // -DEG_DEBUG_TOPO: why a handle has no child-sum side buffer, on stderr
 #else
@@ -89,7 +91,13 @@ int eg_graph::acquire_queue_slice(hipStream_t stream, int** slice, int* slot) co
     const unsigned s = launch_seq.fetch_add(1u, std::memory_order_relaxed) % (unsigned)eg::QUEUE_SLOTS;
     // a handle that has only ever launched on ONE stream needs no events (its launches are ordered); the moment a second stream
     // shows up every launch records one.  Slices last used before that moment carry none: their stream is queried as a whole.
-    if (!any_launch.exchange(1, std::memory_order_acq_rel)) only_stream.store((void*)stream, std::memory_order_release);
+    // (the first launch publishes its stream with ONE compare-and-swap from the "none yet" sentinel, and any_launch only afterwards:
+    //  a second thread can no longer see any_launch set while only_stream still reads as the legacy default stream)
+    {
+        void* none = EG_NO_STREAM_YET;
+        only_stream.compare_exchange_strong(none, (void*)stream, std::memory_order_acq_rel);
+        any_launch.store(1, std::memory_order_release);
+    }
     // A capturing stream queries nothing (a query of another stream is not a capturable call, and the answer would describe the
     // moment of the capture, not of a replay): a captured launch is ordered with the handle's other users by the CALLER (header).
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -685,6 +693,7 @@ int eg_topo_create(int frame, int naux, int main_only, int coord_nodes, int conn
         if (EG_DEBUG_TOPO_ON) fprintf(stderr, "topo: %zu tiles, %zu patterns, kidsum %d\n", tiles.size(), pats.size() / 128, (int)kidsum_ok);
     }
     eg_graph* g = new eg_graph{};
+    g->only_stream.store(EG_NO_STREAM_YET, std::memory_order_relaxed);
     g->kind = GRAPH_TOPO;
     g->knobs = read_knobs();
     g->n_nodes = T.n_nodes;
@@ -804,6 +813,7 @@ static int eg::csr_build(const int64_t* ei, int64_t n_nodes, int64_t n_edges, hi
     const int n = (int)n_nodes;
     const int m = (int)n_edges;
     eg_graph* g = new eg_graph{};
+    g->only_stream.store(EG_NO_STREAM_YET, std::memory_order_relaxed);
     g->kind = GRAPH_CSR;
     g->knobs = read_knobs();
     g->n_nodes = n_nodes;

@@ -38,39 +38,6 @@ __device__ inline double block_sum(double v, double* red, int tid) {
     return red[0];
 }
 
-// max of v with the LOWEST index among equal maxima
-__device__ inline void block_argmax(float& v, int& idx, float* fv, int* fi, int tid) {
-    __syncthreads();
-    fv[tid] = v; fi[tid] = idx;
-    __syncthreads();
-#pragma unroll
-    for (int s = HM_THREADS / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            const float o = fv[tid + s]; const int oi = fi[tid + s];
-            if (o > fv[tid] || (o == fv[tid] && oi < fi[tid])) { fv[tid] = o; fi[tid] = oi; }
-        }
-        __syncthreads();
-    }
-    v = fv[0]; idx = fi[0];
-}
-
-// label maxima: value, min h and min w over all positions that hold the maximum
-__device__ inline void block_gtmax(float& g, int& gh, int& gw, float* fv, int* fi, int* fj, int tid) {
-    __syncthreads();
-    fv[tid] = g; fi[tid] = gh; fj[tid] = gw;
-    __syncthreads();
-#pragma unroll
-    for (int s = HM_THREADS / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            const float o = fv[tid + s];
-            if (o > fv[tid]) { fv[tid] = o; fi[tid] = fi[tid + s]; fj[tid] = fj[tid + s]; }
-            else if (o == fv[tid]) { fi[tid] = min(fi[tid], fi[tid + s]); fj[tid] = min(fj[tid], fj[tid + s]); }
-        }
-        __syncthreads();
-    }
-    g = fv[0]; gh = fi[0]; gw = fj[0];
-}
-
 // ---- wave-level merges (64 lanes, xor tree: a fixed order, so the same bits on every run); a workgroup combines its 4 waves through
 // one LDS hand-over.  (The first version ran every reduction as an 8-step LDS tree with a barrier per step: ~200 barriers per
 // workgroup, 31 us for a pass over 1.2 MB at batch 1 -- all of it barrier latency.)

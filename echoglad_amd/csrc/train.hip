@@ -634,6 +634,11 @@ const unsigned long long* eg_epoch_ptr() {
     }
     return epoch_dev[dev];
 }
+int eg_epoch_required(float dropout_p) {
+    if (dropout_p > 0.f && !eg_epoch_ptr())
+        return set_error(EG_ERR_HIP, "the dropout epoch word could not be allocated (first train-mode launch of this device inside a stream capture?)");
+    return EG_OK;
+}
 }  // namespace eg
 
 static int epoch_update(uint64_t v, int add, eg_stream_t stream) {
@@ -675,6 +680,7 @@ int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const floa
         return set_error(EG_ERR_ARG, "bad argument");
     if (!dz && !(dw && x)) return set_error(EG_ERR_ARG, "dz may only be NULL when the fused weight gradient is computed");
     if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    if (int rc = eg_epoch_required(dropout_p)) return rc;
     const ActArgs a = make_act(rows, relu, dropout_p, seed);
     double* partial = (double*)workspace;
     const int nb = red_blocks(rows);
@@ -745,6 +751,7 @@ int eg_bn_act_fwd(const float* z, int64_t rows, const float* scale, const float*
                   int relu, float dropout_p, uint64_t seed, float* out, eg_stream_t stream) {
     if (!z || !scale || !shift || !out || rows < 1) return set_error(EG_ERR_ARG, "bad argument");
     if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    if (int rc = eg_epoch_required(dropout_p)) return rc;
     const ActArgs a = make_act(rows, relu, dropout_p, seed);
     long long blocks = (rows * (C / 4) + 255) / 256;
     if (blocks > 65536) blocks = 65536;        // (measured at batch 32: 4.6 - 4.9 TB/s with 1k - 16k blocks, 5.2 TB/s with 64k)
@@ -775,6 +782,7 @@ int eg_gcn_layer_train_fwd(const eg_graph* g, int batch, const float* x, const f
     if (!g || !x || !W || !gamma || !beta || !workspace || !z || !bn) return set_error(EG_ERR_ARG, "NULL argument");
     if (!out && kidsum_out) return set_error(EG_ERR_ARG, "kidsum_out are the child sums of out: out must not be NULL");
     if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    if (int rc = eg_epoch_required(dropout_p)) return rc;
     if (batch < 1) return set_error(EG_ERR_ARG, "batch must be >= 1");
     if ((kidsum_in || kidsum_out) && (g->kind != GRAPH_TOPO || g->kid_rows == 0))
         return set_error(EG_ERR_UNSUPPORTED, "child sums need a topology handle with eg_graph_kidsum_rows() > 0");
@@ -825,7 +833,7 @@ static int gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, cons
             return set_error(EG_ERR_ARG, "incomplete eg_lower_sums");
         if (lower->dropout_p < 0.f || lower->dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
         if (!dx || !residual || !train_ps_on || g_bwd->kind != GRAPH_TOPO) return EG_ERR_UNSUPPORTED;
-        if (lower->dropout_p > 0.f && !eg_epoch_ptr()) return set_error(EG_ERR_HIP, "the dropout epoch word could not be allocated");
+        if (int rc = eg_epoch_required(lower->dropout_p)) return rc;
     }
     if (!dz_scratch && (dx || !dw)) return set_error(EG_ERR_ARG, "dz_scratch may only be NULL when dx is not wanted and dw is");
     if (dw && !agg) return set_error(EG_ERR_ARG, "dW needs the aggregated input kept by eg_gcn_layer_train_fwd");

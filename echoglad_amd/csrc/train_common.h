@@ -47,6 +47,9 @@ __device__ inline f32x2 keep_scale2(unsigned long long seed, unsigned long long 
 // step captured into a HIP graph freezes its kernel arguments -- the epoch word, bumped by a node of the graph itself, is what
 // gives every replay fresh masks (echoglad_amd/engine.py GraphedTrainStep).  Host side: train.hip.
 const unsigned long long* eg_epoch_ptr();            // this device's epoch word (allocated and zeroed at first use; NULL on failure)
+// EG_OK, or EG_ERR_HIP with the error text set when a launch that draws a mask (p > 0) cannot get the epoch word: with a NULL
+// pointer the kernels would hash with epoch 0 -- every replay of a captured step the same masks, and no error anywhere
+int eg_epoch_required(float dropout_p);
 
 // arguments of the BN affine + dropout + ReLU (+ residual) activation
 struct ActArgs {
