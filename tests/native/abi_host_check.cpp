@@ -42,6 +42,30 @@ int main() {
         EXPECT(eg_conv1x1_relu_pack_levels(maps, maps, nullptr, chans, side17, 1, 1, 289, 0, dummy, nullptr) == EG_ERR_ARG,
                "eg_conv1x1_relu_pack_levels(0 input channels)");
     }
+    {   // round 6's entry points: everything that can be refused on the host is refused before a launch
+        int sides[3] = {2, 4, 8}, bad_order[2] = {8, 4}, too_big[1] = {64};
+        float* outs[3] = {dummy, dummy, dummy};
+        const float* grads[3] = {dummy, dummy, dummy};
+        EXPECT(eg_avg_pool_pyramid_fwd(nullptr, 4, 16, sides, 3, outs, nullptr) == EG_ERR_ARG, "eg_avg_pool_pyramid_fwd(x = NULL)");
+        EXPECT(eg_avg_pool_pyramid_fwd(dummy, 4, 16, bad_order, 2, outs, nullptr) == EG_ERR_ARG, "eg_avg_pool_pyramid_fwd(sides not ascending)");
+        EXPECT(eg_avg_pool_pyramid_fwd(dummy, 4, 16, too_big, 1, outs, nullptr) == EG_ERR_ARG, "eg_avg_pool_pyramid_fwd(side > frame)");
+        EXPECT(eg_avg_pool_pyramid_fwd(dummy, 0, 16, sides, 3, outs, nullptr) == EG_ERR_ARG, "eg_avg_pool_pyramid_fwd(no planes)");
+        EXPECT(eg_avg_pool_pyramid_bwd(grads, nullptr, 4, 1024, sides, 3, dummy, nullptr) == EG_ERR_ARG, "eg_avg_pool_pyramid_bwd(frame > 512)");
+        EXPECT(eg_avg_pool_pyramid_bwd(grads, nullptr, 4, 16, sides, 3, nullptr, nullptr) == EG_ERR_ARG, "eg_avg_pool_pyramid_bwd(dx = NULL)");
+        EXPECT(eg_criteria_workspace_bytes(2, sides, 3) > 0 && eg_criteria_workspace_bytes(0, sides, 3) == 0, "eg_criteria_workspace_bytes");
+        int start[3] = {0, 4, 20};
+        EXPECT(eg_criteria_fwd(dummy, dummy, nullptr, 1, 84, start, sides, 3, dummy, 9000.f, 1.f, 10.f, nullptr, nullptr, 0, 1.f, dummy, dummy, dummy,
+                               dummy, nullptr, dummy, dummy, dummy, dummy, nullptr, nullptr) == EG_ERR_ARG, "eg_criteria_fwd(valid = NULL)");
+        EXPECT(eg_criteria_fwd(dummy, dummy, dummy, 1, 84, start, sides, 3, dummy, 9000.f, 1.f, 10.f, dummy, nullptr, 8, 1.f, dummy, dummy, dummy,
+                               dummy, dummy, dummy, dummy, dummy, dummy, dummy, nullptr) == EG_ERR_ARG, "eg_criteria_fwd(coord_pred without coord_y)");
+        EXPECT(eg_criteria_bwd(dummy, dummy, dummy, 1, 10, start, sides, 3, 9000.f, dummy, dummy, dummy, dummy, nullptr, 0, nullptr, nullptr, nullptr,
+                               nullptr, dummy, nullptr, nullptr) == EG_ERR_ARG, "eg_criteria_bwd(levels outside the frame's rows)");
+        eg_lower_sums ls{};
+        EXPECT(eg_gcn_layer_bwd_lower(nullptr, 1, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 1, 0.f, 0, 1, dummy, dummy, dummy, dummy, dummy, dummy,
+                                      dummy, nullptr, &ls, nullptr) == EG_ERR_ARG, "eg_gcn_layer_bwd_lower(g = NULL)");
+        EXPECT(eg_bilinear4_bwd_rows_sums(dummy, 512, dummy, dummy, 1, 4, 100, 0, 8, dummy, dummy, &ls, dummy, nullptr) == EG_ERR_ARG,
+               "eg_bilinear4_bwd_rows_sums(incomplete eg_lower_sums)");
+    }
     EXPECT(eg_workspace_bytes() > 0, "eg_workspace_bytes");
     EXPECT(std::strlen(eg_last_error()) > 0, "eg_last_error carries the last message");
     // ---- topology tables: every BASELINE shape and the odd ones of the parity tests (host tables are complete before the first
