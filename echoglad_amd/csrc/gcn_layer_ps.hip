@@ -452,12 +452,8 @@ __global__ __launch_bounds__(PS_THREADS, 2) void k_gcn_layer_ps(const float* __r
                     const int node = seg_first[i0 + e] + u8;
                     const bool live = u8 < seg_cnt[i0 + e] && node < a.lower.row_hi;      // not a repeated / absent row, not a coordinate node
                     f32x4 g = o[e];
-#ifdef EG_ABL_SUMS_NOHASH          // (timing-only: what does the lower layer's dropout mask cost in this launch?)
-                    g *= a.lower.inv_keep;
-#else
                     if (a.lower.p > 0.f)
                         g *= keep_scale4(lseed, ((unsigned long long)frame * a.n_per_frame + node) * C + 32 * wave + c4, a.lower.p, a.lower.inv_keep);
-#endif
                     const f32x4 zz = zr[i0 + e];
                     const f32x4 v = zz * lsc + lsh;
 #pragma unroll
