@@ -15,7 +15,7 @@ LIB_PATH = Path(os.environ.get("ECHOGLAD_LIB", _PKG / "lib" / "libechoglad_hip.s
 HEADER_PATH = _PKG.parent / "include" / "echoglad_hip.h"
 
 EG_OK, EG_ERR_ARG, EG_ERR_UNSUPPORTED, EG_ERR_HIP = 0, -1, -2, -3
-ABI_VERSION = 135          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
+ABI_VERSION = 136          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
 
 _lib: Optional[ct.CDLL] = None
 
@@ -90,9 +90,9 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_gcn_layer_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _f, _u64, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "eg_classifier_train_workspace_bytes": (ct.c_size_t, []),
     "eg_classifier_train_fwd": (_i, [_p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _i, _p, _p]),
-    "eg_classifier_train_fwd_act": (_i, [_p, _p, _p, _i, _f, _u64, _p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _i, _p, _p]),
+    "eg_classifier_train_fwd_act": (_i, [_p, _p, _p, _i, _f, _u64, _p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _i, _p, _i, _p]),
     "eg_classifier_bwd": (_i, [_p, _p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "eg_classifier_bwd_sums": (_i, [_p, _p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _u64, _p, _p]),
+    "eg_classifier_bwd_sums": (_i, [_p, _p, _i, _i64, _i64, _i64, _pp, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _u64, _p, _p, _i, _p]),
     "eg_gcn_layer_bwd_presummed": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _f, _u64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i,
                                         _i64, _i64, _p]),
     "eg_gcn_layer_bwd_lower": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _f, _u64, _i, _p, _p, _p, _p, _p, _p, _p,

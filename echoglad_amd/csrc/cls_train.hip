@@ -63,6 +63,9 @@ struct LinAct {
     const float *z, *scale, *shift, *residual;
     float* h;
     ActArgs a;
+    int h_skip_lo, h_skip_hi;       // rows [h_skip_lo, h_skip_hi) of every frame are NOT written to h (0, 0: all rows are): the heads' backward
+                                    // recomputes them from z and the residual (eg_classifier_bwd_sums recompute_h), so only the rows the
+                                    // heads' filter drops -- the coordinate rows the landmark MLP reads -- ever reach memory
 };
 
 template <bool STATS, bool ACT>
@@ -235,7 +238,9 @@ __global__ __launch_bounds__(256, 2) void k_act_lin128(const float* __restrict__
                 if (act.a.p > 0.f) v *= keep_scale4(act.a.seed, (unsigned long long)off, act.a.p, act.a.inv_keep);
                 if (act.a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 v += pr[k];
-                *reinterpret_cast<f32x4*>(act.h + off) = v;             // (a missing row: the last row's value once more)
+                const int rf = n0 + (r < rows_here ? r : rows_here - 1);
+                if (rf < act.h_skip_lo || rf >= act.h_skip_hi)
+                    *reinterpret_cast<f32x4*>(act.h + off) = v;         // (a missing row: the last row's value once more)
                 *reinterpret_cast<f32x4*>(&s_a[r * LDA + 4 * pl.q]) = v;
             }
         }
@@ -713,6 +718,9 @@ struct FirstBwdArgs {
     // g = dh * that layer's dropout / ReLU mask), taken in the tile's store phase where dh passes through registers anyway:
     // the layer's own sums pass (a read of dh and z: 2.4 GB at batch 32) then only has the filtered-out rows left
     const float *lz, *lmean, *linvstd, *lgamma, *lbeta;      // the layer's z [batch * stride, 128] and BatchNorm vectors
+    const float *lscale, *lshift;                            // its forward scale / shift (hrec)
+    int hrec;                                                // `h` holds the layer's RESIDUAL rows (NULL: none) and the h tile is recomputed as
+                                                             // act(z) + residual with the forward's expression: h itself was never written
     ActArgs la;                                              // its (relu, p, seed)
     float* partial_lsums;                                    // [blocks][2][128]
     unsigned bytes_c, bytes_m;                               // sizes of the compact [rows,128] / unfiltered [batch * stride,128] arrays
@@ -926,7 +934,7 @@ __device__ inline void first_bwd_role_direct(const FirstBwdArgs& a, float* s_g, 
     f32x4 lsg = {0.f, 0.f, 0.f, 0.f}, lsx = lsg;
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dh1), 0, (int)a.bytes_c, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.z1), 0, (int)a.bytes_c, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h), 0, (int)a.bytes_m, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h), 0, a.h ? (int)a.bytes_m : 0, 0x00020000);   // (hrec without a residual: every row reads as zero)
     const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SUMS ? a.lz : a.h), 0, (int)a.bytes_m, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, (int)a.bytes_m, 0x00020000);
     const int rl0 = tid >> 5;                     // this thread's rows of a tile: rl0 + 16 q
@@ -979,6 +987,26 @@ __device__ inline void first_bwd_role_direct(const FirstBwdArgs& a, float* s_g, 
         FB_T0
         FB_MARK(0);                               // wait for the prefetched rows
         const bool ragged = (t + 1) * TILE > rows;            // the array's last tile: rows past the end must not reach the sums
+        unsigned lkeep = 0xFFFFu;              // the layer's dropout mask over this thread's 4 x 4 elements of the tile: hashed once, used
+        if (SUMS && a.la.p > 0.f) {            // for the rebuilt h here and for the gate of the sums where dh leaves the tile
+            const Tile Tc = tile_of(t);
+            lkeep = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                lkeep |= keep_bits4(a.la.seed, (unsigned long long)(((unsigned)Tc.soff_m + (unsigned)vm(Tc, q)) >> 2), a.la.p) << (4 * q);
+        }
+        if (SUMS && a.hrec) {
+            // the layer's output h = act(z) + residual was never written (k_act_lin128 h_skip_*): rebuilt here from the z rows this tile
+            // holds for its sums anyway and the residual rows (prefetched in h's place), with the forward's own expression and mask
+            const f32x4 lsc = *reinterpret_cast<const f32x4*>(s_c + 10 * H1 + c4), lsh = *reinterpret_cast<const f32x4*>(s_c + 11 * H1 + c4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = pl[SUMS ? q : 0] * lsc + lsh;
+                if (a.la.p > 0.f) v *= keep_scale_of_bits(lkeep >> (4 * q), a.la.inv_keep);
+                if (a.la.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                px[q] = v + px[q];
+            }
+        }
         {
             const f32x4 mn = *reinterpret_cast<const f32x4*>(s_c + 0 * H1 + c4), is = *reinterpret_cast<const f32x4*>(s_c + 1 * H1 + c4);
             const f32x4 ga = *reinterpret_cast<const f32x4*>(s_c + 2 * H1 + c4), be = *reinterpret_cast<const f32x4*>(s_c + 3 * H1 + c4);
@@ -1059,7 +1087,7 @@ __device__ inline void first_bwd_role_direct(const FirstBwdArgs& a, float* s_g, 
 #ifdef EG_ABL_HASH_FIRST      // (timing-only)
                     g *= a.la.inv_keep;
 #else
-                    if (a.la.p > 0.f) g *= keep_scale4(a.la.seed, (unsigned long long)(((unsigned)T.soff_m + (unsigned)vo) >> 2), a.la.p, a.la.inv_keep);
+                    if (a.la.p > 0.f) g *= keep_scale_of_bits(lkeep >> (4 * q), a.la.inv_keep);
 #endif
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -1121,7 +1149,7 @@ __global__ __launch_bounds__(512) void k_cls_first_bwd(const FirstBwdArgs a_, co
     float* s_g = fb_smem;                         // [64][LDA]  dz1 tile
     float* s_x = fb_smem + TILE * LDA;            // [64][LDA]  h tile (valid rows)
     float* s_o = fb_smem + 2 * TILE * LDA;        // [64][LDA]  dh tile on its way out
-    float* s_c = fb_smem + 3 * TILE * LDA;        // [6 | 10][128]   mean, invstd, gamma, beta, mean g, mean g xhat (+ SUMS: the layer's mean, invstd, gamma, beta)
+    float* s_c = fb_smem + 3 * TILE * LDA;        // [6 | 12][128]   mean, invstd, gamma, beta, mean g, mean g xhat (+ SUMS: the layer's mean, invstd, gamma, beta, scale, shift)
     const int tid = threadIdx.x, wave = wave_id();
     if (tid < H1) {
         const double inv_n = 1.0 / (double)a.rows;
@@ -1136,6 +1164,8 @@ __global__ __launch_bounds__(512) void k_cls_first_bwd(const FirstBwdArgs a_, co
             s_c[7 * H1 + tid] = a.linvstd[tid];
             s_c[8 * H1 + tid] = a.lgamma[tid];
             s_c[9 * H1 + tid] = a.lbeta[tid];
+            s_c[10 * H1 + tid] = a.hrec ? a.lscale[tid] : 1.f;
+            s_c[11 * H1 + tid] = a.hrec ? a.lshift[tid] : 0.f;
         }
     }
     __syncthreads();
@@ -1265,7 +1295,7 @@ int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int6
 int eg_classifier_train_fwd_act(const float* z, const float* layer_bn, const float* residual, int relu, float dropout_p, uint64_t seed,
                                 float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                                 const eg_cls_train_params* P, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
-                                float* logits, eg_stream_t stream) {
+                                float* logits, int h_sparse, eg_stream_t stream) {
     if (!z || !layer_bn || !h) return set_error(EG_ERR_ARG, "NULL argument");
     if (dropout_p < 0.f || dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
     if (h == z || h == residual) return set_error(EG_ERR_ARG, "h must not alias z or the residual");
@@ -1273,6 +1303,7 @@ int eg_classifier_train_fwd_act(const float* z, const float* layer_bn, const flo
     act.z = z; act.scale = layer_bn + 2 * C; act.shift = layer_bn + 3 * C; act.residual = residual; act.h = h;
     act.a.rows = (long long)batch * n_per_frame; act.a.relu = relu; act.a.p = dropout_p;
     act.a.inv_keep = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f; act.a.seed = seed; act.a.epoch = eg_epoch_ptr();
+    if (h_sparse) { act.h_skip_lo = (int)row_lo; act.h_skip_hi = (int)(row_lo + n_valid); }
     return classifier_train_fwd(nullptr, &act, batch, n_per_frame, row_lo, n_valid, P, workspace, z1, z2, bn, sigmoid, logits, stream);
 }
 
@@ -1282,6 +1313,8 @@ struct LayerSumsReq {               // eg_classifier_bwd_sums: the layer in fron
     float p;
     uint64_t seed;
     double* sums;                   // out [2][128]
+    const float* residual;          // recompute_h: the layer's residual rows (NULL: none)
+    int recompute_h;                // h was not written (eg_classifier_train_fwd_act h_sparse): the first-layers kernel rebuilds its tile
 };
 
 static bool first_bwd_covers(const float* dh, int batch, int64_t n_per_frame, int64_t n_valid) {
@@ -1294,12 +1327,16 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
                           float* dh1_scratch, float* dh, float* grads, const LayerSumsReq* ls, eg_stream_t stream_) {
     if (P) { if (int rc_ = eg_epoch_required(P->p1 > P->p2 ? P->p1 : P->p2)) return rc_; }
     if (ls) { if (int rc_ = eg_epoch_required(ls->p)) return rc_; }
-    if (!dlogits || !h || !P || !z1 || !z2 || !bn || !workspace || !dh1_scratch || !grads)
+    const bool hrec = ls && ls->recompute_h;
+    if (!dlogits || (!h && !hrec) || !P || !z1 || !z2 || !bn || !workspace || !dh1_scratch || !grads)
         return set_error(EG_ERR_ARG, "NULL argument");
     if (batch < 1 || n_per_frame < 1 || row_lo < 0 || n_valid < 1 || row_lo + n_valid > n_per_frame)
         return set_error(EG_ERR_ARG, "bad row range");
     if (ls && !first_bwd_covers(dh, batch, n_per_frame, n_valid))
         return set_error(EG_ERR_UNSUPPORTED, "the layer's sums come out of the fused first-layers kernel: dh wanted, n_valid >= 64, < 2^32 elements");
+    // (decided before anything is launched: the recomputed h tile exists in the buffer-descriptor form of the kernel only)
+    if (hrec && !((long long)batch * n_valid * (C * 4) < (1ll << 31) - (1ll << 20) && (long long)batch * n_per_frame * (C * 4) < (1ll << 31) - (1ll << 20)))
+        return set_error(EG_ERR_UNSUPPORTED, "recompute_h needs arrays below 2 GB");
     hipStream_t stream = (hipStream_t)stream_;
     const long long rows = (long long)batch * n_valid;
     float* partial = (float*)workspace;
@@ -1347,13 +1384,17 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
         const long long nt = (rows + TILE - 1) / TILE;
         const int nf = (int)(nt < FB_BLOCKS ? nt : FB_BLOCKS);
         float* slabs = (float*)((char*)shared + eg_workspace_bytes() - (size_t)FB_BLOCKS * C * C * sizeof(float));
-        const size_t lds = (size_t)(3 * TILE * LDA + 10 * H1) * sizeof(float);
+        const size_t lds = (size_t)(3 * TILE * LDA + 12 * H1) * sizeof(float);
         FirstBwdArgs fa{dh1_scratch, z1, h, P->w1, (const double*)tot_bn1, rows, xm, d1, dh, slabs, masked ? 1 : 0};
         {
             const long long bc = rows * (C * 4), bm = (long long)batch * n_per_frame * (C * 4);
             fa.direct = bc < (1ll << 31) - (1ll << 20) && bm < (1ll << 31) - (1ll << 20);   // (32-bit offsets incl. a tile's overhang)
             fa.bytes_c = fa.direct ? (unsigned)bc : 0u;
             fa.bytes_m = fa.direct ? (unsigned)bm : 0u;
+        }
+        if (ls && ls->recompute_h) {
+            if (!fa.direct) return set_error(EG_ERR_UNSUPPORTED, "recompute_h needs arrays below 2 GB (the buffer-descriptor form of the kernel)");
+            fa.h = ls->residual; fa.hrec = 1; fa.lscale = ls->bn + 2 * C; fa.lshift = ls->bn + 3 * C;
         }
         if (ls) {
             fa.lz = ls->z; fa.lmean = ls->bn; fa.linvstd = ls->bn + C; fa.lgamma = ls->gamma; fa.lbeta = ls->beta;
@@ -1401,10 +1442,12 @@ int eg_classifier_bwd_sums(const float* dlogits, const float* h, int batch, int6
                            const eg_cls_train_params* P, const float* z1, const float* z2, const float* bn, void* workspace,
                            float* dh1_scratch, float* dh, float* grads, const float* layer_z, const float* layer_bn,
                            const float* layer_gamma, const float* layer_beta, int layer_relu, float layer_dropout_p,
-                           uint64_t layer_seed, double* layer_sums, eg_stream_t stream) {
+                           uint64_t layer_seed, double* layer_sums, const float* layer_residual, int recompute_h, eg_stream_t stream) {
     if (!layer_z || !layer_bn || !layer_gamma || !layer_beta || !layer_sums) return set_error(EG_ERR_ARG, "NULL argument");
     if (layer_dropout_p < 0.f || layer_dropout_p >= 1.f) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
-    const LayerSumsReq ls{layer_z, layer_bn, layer_gamma, layer_beta, layer_relu, layer_dropout_p, layer_seed, layer_sums};
+    if (!recompute_h && !h) return set_error(EG_ERR_ARG, "h is NULL and recompute_h is not set");
+    const LayerSumsReq ls{layer_z, layer_bn, layer_gamma, layer_beta, layer_relu, layer_dropout_p, layer_seed, layer_sums, layer_residual,
+                          recompute_h ? 1 : 0};
     return classifier_bwd(dlogits, h, batch, n_per_frame, row_lo, n_valid, P, z1, z2, bn, workspace, dh1_scratch, dh, grads, &ls, stream);
 }
 

@@ -34,6 +34,19 @@ __device__ inline f32x4 keep_scale4(unsigned long long seed, unsigned long long 
     return f32x4{keep_field(w, 0, thr, inv_keep), keep_field(w, 1, thr, inv_keep), keep_field(w, 2, thr, inv_keep),
                  keep_field(w, 3, thr, inv_keep)};
 }
+// the keep flags of the 4 elements idx .. idx + 3 as bits 0..3 (for a kernel that needs the same mask twice, far apart: 4 bits to
+// hold instead of a second hash), and the factors back from them
+__device__ inline unsigned keep_bits4(unsigned long long seed, unsigned long long idx, float p) {
+    const unsigned long long w = mask_word(seed, idx >> 2);
+    const unsigned thr = drop_threshold(p);
+    unsigned b = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b |= (((unsigned)(w >> (16 * u)) & 0xFFFFu) >= thr ? 1u : 0u) << u;
+    return b;
+}
+__device__ inline f32x4 keep_scale_of_bits(unsigned bits, float inv_keep) {
+    return f32x4{(bits & 1u) ? inv_keep : 0.0f, (bits & 2u) ? inv_keep : 0.0f, (bits & 4u) ? inv_keep : 0.0f, (bits & 8u) ? inv_keep : 0.0f};
+}
 // the 2 elements idx, idx + 1, idx even
 __device__ inline f32x2 keep_scale2(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
     const unsigned long long w = mask_word(seed, idx >> 2);

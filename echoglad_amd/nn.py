@@ -144,6 +144,7 @@ class Routes:
     train_chain = True              # child sums handed from layer to layer in the train forward
     jk_fused = True                 # JumpingKnowledge('max') as a running maximum inside the layer kernels
     stacked_heads = True            # the four heads as one stacked network in train mode
+    heads_recompute_h = True        # the last layer's output is never written in full: the heads' backward rebuilds its tile (off: h is kept)
     chain_layers = True             # eval: child sums handed from layer to layer (default of HierarchicalPatchModel.chain_layers)
     fuse_classifier = True          # eval: the heads inside the last layer's kernel (default of HierarchicalPatchModel.fuse_classifier)
 
@@ -288,8 +289,10 @@ class _LayerTrainFn(torch.autograd.Function):
 _MLP_NAMES = ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3", "b3")
 
 
-def _coord_update_fwd(h, coords_prev, dims, mlp_cfg, mlp_params, want_backward=True):
-    """h [B*N,128] (coordinate rows overwritten IN PLACE) -> (new coords [4B,2], state for _coord_update_bwd)."""
+def _coord_update_fwd(h, coords_prev, dims, mlp_cfg, mlp_params, want_backward=True, sample=True):
+    """h [B*N,128] (coordinate rows overwritten IN PLACE) -> (new coords [4B,2], state for _coord_update_bwd).
+    sample=False: the coordinate rows are NOT resampled (after the last layer nobody reads them -- the heads drop the coordinate
+    rows, models.py:485 -- and with h written sparsely the main grid the samples would come from does not exist)."""
     B, n, main_base, frame, coord_base = dims
     P = dict(mlp_cfg)
     P.update({k: p.detach().contiguous() for k, p in zip(_MLP_NAMES, mlp_params)})
@@ -298,7 +301,8 @@ def _coord_update_fwd(h, coords_prev, dims, mlp_cfg, mlp_params, want_backward=T
     # the samples are written straight into them: no gather / scatter launches around the two kernels
     lm = torch.empty(B * 4, C, dtype=torch.float32, device=h.device)
     new, saved = ops.coord_mlp_fwd(lm, flat, B, P, True, frame, want_backward, in_rows=(h, n, coord_base))
-    ops.bilinear4_fwd(h, new, B, n, main_base, frame, out_rows=(h, n, coord_base))
+    if sample:
+        ops.bilinear4_fwd(h, new, B, n, main_base, frame, out_rows=(h, n, coord_base))
     return new, (lm, flat, saved, {k: v for k, v in P.items() if not k.startswith("running")})
 
 
@@ -513,11 +517,16 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
                                                 residual, want_agg=need_w, kidsum_in=kid_in, want_out=False)
         B, n, row_lo, n_valid = dims5
         P = _stack_head_params(params[k1:], cls_cfg)
+        # h = act(z) + h_prev feeds the heads' first product (inside this kernel) and, backwards, dW1 = dz1^T h: where the backward takes
+        # the layer's sums in the heads' kernel it holds z anyway and rebuilds its h tile from z and h_prev, so h is never written in
+        # full (1.18 GB per step at batch 32) -- only the coordinate rows the landmark MLP reads are
+        sparse = bool(ROUTES.heads_recompute_h and ROUTES.layer_sums_in_heads and ops.classifier_recompute_h_supported(B, n, n_valid))
         h, logits, z1, z2, cbn = ops.classifier_train_fwd_act(z, bn, h_prev if residual else None, relu, p, seed, B, n, row_lo,
-                                                              n_valid, P, sigmoid)
+                                                              n_valid, P, sigmoid, h_sparse=sparse)
+        ctx.h_sparse = sparse
         new, st = None, None
         if has_coord:
-            new, st = _coord_update_fwd(h, coords_mid, cdims, mlp_cfg, params[k0:k1])
+            new, st = _coord_update_fwd(h, coords_mid, cdims, mlp_cfg, params[k0:k1], sample=not sparse)
         ctx.P = {k: v for k, v in P.items() if not k.startswith("running")}
         ctx.cfg = (graph, batch, relu, p, seed, residual, need_w, dims5, sigmoid, cdims, has_coord, has_prev,
                    st[3] if has_coord else None, st_prev[3] if has_prev else None)
@@ -551,9 +560,10 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
         # the layer's BatchNorm-backward sums over the heads' rows are taken where dh leaves the heads' backward (no separate
         # sums pass over dh and z for the layer afterwards: only the rows the filter drops are added there)
         presum = None
-        if ops.classifier_layer_sums_supported(B, n, n_valid) and ROUTES.layer_sums_in_heads:
+        if ctx.h_sparse or (ops.classifier_layer_sums_supported(B, n, n_valid) and ROUTES.layer_sums_in_heads):
             dh, g, sums = ops.classifier_bwd(dl, h, B, n, row_lo, n_valid, ctx.P, z1, z2, cbn, True,
-                                             layer=(z, bn, gamma, beta, relu, p, seed))
+                                             layer=(z, bn, gamma, beta, relu, p, seed),
+                                             recompute=((h_prev if residual else None),) if ctx.h_sparse else False)
             presum = None if sums is None else (sums, B, row_lo, n_valid)
         else:
             dh, g = ops.classifier_bwd(dl, h, B, n, row_lo, n_valid, ctx.P, z1, z2, cbn, True)     # (a buffer of this node)

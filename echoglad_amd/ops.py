@@ -580,11 +580,20 @@ def classifier_train_fwd(h, batch: int, n_per_frame: int, row_lo: int, n_valid: 
     return logits, z1, z2, bn
 
 
+def classifier_recompute_h_supported(batch: int, n_per_frame: int, n_valid: int) -> bool:
+    """May the heads' backward rebuild the layer output it needs from z and the residual (classifier_bwd(recompute=), so that
+    classifier_train_fwd_act(h_sparse=True) never writes it)?  Where the layer's sums come out of the heads' backward, arrays < 2 GB."""
+    lim = (1 << 31) - (1 << 20)
+    return (classifier_layer_sums_supported(batch, n_per_frame, n_valid) and batch * n_valid * C * 4 < lim and
+            batch * n_per_frame * C * 4 < lim)
+
+
 def classifier_train_fwd_act(z, layer_bn, residual, relu: bool, dropout_p: float, seed: int, batch: int, n_per_frame: int,
-                             row_lo: int, n_valid: int, P: dict, sigmoid: bool):
+                             row_lo: int, n_valid: int, P: dict, sigmoid: bool, h_sparse: bool = False):
     """The heads' train forward with the last GNN layer's activation pass folded in (eg_classifier_train_fwd_act): z, layer_bn =
     what gcn_layer_train_fwd(..., want_out=False) returned, residual = that layer's input rows or None.
-    -> (h [batch*n_per_frame,128], logits [batch*n_valid,4], z1, z2, bn [768])"""
+    -> (h [batch*n_per_frame,128], logits [batch*n_valid,4], z1, z2, bn [768]).  h_sparse: only the rows of h OUTSIDE the heads'
+    filter are written (the rest of the tensor is uninitialised memory: the backward must take classifier_bwd(recompute=))."""
     _check_rows(z, "z", batch * n_per_frame)
     if residual is not None:
         _check_rows(residual, "residual", batch * n_per_frame)
@@ -599,7 +608,7 @@ def classifier_train_fwd_act(z, layer_bn, residual, relu: bool, dropout_p: float
     _lib.check(_lib.load().eg_classifier_train_fwd_act(
         _ptr(z), _ptr(layer_bn), _ptr(residual), int(relu), float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(h), batch,
         n_per_frame, row_lo, n_valid, ct.byref(s), _ptr(_cls_workspace(dev)), _ptr(z1), _ptr(z2), _ptr(bn), int(sigmoid),
-        _ptr(logits), _stream()), "eg_classifier_train_fwd_act")
+        _ptr(logits), int(bool(h_sparse)), _stream()), "eg_classifier_train_fwd_act")
     return h, logits, z1, z2, bn
 
 
@@ -609,11 +618,13 @@ def classifier_layer_sums_supported(batch: int, n_per_frame: int, n_valid: int) 
 
 
 def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_valid: int, P: dict, z1, z2, bn, need_dh: bool,
-                   layer=None):
+                   layer=None, recompute=False):
     """-> (dh | None [batch*n_per_frame,128], grads [19076] packed as in include/echoglad_hip.h)
     layer = (z, bn, gamma, beta, relu, dropout_p, seed) of the GNN layer whose output h is: also returns that layer's
     BatchNorm-backward sums over the heads' rows, -> (dh, grads, sums [256] float64 | None) (eg_classifier_bwd_sums; None where
-    the entry point does not cover the shape -- see classifier_layer_sums_supported -- and the plain backward ran instead)."""
+    the entry point does not cover the shape -- see classifier_layer_sums_supported -- and the plain backward ran instead).
+    recompute = (residual rows | None,): h was written sparsely (classifier_train_fwd_act(h_sparse=True)); the kernel rebuilds the
+    rows it needs from the layer's z and residual (needs ``layer``; classifier_recompute_h_supported)."""
     rows = batch * n_valid
     dev = h.device
     _check_logits(dlogits, "dlogits", rows)
@@ -631,8 +642,14 @@ def classifier_bwd(dlogits, h, batch: int, n_per_frame: int, row_lo: int, n_vali
     _check_vec(lgamma, "layer gamma", C)
     _check_vec(lbeta, "layer beta", C)
     sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+    rec = recompute is not False and recompute is not None
+    res = recompute[0] if rec else None
+    if res is not None:
+        _check_rows(res, "layer residual", batch * n_per_frame)
     rc = _lib.load().eg_classifier_bwd_sums(*common, _ptr(lz), _ptr(lbn), _ptr(lgamma), _ptr(lbeta), int(relu), float(p),
-                                            int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(sums), _stream())
+                                            int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(sums), _ptr(res), int(rec), _stream())
+    if rc == _lib.EG_ERR_UNSUPPORTED and rec:
+        raise RuntimeError("classifier_bwd(recompute=): " + _lib.last_error())      # (h does not exist: there is no plain backward to fall back to)
     if rc == _lib.EG_ERR_UNSUPPORTED:           # nothing was launched (include/echoglad_hip.h): the plain backward, no sums
         _lib.check(_lib.load().eg_classifier_bwd(*common, _stream()), "eg_classifier_bwd")
         return dh, grads, None

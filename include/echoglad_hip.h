@@ -84,7 +84,7 @@ extern "C" {
  * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_*, eg_elm_reduce, eg_coord_mlp_*_rows, eg_bilinear4_*_rows (round 5).
  * 134: eg_dropout_epoch_add / _set, eg_debug_dropout_epoch (round 5: a whole train step as one HIP graph).
  * 135: eg_gcn_layer_bwd_lower, eg_bilinear4_bwd_rows_sums, eg_avg_pool_pyramid_fwd / _bwd, eg_criteria_* (round 6). */
-#define EG_ABI_VERSION 135
+#define EG_ABI_VERSION 136
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
 
@@ -359,7 +359,9 @@ int eg_classifier_train_fwd(const float* h, int batch, int64_t n_per_frame, int6
 int eg_classifier_train_fwd_act(const float* z, const float* layer_bn, const float* residual, int relu, float dropout_p, uint64_t seed,
                                 float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                                 const eg_cls_train_params* params, void* workspace, float* z1, float* z2, float* bn, int sigmoid,
-                                float* logits, eg_stream_t stream);
+                                float* logits, int h_sparse, eg_stream_t stream);
+/* h_sparse != 0: only the rows of h OUTSIDE [row_lo, row_lo + n_valid) of every frame are written (the coordinate rows the landmark
+ * MLP reads; with no such rows nothing is); the heads' backward then takes recompute_h (eg_classifier_bwd_sums). */
 int eg_classifier_bwd(const float* dlogits, const float* h, int batch, int64_t n_per_frame, int64_t row_lo, int64_t n_valid,
                       const eg_cls_train_params* params, const float* z1, const float* z2, const float* bn, void* workspace,
                       float* dh1_scratch, float* dh, float* grads, eg_stream_t stream);
@@ -376,7 +378,11 @@ int eg_classifier_bwd_sums(const float* dlogits, const float* h, int batch, int6
                            const eg_cls_train_params* params, const float* z1, const float* z2, const float* bn, void* workspace,
                            float* dh1_scratch, float* dh, float* grads, const float* layer_z, const float* layer_bn,
                            const float* layer_gamma, const float* layer_beta, int layer_relu, float layer_dropout_p,
-                           uint64_t layer_seed, double* layer_sums, eg_stream_t stream);
+                           uint64_t layer_seed, double* layer_sums, const float* layer_residual, int recompute_h, eg_stream_t stream);
+/* recompute_h != 0 (round 6): the layer's output h = act(z) + residual was never written in full (eg_classifier_train_fwd_act with
+ * h_sparse: only the rows the heads' filter drops reach memory) -- `h` is ignored (may be NULL) and the first-layers kernel rebuilds
+ * its h tile from layer_z (which it reads for the sums anyway) and layer_residual (the layer's input rows; NULL: no residual)
+ * with the forward's own expression and dropout mask: 1.18 GB less written per step at batch 32.  Arrays below 2 GB. */
 int eg_gcn_layer_bwd_presummed(const eg_graph* g_bwd, int batch, const float* dy, const float* z, const float* agg, const float* W,
                                const float* gamma, const float* beta, const float* bn, int relu, float dropout_p, uint64_t seed,
                                int residual, void* workspace, float* dz_scratch, float* dx, float* dw, float* db, float* dgamma,

@@ -663,10 +663,11 @@ def test_train_step_with_the_activation_inside_the_heads_equals_the_separate_pas
     coords0 = initial_coords(B, frame).to(DEV) if coord else None
     state = {k: v.clone() for k, v in hip.state_dict().items()}
     res = {}
-    for knob in ("1", "0", "sums"):
+    for knob in ("1", "0", "sums", "sums_h_kept"):
         from echoglad_amd import nn as egnn
         monkeypatch.setattr(egnn.ROUTES, "act_in_heads", knob != "0")
-        monkeypatch.setattr(egnn.ROUTES, "layer_sums_in_heads", knob == "sums")
+        monkeypatch.setattr(egnn.ROUTES, "layer_sums_in_heads", knob.startswith("sums"))
+        monkeypatch.setattr(egnn.ROUTES, "heads_recompute_h", knob != "sums_h_kept")
         hip.load_state_dict(state)
         for q in hip.parameters():
             q.grad = None
@@ -688,6 +689,16 @@ def test_train_step_with_the_activation_inside_the_heads_equals_the_separate_pas
     assert torch.equal(a[0], c[0])
     for k in a[2]:
         assert float((a[2][k] - c[2][k]).abs().max()) <= 5e-5 * float(a[2][k].abs().max()) + 1e-9, k
+    # ... and with the layer's output never written in full (the default on top of it: the heads' backward rebuilds its rows from z
+    # and the residual with the forward's own expression and mask) against the same route with h kept: bit for bit
+    d = res["sums_h_kept"]
+    assert torch.equal(c[0], d[0])
+    if coord:
+        assert torch.equal(c[1], d[1])
+    for k in c[2]:
+        assert torch.equal(c[2][k], d[2][k]), k
+    for k in c[3]:
+        assert torch.equal(c[3][k], d[3][k]), k
 
 
 @pytest.mark.parametrize("coord,conn,relu,p", [(True, False, False, 0.5), (True, False, True, 0.3), (False, False, False, 0.0),
@@ -742,6 +753,23 @@ def test_layer_backward_with_sums_taken_in_the_heads_backward(coord, conn, relu,
         tol = 2e-5 * scale + (noise if name in ("dgamma", "dbeta") else noise / (B * n) * (128 if name == "dw" else 1) * 50)
         assert float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), scale, tol)
     assert torch.equal(run(True)[2][0], o1[0])                                 # deterministic
+    # the same backward with h never written over the heads' rows (h_sparse: those rows hold garbage -- NaN here) and rebuilt in the
+    # kernel from z and the residual rows: dh, the heads' gradients and the layer's sums bit for bit
+    hs, logits_s, z1s, z2s, cbns = ops.classifier_train_fwd_act(z, bn, x, relu, p, 4321, B, n, n_conn, n_valid, P, False, h_sparse=True)
+    assert torch.equal(logits_s, logits) and torch.equal(z1s, z1) and torch.equal(z2s, z2) and torch.equal(cbns, cbn)
+    assert torch.equal(hs.view(B, n, 128)[:, keep.to(DEV), :], h.view(B, n, 128)[:, keep.to(DEV), :])
+    hs.view(B, n, 128)[:, (~keep).to(DEV), :] = float("nan")
+    dh2, gr2, sums2 = ops.classifier_bwd(dl, hs, B, n, n_conn, n_valid, P, z1, z2, cbn, True, layer=(z, bn, gamma, beta, relu, p, 4321),
+                                         recompute=(x,))
+    dh3, gr3, sums3 = ops.classifier_bwd(dl, h, B, n, n_conn, n_valid, P, z1, z2, cbn, True, layer=(z, bn, gamma, beta, relu, p, 4321))
+    assert torch.equal(dh2, dh3) and torch.equal(gr2, gr3) and torch.equal(sums2, sums3)
+    # without a residual: h = act(z)
+    h4, *_ = ops.classifier_train_fwd_act(z, bn, None, relu, p, 4321, B, n, n_conn, n_valid, P, False)
+    _, _, z1n, z2n, cbnn = ops.classifier_train_fwd_act(z, bn, None, relu, p, 4321, B, n, n_conn, n_valid, P, False, h_sparse=True)
+    a4 = ops.classifier_bwd(dl, h4, B, n, n_conn, n_valid, P, z1n, z2n, cbnn, True, layer=(z, bn, gamma, beta, relu, p, 4321))
+    b4 = ops.classifier_bwd(dl, hs, B, n, n_conn, n_valid, P, z1n, z2n, cbnn, True, layer=(z, bn, gamma, beta, relu, p, 4321), recompute=(None,))
+    for u, v in zip(a4, b4):
+        assert torch.equal(u, v)
 
 
 def test_layer_train_composites_on_a_directed_graph():
