@@ -2,37 +2,9 @@
 // (src/core/models.py:539-553: hat weights relu(1-|c-i|) along h and w, outer product, weighted sum over
 // the whole [C,F,F] map = 103 MB of temporaries per frame at 224x224) is mathematically a 4-tap sample.
 // One wave per landmark gathers the <= 4 node rows of the main grid it touches (lane = channel pair).
-#include "train_common.h"
+#include "coord_common.h"
 
 namespace eg {
-
-struct BilArgs {
-    int batch, points, frame;     // points per frame (4 in the reference)
-    long long n_per_frame, main_base;
-    long long row_stride;         // floats between two frames' sample rows in out / dout (points * 128: a packed [batch * points, 128] array)
-};
-
-struct Taps {
-    int i[2];
-    float w[2], dw[2];            // hat weight and its derivative wrt the coordinate
-};
-
-__device__ inline Taps taps_1d(float c, int F) {
-    Taps t;
-    const float f = floorf(c);
-    const int i0 = (int)f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = i0 + k;
-        const float d = c - (float)i;
-        const float w = 1.0f - fabsf(d);
-        const bool ok = i >= 0 && i < F && w > 0.0f;
-        t.i[k] = ok ? i : 0;
-        t.w[k] = ok ? w : 0.0f;
-        t.dw[k] = ok ? (d > 0.f ? -1.0f : (d < 0.f ? 1.0f : 0.0f)) : 0.0f;   // d/dc relu(1-|c-i|); 0 at the kink like torch.abs
-    }
-    return t;
-}
 
 __global__ __launch_bounds__(256) void k_bilinear4_fwd(const float* __restrict__ h, const float* __restrict__ coords,
                                                        float* __restrict__ out, const BilArgs a) {
@@ -40,37 +12,17 @@ __global__ __launch_bounds__(256) void k_bilinear4_fwd(const float* __restrict__
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= a.batch * a.points) return;
     const int frame = p / a.points;
-    const Taps th = taps_1d(coords[2 * p + 0], a.frame), tw = taps_1d(coords[2 * p + 1], a.frame);
-    const float* base = h + ((size_t)frame * a.n_per_frame + a.main_base) * C + 2 * lane;
-    f32x2 acc = {0.f, 0.f};
-#pragma unroll
-    for (int ka = 0; ka < 2; ++ka)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const float w = th.w[ka] * tw.w[kb];
-            const f32x2 v = *reinterpret_cast<const f32x2*>(base + ((size_t)th.i[ka] * a.frame + tw.i[kb]) * C);
-            acc += w * v;
-        }
+    const f32x2 acc = bilinear_sample(h + ((size_t)frame * a.n_per_frame + a.main_base) * C + 2 * lane, coords[2 * p + 0], coords[2 * p + 1], a.frame);
     *reinterpret_cast<f32x2*>(out + (size_t)frame * a.row_stride + (size_t)(p - frame * a.points) * C + 2 * lane) = acc;
 }
 
-// what the taps add to a dy whose BatchNorm-backward sums exist already (eg_gcn_layer_bwd_lower): the additions' own sums
-struct TapSums {
-    const float* z;           // NULL: not wanted
-    const float* bn;          // mean, invstd, scale, shift
-    int relu;
-    float p, inv_keep;
-    unsigned long long seed;
-    const unsigned long long* epoch;
-    float* out;               // [batch][2][128]
-};
-
-// one wave per FRAME walks its landmarks in order, so two landmarks that touch the same pixel never race
+// one wave per FRAME, so two landmarks that touch the same pixel never race (4 points: coord_common.h's form with every load up front;
+// any other count: the walk, landmark after landmark)
 __global__ __launch_bounds__(256) void k_bilinear4_bwd(const float* __restrict__ dout, const float* __restrict__ h,
                                                        const float* __restrict__ coords, float* __restrict__ dh,
                                                        float* __restrict__ dcoords, const BilArgs a, const TapSums ts) {
     const int lane = threadIdx.x & 63;
-    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int frame = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (frame >= a.batch) return;
     const size_t fbase = ((size_t)frame * a.n_per_frame + a.main_base) * C + 2 * lane;
     f32x2 tmn = {0.f, 0.f}, tis = tmn, tsc = tmn, tsh = tmn, ts1 = tmn, ts2 = tmn;
@@ -80,6 +32,19 @@ __global__ __launch_bounds__(256) void k_bilinear4_bwd(const float* __restrict__
         tsc = *reinterpret_cast<const f32x2*>(ts.bn + 2 * C + 2 * lane); tsh = *reinterpret_cast<const f32x2*>(ts.bn + 3 * C + 2 * lane);
         tseed = ts.seed + epoch_now(ts.epoch);
     }
+    if (a.points == 4) {
+        float gh[4], gw[4];
+        const float* dout_f = dout + (size_t)frame * a.row_stride;
+        const size_t fb = ((size_t)frame * a.n_per_frame + a.main_base) * C;
+        if (ts.z) bilinear_bwd_frame4<true>(dout_f, h, coords + 8 * frame, dh, fb, a.frame, ts, tseed, lane, gh, gw, ts1, ts2);
+        else bilinear_bwd_frame4<false>(dout_f, h, coords + 8 * frame, dh, fb, a.frame, ts, tseed, lane, gh, gw, ts1, ts2);
+        if (dcoords && lane < 8) {
+            float vsel = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { vsel = lane == 2 * q ? gh[q] : vsel; vsel = lane == 2 * q + 1 ? gw[q] : vsel; }
+            dcoords[8 * frame + lane] = vsel;
+        }
+    } else
     for (int q = 0; q < a.points; ++q) {
         const int p = frame * a.points + q;
         const Taps th = taps_1d(coords[2 * p + 0], a.frame), tw = taps_1d(coords[2 * p + 1], a.frame);

@@ -8,7 +8,7 @@
 // another; BatchNorm uses batch statistics over the R rows (train) or the running ones (eval), Dropout is the same
 // counter-based mask as everywhere else (train_common.h), hidden activations are recomputed from the saved pre-BatchNorm
 // z1 / z2.  All reductions run in a fixed order inside the workgroup: bitwise reproducible.
-#include "train_common.h"
+#include "coord_common.h"
 
 namespace eg {
 
@@ -44,7 +44,7 @@ struct CoordMlpFwd {
 };
 
 struct CoordMlpBwd {
-    const float *dnew, *lm, *coords, *pre, *z1, *z2, *bn;
+    const float *dnew, *dnew2, *lm, *coords, *pre, *z1, *z2, *bn;     // d new_coords = dnew + dnew2 (either may be NULL)
     long long lm_stride, dlm_stride;            // floats between two frames' rows of lm / dlm (4 * 128: packed)
     int dlm_acc;                                // dlm += instead of dlm =
     int rows;
@@ -237,7 +237,163 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd 
     }
 }
 
-__global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd a_) {
+// ---- up to 64 rows (batch <= 16): the whole update in LDS -----------------------------------------------------------------
+// The general kernel above round-trips z1 / z2 through global memory between its phases and fetches its small parameters where it
+// needs them: ~15 dependent global round trips, 20 us for a kernel with 70 KB of work -- and at batch 1, where a whole training step
+// is ~1 ms, there are three of them forward and three backward.  With R <= 64 everything fits one tile: every global load is issued
+// at the top, z1 / z2 stay in LDS (and go out to global once, for the backward), and the resampling of the coordinate rows
+// (k_bilinear4_fwd, a launch of its own otherwise) runs at the end on the coordinates still in LDS.  Same arithmetic, same order of
+// additions as the general kernel.
+struct CoordSample {            // resampling behind the MLP (h == NULL: none)
+    const float* h;             // [batch * n_per_frame, 128]
+    float* out;                 // row 0 of frame 0's sample rows; frame stride row_stride floats
+    long long n_per_frame, main_base, row_stride;
+    int frame;
+};
+
+// small parameters in LDS: b1 g1 be1 m1 v1 (32 each) | b2 g2 be2 m2 v2 (16 each) | b3 (2)
+constexpr int SP_B1 = 0, SP_G1 = 32, SP_BE1 = 64, SP_M1 = 96, SP_V1 = 128, SP_B2 = 160, SP_G2 = 176, SP_BE2 = 192, SP_M2 = 208, SP_V2 = 224,
+              SP_B3 = 240, SP_TOTAL = 242;
+
+__device__ inline void load_small_params(const CoordMlpW& w, const float* rm1, const float* rv1, const float* rm2, const float* rv2, float* s_par) {
+    const int t = threadIdx.x;
+    if (t < 32) { s_par[SP_B1 + t] = w.b1[t]; s_par[SP_G1 + t] = w.gamma1[t]; s_par[SP_BE1 + t] = w.beta1[t]; }
+    else if (t < 64) { const int c = t - 32; s_par[SP_M1 + c] = rm1 ? rm1[c] : 0.f; s_par[SP_V1 + c] = rv1 ? rv1[c] : 1.f; }
+    else if (t < 80) { const int c = t - 64; s_par[SP_B2 + c] = w.b2[c]; s_par[SP_G2 + c] = w.gamma2[c]; s_par[SP_BE2 + c] = w.beta2[c]; }
+    else if (t < 96) { const int c = t - 80; s_par[SP_M2 + c] = rm2 ? rm2[c] : 0.f; s_par[SP_V2 + c] = rv2 ? rv2[c] : 1.f; }
+    else if (t < 98) s_par[SP_B3 + t - 96] = w.b3[t - 96];
+}
+
+// bn_setup with z in LDS and the parameters in s_par
+template <int W>
+__device__ inline void bn_setup_lds(const float* s_z, int rows, int train, const float* s_gamma, const float* s_beta, const float* s_rm,
+                                    const float* s_rv, float eps, float mom, float* rm, float* rv, float* bn_mean, float* bn_inv,
+                                    float* s_red, float* s_mean, float* s_var, float* s_scale, float* s_shift) {
+    if (train) column_stats<W>(s_z, rows, s_red, s_mean, s_var);
+    if (threadIdx.x < W) {
+        const int c = threadIdx.x;
+        float mean, var;
+        if (train) {
+            mean = s_mean[c];
+            var = s_var[c];
+            if (rm && mom >= 0.f) {
+                const float unbiased = rows > 1 ? var * (float)rows / (float)(rows - 1) : var;
+                rm[c] = (1.0f - mom) * s_rm[c] + mom * mean;
+                rv[c] = (1.0f - mom) * s_rv[c] + mom * unbiased;
+            }
+        } else {
+            mean = s_rm[c];
+            var = s_rv[c];
+        }
+        const float inv = 1.0f / sqrtf(var + eps);
+        bn_mean[c] = mean;
+        bn_inv[c] = inv;
+        const float sc = s_gamma[c] * inv;
+        s_scale[c] = sc;
+        s_shift[c] = s_beta[c] - mean * sc;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(CM_THREADS) void k_coord_update_fwd_small(const CoordMlpFwd a_, const CoordSample sp) {
+    CoordMlpFwd a = a_;
+    __shared__ __attribute__((aligned(16))) float s_in[CM_TILE * CM_LDI];
+    __shared__ float s_w1[CM_H1 * CM_LDW1], s_w2[CM_H2 * CM_LDW2], s_w3[CM_OUT * CM_H2], s_par[SP_TOTAL];
+    __shared__ float s_z1[CM_TILE * CM_H1], s_z2[CM_TILE * CM_H2], s_h1[CM_TILE * CM_LDH], s_newc[CM_TILE * 2];
+    __shared__ float s_red[CM_THREADS], s_mean[CM_H1], s_var[CM_H1], s_sc1[CM_H1], s_sh1[CM_H1], s_sc2[CM_H2], s_sh2[CM_H2];
+    const int t = threadIdx.x, R = a.rows;
+    const float* __restrict__ lm = a.lm;
+    const float* __restrict__ coords = a.coords;
+    // ---- every global load of the kernel
+    const unsigned long long e = epoch_now(a.w.epoch);
+    load_weights(a.w, s_w1, s_w2, s_w3);
+    load_small_params(a.w, a.rm1, a.rv1, a.rm2, a.rv2, s_par);
+    stage_inputs(lm, a.lm_stride, coords, 0, R, s_in, a.lm_copy);
+    const float c_own = t < R * CM_OUT ? coords[t] : 0.f;
+    a.w.seed1 += e;
+    a.w.seed2 += e;
+    __syncthreads();
+    // ---- z1 = in W1^T + b1: thread -> (row t >> 5 and +32, output channel t & 31)
+    {
+        const int o = t & 31;
+        const float b = s_par[SP_B1 + o];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int r = (t >> 5) + 32 * half;
+            if (32 * half >= R) break;                  // (uniform)
+            float acc = b;
+#pragma unroll 8
+            for (int i = 0; i < CM_IN; ++i) acc += s_w1[o * CM_LDW1 + i] * s_in[r * CM_LDI + i];
+            s_z1[r * CM_H1 + o] = acc;
+            if (r < R) a.z1[r * CM_H1 + o] = acc;
+        }
+    }
+    __syncthreads();
+    bn_setup_lds<CM_H1>(s_z1, R, a.train, s_par + SP_G1, s_par + SP_BE1, s_par + SP_M1, s_par + SP_V1, a.eps1, a.mom1, a.rm1, a.rv1, a.bn,
+                        a.bn + CM_H1, s_red, s_mean, s_var, s_sc1, s_sh1);
+    // ---- z2 = h1 W2^T + b2: thread -> (row t >> 4, output channel t & 15)
+    for (int el = t; el < CM_TILE * CM_H1; el += CM_THREADS) {
+        const int r = el >> 5, i = el & 31;
+        float k, h = 0.f;
+        if (r < R) h = hidden_act(s_z1[r * CM_H1 + i], s_sc1[i], s_sh1[i], a.w.seed1, (unsigned long long)r * CM_H1 + i, a.w.p1, a.w.ik1, &k);
+        s_h1[r * CM_LDH + i] = h;
+    }
+    __syncthreads();
+    {
+        const int r = t >> 4, o = t & 15;
+        float acc = s_par[SP_B2 + o];
+#pragma unroll
+        for (int i = 0; i < CM_H1; ++i) acc += s_w2[o * CM_LDW2 + i] * s_h1[r * CM_LDH + i];
+        s_z2[r * CM_H2 + o] = acc;
+        if (r < R) a.z2[r * CM_H2 + o] = acc;
+    }
+    __syncthreads();
+    bn_setup_lds<CM_H2>(s_z2, R, a.train, s_par + SP_G2, s_par + SP_BE2, s_par + SP_M2, s_par + SP_V2, a.eps2, a.mom2, a.rm2, a.rv2,
+                        a.bn + 2 * CM_H1, a.bn + 2 * CM_H1 + CM_H2, s_red, s_mean, s_var, s_sc2, s_sh2);
+    // ---- delta = h2 W3^T + b3; coords <- clamp(coords + delta)
+    if (t < R * CM_OUT) {
+        const int r = t >> 1, d = t & 1;
+        float acc = s_par[SP_B3 + d];
+#pragma unroll
+        for (int i = 0; i < CM_H2; ++i) {
+            float k;
+            const float h = hidden_act(s_z2[r * CM_H2 + i], s_sc2[i], s_sh2[i], a.w.seed2, (unsigned long long)r * CM_H2 + i, a.w.p2, a.w.ik2, &k);
+            acc += s_w3[d * CM_H2 + i] * h;
+        }
+        const float pre = c_own + acc;
+        if (a.pre) a.pre[t] = pre;
+        const float nc = fminf(fmaxf(pre, 0.f), a.cmax);
+        a.newc[t] = nc;
+        s_newc[t] = nc;
+    }
+    // ---- the coordinate rows resampled at the new positions (models.py:455-473): one wave per point
+    if (sp.h) {
+        __syncthreads();
+        const int lane = t & 63;
+        for (int p = t >> 6; p < R; p += CM_WAVES) {
+            const int f = p >> 2;
+            const f32x2 acc = bilinear_sample(sp.h + ((size_t)f * sp.n_per_frame + sp.main_base) * C + 2 * lane, s_newc[2 * p], s_newc[2 * p + 1], sp.frame);
+            *reinterpret_cast<f32x2*>(sp.out + (size_t)f * sp.row_stride + (size_t)(p & 3) * C + 2 * lane) = acc;
+        }
+    }
+}
+
+// backward of the resampling, run in FRONT of the MLP's backward by the small form (h == NULL: the samples were not used)
+struct CoordResampleBwd {
+    const float* h;             // the tensor the samples were taken from
+    const float* newc;          // [R,2] the positions
+    float* dx;                  // the gradient tensor: its coordinate rows hold the samples' gradient (read here, before dlm overwrites
+                                // them), its main-grid rows receive the taps
+    long long n_per_frame, main_base, coord_base;
+    int frame;
+    TapSums ts;                 // ts.z != NULL: the additions' own BatchNorm-backward sums (coord_common.h)
+};
+
+// SMALL (R <= 64, batch <= 16): one tile -- z1 / z2 / the inputs are loaded once at the top, the scratch lives in LDS, the resampling's
+// backward (k_bilinear4_bwd + the addition of its d coords, two launches of their own otherwise) runs first, one wave per frame.
+// The general form round-trips the scratch through global memory between its phases: ~12 dependent round trips, 21 us at batch 1.
+template <bool SMALL>
+__global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd a_, const CoordResampleBwd rb) {
     CoordMlpBwd a = a_;
     a.w = resolved(a_.w);
     __shared__ __attribute__((aligned(16))) float s_in[CM_TILE * CM_LDI];       // input tile; before that h1 | keep1 | xhat1 tiles
@@ -245,31 +401,74 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
     __shared__ float s_dz[CM_TILE * CM_LDH];                                    // dz2 tile [64][17], later dz1 tile [64][33]
     __shared__ float s_red[4][CM_THREADS], s_part[CM_WAVES];
     __shared__ float s_gm[CM_H1], s_gxm[CM_H1], s_sc1[CM_H1], s_sh1[CM_H1], s_sc2[CM_H2], s_sh2[CM_H2];
+    __shared__ float s_bn[2 * CM_H1 + 2 * CM_H2], s_g1[CM_H1], s_g2[CM_H2];    // mean1 | invstd1 | mean2 | invstd2, gamma1, gamma2
+    __shared__ float s_z1l[SMALL ? CM_TILE * CM_H1 : 1], s_z2l[SMALL ? CM_TILE * CM_H2 : 1], s_scr[SMALL ? CM_TILE * CM_SCR : 1];
+    __shared__ float s_hkx[SMALL ? 3 * CM_TILE * CM_LDH : 1], s_dd[SMALL ? CM_TILE * 2 : 1];
     const int t = threadIdx.x, R = a.rows;
     const float* __restrict__ lm = a.lm;
     const float* __restrict__ coords = a.coords;
-    const float* __restrict__ z1 = a.z1;
-    const float* __restrict__ z2 = a.z2;
-    const float* mean1 = a.bn;
-    const float* inv1 = a.bn + CM_H1;
-    const float* mean2 = a.bn + 2 * CM_H1;
-    const float* inv2 = a.bn + 2 * CM_H1 + CM_H2;
+    const float* __restrict__ z1 = SMALL ? s_z1l : a.z1;
+    const float* __restrict__ z2 = SMALL ? s_z2l : a.z2;
+    float* const scratch = SMALL ? s_scr : a.scratch;
+    const float* mean1 = s_bn;
+    const float* inv1 = s_bn + CM_H1;
+    const float* mean2 = s_bn + 2 * CM_H1;
+    const float* inv2 = s_bn + 2 * CM_H1 + CM_H2;
+    // ---- every global load the first phases need
     load_weights(a.w, s_w1, s_w2, s_w3);
     if (t < CM_H1) {
-        const float sc = a.w.gamma1[t] * inv1[t];
+        const float g = a.w.gamma1[t], m = a.bn[t], iv = a.bn[CM_H1 + t], sc = g * iv;
+        s_g1[t] = g; s_bn[t] = m; s_bn[CM_H1 + t] = iv;
         s_sc1[t] = sc;
-        s_sh1[t] = a.w.beta1[t] - mean1[t] * sc;
+        s_sh1[t] = a.w.beta1[t] - m * sc;
     } else if (t < CM_H1 + CM_H2) {
         const int c = t - CM_H1;
-        const float sc = a.w.gamma2[c] * inv2[c];
+        const float g = a.w.gamma2[c], m = a.bn[2 * CM_H1 + c], iv = a.bn[2 * CM_H1 + CM_H2 + c], sc = g * iv;
+        s_g2[c] = g; s_bn[2 * CM_H1 + c] = m; s_bn[2 * CM_H1 + CM_H2 + c] = iv;
         s_sc2[c] = sc;
-        s_sh2[c] = a.w.beta2[c] - mean2[c] * sc;
+        s_sh2[c] = a.w.beta2[c] - m * sc;
+    }
+    if (SMALL) {
+        for (int e = t; e < R * CM_H1; e += CM_THREADS) s_z1l[e] = a.z1[e];
+        if (t < R * CM_H2) s_z2l[t] = a.z2[t];
+        stage_inputs(lm, a.lm_stride, coords, 0, R, s_in);
+        float dcur = 0.f, pre = 0.f;
+        if (t < R * 2) { dcur = a.dnew ? a.dnew[t] : 0.f; pre = a.pre[t]; }
+        if (rb.h) {
+            // the resampling's backward: wave = frame (batch <= 16 = the workgroup's waves)
+            const int lane = t & 63, f = __builtin_amdgcn_readfirstlane(t >> 6);
+            if (f * 4 < R) {
+                const size_t fbase = ((size_t)f * rb.n_per_frame + rb.main_base) * C;
+                const float* dout_f = rb.dx + ((size_t)f * rb.n_per_frame + rb.coord_base) * C;
+                float gh[4], gw[4];
+                f32x2 ts1 = {0.f, 0.f}, ts2 = ts1;
+                if (rb.ts.z) {
+                    const unsigned long long tseed = rb.ts.seed + epoch_now(rb.ts.epoch);
+                    bilinear_bwd_frame4<true>(dout_f, rb.h, rb.newc + 8 * f, rb.dx, fbase, rb.frame, rb.ts, tseed, lane, gh, gw, ts1, ts2);
+                    *reinterpret_cast<f32x2*>(rb.ts.out + (size_t)f * 2 * C + 2 * lane) = ts1;
+                    *reinterpret_cast<f32x2*>(rb.ts.out + (size_t)f * 2 * C + C + 2 * lane) = ts2;
+                } else {
+                    bilinear_bwd_frame4<false>(dout_f, rb.h, rb.newc + 8 * f, rb.dx, fbase, rb.frame, rb.ts, 0ull, lane, gh, gw, ts1, ts2);
+                }
+                if (lane < 8) {
+                    float vsel = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { vsel = lane == 2 * q ? gh[q] : vsel; vsel = lane == 2 * q + 1 ? gw[q] : vsel; }
+                    s_dd[8 * f + lane] = vsel;
+                }
+            }
+            __syncthreads();
+            if (t < R * 2) dcur += s_dd[t];
+            __syncthreads();
+        }
+        if (t < R * 2) s_dd[t] = (pre >= 0.f && pre <= a.cmax) ? dcur : 0.f;      // gradient of the clamp (torch.clamp: passes where min <= x <= max)
     }
     __syncthreads();
-    // gradient of the clamp (torch.clamp: passes where min <= x <= max)
     auto dd = [&](int r, int d) -> float {
+        if (SMALL) return s_dd[r * 2 + d];
         const float pre = a.pre[r * 2 + d];
-        return (pre >= 0.f && pre <= a.cmax) ? a.dnew[r * 2 + d] : 0.f;
+        const float g = (a.dnew ? a.dnew[r * 2 + d] : 0.f) + (a.dnew2 ? a.dnew2[r * 2 + d] : 0.f);
+        return (pre >= 0.f && pre <= a.cmax) ? g : 0.f;
     };
     // ---- output layer: g2 = (dd W3) mask2, its BatchNorm sums, dW3, db3
     {
@@ -312,15 +511,15 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
             hidden_act(z, s_sc2[cc], s_sh2[cc], a.w.seed2, (unsigned long long)e, a.w.p2, a.w.ik2, &k);
             const float g = (dd(r, 0) * s_w3[cc] + dd(r, 1) * s_w3[CM_H2 + cc]) * k;
             const float xh = (z - mean2[cc]) * inv2[cc];
-            a.scratch[r * CM_SCR + cc] = a.w.gamma2[cc] * inv2[cc] * (g - s_gm[cc] - xh * s_gxm[cc]);
+            scratch[r * CM_SCR + cc] = s_g2[cc] * inv2[cc] * (g - s_gm[cc] - xh * s_gxm[cc]);
         }
         __syncthreads();
     }
     // ---- hidden layer 2, 64 rows at a time: dW2 = dz2^T h1;  g1 = (dz2 W2) mask1 (-> scratch) and its BatchNorm sums
     {
-        float* s_h1 = s_in;
-        float* s_k1 = s_in + CM_TILE * CM_LDH;
-        float* s_x1 = s_in + 2 * CM_TILE * CM_LDH;
+        float* s_h1 = SMALL ? s_hkx : s_in;                                  // (SMALL: s_in keeps the input tile staged at the top)
+        float* s_k1 = s_h1 + CM_TILE * CM_LDH;
+        float* s_x1 = s_h1 + 2 * CM_TILE * CM_LDH;
         const int wo = (t & 511) >> 5, wi = t & 31, whalf = t >> 9;         // dW2[wo][wi], rows 32 * whalf .. + 32 of the tile
         const int c = t & 31, part = t >> 5;                                 // g1 column c, rows part and part + 32 of the tile
         float dw2 = 0.f, sg = 0.f, sgx = 0.f;
@@ -340,7 +539,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
             }
             {
                 const int r = t >> 4, o = t & 15;
-                s_dz[r * CM_LDZ2 + o] = row0 + r < R ? a.scratch[(row0 + r) * CM_SCR + o] : 0.f;
+                s_dz[r * CM_LDZ2 + o] = row0 + r < R ? scratch[(row0 + r) * CM_SCR + o] : 0.f;
             }
             __syncthreads();
 #pragma unroll 8
@@ -354,7 +553,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
                 const float g = gp * s_k1[r * CM_LDH + c];
                 sg += g;
                 sgx += g * s_x1[r * CM_LDH + c];
-                if (row0 + r < R) a.scratch[(row0 + r) * CM_SCR + CM_H2 + c] = g;
+                if (row0 + r < R) scratch[(row0 + r) * CM_SCR + CM_H2 + c] = g;
             }
         }
         s_red[0][t] = sg; s_red[1][t] = sgx; s_red[2][t] = dw2;
@@ -373,8 +572,8 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
         for (int e = t; e < R * CM_H1; e += CM_THREADS) {
             const int r = e >> 5, cc = e & 31;
             const float xh = (z1[e] - mean1[cc]) * inv1[cc];
-            float* p = a.scratch + r * CM_SCR + CM_H2 + cc;
-            *p = a.w.gamma1[cc] * inv1[cc] * (*p - s_gm[cc] - xh * s_gxm[cc]);
+            float* p = scratch + r * CM_SCR + CM_H2 + cc;
+            *p = s_g1[cc] * inv1[cc] * (*p - s_gm[cc] - xh * s_gxm[cc]);
         }
     }
     // ---- first layer, 64 rows at a time: dW1 = dz1^T in;  d in = dz1 W1 -> d lm, d shape_feats
@@ -386,10 +585,10 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         for (int row0 = 0; row0 < R; row0 += CM_TILE) {
             __syncthreads();
-            stage_inputs(lm, a.lm_stride, coords, row0, R, s_in);
+            if (!SMALL) stage_inputs(lm, a.lm_stride, coords, row0, R, s_in);
             for (int e = t; e < CM_TILE * CM_H1; e += CM_THREADS) {
                 const int r = e >> 5, i = e & 31;
-                s_dz[r * CM_LDH + i] = row0 + r < R ? a.scratch[(row0 + r) * CM_SCR + CM_H2 + i] : 0.f;
+                s_dz[r * CM_LDH + i] = row0 + r < R ? scratch[(row0 + r) * CM_SCR + CM_H2 + i] : 0.f;
             }
             __syncthreads();
 #pragma unroll 4
@@ -412,7 +611,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
                 float acc = 0.f;
 #pragma unroll
                 for (int o = 0; o < CM_H1; ++o) acc += s_dz[r * CM_LDH + o] * s_w1[o * CM_LDW1 + i];
-                if (row0 + r < R) a.scratch[(row0 + r) * CM_SCR + CM_H2 + CM_H1 + (t & 7)] = acc;
+                if (row0 + r < R) scratch[(row0 + r) * CM_SCR + CM_H2 + CM_H1 + (t & 7)] = acc;
             }
         }
         *reinterpret_cast<f32x4*>(a.grads + CG_DW1 + o0 * CM_IN + 4 * q0) = acc0;
@@ -422,7 +621,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
     // ---- d coords: through the clamp directly, as "the other landmark" k = m of all 4 rows of the frame (+), and as
     //      "self" of row m for all k (-)
     if (a.dcoords) {
-        const float* dsf = a.scratch + CM_H2 + CM_H1;
+        const float* dsf = scratch + CM_H2 + CM_H1;
         for (int e = t; e < R * 2; e += CM_THREADS) {
             const int r = e >> 1, d = e & 1, f4 = r & ~3, m = r & 3;
             float acc = dd(r, d);
@@ -470,7 +669,39 @@ int eg_coord_mlp_fwd_rows(const float* lm, int64_t lm_frame_stride, float* lm_co
     a.rm1 = P->running_mean1; a.rv1 = P->running_var1; a.rm2 = P->running_mean2; a.rv2 = P->running_var2;
     a.eps1 = P->eps1; a.eps2 = P->eps2; a.mom1 = P->momentum1; a.mom2 = P->momentum2; a.cmax = (float)(frame - 1);
     a.z1 = z1; a.z2 = z2; a.bn = bn; a.pre = pre; a.newc = new_coords;
-    hipLaunchKernelGGL(k_coord_mlp_fwd, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a);
+    if (a.rows <= CM_TILE) hipLaunchKernelGGL(k_coord_update_fwd_small, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a, CoordSample{});
+    else hipLaunchKernelGGL(k_coord_mlp_fwd, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a);
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_coord_update_fwd(float* h, int64_t n_per_frame, int64_t coord_base, int64_t main_base, const float* coords, int batch,
+                        const eg_cls_train_params* P, int train, int frame, int resample, float* lm_copy, float* z1, float* z2, float* bn,
+                        float* pre, float* new_coords, eg_stream_t stream) {
+    if (!h) return set_error(EG_ERR_ARG, "NULL argument");
+    if (batch < 1 || frame < 1 || coord_base < 0 || coord_base + 4 > n_per_frame || main_base < 0 || main_base + (int64_t)frame * frame > n_per_frame ||
+        (coord_base < main_base + (int64_t)frame * frame && coord_base + 4 > main_base))
+        return set_error(EG_ERR_ARG, "bad batch / frame / row ranges");
+    float* rows = h + (size_t)coord_base * C;
+    if (!resample || 4 * batch > CM_TILE) {
+        if (int rc = eg_coord_mlp_fwd_rows(rows, n_per_frame * C, lm_copy, coords, batch, P, train, frame, z1, z2, bn, pre, new_coords, stream)) return rc;
+        if (!resample) return EG_OK;
+        return eg_bilinear4_fwd_rows(h, new_coords, batch, 4, n_per_frame, main_base, frame, rows, n_per_frame * C, stream);
+    }
+    // (argument checks of the MLP: the same as eg_coord_mlp_fwd_rows)
+    if (!coords || !z1 || !z2 || !bn || !new_coords || !params_ok(P)) return set_error(EG_ERR_ARG, "NULL argument");
+    if (!train && (!P->running_mean1 || !P->running_var1 || !P->running_mean2 || !P->running_var2))
+        return set_error(EG_ERR_ARG, "eval mode needs the running statistics");
+    if (!(P->p1 >= 0.f && P->p1 < 1.f && P->p2 >= 0.f && P->p2 < 1.f)) return set_error(EG_ERR_ARG, "dropout p must be in [0, 1)");
+    if (train) { if (int rc_ = eg_epoch_required(P->p1 > P->p2 ? P->p1 : P->p2)) return rc_; }
+    CoordMlpFwd a{};
+    a.lm = rows; a.lm_stride = n_per_frame * C; a.lm_copy = lm_copy; a.coords = coords; a.rows = 4 * batch; a.train = train ? 1 : 0;
+    a.w = weights_of(P, train != 0);
+    a.rm1 = P->running_mean1; a.rv1 = P->running_var1; a.rm2 = P->running_mean2; a.rv2 = P->running_var2;
+    a.eps1 = P->eps1; a.eps2 = P->eps2; a.mom1 = P->momentum1; a.mom2 = P->momentum2; a.cmax = (float)(frame - 1);
+    a.z1 = z1; a.z2 = z2; a.bn = bn; a.pre = pre; a.newc = new_coords;
+    const CoordSample sp{h, rows, (long long)n_per_frame, (long long)main_base, (long long)n_per_frame * C, frame};
+    hipLaunchKernelGGL(k_coord_update_fwd_small, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a, sp);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }
@@ -492,7 +723,52 @@ int eg_coord_mlp_bwd_rows(const float* dnew_coords, const float* lm, const float
     a.w = weights_of(P, true);
     a.cmax = (float)(frame - 1);
     a.scratch = scratch; a.dlm = dlm; a.dlm_stride = dlm_frame_stride; a.dlm_acc = dlm_accumulate ? 1 : 0; a.dcoords = dcoords; a.grads = grads;
-    hipLaunchKernelGGL(k_coord_mlp_bwd, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a);
+    if (a.rows <= CM_TILE) hipLaunchKernelGGL(k_coord_mlp_bwd<true>, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a, CoordResampleBwd{});
+    else hipLaunchKernelGGL(k_coord_mlp_bwd<false>, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a, CoordResampleBwd{});
+    EG_HIP_TRY(hipGetLastError());
+    return EG_OK;
+}
+
+int eg_coord_update_bwd(float* dx, int64_t n_per_frame, int64_t coord_base, int64_t main_base, const float* h, const float* new_coords,
+                        const float* dnew_coords, const float* lm, const float* coords, int batch, const eg_cls_train_params* P, int frame,
+                        const float* z1, const float* z2, const float* bn, const float* pre, float* scratch, float* dbil,
+                        const eg_lower_sums* lower, float* tap_sums, float* dcoords, float* grads, eg_stream_t stream) {
+    if (!dx || !h || !new_coords || !lm || !coords || !z1 || !z2 || !bn || !pre || !scratch || !dbil || !grads || !params_ok(P))
+        return set_error(EG_ERR_ARG, "NULL argument");
+    if (batch < 1 || frame < 1 || batch > (1 << 20) || coord_base < 0 || coord_base + 4 > n_per_frame || main_base < 0 ||
+        main_base + (int64_t)frame * frame > n_per_frame || (coord_base < main_base + (int64_t)frame * frame && coord_base + 4 > main_base))
+        return set_error(EG_ERR_ARG, "bad batch / frame / row ranges");
+    if (lower && (!lower->z || !lower->bn || !tap_sums)) return set_error(EG_ERR_ARG, "NULL argument (lower sums)");
+    if (lower && (lower->dropout_p < 0.f || lower->dropout_p >= 1.f)) return set_error(EG_ERR_ARG, "dropout_p must be in [0, 1)");
+    float* rows = dx + (size_t)coord_base * C;
+    if (4 * batch > CM_TILE) {
+        // three launches: the resampling's backward (d coords -> dbil), then the MLP's with d new_coords = dnew_coords + dbil
+        int rc = lower ? eg_bilinear4_bwd_rows_sums(rows, n_per_frame * C, h, new_coords, batch, 4, n_per_frame, main_base, frame, dx, dbil, lower, tap_sums, stream)
+                       : eg_bilinear4_bwd_rows(rows, n_per_frame * C, h, new_coords, batch, 4, n_per_frame, main_base, frame, dx, dbil, stream);
+        if (rc) return rc;
+        if (int rc_ = eg_epoch_required(P->p1 > P->p2 ? P->p1 : P->p2)) return rc_;
+        CoordMlpBwd a{};
+        a.dnew = dnew_coords; a.dnew2 = dbil; a.lm = lm; a.lm_stride = 4 * C; a.coords = coords; a.pre = pre; a.z1 = z1; a.z2 = z2; a.bn = bn; a.rows = 4 * batch;
+        a.w = weights_of(P, true);
+        a.cmax = (float)(frame - 1);
+        a.scratch = scratch; a.dlm = rows; a.dlm_stride = n_per_frame * C; a.dlm_acc = 0; a.dcoords = dcoords; a.grads = grads;
+        hipLaunchKernelGGL(k_coord_mlp_bwd<false>, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a, CoordResampleBwd{});
+        EG_HIP_TRY(hipGetLastError());
+        return EG_OK;
+    }
+    float pmax = P->p1 > P->p2 ? P->p1 : P->p2;
+    if (lower && lower->dropout_p > pmax) pmax = lower->dropout_p;
+    if (int rc_ = eg_epoch_required(pmax)) return rc_;
+    CoordMlpBwd a{};
+    a.dnew = dnew_coords; a.lm = lm; a.lm_stride = 4 * C; a.coords = coords; a.pre = pre; a.z1 = z1; a.z2 = z2; a.bn = bn; a.rows = 4 * batch;
+    a.w = weights_of(P, true);
+    a.cmax = (float)(frame - 1);
+    a.scratch = scratch; a.dlm = rows; a.dlm_stride = n_per_frame * C; a.dlm_acc = 0; a.dcoords = dcoords; a.grads = grads;
+    CoordResampleBwd rb{h, new_coords, dx, (long long)n_per_frame, (long long)main_base, (long long)coord_base, frame, TapSums{}};
+    if (lower)
+        rb.ts = TapSums{lower->z, lower->bn, lower->relu, lower->dropout_p, lower->dropout_p > 0.f ? 1.0f / (1.0f - lower->dropout_p) : 1.0f,
+                        (unsigned long long)lower->seed, eg_epoch_ptr(), tap_sums};
+    hipLaunchKernelGGL(k_coord_mlp_bwd<true>, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a, rb);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

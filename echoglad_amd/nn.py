@@ -299,10 +299,7 @@ def _coord_update_fwd(h, coords_prev, dims, mlp_cfg, mlp_params, want_backward=T
     flat = coords_prev.reshape(B * 4, 2).contiguous()
     # the MLP reads the coordinate rows where they live (and leaves the packed copy the backward needs: the rows change below),
     # the samples are written straight into them: no gather / scatter launches around the two kernels
-    lm = torch.empty(B * 4, C, dtype=torch.float32, device=h.device)
-    new, saved = ops.coord_mlp_fwd(lm, flat, B, P, True, frame, want_backward, in_rows=(h, n, coord_base))
-    if sample:
-        ops.bilinear4_fwd(h, new, B, n, main_base, frame, out_rows=(h, n, coord_base))
+    new, lm, saved = ops.coord_update_fwd(h, flat, B, n, coord_base, main_base, P, True, frame, want_backward, resample=sample)
     return new, (lm, flat, saved, {k: v for k, v in P.items() if not k.startswith("running")})
 
 
@@ -312,21 +309,19 @@ def _coord_update_bwd(dx, dcoords_new, h, new, lm, flat, saved, P, dims, need_dp
     lower: dx is the dy of a layer whose BatchNorm-backward sums were taken before this call (ops.gcn_layer_bwd(lower=)): the sums
     of what the 16 taps per frame add are returned as taps [B,2,128]."""
     B, n, main_base, frame, coord_base = dims
-    total = dcoords_new
-    taps = None
     if sampled_rows_used:
-        # the sampled rows' gradient is read where it lies (the coordinate rows of dx), 16 taps per frame go into dx's main-grid
-        # rows; the coordinate rows themselves are overwritten below (their old values were overwritten in the forward)
-        dbil = ops.bilinear4_bwd(None, h, new, B, n, main_base, frame, dh=dx, want_dcoords=True, dout_rows=(dx, n, coord_base),
-                                 lower=lower)
-        if lower is not None:
-            dbil, taps = dbil
-        total = dbil if total is None else total + dbil
+        # the sampled rows' gradient is read where it lies (the coordinate rows of dx), 16 taps per frame go into dx's main-grid rows,
+        # d lm is written into the coordinate rows (their old values were overwritten in the forward): one launch up to batch 16
+        dprev, g, taps = ops.coord_update_bwd(dx, None if dcoords_new is None else dcoords_new.contiguous().view(B * 4, 2), h, new, lm, flat, B, n,
+                                              coord_base, main_base, P, frame, saved, need_dprev, lower=lower)
+        return dprev, g, taps
+    total = dcoords_new
     if total is None:
         total = torch.zeros(B * 4, 2, dtype=torch.float32, device=dx.device)
-    # d lm goes straight into the coordinate rows: they fed the MLP and nothing else (= when their samples were used, += otherwise)
+    # d lm is ADDED to the coordinate rows: they fed the MLP and nothing else, and their samples were not used
     _, dprev, g = ops.coord_mlp_bwd(total.contiguous().view(B * 4, 2), lm, flat, B, P, frame, saved, True, need_dprev,
-                                    out_rows=(dx, n, coord_base), accumulate=not sampled_rows_used)
+                                    out_rows=(dx, n, coord_base), accumulate=True)
+    taps = None
     return dprev, g, taps
 
 

@@ -730,6 +730,62 @@ def coord_mlp_bwd(dnew, lm, coords, batch: int, P: dict, frame: int, saved, need
     return dlm, dcoords, grads
 
 
+def coord_update_fwd(h, coords, batch: int, n_per_frame: int, coord_base: int, main_base: int, P: dict, train: bool, frame: int,
+                     want_backward: bool, resample: bool = True):
+    """The coordinate update of one GNN layer on the node array IN PLACE (eg_coord_update_fwd: models.py:438-473): the landmark MLP on
+    the 4 coordinate rows of every frame of h, then (resample) those rows overwritten with the main grid sampled at the new positions.
+    One launch up to batch 16.  -> (new_coords [4*batch,2], lm = packed copy of the rows the MLP read, saved = (z1, z2, bn, pre) | None)"""
+    rows = 4 * batch
+    _check_rows(h, "h", batch * n_per_frame)
+    _check_coords(coords, batch, 4)
+    for k, shape in (("w1", (32, C + 8)), ("w2", (16, 32)), ("w3", (2, 16))):
+        if tuple(P[k].shape) != shape:
+            raise RuntimeError(f"coordinate MLP {k} must be {shape}, got {tuple(P[k].shape)}")
+    dev = h.device
+    lm = torch.empty(rows, C, dtype=torch.float32, device=dev)
+    z1 = torch.empty(rows, 32, dtype=torch.float32, device=dev)
+    z2 = torch.empty(rows, 16, dtype=torch.float32, device=dev)
+    bn = torch.empty(96, dtype=torch.float32, device=dev)
+    pre = torch.empty(rows, 2, dtype=torch.float32, device=dev) if want_backward else None
+    new = torch.empty(rows, 2, dtype=torch.float32, device=dev)
+    s = _cls_params(P)
+    _lib.check(_lib.load().eg_coord_update_fwd(_ptr(h), n_per_frame, coord_base, main_base, _ptr(coords), batch, ct.byref(s), int(train),
+                                               frame, int(bool(resample)), _ptr(lm), _ptr(z1), _ptr(z2), _ptr(bn), _ptr(pre), _ptr(new),
+                                               _stream()), "eg_coord_update_fwd")
+    return new, lm, ((z1, z2, bn, pre) if want_backward else None)
+
+
+def coord_update_bwd(dx, dnew, h, new, lm, coords, batch: int, n_per_frame: int, coord_base: int, main_base: int, P: dict, frame: int,
+                     saved, need_dcoords: bool, lower=None):
+    """Backward of coord_update_fwd(resample=True) on the gradient array dx IN PLACE (eg_coord_update_bwd): dx is the gradient w.r.t. the
+    tensor after the update and leaves as the gradient w.r.t. the tensor before it.  dnew: d new_coords from downstream or None;
+    h: the tensor the samples were taken from (after the update); lower as in bilinear4_bwd.
+    -> (dcoords | None, grads [5042], taps [batch,2,128] | None).  One launch up to batch 16."""
+    rows = 4 * batch
+    z1, z2, bn, pre = saved
+    _check_rows(dx, "dx", batch * n_per_frame)
+    _check_rows(h, "h", batch * n_per_frame)
+    if dnew is not None and (not dnew.is_cuda or dnew.dtype != torch.float32 or not dnew.is_contiguous() or dnew.numel() != rows * 2):
+        raise RuntimeError(f"dnew must be contiguous CUDA float32 with {rows * 2} elements")
+    dev = dx.device
+    scratch = torch.empty(rows, 56, dtype=torch.float32, device=dev)
+    dbil = torch.empty(rows, 2, dtype=torch.float32, device=dev)
+    dcoords = torch.empty(rows, 2, dtype=torch.float32, device=dev) if need_dcoords else None
+    grads = torch.empty(COORD_MLP_GRADS_FLOATS, dtype=torch.float32, device=dev)
+    taps, ls = None, None
+    if lower is not None:
+        lz, lbn, lrelu, lp, lseed = lower[:5]
+        _check_rows(lz, "lower z", batch * n_per_frame)
+        taps = torch.empty(batch, 2, C, dtype=torch.float32, device=dev)
+        ls = ct.byref(_lib.LowerSums(_ptr(lz), _ptr(lbn), int(lrelu), float(lp), int(lseed) & 0xFFFFFFFFFFFFFFFF, 0, None, None))
+    s = _cls_params(P)
+    _lib.check(_lib.load().eg_coord_update_bwd(_ptr(dx), n_per_frame, coord_base, main_base, _ptr(h), _ptr(new), _ptr(dnew), _ptr(lm),
+                                               _ptr(coords), batch, ct.byref(s), frame, _ptr(z1), _ptr(z2), _ptr(bn), _ptr(pre),
+                                               _ptr(scratch), _ptr(dbil), ls, _ptr(taps), _ptr(dcoords), _ptr(grads), _stream()),
+               "eg_coord_update_bwd")
+    return dcoords, grads, taps
+
+
 # ---------------------------------------------------------------------------
 # coordinate-graph resampling
 # ---------------------------------------------------------------------------

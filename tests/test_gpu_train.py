@@ -455,6 +455,85 @@ def test_coordinate_mlp_kernels_vs_torch_autograd(p, B, frame):
         assert torch.allclose(b1, b2, rtol=1e-4, atol=1e-5), n1
 
 
+@pytest.mark.parametrize("B,frame,naux,p,with_lower", [(1, 16, 3, 0.5, True), (3, 30, 3, 0.3, False), (16, 16, 3, 0.5, True),
+                                                       (20, 16, 3, 0.5, True), (2, 32, 4, 0.0, False)])
+def test_coordinate_update_in_one_launch_equals_the_separate_launches(B, frame, naux, p, with_lower):
+    """eg_coord_update_fwd / _bwd (up to batch 16: ONE single-workgroup launch each -- landmark MLP + resampling, everything in LDS,
+    the resampling's backward with all loads up front and its read-modify-writes resolved in registers; above: the launches below)
+    against eg_coord_mlp_fwd_rows + eg_bilinear4_fwd_rows and eg_bilinear4_bwd_rows[_sums] + add + eg_coord_mlp_bwd_rows.  Landmarks
+    on the same pixel, on integer positions and on the border: the taps collide."""
+    from echoglad_amd.topology import TopologySpec, get_topology
+    topo = get_topology(TopologySpec(frame, naux, False, True))
+    n, main_base, coord_base = topo.num_nodes, topo.main.base, topo.coord_base
+    hip, _ = model_pair(16, 3, 1, coord=True, seed=3 + B)
+    mlp = hip.node_coordinate_mlp[0]
+    mlp[3].p = mlp[7].p = p
+    hip.train()
+    from echoglad_amd.nn import _MLP_NAMES
+    cfg, params = hip._coord_mlp_train_cfg(mlp)
+    P = dict(cfg)
+    P.update({k: q.detach().contiguous() for k, q in zip(_MLP_NAMES, params)})
+    P = dict(P)
+    P.update(seed1=101, seed2=202)
+    running = [k for k in P if k.startswith("running") and P[k] is not None]
+    running0 = {k: P[k].clone() for k in running}
+    rs = np.random.RandomState(5 + B)
+    h0 = rand_rows(B * n, seed=21).to(DEV)
+    c = rs.uniform(-0.5, frame - 0.5, (B, 4, 2)).astype(np.float32)
+    c[0, 1] = c[0, 0]                                   # two landmarks on the same position
+    c[0, 2] = np.floor(c[0, 2])                         # integer position: two taps of weight 0
+    c[-1, 3] = [frame - 1, 0]                           # on the border
+    c0 = torch.from_numpy(c.reshape(B * 4, 2)).to(DEV)
+
+    def forward(fused):
+        h = h0.clone()
+        for k in running:
+            P[k] = running0[k].clone()
+        if fused:
+            new, lm, saved = ops.coord_update_fwd(h, c0, B, n, coord_base, main_base, P, True, frame, True)
+        else:
+            lm = torch.empty(B * 4, 128, device=DEV)
+            new, saved = ops.coord_mlp_fwd(lm, c0, B, P, True, frame, True, in_rows=(h, n, coord_base))
+            ops.bilinear4_fwd(h, new, B, n, main_base, frame, out_rows=(h, n, coord_base))
+        return h, new, lm, saved, {k: P[k].clone() for k in running}
+
+    ha, na, lma, sa, ra = forward(True)
+    hb, nb, lmb, sb, rb = forward(False)
+    assert torch.equal(lma, lmb)
+    for u, v in zip(sa, sb):
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(na, nb, rtol=1e-5, atol=1e-5) and torch.allclose(ha, hb, rtol=1e-5, atol=1e-5)
+    for k in running:
+        assert torch.allclose(ra[k], rb[k], rtol=1e-5, atol=1e-7), k
+    # the backward, both ways from the SAME forward state (the separate launches')
+    dx0 = rand_rows(B * n, seed=23).to(DEV)
+    dnew = torch.from_numpy(rs.standard_normal((B * 4, 2)).astype(np.float32)).to(DEV)
+    lower = None
+    if with_lower:
+        lz = rand_rows(B * n, seed=25).to(DEV)
+        lbn = torch.cat([lz.mean(0), 1.0 / lz.std(0), torch.ones(128, device=DEV) * 0.9, torch.zeros(128, device=DEV) + 0.05]).contiguous()
+        lower = (lz, lbn, True, 0.3, 999)
+    for dn in (dnew, None):
+        dxa = dx0.clone()
+        dpa, ga, ta = ops.coord_update_bwd(dxa, dn, hb, nb, lmb, c0, B, n, coord_base, main_base, P, frame, sb, True, lower=lower)
+        dxb = dx0.clone()
+        dbil = ops.bilinear4_bwd(None, hb, nb, B, n, main_base, frame, dh=dxb, want_dcoords=True, dout_rows=(dxb, n, coord_base), lower=lower)
+        tb = None
+        if lower is not None:
+            dbil, tb = dbil
+        total = dbil if dn is None else dn + dbil
+        _, dpb, gb = ops.coord_mlp_bwd(total.contiguous(), lmb, c0, B, P, frame, sb, True, True, out_rows=(dxb, n, coord_base), accumulate=False)
+        scale = float(dxb.abs().max())
+        assert float((dxa - dxb).abs().max()) <= 2e-5 * scale
+        assert float((dpa - dpb).abs().max()) <= 2e-5 * float(dpb.abs().max()) + 1e-6
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-6
+        if lower is not None:
+            assert float((ta - tb).abs().max()) <= 2e-5 * float(tb.abs().max()) + 1e-6
+        dxc = dx0.clone()
+        again = ops.coord_update_bwd(dxc, dn, hb, nb, lmb, c0, B, n, coord_base, main_base, P, frame, sb, True, lower=lower)
+        assert torch.equal(dxc, dxa) and torch.equal(again[0], dpa) and torch.equal(again[1], ga)      # run to run: the same bits
+
+
 def test_coordinate_mlp_kernel_eval_mode_and_fallbacks():
     """train == 0: running statistics, no dropout (== the torch modules in eval mode); module states the kernel does not
     implement fall back to the modules (None)."""
