@@ -1190,25 +1190,65 @@ __global__ void k_zero_rows(float* __restrict__ x, int batch, int stride, int lo
     }
 }
 
-__global__ void k_cls_grads_final(const double* __restrict__ tot_out, const double* __restrict__ tot_dw2, const double* __restrict__ tot_bn1,
-                                  float* __restrict__ grads) {
-    // grads layout: eg_classifier_bwd in the header
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    float* dw2 = grads + 128 * 128 + 3 * 128;
+// Behind the mid kernel, ONE launch (it was four): both of its column reductions (k_reduce_f32_partials' arithmetic: dW2 -> grads; the
+// first layers' BatchNorm-backward sums -> tot_bn1 for the first-layers kernel and dgamma1 / dbeta1 -> grads), the packing of the
+// third layers' totals into grads (k_cls_grads_final's) and the zeroing of dh's rows outside the heads' filter (k_zero_rows').
+// Workgroups: 64 (dW2, 2048 columns) + 8 (256 columns) + 1.
+struct MidFinal {
+    const float *partial2, *partial_bn1;
+    int gb;
+    const double* tot_out;
+    double* tot_bn1;
+    float* grads;
+    float* dh;                      // nullable: nothing to zero
+    int batch, stride, lo, n_valid;
+};
+__global__ __launch_bounds__(RED_F32_THREADS) void k_cls_mid_final(const MidFinal a) {
+    __shared__ double red[RED_F32_THREADS];
+    const int t = threadIdx.x, sl = t >> 5;
+    float* dw2 = a.grads + 128 * 128 + 3 * 128;
     float* tail = dw2 + 4 * 16 * 32;                        // db2[64], dgamma2[64], dbeta2[64], dw3[64], db3[4]
-    if (t < 4 * 16 * 32) dw2[t] = (float)tot_dw2[t];
-    if (t < H2) {
-        tail[t] = 0.f;                                      // db2: a bias in front of a train-mode BatchNorm
-        tail[H2 + t] = (float)tot_out[H2 + t];              // dgamma2 = sum g2 xhat2
-        tail[2 * H2 + t] = (float)tot_out[t];               // dbeta2 = sum g2
-        tail[3 * H2 + t] = (float)tot_out[2 * H2 + t];      // dw3
+    constexpr int NB2 = 4 * 16 * 32 / 32, NB1 = 2 * H1 / 32;
+    if (blockIdx.x == NB2 + NB1) {
+        if (t < H2) {
+            tail[t] = 0.f;                                      // db2: a bias in front of a train-mode BatchNorm
+            tail[H2 + t] = (float)a.tot_out[H2 + t];            // dgamma2 = sum g2 xhat2
+            tail[2 * H2 + t] = (float)a.tot_out[t];             // dbeta2 = sum g2
+            tail[3 * H2 + t] = (float)a.tot_out[2 * H2 + t];    // dw3
+        }
+        if (t < 4) tail[4 * H2 + t] = (float)a.tot_out[3 * H2 + t];
+        if (t < 128) a.grads[128 * 128 + t] = 0.f;              // db1
+        if (a.dh) {
+            // rows [0, lo) and [lo + n_valid, stride) of every frame (the rows the node-type filter drops: their gradient is zero)
+            const int per = a.stride - a.n_valid;
+            const long long n4 = (long long)a.batch * per * (C / 4);
+            for (long long i = t; i < n4; i += RED_F32_THREADS) {
+                const long long rr = i / (C / 4);
+                const int f = (int)(rr / per), k = (int)(rr - (long long)f * per);
+                const int row = k < a.lo ? k : a.n_valid + k;
+                *reinterpret_cast<f32x4*>(a.dh + ((size_t)f * a.stride + row) * C + (i % (C / 4)) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        return;
     }
-    if (t < 4) tail[4 * H2 + t] = (float)tot_out[3 * H2 + t];
-    if (t < 128) {
-        grads[128 * 128 + t] = 0.f;                         // db1
-        grads[128 * 128 + 128 + t] = (float)tot_bn1[H1 + t];      // dgamma1 = sum g1 xhat1
-        grads[128 * 128 + 256 + t] = (float)tot_bn1[t];           // dbeta1 = sum g1
+    const bool second = blockIdx.x >= NB2;
+    const float* __restrict__ partial = second ? a.partial_bn1 : a.partial2;
+    const int n = second ? 2 * H1 : 4 * 16 * 32;
+    const int col = (second ? blockIdx.x - NB2 : blockIdx.x) * 32 + (t & 31);
+    double s = 0.0;
+    for (int b = sl; b < a.gb; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * n + col];
+    red[t] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = RED_F32_THREADS / 64; st > 0; st >>= 1) {
+        if (sl < st) red[t] += red[t + 32 * st];
+        __syncthreads();
     }
+    if (sl != 0) return;
+    if (!second) { dw2[col] = (float)red[t]; return; }
+    a.tot_bn1[col] = red[t];
+    if (col < H1) a.grads[128 * 128 + 256 + col] = (float)red[t];           // dbeta1 = sum g1
+    else a.grads[128 * 128 + 128 + col - H1] = (float)red[t];               // dgamma1 = sum g1 xhat1
 }
 
 static int grid_for(long long work_items, int per_block, int cap) {
@@ -1361,14 +1401,14 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
     const bool masked = fused;                        // the masked gradient is handed over (the unfused route below applies the mask itself)
     hipLaunchKernelGGL(masked ? k_cls_mid_bwd<true> : k_cls_mid_bwd<false>, dim3(gb), dim3(CT_THREADS), 0, stream, dlogits, z2, z1, rows,
                        bn1, d1, bn2, d2, P->w2, P->w3, totals, dh1_scratch, partial2, partial_bn1);
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(4 * 16 * 32 / 32), dim3(RED_F32_THREADS), 0, stream, partial2, gb, 4 * 16 * 32, totals + 256);
-    hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(RED_F32_THREADS), 0, stream, partial_bn1, gb, 2 * H1, tot_bn1);
-    hipLaunchKernelGGL(k_cls_grads_final, dim3(8), dim3(256), 0, stream, totals, totals + 256, tot_bn1, grads);
+    {
+        const MidFinal mf{partial2, partial_bn1, gb, totals, tot_bn1, grads, (fused && n_valid < n_per_frame) ? dh : nullptr, batch, (int)n_per_frame,
+                          (int)row_lo, (int)n_valid};
+        hipLaunchKernelGGL(k_cls_mid_final, dim3(4 * 16 * 32 / 32 + 2 * H1 / 32 + 1), dim3(RED_F32_THREADS), 0, stream, mf);
+    }
     EG_HIP_TRY(hipGetLastError());
     // ---- first layers: dz1 formed on the fly, dW1 = dz1^T h[valid rows] and dh[valid rows] = dz1 W1 in ONE kernel
     if (fused) {
-        if (n_valid < n_per_frame)
-            hipLaunchKernelGGL(k_zero_rows, dim3(64), dim3(256), 0, stream, dh, batch, (int)n_per_frame, (int)row_lo, (int)n_valid);
         {
             static std::atomic<bool> attr_set[64];
             int dev = 0;
@@ -1402,11 +1442,13 @@ static int classifier_bwd(const float* dlogits, const float* h, int batch, int64
             fa.la.inv_keep = ls->p > 0.f ? 1.0f / (1.0f - ls->p) : 1.0f; fa.la.seed = ls->seed; fa.la.epoch = eg_epoch_ptr();
             fa.partial_lsums = partial_bn1;                                       // (reduced into tot_bn1 already)
             hipLaunchKernelGGL((fa.direct ? k_cls_first_bwd<true, true> : k_cls_first_bwd<true, false>), dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
-            hipLaunchKernelGGL(k_reduce_f32_partials, dim3(2 * H1 / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)partial_bn1, nf, 2 * H1, ls->sums);
+            // dW1 from the slabs and the layer's sums from the column partials: one launch
+            hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32 + 2 * H1 / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nf, grads,
+                               ExtraReduce{(const float*)partial_bn1, nf, 2 * H1, ls->sums});
         } else {
             hipLaunchKernelGGL((fa.direct ? k_cls_first_bwd<false, true> : k_cls_first_bwd<false, false>), dim3(nf), dim3(512), lds, stream, fa, bn1, P->beta1);
+            hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nf, grads, ExtraReduce{});
         }
-        hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nf, grads);
         EG_HIP_TRY(hipGetLastError());
         return EG_OK;
     }

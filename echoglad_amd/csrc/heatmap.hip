@@ -7,18 +7,19 @@
 //
 // The logits of a frame are [n_rows, 4] with the levels stacked row-major (2x2, 4x4, ..., FxF).  All per-level
 // statistics of one (frame, level, channel) come out of ONE pass structure:
-//   k_hm_partial  one workgroup per 2048-row chunk of a level: chunk max, first arg max, sum exp(x - max),
+//   k_hm_partial  one workgroup per 1024-row chunk of a level: chunk max, first arg max, sum exp(x - max),
 //                 sum exp * h, sum exp * w (fp64 accumulators, fixed tree order), label max / min h / min w of
 //                 the label maxima, sum of valid
 //   k_hm_final    merges the chunks of a level in order (softmax merge in fp64)
 // so the result is bitwise reproducible and independent of the grid.  Bandwidth is trivial (16 B per node).
-#include "common.h"
+#include "train_common.h"
 
 namespace eg {
 
 constexpr int HM_MAX_LEVELS = 16;
-constexpr int HM_CHUNK = 2048;
+constexpr int HM_CHUNK = 1024;
 constexpr int HM_THREADS = 256;
+constexpr int HM_RPT = HM_CHUNK / HM_THREADS;      // rows per thread
 constexpr int HM_REC = 10;          // doubles per (frame, chunk, channel): m, s, sh, sw, best, bidx, g, gh, gw, vsum
 
 struct HmLevels {
@@ -46,66 +47,106 @@ __device__ inline double wave_sum(double v) {
     for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
     return v;
 }
-__device__ inline void wave_argmax(float& v, int& idx) {           // max, LOWEST index among equal maxima
+// (by value, with selects: references into the per-channel arrays and branches around the updates kept those arrays in scratch memory --
+//  and a dispatch that needs scratch waits for its set-up: 30 us for a 5-us kernel at batch 1)
+struct ArgMax { float v; int i; };
+struct GtMax { float g; int h, w; };
+__device__ inline ArgMax wave_argmax(ArgMax a) {                   // max, LOWEST index among equal maxima
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
-        const float o = __shfl_xor(v, s); const int oi = __shfl_xor(idx, s);
-        if (o > v || (o == v && oi < idx)) { v = o; idx = oi; }
+        const float o = __shfl_xor(a.v, s); const int oi = __shfl_xor(a.i, s);
+        const bool take = o > a.v || (o == a.v && oi < a.i);
+        a.v = take ? o : a.v; a.i = take ? oi : a.i;
     }
+    return a;
 }
-__device__ inline void wave_gtmax(float& g, int& gh, int& gw) {    // max, min h and min w over all positions that hold it
+__device__ inline GtMax wave_gtmax(GtMax a) {                      // max, min h and min w over all positions that hold it
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
-        const float o = __shfl_xor(g, s); const int oh = __shfl_xor(gh, s), ow = __shfl_xor(gw, s);
-        if (o > g) { g = o; gh = oh; gw = ow; }
-        else if (o == g) { gh = min(gh, oh); gw = min(gw, ow); }
+        const float o = __shfl_xor(a.g, s); const int oh = __shfl_xor(a.h, s), ow = __shfl_xor(a.w, s);
+        const bool gt = o > a.g, eq = o == a.g;
+        a.h = gt ? oh : (eq ? min(a.h, oh) : a.h);
+        a.w = gt ? ow : (eq ? min(a.w, ow) : a.w);
+        a.g = gt ? o : a.g;
     }
+    return a;
 }
 
+__device__ inline float bce_logits(float x, float y) { return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))); }
+
+// BCE: the levels tile the frame's rows (the training step's criteria: eg_criteria_fwd checks it), so this pass sees every logit, label
+// and valid flag once anyway -- the weighted BCE's partial sums (k_bce_partial's arithmetic per element) come out of it as well, one
+// (sum, sum valid) pair per workgroup at bce_part[2 * blockIdx.x]: no pass of its own over the same three arrays.
+template <bool BCE>
 __global__ __launch_bounds__(HM_THREADS) void k_hm_partial(const float* __restrict__ logits, const float* __restrict__ y,
                                                            const float* __restrict__ valid, double* __restrict__ part,
-                                                           const HmLevels L) {
+                                                           const HmLevels L, float ones_weight, double* __restrict__ bce_part) {
     constexpr int NW = HM_THREADS / 64;
     __shared__ float s_m[NW][4], s_g[NW][4];
     __shared__ int s_bi[NW][4], s_gh[NW][4], s_gw[NW][4];
-    __shared__ double s_vs[NW][4], s_s[NW][4][3];
+    __shared__ double s_vs[NW][4], s_s[NW][4][3], s_b[NW][2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x / L.total_chunks, chunk = blockIdx.x - b * L.total_chunks;
-    int l = 0;
-    for (int k = 1; k < L.n_levels; ++k) l += chunk >= L.chunk0[k] ? 1 : 0;
-    const int side = L.side[l], n_lvl = side * side;
-    const int r0 = (chunk - L.chunk0[l]) * HM_CHUNK, r1 = min(r0 + HM_CHUNK, n_lvl);
-    const size_t base = ((size_t)b * L.n_rows + L.start[l]) * 4;
+    // (the level's entries by static indices: a run-time index into the by-value table puts the table into scratch memory, and a
+    //  dispatch that needs scratch waits for its set-up)
+    int side = L.side[0], start = L.start[0], c0 = L.chunk0[0];
+#pragma unroll
+    for (int k = 1; k < HM_MAX_LEVELS; ++k)
+        if (k < L.n_levels && chunk >= L.chunk0[k]) { side = L.side[k]; start = L.start[k]; c0 = L.chunk0[k]; }
+    const int n_lvl = side * side;
+    const int r0 = (chunk - c0) * HM_CHUNK, r1 = min(r0 + HM_CHUNK, n_lvl);
+    const size_t base = ((size_t)b * L.n_rows + start) * 4;
     const float NEG = -__builtin_inff();
 
     float m[4] = {NEG, NEG, NEG, NEG}, g[4] = {NEG, NEG, NEG, NEG};
     int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     int gh[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff}, gw[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-    double vs[4] = {0, 0, 0, 0};
-    for (int r = r0 + tid; r < r1; r += HM_THREADS) {
-        const float4 x = *reinterpret_cast<const float4*>(logits + base + (size_t)r * 4);
-        const float xv[4] = {x.x, x.y, x.z, x.w};
+    double vs[4] = {0, 0, 0, 0}, bce_a = 0, bce_v = 0;
+    // the thread's HM_RPT rows: every load of the kernel is issued here, before the first use (a loop that loads, waits and updates row
+    // after row is HM_RPT dependent memory round trips -- 2/3 of this kernel's 30 us at batch 1 with 8 rows per thread and a second
+    // pass that loaded the logits again); the logits stay in registers for the sums below
+    f32x4 xs[HM_RPT], ys[HM_RPT], vv[HM_RPT];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (xv[c] > m[c]) { m[c] = xv[c]; bi[c] = r; }        // rows ascend: first max kept
+    for (int i = 0; i < HM_RPT; ++i) {
+        const int r = r0 + tid + i * HM_THREADS;
+        const size_t o = base + (size_t)(r < r1 ? r : r0) * 4;
+        xs[i] = *reinterpret_cast<const f32x4*>(logits + o);
+        ys[i] = y ? *reinterpret_cast<const f32x4*>(y + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+        vv[i] = valid ? *reinterpret_cast<const f32x4*>(valid + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < HM_RPT; ++i) {
+        const int r = r0 + tid + i * HM_THREADS;
+        if (r >= r1) continue;
+        const float xv[4] = {xs[i].x, xs[i].y, xs[i].z, xs[i].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const bool take = xv[c] > m[c]; m[c] = take ? xv[c] : m[c]; bi[c] = take ? r : bi[c]; }   // rows ascend: first max kept
         if (y) {
-            const float4 t = *reinterpret_cast<const float4*>(y + base + (size_t)r * 4);
-            const float tv[4] = {t.x, t.y, t.z, t.w};
+            const float tv[4] = {ys[i].x, ys[i].y, ys[i].z, ys[i].w};
             const int h = r / side, w = r - h * side;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (tv[c] > g[c]) { g[c] = tv[c]; gh[c] = h; gw[c] = w; }
-                else if (tv[c] == g[c]) { gh[c] = min(gh[c], h); gw[c] = min(gw[c], w); }
+                const bool gt = tv[c] > g[c], eq = tv[c] == g[c];
+                gh[c] = gt ? h : (eq ? min(gh[c], h) : gh[c]);
+                gw[c] = gt ? w : (eq ? min(gw[c], w) : gw[c]);
+                g[c] = gt ? tv[c] : g[c];
             }
         }
-        if (valid) {
-            const float4 t = *reinterpret_cast<const float4*>(valid + base + (size_t)r * 4);
-            vs[0] += t.x; vs[1] += t.y; vs[2] += t.z; vs[3] += t.w;
+        if (valid) { vs[0] += vv[i].x; vs[1] += vv[i].y; vs[2] += vv[i].z; vs[3] += vv[i].w; }
+        if (BCE) {
+            const float tv[4] = {ys[i].x, ys[i].y, ys[i].z, ys[i].w}, va[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float wgt = (ones_weight > 1.0f && tv[c] == 1.0f) ? ones_weight : 1.0f;
+                bce_a += (double)(wgt * bce_logits(xv[c], tv[c])) * va[c];
+                bce_v += va[c];
+            }
         }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        wave_argmax(m[c], bi[c]);
-        if (y) wave_gtmax(g[c], gh[c], gw[c]);
+        { const ArgMax r = wave_argmax(ArgMax{m[c], bi[c]}); m[c] = r.v; bi[c] = r.i; }
+        if (y) { const GtMax r = wave_gtmax(GtMax{g[c], gh[c], gw[c]}); g[c] = r.g; gh[c] = r.h; gw[c] = r.w; }
         if (valid) vs[c] = wave_sum(vs[c]);
         if (lane == 0) { s_m[wv][c] = m[c]; s_bi[wv][c] = bi[c]; s_g[wv][c] = g[c]; s_gh[wv][c] = gh[c]; s_gw[wv][c] = gw[c]; s_vs[wv][c] = vs[c]; }
     }
@@ -115,16 +156,23 @@ __global__ __launch_bounds__(HM_THREADS) void k_hm_partial(const float* __restri
         m[c] = s_m[0][c]; bi[c] = s_bi[0][c]; g[c] = s_g[0][c]; gh[c] = s_gh[0][c]; gw[c] = s_gw[0][c]; vs[c] = s_vs[0][c];
 #pragma unroll
         for (int k = 1; k < NW; ++k) {
-            if (s_m[k][c] > m[c] || (s_m[k][c] == m[c] && s_bi[k][c] < bi[c])) { m[c] = s_m[k][c]; bi[c] = s_bi[k][c]; }
-            if (s_g[k][c] > g[c]) { g[c] = s_g[k][c]; gh[c] = s_gh[k][c]; gw[c] = s_gw[k][c]; }
-            else if (s_g[k][c] == g[c]) { gh[c] = min(gh[c], s_gh[k][c]); gw[c] = min(gw[c], s_gw[k][c]); }
+            const float om = s_m[k][c], og = s_g[k][c];
+            const int oi = s_bi[k][c], oh = s_gh[k][c], ow = s_gw[k][c];
+            const bool take = om > m[c] || (om == m[c] && oi < bi[c]);
+            m[c] = take ? om : m[c]; bi[c] = take ? oi : bi[c];
+            const bool gt = og > g[c], eq = og == g[c];
+            gh[c] = gt ? oh : (eq ? min(gh[c], oh) : gh[c]);
+            gw[c] = gt ? ow : (eq ? min(gw[c], ow) : gw[c]);
+            g[c] = gt ? og : g[c];
             vs[c] += s_vs[k][c];
         }
     }
     double s[4] = {0, 0, 0, 0}, sh[4] = {0, 0, 0, 0}, sw[4] = {0, 0, 0, 0};
-    for (int r = r0 + tid; r < r1; r += HM_THREADS) {
-        const float4 x = *reinterpret_cast<const float4*>(logits + base + (size_t)r * 4);
-        const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int i = 0; i < HM_RPT; ++i) {
+        const int r = r0 + tid + i * HM_THREADS;
+        if (r >= r1) continue;
+        const float xv[4] = {xs[i].x, xs[i].y, xs[i].z, xs[i].w};
         const int h = r / side, w = r - h * side;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -137,22 +185,42 @@ __global__ __launch_bounds__(HM_THREADS) void k_hm_partial(const float* __restri
         s[c] = wave_sum(s[c]); sh[c] = wave_sum(sh[c]); sw[c] = wave_sum(sw[c]);
         if (lane == 0) { s_s[wv][c][0] = s[c]; s_s[wv][c][1] = sh[c]; s_s[wv][c][2] = sw[c]; }
     }
+    if (BCE) {
+        bce_a = wave_sum(bce_a); bce_v = wave_sum(bce_v);
+        if (lane == 0) { s_b[wv][0] = bce_a; s_b[wv][1] = bce_v; }
+    }
     __syncthreads();
+    if (BCE && tid == 64) {
+        double A = 0, V = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { A += s_b[k][0]; V += s_b[k][1]; }
+        bce_part[2 * (size_t)blockIdx.x] = A; bce_part[2 * (size_t)blockIdx.x + 1] = V;
+    }
     if (tid < 4) {
         const int c = tid;
         double S = 0, SH = 0, SW = 0;
 #pragma unroll
         for (int k = 0; k < NW; ++k) { S += s_s[k][c][0]; SH += s_s[k][c][1]; SW += s_s[k][c][2]; }
         double* q = part + ((size_t)blockIdx.x * 4 + c) * HM_REC;
-        q[0] = m[c]; q[1] = S; q[2] = SH; q[3] = SW; q[4] = m[c]; q[5] = bi[c];
-        q[6] = g[c]; q[7] = gh[c]; q[8] = gw[c]; q[9] = vs[c];
+        // (channel c's values by selects over static indices: `m[c]` with c = tid is a run-time index, and ONE of those puts all six
+        //  per-channel arrays into scratch memory -- a dispatch that needs scratch waits for its set-up: this 5-us kernel took 30)
+        float mc = m[0], gc = g[0];
+        int bic = bi[0], ghc = gh[0], gwc = gw[0];
+        double vsc = vs[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            mc = c == k ? m[k] : mc; gc = c == k ? g[k] : gc; bic = c == k ? bi[k] : bic; ghc = c == k ? gh[k] : ghc; gwc = c == k ? gw[k] : gwc;
+            vsc = c == k ? vs[k] : vsc;
+        }
+        q[0] = mc; q[1] = S; q[2] = SH; q[3] = SW; q[4] = mc; q[5] = bic;
+        q[6] = gc; q[7] = ghc; q[8] = gwc; q[9] = vsc;
     }
 }
 
 // one WAVE per (frame, level, channel): lane k merges chunks k, k + 64, ... of the level in ascending order, the lanes merge
 // through a fixed xor tree (softmax merge in fp64)
-__global__ __launch_bounds__(256) void k_hm_final(const double* __restrict__ part, float* __restrict__ expect, float* __restrict__ stats,
-                                                  int64_t* __restrict__ argmax, float* __restrict__ gt, float* __restrict__ vmean, const HmLevels L) {
+__device__ inline void hm_final_wave(const double* __restrict__ part, float* __restrict__ expect, float* __restrict__ stats,
+                                     int64_t* __restrict__ argmax, float* __restrict__ gt, float* __restrict__ vmean, const HmLevels& L) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= L.batch * L.n_levels * 4) return;
     const int c = t & 3, l = (t >> 2) % L.n_levels, b = (t >> 2) / L.n_levels;
@@ -189,6 +257,10 @@ __global__ __launch_bounds__(256) void k_hm_final(const double* __restrict__ par
     if (gt) { gt[o * 2] = (float)gh; gt[o * 2 + 1] = (float)gw; }
     if (vmean) vmean[o] = (float)(VS / ((double)L.side[l] * L.side[l]));
 }
+__global__ __launch_bounds__(256) void k_hm_final(const double* __restrict__ part, float* __restrict__ expect, float* __restrict__ stats,
+                                                  int64_t* __restrict__ argmax, float* __restrict__ gt, float* __restrict__ vmean, const HmLevels L) {
+    hm_final_wave(part, expect, stats, argmax, gt, vmean, L);
+}
 
 // d logits[r, c] = p * ((h - E_h) * g_h + (w - E_w) * g_w),  p = exp(x - m) / s
 __global__ __launch_bounds__(HM_THREADS) void k_hm_bwd(const float* __restrict__ logits, const float* __restrict__ expect,
@@ -220,7 +292,6 @@ __global__ __launch_bounds__(HM_THREADS) void k_hm_bwd(const float* __restrict__
 // ---- weighted BCE with logits ---------------------------------------------------------------------------------
 constexpr int BCE_BLOCKS = 2048;
 
-__device__ inline float bce_logits(float x, float y) { return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))); }
 
 // 16 B per operand and lane, two float4 groups in flight per stream (one element per lane and iteration made the pass a chain
 // of dependent memory round trips: 84 us for 110 MB at batch 32); n4 = n / 4 whole groups, the last n % 4 elements by lane 0 of
@@ -348,11 +419,13 @@ struct CriteriaFinal {
     float* bce_scale;                       // w_bce / sum(valid): what every element of the BCE gradient is multiplied by
 };
 
-__global__ __launch_bounds__(128) void k_criteria_final(const CriteriaFinal a) {
+// (the first 128 threads of the workgroup work; every thread of it must come here: one barrier)
+__device__ inline void criteria_final_body(const CriteriaFinal& a) {
     __shared__ double s_part[128];
     __shared__ double s_bce[2][128];
     __shared__ double s_coord[128];
     const int t = threadIdx.x, n = a.n_levels * 8;
+    if (t >= 128) { __syncthreads(); return; }
     // ExpectedLandmarkMSE (k_elm_reduce's arithmetic)
     double part = 0.0;
     if (t < n) {
@@ -400,6 +473,14 @@ __global__ __launch_bounds__(128) void k_criteria_final(const CriteriaFinal a) {
         *a.total = (f_bce + f_elm) + f_coord;
         *a.bce_scale = a.w_bce / (float)V;
     }
+}
+__global__ __launch_bounds__(128) void k_criteria_final(const CriteriaFinal a) { criteria_final_body(a); }
+// k_hm_final and, in the workgroup that finishes last (last_workgroup_out), k_criteria_final: one launch
+__global__ __launch_bounds__(256) void k_hm_final_criteria(const double* __restrict__ part, float* __restrict__ expect, float* __restrict__ stats,
+                                                           float* __restrict__ gt, float* __restrict__ vmean, const HmLevels L,
+                                                           const CriteriaFinal a, unsigned* ticket) {
+    hm_final_wave(part, expect, stats, (int64_t*)nullptr, gt, vmean, L);
+    if (last_workgroup_out(ticket, gridDim.x)) criteria_final_body(a);
 }
 
 struct CriteriaBwd {
@@ -472,8 +553,8 @@ int eg_heatmap_expect_fwd(const float* logits, const float* labels, const float*
     int rc = fill_levels(batch, n_rows, level_start, level_side, n_levels, L);
     if (rc != EG_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_hm_partial, dim3((unsigned)(batch * L.total_chunks)), dim3(HM_THREADS), 0, s, logits,
-                       gt ? labels : nullptr, vmean ? valid : nullptr, (double*)workspace, L);
+    hipLaunchKernelGGL(k_hm_partial<false>, dim3((unsigned)(batch * L.total_chunks)), dim3(HM_THREADS), 0, s, logits,
+                       gt ? labels : nullptr, vmean ? valid : nullptr, (double*)workspace, L, 0.f, (double*)nullptr);
     const int n_out = batch * n_levels * 4;
     hipLaunchKernelGGL(k_hm_final, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, s, (const double*)workspace, expect,
                        stats, argmax, gt, vmean, L);
@@ -528,11 +609,17 @@ int eg_elm_reduce(const float* expect, const float* gt, const float* vmean, cons
     return EG_OK;
 }
 
+// (sum, sum valid) pairs of the BCE behind the heat-map records: one per heat-map workgroup, or k_bce_partial's BCE_BLOCKS
+static size_t criteria_bce_slots(int batch, size_t chunks) {
+    const size_t w = (size_t)batch * chunks;
+    return w > (size_t)BCE_BLOCKS ? w : (size_t)BCE_BLOCKS;
+}
+
 size_t eg_criteria_workspace_bytes(int batch, const int* level_side, int n_levels) {
     if (batch < 1 || !level_side || n_levels < 1 || n_levels > HM_MAX_LEVELS) return 0;
     size_t chunks = 0;
     for (int l = 0; l < n_levels; ++l) chunks += ((size_t)level_side[l] * level_side[l] + HM_CHUNK - 1) / HM_CHUNK;
-    return (size_t)batch * chunks * 4 * HM_REC * sizeof(double) + (size_t)BCE_BLOCKS * 2 * sizeof(double) +
+    return (size_t)batch * chunks * 4 * HM_REC * sizeof(double) + criteria_bce_slots(batch, chunks) * 2 * sizeof(double) +
            (size_t)batch * n_levels * 12 * sizeof(float);           // + gt [B,L,4,2] and vmean [B,L,4]
 }
 
@@ -553,21 +640,42 @@ int eg_criteria_fwd(const float* logits, const float* labels, const float* valid
     double* hm_part = (double*)workspace;
     double* bce_part = hm_part + (size_t)batch * L.total_chunks * 4 * HM_REC;
     const long long n = (long long)batch * n_rows * 4;
-    long long blocks = ((n >> 2) + 2 * HM_THREADS - 1) / (2 * HM_THREADS);
-    if (blocks < 1) blocks = 1;
-    if (blocks > BCE_BLOCKS) blocks = BCE_BLOCKS;
-    hipLaunchKernelGGL(k_bce_partial, dim3((unsigned)blocks), dim3(HM_THREADS), 0, s, logits, labels, valid, n, bce_ones_weight, bce_part);
+    // do the levels tile the frame's rows (each row in exactly one level)?  Then the heat-map pass takes the BCE's partial sums as well
+    bool tiled = true;
+    {
+        long long covered = 0;
+        for (int l = 0; l < n_levels; ++l) covered += (long long)level_side[l] * level_side[l];
+        if (covered != n_rows) tiled = false;
+        for (int l = 0; l < n_levels && tiled; ++l)
+            for (int k = 0; k < l; ++k) {
+                const long long a0 = level_start[l], a1 = a0 + (long long)level_side[l] * level_side[l];
+                const long long b0 = level_start[k], b1 = b0 + (long long)level_side[k] * level_side[k];
+                if (a0 < b1 && b0 < a1) tiled = false;
+            }
+    }
+    long long blocks = (long long)batch * L.total_chunks;
     // gt / vmean of the heat maps live behind the expectations' statistics in `stats`'s sibling buffers: the caller's d_expect doubles
     // as scratch for neither -- they are written into the tail of the workspace the final kernel reads them from
-    float* gt = (float*)(bce_part + (size_t)BCE_BLOCKS * 2);
+    float* gt = (float*)(bce_part + criteria_bce_slots(batch, L.total_chunks) * 2);
     float* vmean = gt + (size_t)batch * n_levels * 8;
-    hipLaunchKernelGGL(k_hm_partial, dim3((unsigned)(batch * L.total_chunks)), dim3(HM_THREADS), 0, s, logits, labels, valid, hm_part, L);
+    if (tiled) {
+        hipLaunchKernelGGL(k_hm_partial<true>, dim3((unsigned)(batch * L.total_chunks)), dim3(HM_THREADS), 0, s, logits, labels, valid, hm_part, L,
+                           bce_ones_weight, bce_part);
+    } else {
+        blocks = ((n >> 2) + 2 * HM_THREADS - 1) / (2 * HM_THREADS);
+        if (blocks < 1) blocks = 1;
+        if (blocks > BCE_BLOCKS) blocks = BCE_BLOCKS;
+        hipLaunchKernelGGL(k_bce_partial, dim3((unsigned)blocks), dim3(HM_THREADS), 0, s, logits, labels, valid, n, bce_ones_weight, bce_part);
+        hipLaunchKernelGGL(k_hm_partial<false>, dim3((unsigned)(batch * L.total_chunks)), dim3(HM_THREADS), 0, s, logits, labels, valid, hm_part, L,
+                           0.f, (double*)nullptr);
+    }
     const int n_out = batch * n_levels * 4;
-    hipLaunchKernelGGL(k_hm_final, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, s, (const double*)hm_part, expect, stats,
-                       (int64_t*)nullptr, gt, vmean, L);
     CriteriaFinal a{expect, gt, vmean, inv_side, batch, n_levels, w_elm, d_expect, bce_part, (int)blocks, w_bce, coord_pred, coord_y,
                     (int)n_coord, w_coord, d_coord, total, bce, elm, coord, bce_scale};
-    hipLaunchKernelGGL(k_criteria_final, dim3(1), dim3(128), 0, s, a);
+    unsigned* ticket = eg_ticket_ptr((void*)s, 1);
+    if (!ticket) return set_error(EG_ERR_HIP, "no device memory for a ticket word");
+    hipLaunchKernelGGL(k_hm_final_criteria, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, s, (const double*)hm_part, expect, stats, gt, vmean, L,
+                       a, ticket);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }

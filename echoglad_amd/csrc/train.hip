@@ -9,6 +9,7 @@
 // pass), so results are bitwise reproducible run to run: no float atomics anywhere.
 #include <stdlib.h>
 
+#include <map>
 #include <mutex>
 
 #include "train_common.h"
@@ -344,6 +345,32 @@ __global__ __launch_bounds__(1024) void k_tile_sums_stage2(const double* __restr
         sums[C + c] = (double)invstd[c] * (t1 - (double)mean[c] * s1);
     }
 }
+// Up to TILE_SUMS_SMALL tiles (batch 1 - 3 at 224 / 7): ONE launch of C / 16 workgroups, each owning 16 channels x {sum g, sum g z}:
+// thread (column, slice) sums every 32nd tile in ascending order, the 32 slices are added in a fixed tree, the sum g xhat transform
+// follows in the same workgroup.  (Two stages for a list this short are two nodes of a captured batch-1 step, ~4.5 us each whatever
+// they do; one stage for a long list is 8 workgroups pulling 37 MB at batch 32.)
+constexpr int TILE_SUMS_SMALL = 4096;
+__global__ __launch_bounds__(RED_F32_THREADS) void k_tile_sums_small(const float* __restrict__ partial, int n_tiles, const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd, double* __restrict__ sums) {
+    __shared__ double red[RED_F32_THREADS];
+    const int t = threadIdx.x, j = t & 31, sl = t >> 5;
+    const int c = blockIdx.x * 16 + (j & 15), col = (j >> 4) * C + c;          // j >> 4: 0 = sum g, 1 = sum g z
+    double s = 0.0;
+#pragma unroll 4
+    for (int b = sl; b < n_tiles; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * 2 * C + col];
+    red[t] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = RED_F32_THREADS / 64; st > 0; st >>= 1) {
+        if (sl < st) red[t] += red[t + 32 * st];
+        __syncthreads();
+    }
+    if (t < 16) {
+        const double s1 = red[t], t1 = red[t + 16];
+        sums[c] = s1;
+        sums[C + c] = (double)invstd[c] * (t1 - (double)mean[c] * s1);
+    }
+}
 
 __global__ void k_bn_bwd_final(const double* __restrict__ totals, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db) {
     const int c = threadIdx.x;
@@ -431,9 +458,25 @@ __global__ __launch_bounds__(256) void k_dweight_partial(const float* __restrict
 }
 
 // fixed-order sum of the per-workgroup slabs: workgroup = 32 elements x 8 slices of the slab list (launch with C*C/32 workgroups)
-__global__ __launch_bounds__(RED_F32_THREADS) void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw) {
+__global__ __launch_bounds__(RED_F32_THREADS) void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw, const ExtraReduce extra) {
     __shared__ double red[RED_F32_THREADS];
-    const int t = threadIdx.x, idx = blockIdx.x * 32 + (t & 31), sl = t >> 5;
+    const int t = threadIdx.x, sl = t >> 5;
+    if (blockIdx.x >= C * C / 32) {                          // the extra column reduction: k_reduce_f32_partials' arithmetic
+        const int col = (blockIdx.x - C * C / 32) * 32 + (t & 31);
+        double s = 0.0;
+        if (col < extra.n)
+            for (int b = sl; b < extra.nblocks; b += RED_F32_THREADS / 32) s += (double)extra.partial[(size_t)b * extra.n + col];
+        red[t] = s;
+        __syncthreads();
+#pragma unroll
+        for (int st = RED_F32_THREADS / 64; st > 0; st >>= 1) {
+            if (sl < st) red[t] += red[t + 32 * st];
+            __syncthreads();
+        }
+        if (sl == 0 && col < extra.n) extra.totals[col] = red[t];
+        return;
+    }
+    const int idx = blockIdx.x * 32 + (t & 31);
     double s = 0.0;
     for (int b = sl; b < nblocks; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * C * C + idx];
     red[t] = s;
@@ -610,7 +653,7 @@ int eg_launch_dweight(const float* g, const float* x, long long rows, const eg::
     const RowMap xm = xmap ? *xmap : RowMap{0, 0, 0};
     float* slabs = (float*)((char*)workspace + WS_RED_BYTES);
     hipLaunchKernelGGL(k_dweight_partial, dim3(nb), dim3(256), 0, stream, g, x, rows, slabs, xm);
-    hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nb, dw);
+    hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nb, dw, ExtraReduce{});
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }
@@ -621,6 +664,23 @@ __global__ void k_epoch_update(unsigned long long* __restrict__ e, unsigned long
 
 static std::mutex epoch_mu;
 static unsigned long long* epoch_dev[64];
+
+// tickets of last_workgroup_out (train_common.h): one zeroed word per (device, stream, slot)
+static std::mutex ticket_mu;
+static std::map<std::pair<int, void*>, unsigned*> ticket_dev;
+unsigned* eg_ticket_ptr(void* stream, int slot) {
+    int dev = 0;
+    if (slot < 0 || slot >= EG_TICKET_SLOTS || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(ticket_mu);
+    unsigned*& p = ticket_dev[{dev, stream}];
+    if (!p) {
+        unsigned* q = nullptr;
+        if (hipMalloc((void**)&q, EG_TICKET_SLOTS * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(q, 0, EG_TICKET_SLOTS * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(q); return nullptr; }
+        p = q;
+    }
+    return p + slot;
+}
 
 const unsigned long long* eg_epoch_ptr() {
     int dev = 0;
@@ -705,7 +765,7 @@ int eg_launch_bn_bwd(const float* dy, const float* z, long long rows, const floa
         // with a row map (the heads' filtered rows) the flat-address form is the faster one (1.12 vs 1.35 ms at B = 32)
         if (direct && xm.n_valid == 0) launch(k_bn_bwd_apply_dw<true, false>);
         else launch(k_bn_bwd_apply_dw<false, true>);                   // (the generic form reads the map at run time)
-        hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nd, dw);
+        hipLaunchKernelGGL(k_dweight_final, dim3(C * C / 32), dim3(RED_F32_THREADS), 0, stream, (const float*)slabs, nd, dw, ExtraReduce{});
     } else {
         long long blocks = (rows + 3) / 4;
         if (blocks > 4096) blocks = 4096;
@@ -858,10 +918,15 @@ static int gcn_layer_bwd(const eg_graph* g_bwd, int batch, const float* dy, cons
             const int chunks = n_tiles < TILE_SUM_CHUNKS ? n_tiles : TILE_SUM_CHUNKS;
             const int per = (n_tiles + chunks - 1) / chunks;
             double* chunk_sums = (double*)workspace;             // (the reduction area of the workspace: this layer's own passes are done with it)
-            hipLaunchKernelGGL(k_tile_sums_stage1, dim3(2 * C / 32, chunks), dim3(RED_F32_THREADS), 0, stream, (const float*)lower->tile_scratch,
-                               n_tiles, per, chunk_sums);
-            hipLaunchKernelGGL(k_tile_sums_stage2, dim3(1), dim3(1024), 0, stream, (const double*)chunk_sums, chunks, lower->bn, lower->bn + C,
-                               lower->sums_out);
+            if (n_tiles <= TILE_SUMS_SMALL) {
+                hipLaunchKernelGGL(k_tile_sums_small, dim3(C / 16), dim3(RED_F32_THREADS), 0, stream, (const float*)lower->tile_scratch, n_tiles,
+                                   lower->bn, lower->bn + C, lower->sums_out);
+            } else {
+                hipLaunchKernelGGL(k_tile_sums_stage1, dim3(2 * C / 32, chunks), dim3(RED_F32_THREADS), 0, stream, (const float*)lower->tile_scratch,
+                                   n_tiles, per, chunk_sums);
+                hipLaunchKernelGGL(k_tile_sums_stage2, dim3(1), dim3(1024), 0, stream, (const double*)chunk_sums, chunks, lower->bn, lower->bn + C,
+                                   lower->sums_out);
+            }
             EG_HIP_TRY(hipGetLastError());
         } else if (train_ps && residual)
             rc = eg_launch_layer_ps(g_bwd, batch, dz_scratch, W, nullptr, nullptr, dy, 0, 1, dx, nullptr, nullptr, nullptr, stream);

@@ -79,6 +79,33 @@ __device__ inline ActArgs resolved(const ActArgs& a) {
     return r;
 }
 
+// ---- "last workgroup out" --------------------------------------------------------------------------------------------------------
+// A kernel whose workgroups leave partial results for a small epilogue (a reduction of the partials, a finalisation) runs the epilogue
+// itself, in whichever workgroup arrives last, instead of leaving it to a launch of its own: every node of a captured batch-1 training
+// step costs ~4.5 us whatever it does.  Every workgroup calls this after its last global store of what the epilogue reads (all threads,
+// uniformly); it returns true in exactly one workgroup, with the other workgroups' stores visible to all of its threads.  *ticket is 0
+// before the launch and 0 again after it (atomicInc wraps at total - 1): no reset, no memset node.  The epilogue must read the
+// partials in a fixed order (never "in arrival order"), so the result does not depend on which workgroup runs it.
+__device__ inline bool last_workgroup_out(unsigned* ticket, unsigned total) {
+    // ONE thread fences per workgroup: a device-scope release writes the XCD's L2 back (8 XCDs, an L2 each) -- with every thread of
+    // 512 workgroups doing it a 10-us reduction took 124 us.  The barrier in front makes the workgroup's stores happen-before thread 0's
+    // release (cumulative); so: worth it for a handful of workgroups, not for hundreds.
+    __shared__ unsigned s_last_out;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+        __threadfence();                              // release, device scope
+        const unsigned last = atomicInc(ticket, total - 1) == total - 1 ? 1u : 0u;
+        if (last) __threadfence();                    // acquire: the others' stores
+        s_last_out = last;
+    }
+    __syncthreads();
+    return s_last_out != 0u;
+}
+// host side (train.hip): a zeroed device word per (device, stream, slot); allocated at first use -- never inside a stream capture, a
+// warm-up step in front of the capture has been here (like eg_epoch_ptr).  NULL on failure.
+constexpr int EG_TICKET_SLOTS = 16;
+unsigned* eg_ticket_ptr(void* stream, int slot);
+
 // non-temporal 16-B load of a streaming pass (every operand is read once)
 __device__ inline f32x4 ldnt4(const float* p) {
     return f32x4{__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
@@ -100,7 +127,14 @@ constexpr int RED_F32_THREADS = 1024;      // k_reduce_f32_partials, k_dweight_f
 __global__ void k_reduce_f32_partials(const float* __restrict__ partial, int nblocks, int n, double* __restrict__ totals);
 
 // fixed-order sum of per-workgroup [128,128] float slabs -> dw (launch with 128 * 128 / 32 workgroups of RED_F32_THREADS = 1024 threads; train.hip)
-__global__ void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw);
+// -- and, with `extra.partial` set and ceil(extra.n / 32) workgroups MORE, a k_reduce_f32_partials of the same producer's column
+// partials in the same launch (every node of a captured batch-1 training step costs ~4.5 us whatever it does)
+struct ExtraReduce {
+    const float* partial;       // [nblocks][n]; NULL: none
+    int nblocks, n;
+    double* totals;             // [n]
+};
+__global__ void k_dweight_final(const float* __restrict__ partial, int nblocks, float* __restrict__ dw, const ExtraReduce extra);
 
 // Train-mode BatchNorm1d from column totals: totals[0..cc) = sum, totals[cc..2cc) = sum of squares over `rows` rows.
 //   mean, invstd = 1/sqrt(var_biased + eps), scale = gamma * invstd, shift = beta - mean * scale,
