@@ -227,7 +227,7 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
         reducer.profile = False          # (two timing events per step while on: switched on around the measured steps only)
 
     def step():
-        preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0.clone())
+        preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0)      # (the model does not write into its coordinate input)
         ls = engine.compute_loss(crit, preds, y, coord_preds, coord_y, valid, B)
         loss = engine.total_loss(ls)
         opt.zero_grad(set_to_none=True)
@@ -238,7 +238,7 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
         return loss
 
     def loss_fn():                         # (what engine.GraphedTrainStep captures: the same step without the optimizer calls)
-        preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0.clone())
+        preds, coord_preds = model.forward_nodes(feats, edge_index, B, coords0)
         return engine.total_loss(engine.compute_loss(crit, preds, y, coord_preds, coord_y, valid, B))
 
     step.reducer = reducer

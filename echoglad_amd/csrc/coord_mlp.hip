@@ -12,6 +12,9 @@
 
 namespace eg {
 
+#ifndef EG_CM_ABL            // timing-only ablations of k_coord_update_fwd_small (tools/coord_kernel_time.py): bit 0 no z1 product, 1 no
+#define EG_CM_ABL 0          // statistics, 2 no weight load, 3 no input staging, 4 no hidden activations / z2
+#endif
 constexpr int CM_IN = 136, CM_H1 = 32, CM_H2 = 16, CM_OUT = 2;
 constexpr int CM_THREADS = 1024, CM_WAVES = CM_THREADS / 64;
 constexpr int CM_TILE = 64;                     // rows staged in LDS at a time
@@ -41,6 +44,7 @@ struct CoordMlpFwd {
     float *rm1, *rv1, *rm2, *rv2;
     float eps1, eps2, mom1, mom2, cmax;
     float *z1, *z2, *bn, *pre, *newc;           // [R,32], [R,16], [96], [R,2], [R,2]
+    float* newc2;                               // nullable: a second copy of the new coordinates (one for the caller to hand out, one to keep)
 };
 
 struct CoordMlpBwd {
@@ -60,10 +64,35 @@ __device__ inline float mlp_in(const float* __restrict__ lm, long long lm_stride
     return coords[((r & ~3) + k) * 2 + d] - coords[r * 2 + d];
 }
 
-// rows row0 .. row0 + 63 of cat(lm, shape_feats) -> s_in[64][CM_LDI] (rows past the end: zeros)
+// rows row0 .. row0 + 63 of cat(lm, shape_feats) -> s_in[64][CM_LDI] (rows past the end: zeros).  Every global load is issued before
+// the first LDS store: a loop that loads, stores and goes round again is one dependent memory round trip per iteration (8.5 of them
+// here: 6 us of a 16-us kernel).
 __device__ inline void stage_inputs(const float* __restrict__ lm, long long lm_stride, const float* __restrict__ coords, int row0, int R,
                                     float* s_in, float* __restrict__ lm_copy = nullptr) {
-    for (int e = threadIdx.x; e < CM_TILE * CM_IN; e += CM_THREADS) {
+    const int t = threadIdx.x;
+    if ((((uintptr_t)lm | (uintptr_t)lm_copy) & 15) == 0 && (lm_stride & 3) == 0) {
+        // landmark features: 64 rows x 32 float4, two per thread (rows r and r + 32)
+        const int q = t & 31;
+        f32x4 v[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = row0 + (t >> 5) + 32 * k;
+            v[k] = row < R ? *reinterpret_cast<const f32x4*>(lm + (size_t)(row >> 2) * lm_stride + (row & 3) * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // offsets to the frame's 4 landmarks: 64 rows x 8, thread t < 512 -> (row, k, d)
+        float sf = 0.f;
+        const int sr = t >> 3, sk = (t & 7) >> 1, sd = t & 1, srow = row0 + sr;
+        if (t < CM_TILE * 8 && srow < R) sf = coords[((srow & ~3) + sk) * 2 + sd] - coords[srow * 2 + sd];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = (t >> 5) + 32 * k, row = row0 + r;
+            *reinterpret_cast<f32x4*>(&s_in[r * CM_LDI + 4 * q]) = v[k];
+            if (lm_copy && row < R) *reinterpret_cast<f32x4*>(lm_copy + (size_t)row * C + 4 * q) = v[k];
+        }
+        if (t < CM_TILE * 8) s_in[sr * CM_LDI + C + (t & 7)] = sf;
+        return;
+    }
+    for (int e = t; e < CM_TILE * CM_IN; e += CM_THREADS) {
         const int r = e / CM_IN, i = e - r * CM_IN, row = row0 + r;
         const float v = row < R ? mlp_in(lm, lm_stride, coords, row, i) : 0.f;
         s_in[r * CM_LDI + i] = v;
@@ -80,9 +109,35 @@ __device__ inline float hidden_act(float z, float scale, float shift, unsigned l
 }
 
 __device__ inline void load_weights(const CoordMlpW& w, float* s_w1, float* s_w2, float* s_w3) {
-    for (int i = threadIdx.x; i < CM_H1 * CM_IN; i += CM_THREADS) s_w1[(i / CM_IN) * CM_LDW1 + i % CM_IN] = w.w1[i];
-    for (int i = threadIdx.x; i < CM_H2 * CM_H1; i += CM_THREADS) s_w2[(i / CM_H1) * CM_LDW2 + i % CM_H1] = w.w2[i];
-    if (threadIdx.x < CM_OUT * CM_H2) s_w3[threadIdx.x] = w.w3[threadIdx.x];
+    const int t = threadIdx.x;
+    if ((((uintptr_t)w.w1 | (uintptr_t)w.w2) & 15) == 0) {
+        // all loads first (w1: 1088 float4 -- one per thread and a second one for 64 of them; w2: 128; w3: 32 floats), then the stores
+        static_assert(CM_H1 * CM_IN / 4 == CM_THREADS + 64 && CM_IN % 4 == 0 && CM_H2 * CM_H1 / 4 == 128, "thread -> float4 assignment");
+        const f32x4 a0 = reinterpret_cast<const f32x4*>(w.w1)[t];
+        const f32x4 a1 = t < 64 ? reinterpret_cast<const f32x4*>(w.w1)[CM_THREADS + t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 b0 = t < 128 ? reinterpret_cast<const f32x4*>(w.w2)[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float c0 = t < CM_OUT * CM_H2 ? w.w3[t] : 0.f;
+        {
+            const int i = 4 * t, o = i / CM_IN, k = i - o * CM_IN;
+            float* d = s_w1 + o * CM_LDW1 + k;
+            d[0] = a0.x; d[1] = a0.y; d[2] = a0.z; d[3] = a0.w;
+        }
+        if (t < 64) {
+            const int i = 4 * (CM_THREADS + t), o = i / CM_IN, k = i - o * CM_IN;
+            float* d = s_w1 + o * CM_LDW1 + k;
+            d[0] = a1.x; d[1] = a1.y; d[2] = a1.z; d[3] = a1.w;
+        }
+        if (t < 128) {
+            const int i = 4 * t, o = i / CM_H1, k = i - o * CM_H1;
+            float* d = s_w2 + o * CM_LDW2 + k;
+            d[0] = b0.x; d[1] = b0.y; d[2] = b0.z; d[3] = b0.w;
+        }
+        if (t < CM_OUT * CM_H2) s_w3[t] = c0;
+        return;
+    }
+    for (int i = t; i < CM_H1 * CM_IN; i += CM_THREADS) s_w1[(i / CM_IN) * CM_LDW1 + i % CM_IN] = w.w1[i];
+    for (int i = t; i < CM_H2 * CM_H1; i += CM_THREADS) s_w2[(i / CM_H1) * CM_LDW2 + i % CM_H1] = w.w2[i];
+    if (t < CM_OUT * CM_H2) s_w3[t] = w.w3[t];
 }
 
 // s_red[PARTS][W] -> sum for column c, fixed order (threads < W call this after a barrier)
@@ -234,6 +289,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd 
         const float pre = coords[e] + acc;
         if (a.pre) a.pre[e] = pre;
         a.newc[e] = fminf(fmaxf(pre, 0.f), a.cmax);
+        if (a.newc2) a.newc2[e] = a.newc[e];
     }
 }
 
@@ -269,7 +325,7 @@ template <int W>
 __device__ inline void bn_setup_lds(const float* s_z, int rows, int train, const float* s_gamma, const float* s_beta, const float* s_rm,
                                     const float* s_rv, float eps, float mom, float* rm, float* rv, float* bn_mean, float* bn_inv,
                                     float* s_red, float* s_mean, float* s_var, float* s_scale, float* s_shift) {
-    if (train) column_stats<W>(s_z, rows, s_red, s_mean, s_var);
+    if (train && !(EG_CM_ABL & 2)) column_stats<W>(s_z, rows, s_red, s_mean, s_var);
     if (threadIdx.x < W) {
         const int c = threadIdx.x;
         float mean, var;
@@ -306,9 +362,9 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_update_fwd_small(const Coo
     const float* __restrict__ coords = a.coords;
     // ---- every global load of the kernel
     const unsigned long long e = epoch_now(a.w.epoch);
-    load_weights(a.w, s_w1, s_w2, s_w3);
+    if (!(EG_CM_ABL & 4)) load_weights(a.w, s_w1, s_w2, s_w3);
     load_small_params(a.w, a.rm1, a.rv1, a.rm2, a.rv2, s_par);
-    stage_inputs(lm, a.lm_stride, coords, 0, R, s_in, a.lm_copy);
+    if (!(EG_CM_ABL & 8)) stage_inputs(lm, a.lm_stride, coords, 0, R, s_in, a.lm_copy);
     const float c_own = t < R * CM_OUT ? coords[t] : 0.f;
     a.w.seed1 += e;
     a.w.seed2 += e;
@@ -322,6 +378,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_update_fwd_small(const Coo
             const int r = (t >> 5) + 32 * half;
             if (32 * half >= R) break;                  // (uniform)
             float acc = b;
+            if (!(EG_CM_ABL & 1))
 #pragma unroll 8
             for (int i = 0; i < CM_IN; ++i) acc += s_w1[o * CM_LDW1 + i] * s_in[r * CM_LDI + i];
             s_z1[r * CM_H1 + o] = acc;
@@ -364,6 +421,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_update_fwd_small(const Coo
         if (a.pre) a.pre[t] = pre;
         const float nc = fminf(fmaxf(pre, 0.f), a.cmax);
         a.newc[t] = nc;
+        if (a.newc2) a.newc2[t] = nc;
         s_newc[t] = nc;
     }
     // ---- the coordinate rows resampled at the new positions (models.py:455-473): one wave per point
@@ -429,8 +487,11 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
         s_sh2[c] = a.w.beta2[c] - m * sc;
     }
     if (SMALL) {
-        for (int e = t; e < R * CM_H1; e += CM_THREADS) s_z1l[e] = a.z1[e];
-        if (t < R * CM_H2) s_z2l[t] = a.z2[t];
+        {
+            const float za = t < R * CM_H1 ? a.z1[t] : 0.f, zb = t + CM_THREADS < R * CM_H1 ? a.z1[t + CM_THREADS] : 0.f;
+            const float zc = t < R * CM_H2 ? a.z2[t] : 0.f;
+            s_z1l[t] = za; s_z1l[t + CM_THREADS] = zb; s_z2l[t] = zc;
+        }
         stage_inputs(lm, a.lm_stride, coords, 0, R, s_in);
         float dcur = 0.f, pre = 0.f;
         if (t < R * 2) { dcur = a.dnew ? a.dnew[t] : 0.f; pre = a.pre[t]; }
@@ -654,9 +715,9 @@ using namespace eg;
 
 extern "C" {
 
-int eg_coord_mlp_fwd_rows(const float* lm, int64_t lm_frame_stride, float* lm_copy, const float* coords, int batch,
-                          const eg_cls_train_params* P, int train, int frame, float* z1, float* z2, float* bn, float* pre,
-                          float* new_coords, eg_stream_t stream) {
+static int coord_mlp_fwd_rows(const float* lm, int64_t lm_frame_stride, float* lm_copy, const float* coords, int batch,
+                              const eg_cls_train_params* P, int train, int frame, float* z1, float* z2, float* bn, float* pre,
+                              float* new_coords, float* new_coords2, eg_stream_t stream) {
     if (!lm || !coords || !z1 || !z2 || !bn || !new_coords || !params_ok(P)) return set_error(EG_ERR_ARG, "NULL argument");
     if (batch < 1 || frame < 1 || batch > (1 << 20) || lm_frame_stride < 4 * C) return set_error(EG_ERR_ARG, "bad batch / frame / stride");
     if (!train && (!P->running_mean1 || !P->running_var1 || !P->running_mean2 || !P->running_var2))
@@ -668,23 +729,29 @@ int eg_coord_mlp_fwd_rows(const float* lm, int64_t lm_frame_stride, float* lm_co
     a.w = weights_of(P, train != 0);
     a.rm1 = P->running_mean1; a.rv1 = P->running_var1; a.rm2 = P->running_mean2; a.rv2 = P->running_var2;
     a.eps1 = P->eps1; a.eps2 = P->eps2; a.mom1 = P->momentum1; a.mom2 = P->momentum2; a.cmax = (float)(frame - 1);
-    a.z1 = z1; a.z2 = z2; a.bn = bn; a.pre = pre; a.newc = new_coords;
+    a.z1 = z1; a.z2 = z2; a.bn = bn; a.pre = pre; a.newc = new_coords; a.newc2 = new_coords2;
     if (a.rows <= CM_TILE) hipLaunchKernelGGL(k_coord_update_fwd_small, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a, CoordSample{});
     else hipLaunchKernelGGL(k_coord_mlp_fwd, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;
 }
 
+int eg_coord_mlp_fwd_rows(const float* lm, int64_t lm_frame_stride, float* lm_copy, const float* coords, int batch,
+                          const eg_cls_train_params* P, int train, int frame, float* z1, float* z2, float* bn, float* pre,
+                          float* new_coords, eg_stream_t stream) {
+    return coord_mlp_fwd_rows(lm, lm_frame_stride, lm_copy, coords, batch, P, train, frame, z1, z2, bn, pre, new_coords, nullptr, stream);
+}
+
 int eg_coord_update_fwd(float* h, int64_t n_per_frame, int64_t coord_base, int64_t main_base, const float* coords, int batch,
                         const eg_cls_train_params* P, int train, int frame, int resample, float* lm_copy, float* z1, float* z2, float* bn,
-                        float* pre, float* new_coords, eg_stream_t stream) {
+                        float* pre, float* new_coords, float* new_coords2, eg_stream_t stream) {
     if (!h) return set_error(EG_ERR_ARG, "NULL argument");
     if (batch < 1 || frame < 1 || coord_base < 0 || coord_base + 4 > n_per_frame || main_base < 0 || main_base + (int64_t)frame * frame > n_per_frame ||
         (coord_base < main_base + (int64_t)frame * frame && coord_base + 4 > main_base))
         return set_error(EG_ERR_ARG, "bad batch / frame / row ranges");
     float* rows = h + (size_t)coord_base * C;
     if (!resample || 4 * batch > CM_TILE) {
-        if (int rc = eg_coord_mlp_fwd_rows(rows, n_per_frame * C, lm_copy, coords, batch, P, train, frame, z1, z2, bn, pre, new_coords, stream)) return rc;
+        if (int rc = coord_mlp_fwd_rows(rows, n_per_frame * C, lm_copy, coords, batch, P, train, frame, z1, z2, bn, pre, new_coords, new_coords2, stream)) return rc;
         if (!resample) return EG_OK;
         return eg_bilinear4_fwd_rows(h, new_coords, batch, 4, n_per_frame, main_base, frame, rows, n_per_frame * C, stream);
     }
@@ -699,7 +766,7 @@ int eg_coord_update_fwd(float* h, int64_t n_per_frame, int64_t coord_base, int64
     a.w = weights_of(P, train != 0);
     a.rm1 = P->running_mean1; a.rv1 = P->running_var1; a.rm2 = P->running_mean2; a.rv2 = P->running_var2;
     a.eps1 = P->eps1; a.eps2 = P->eps2; a.mom1 = P->momentum1; a.mom2 = P->momentum2; a.cmax = (float)(frame - 1);
-    a.z1 = z1; a.z2 = z2; a.bn = bn; a.pre = pre; a.newc = new_coords;
+    a.z1 = z1; a.z2 = z2; a.bn = bn; a.pre = pre; a.newc = new_coords; a.newc2 = new_coords2;
     const CoordSample sp{h, rows, (long long)n_per_frame, (long long)main_base, (long long)n_per_frame * C, frame};
     hipLaunchKernelGGL(k_coord_update_fwd_small, dim3(1), dim3(CM_THREADS), 0, (hipStream_t)stream, a, sp);
     EG_HIP_TRY(hipGetLastError());

@@ -145,7 +145,11 @@ class GraphedTrainStep:
             ops.dropout_epoch_add(1)
         out = self.loss_fn()
         loss = out[0] if isinstance(out, (tuple, list)) else out
-        loss.backward()
+        # (d loss = 1 from a tensor that exists already: autograd's own ones_like is a fill kernel -- one more node of every replay)
+        one = getattr(self, "_one", None)
+        if one is None or one.device != loss.device or one.dtype != loss.dtype or one.shape != loss.shape:
+            one = self._one = torch.ones_like(loss)
+        loss.backward(gradient=one)
         if isinstance(out, (tuple, list)):
             return tuple(t.detach() for t in out)
         return (loss.detach(),)

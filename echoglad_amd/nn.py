@@ -290,7 +290,8 @@ _MLP_NAMES = ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3"
 
 
 def _coord_update_fwd(h, coords_prev, dims, mlp_cfg, mlp_params, want_backward=True, sample=True):
-    """h [B*N,128] (coordinate rows overwritten IN PLACE) -> (new coords [4B,2], state for _coord_update_bwd).
+    """h [B*N,128] (coordinate rows overwritten IN PLACE) -> (new coords [4B,2], state for _coord_update_bwd + the new coordinates once
+    more, in a tensor of their own: `new` is saved for the backward, the other one is what the node hands out).
     sample=False: the coordinate rows are NOT resampled (after the last layer nobody reads them -- the heads drop the coordinate
     rows, models.py:485 -- and with h written sparsely the main grid the samples would come from does not exist)."""
     B, n, main_base, frame, coord_base = dims
@@ -299,8 +300,8 @@ def _coord_update_fwd(h, coords_prev, dims, mlp_cfg, mlp_params, want_backward=T
     flat = coords_prev.reshape(B * 4, 2).contiguous()
     # the MLP reads the coordinate rows where they live (and leaves the packed copy the backward needs: the rows change below),
     # the samples are written straight into them: no gather / scatter launches around the two kernels
-    new, lm, saved = ops.coord_update_fwd(h, flat, B, n, coord_base, main_base, P, True, frame, want_backward, resample=sample)
-    return new, (lm, flat, saved, {k: v for k, v in P.items() if not k.startswith("running")})
+    (new, new_out), lm, saved = ops.coord_update_fwd(h, flat, B, n, coord_base, main_base, P, True, frame, want_backward, resample=sample)
+    return new, (lm, flat, saved, {k: v for k, v in P.items() if not k.startswith("running")}, new_out)
 
 
 def _coord_update_bwd(dx, dcoords_new, h, new, lm, flat, saved, P, dims, need_dprev, sampled_rows_used=True, lower=None):
@@ -341,7 +342,7 @@ class _CoordLayerTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h_prev, coords_prev, weight, bias, gamma, beta, running_mean, running_var, cfg, *mlp_params):
         graph, batch, relu, p, momentum, eps, seed, residual, dims, mlp_cfg, kid, down = cfg
-        new, (lm, flat, saved, P) = _coord_update_fwd(h_prev, coords_prev, dims, mlp_cfg, mlp_params)
+        new, (lm, flat, saved, P, new_out) = _coord_update_fwd(h_prev, coords_prev, dims, mlp_cfg, mlp_params)
         need_w = weight.requires_grad
         out, z, agg, bn = ops.gcn_layer_train_fwd(graph, batch, h_prev, weight.contiguous(), bias.contiguous(), gamma.contiguous(),
                                                   beta.contiguous(), running_mean, running_var, momentum, eps, relu, p, seed,
@@ -356,7 +357,7 @@ class _CoordLayerTrainFn(torch.autograd.Function):
                               gamma.detach().contiguous(), beta.detach().contiguous(), bn, h_prev, new, lm, flat,
                               *(lower[:2] if lower is not None else ()), *saved)
         ctx.cfg = (graph, batch, relu, p, seed, residual, need_w, dims, P)
-        return out, new.view(dims[0], 4, 2).clone()      # (a tensor of its own: `new` is saved for the backward; dims[0] = frames; `batch` = copies of the handle's graph: 1 for a CSR of the whole batch)
+        return out, new_out.view(dims[0], 4, 2)          # (a tensor of its own: `new` is saved for the backward; dims[0] = frames; `batch` = copies of the handle's graph: 1 for a CSR of the whole batch)
 
     @staticmethod
     def backward(ctx, dy, dcoords):
@@ -461,13 +462,13 @@ class _CoordClassifierTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, coords_prev, dims5, sigmoid, cls_cfg, coord_dims, mlp_cfg, *params):
         batch, n, row_lo, n_valid = dims5
-        new, (lm, flat, saved, Pm) = _coord_update_fwd(h, coords_prev, coord_dims, mlp_cfg, params[:10])
+        new, (lm, flat, saved, Pm, new_out) = _coord_update_fwd(h, coords_prev, coord_dims, mlp_cfg, params[:10])
         P = _stack_head_params(params[10:], cls_cfg)
         logits, z1, z2, bn = ops.classifier_train_fwd(h, batch, n, row_lo, n_valid, P, sigmoid)
         ctx.P = {k: v for k, v in P.items() if not k.startswith("running")}
         ctx.cfg = (batch, n, row_lo, n_valid, sigmoid, coord_dims, Pm)
         ctx.save_for_backward(h, z1, z2, bn, logits if sigmoid else logits.new_zeros(0), new, lm, flat, *saved)
-        return logits, new.view(batch, 4, 2).clone()
+        return logits, new_out.view(batch, 4, 2)
 
     @staticmethod
     def backward(ctx, dy, dcoords):
@@ -537,7 +538,7 @@ class _LastLayerHeadsTrainFn(torch.autograd.Function):
         if lower is not None:
             saved += [lower[0], lower[1]]                 # (at the END: z and bn of the layer below)
         ctx.save_for_backward(*saved)
-        return logits, (new.view(B, 4, 2).clone() if has_coord else None)
+        return logits, (st[4].view(B, 4, 2) if has_coord else None)
 
     @staticmethod
     def backward(ctx, dy, dcoords):

@@ -734,7 +734,8 @@ def coord_update_fwd(h, coords, batch: int, n_per_frame: int, coord_base: int, m
                      want_backward: bool, resample: bool = True):
     """The coordinate update of one GNN layer on the node array IN PLACE (eg_coord_update_fwd: models.py:438-473): the landmark MLP on
     the 4 coordinate rows of every frame of h, then (resample) those rows overwritten with the main grid sampled at the new positions.
-    One launch up to batch 16.  -> (new_coords [4*batch,2], lm = packed copy of the rows the MLP read, saved = (z1, z2, bn, pre) | None)"""
+    One launch up to batch 16.  -> ((new_coords, new_coords_again) [4*batch,2] each: the same coordinates in two tensors -- one to hand
+    out, one to keep for the backward, without a copy launch --, lm = packed copy of the rows the MLP read, saved = (z1, z2, bn, pre) | None)"""
     rows = 4 * batch
     _check_rows(h, "h", batch * n_per_frame)
     _check_coords(coords, batch, 4)
@@ -747,11 +748,11 @@ def coord_update_fwd(h, coords, batch: int, n_per_frame: int, coord_base: int, m
     z2 = torch.empty(rows, 16, dtype=torch.float32, device=dev)
     bn = torch.empty(96, dtype=torch.float32, device=dev)
     pre = torch.empty(rows, 2, dtype=torch.float32, device=dev) if want_backward else None
-    new = torch.empty(rows, 2, dtype=torch.float32, device=dev)
+    new = (torch.empty(rows, 2, dtype=torch.float32, device=dev), torch.empty(rows, 2, dtype=torch.float32, device=dev))
     s = _cls_params(P)
     _lib.check(_lib.load().eg_coord_update_fwd(_ptr(h), n_per_frame, coord_base, main_base, _ptr(coords), batch, ct.byref(s), int(train),
-                                               frame, int(bool(resample)), _ptr(lm), _ptr(z1), _ptr(z2), _ptr(bn), _ptr(pre), _ptr(new),
-                                               _stream()), "eg_coord_update_fwd")
+                                               frame, int(bool(resample)), _ptr(lm), _ptr(z1), _ptr(z2), _ptr(bn), _ptr(pre), _ptr(new[0]),
+                                               _ptr(new[1]), _stream()), "eg_coord_update_fwd")
     return new, lm, ((z1, z2, bn, pre) if want_backward else None)
 
 

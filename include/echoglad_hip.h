@@ -84,8 +84,8 @@ extern "C" {
  * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_*, eg_elm_reduce, eg_coord_mlp_*_rows, eg_bilinear4_*_rows (round 5).
  * 134: eg_dropout_epoch_add / _set, eg_debug_dropout_epoch (round 5: a whole train step as one HIP graph).
  * 135: eg_gcn_layer_bwd_lower, eg_bilinear4_bwd_rows_sums, eg_avg_pool_pyramid_fwd / _bwd, eg_criteria_* (round 6).
- * 136: eg_classifier_train_fwd_act(h_sparse), eg_classifier_bwd_sums(layer_residual, recompute_h).  137: eg_coord_update_fwd / _bwd. */
-#define EG_ABI_VERSION 137
+ * 136: eg_classifier_train_fwd_act(h_sparse), eg_classifier_bwd_sums(layer_residual, recompute_h).  137, 138: eg_coord_update_fwd / _bwd. */
+#define EG_ABI_VERSION 138
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
 
@@ -482,7 +482,8 @@ int eg_bilinear4_bwd_rows_sums(const float* dout, int64_t dout_frame_stride, con
 
 /* ---- the whole coordinate update of one GNN layer (models.py:438-473) on the node array in place -------------------------------
  * eg_coord_update_fwd = eg_coord_mlp_fwd_rows on the 4 coordinate rows of every frame of h (rows coord_base .. coord_base + 3 of
- * each frame's n_per_frame rows; lm_copy, z1, z2, bn, pre, new_coords as there) followed, when resample != 0, by
+ * each frame's n_per_frame rows; lm_copy, z1, z2, bn, pre, new_coords as there; new_coords2, nullable: a second [R,2] copy of the
+ * new coordinates -- one to hand out, one to keep for the backward, without a copy launch) followed, when resample != 0, by
  * eg_bilinear4_fwd_rows at the new positions into those same rows.  Up to batch 16 (64 rows) that is ONE single-workgroup launch
  * with every intermediate in LDS (a training step at batch 1 is ~1 ms: six 20-us launches were 12 % of it); above, the two launches.
  * eg_coord_update_bwd = the backward of both on the gradient array dx (the gradient w.r.t. the tensor AFTER the update, turned in
@@ -493,7 +494,7 @@ int eg_bilinear4_bwd_rows_sums(const float* dout, int64_t dout_frame_stride, con
  * One launch up to batch 16, three above. */
 int eg_coord_update_fwd(float* h, int64_t n_per_frame, int64_t coord_base, int64_t main_base, const float* coords, int batch,
                         const eg_cls_train_params* params, int train, int frame, int resample, float* lm_copy, float* z1, float* z2,
-                        float* bn, float* pre, float* new_coords, eg_stream_t stream);
+                        float* bn, float* pre, float* new_coords, float* new_coords2, eg_stream_t stream);
 int eg_coord_update_bwd(float* dx, int64_t n_per_frame, int64_t coord_base, int64_t main_base, const float* h, const float* new_coords,
                         const float* dnew_coords, const float* lm, const float* coords, int batch, const eg_cls_train_params* params,
                         int frame, const float* z1, const float* z2, const float* bn, const float* pre, float* scratch, float* dbil,

@@ -490,7 +490,8 @@ def test_coordinate_update_in_one_launch_equals_the_separate_launches(B, frame, 
         for k in running:
             P[k] = running0[k].clone()
         if fused:
-            new, lm, saved = ops.coord_update_fwd(h, c0, B, n, coord_base, main_base, P, True, frame, True)
+            (new, again), lm, saved = ops.coord_update_fwd(h, c0, B, n, coord_base, main_base, P, True, frame, True)
+            assert torch.equal(new, again) and new.data_ptr() != again.data_ptr()
         else:
             lm = torch.empty(B * 4, 128, device=DEV)
             new, saved = ops.coord_mlp_fwd(lm, c0, B, P, True, frame, True, in_rows=(h, n, coord_base))
