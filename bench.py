@@ -214,10 +214,16 @@ def train_workload(frame, naux, layers, B, device, world, rank, force_collective
     crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1),
             "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux), "coordinate": engine.MSE(1)}
     params = list(model.parameters())
-    try:                                   # one launch for the whole update instead of a dozen multi-tensor ones (same arithmetic)
-        opt = torch.optim.Adam(params, lr=1e-4, fused=os.environ.get("EG_BENCH_FUSED_ADAM", "1") != "0", capturable=capturable)
-    except (RuntimeError, TypeError):
-        opt = torch.optim.Adam(params, lr=1e-4, capturable=capturable)
+    # the update as ONE launch (echoglad_amd.optim.Adam: torch's fused-Adam arithmetic, the step count on the device);
+    # EG_BENCH_ADAM=torch: torch.optim.Adam(fused=True) -- 4 launches for the 73 parameter tensors
+    if os.environ.get("EG_BENCH_ADAM", "eg") == "eg":
+        from echoglad_amd.optim import Adam
+        opt = Adam(params, lr=1e-4)
+    else:
+        try:
+            opt = torch.optim.Adam(params, lr=1e-4, fused=os.environ.get("EG_BENCH_FUSED_ADAM", "1") != "0", capturable=capturable)
+        except (RuntimeError, TypeError):
+            opt = torch.optim.Adam(params, lr=1e-4, capturable=capturable)
     reducer = None
     if world > 1 or force_collective:
         broadcast_parameters(model)
@@ -752,12 +758,14 @@ def documented_graphed_loop_ms(args, device, B=1, n=24):
         crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1), "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux),
                 "coordinate": engine.MSE(1)}
         params = list(model.parameters()) + list(emb.parameters())
-        opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=True)
+        if os.environ.get("EG_BENCH_ADAM", "eg") == "eg":
+            from echoglad_amd.optim import Adam
+            opt = Adam(params, lr=1e-4)
+        else:
+            opt = torch.optim.Adam(params, lr=1e-4, fused=True, capturable=True)
         md = {"embedder": emb, "landmark": model}
-        coords0 = static.node_coords.clone()
 
-        def loss_fn():
-            static.node_coords = coords0.clone()
+        def loss_fn():                     # (copy_batch_ writes every new batch's landmark guesses into static.node_coords; the model does not write there)
             preds, cp = engine.forward_batch(md, static, True)
             return engine.total_loss(engine.compute_loss(crit, preds, static.y, cp, static.node_coord_y, static.valid_labels, B))
 
@@ -775,7 +783,7 @@ def documented_graphed_loop_ms(args, device, B=1, n=24):
         res = {"ms_per_step": round(ms, 3), "frames_s": round(B / (ms * 1e-3), 1), "final_loss": float(out[0]),
                "edge_index_untouched": static.edge_index._version == v0,
                "what": "INTEGRATION.md E: copy_batch_(static, fresh host batch) + one graph launch per step (embedder, packing, stack, "
-                       "3 criteria, backward, fused Adam)"}
+                       "3 criteria, backward, Adam as one launch)"}
         del step, model, emb, static, host
     except Exception as ex:
         res = {"error": repr(ex)}

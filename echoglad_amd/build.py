@@ -16,7 +16,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIBNAME = "libechoglad_hip.so"
-SOURCES = ["graph.hip", "gcn_layer.hip", "gcn_layer_ps.hip", "conn.hip", "classifier.hip", "train.hip", "bn_act_tiles.hip", "cls_train.hip", "coord.hip", "coord_mlp.hip", "heatmap.hip", "pack.hip", "pool.hip"]
+SOURCES = ["graph.hip", "gcn_layer.hip", "gcn_layer_ps.hip", "conn.hip", "classifier.hip", "train.hip", "bn_act_tiles.hip", "cls_train.hip", "coord.hip", "coord_mlp.hip", "heatmap.hip", "pack.hip", "pool.hip", "adam.hip"]
 ARCH = "gfx950"
 
 

@@ -145,6 +145,7 @@ class Routes:
     jk_fused = True                 # JumpingKnowledge('max') as a running maximum inside the layer kernels
     stacked_heads = True            # the four heads as one stacked network in train mode
     heads_recompute_h = True        # the last layer's output is never written in full: the heads' backward rebuilds its tile (off: h is kept)
+    heads_state_in_place = True     # the 4 heads' parameters and running statistics LIVE in the stacked arrays the kernels take (off: copied per step)
     chain_layers = True             # eval: child sums handed from layer to layer (default of HierarchicalPatchModel.chain_layers)
     fuse_classifier = True          # eval: the heads inside the last layer's kernel (default of HierarchicalPatchModel.fuse_classifier)
 
@@ -424,9 +425,44 @@ _HEAD_NAMES = ("w1", "b1", "gamma1", "beta1", "w2", "b2", "gamma2", "beta2", "w3
 _HEAD_SHAPES = ((4 * 32, C), (128,), (128,), (128,), (4, 16, 32), (64,), (64,), (64,), (64,), (4,))
 
 
+def _head_param_offsets():
+    """Element offset of parameter (head k, array j) = params[10 * k + j] in the flat buffer of _stack_head_params."""
+    offs, start = [0] * 40, 0
+    for j, size in enumerate(_HEAD_SIZES):
+        for k in range(4):
+            offs[10 * k + j] = start + k * size
+        start += 4 * size
+    return offs
+
+
+def _views_of(bank: torch.Tensor, tensors, offsets) -> bool:
+    """Is tensors[i] the contiguous float32 slice of ``bank`` that starts at element offsets[i]?"""
+    base, dev = bank.data_ptr(), bank.device
+    for t, o in zip(tensors, offsets):
+        if t.data_ptr() != base + 4 * o or t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+            return False
+    return True
+
+
+def _move_into(bank: torch.Tensor, tensors, offsets, assign) -> None:
+    """Copies tensors[i] into bank[offsets[i] : + numel] and re-points it there (assign(i, view)): once, not per step."""
+    with torch.no_grad():
+        for i, (t, o) in enumerate(zip(tensors, offsets)):
+            view = bank[o:o + t.numel()].view(t.shape)
+            view.copy_(t)
+            assign(i, view)
+
+
 def _stack_head_params(params, cfg):
     """The 4 x 10 head parameters as the stacked arrays the kernels take: ONE flat buffer filled by one multi-tensor copy (a
     torch.cat / stack per array was 10 launches per step), the arrays are views of it."""
+    bank = cfg.get("_param_bank")
+    if bank is not None and _views_of(bank, params, _head_param_offsets()):
+        P, start = dict(cfg), 0                   # the parameters ARE the stacked arrays (HierarchicalPatchModel._heads_in_place): nothing to copy
+        for size, name, shape in zip(_HEAD_SIZES, _HEAD_NAMES, _HEAD_SHAPES):
+            P[name] = bank[start:start + 4 * size].view(shape)
+            start += 4 * size
+        return P
     flat = torch.empty(4 * sum(_HEAD_SIZES), dtype=torch.float32, device=params[0].device)
     dst, src, start = [], [], 0
     P = dict(cfg)
@@ -791,7 +827,7 @@ def _fold_bn(bn: nn.BatchNorm1d, lin_bias: Optional[torch.Tensor]):
 
 def _versions(module: nn.Module) -> tuple:
     return tuple(t._version for t in list(module.parameters()) + list(module.buffers())) + \
-           tuple(t.data_ptr() for t in module.parameters())
+           tuple(t.data_ptr() for t in list(module.parameters()) + list(module.buffers()))
 
 
 def _mlp_head(in_f, hid, out_f, drop_p, last):
@@ -1275,23 +1311,62 @@ class HierarchicalPatchModel(nn.Module):
         seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if (p1 > 0 or p2 > 0) else [0, 0]      # host RNG, like the layers
         if self.dropout_seed_hook is not None:
             self.dropout_seed_hook("heads", self.node_classifiers, tuple(seeds))
-        with torch.no_grad():                              # stacked copies of the running statistics: one multi-tensor copy
-            stats = torch.empty(2 * 128 + 2 * 64, dtype=torch.float32, device=bn1[0].running_mean.device)
+        params = [p for hd in heads for p in _seq_params(hd)]
+        stat_list = [b.running_mean for b in bn1] + [b.running_var for b in bn1] + [b.running_mean for b in bn2] + [b.running_var for b in bn2]
+        banks = self._heads_in_place(params, stat_list, bn1, bn2)
+        with torch.no_grad():
+            if banks is not None:                          # the modules' running statistics ARE the stacked arrays: nothing to copy, either way
+                stats = banks[1]
+            else:                                          # stacked copies of the running statistics: one multi-tensor copy
+                stats = torch.empty(2 * 128 + 2 * 64, dtype=torch.float32, device=bn1[0].running_mean.device)
             rm1, rv1, rm2, rv2 = stats[:128], stats[128:256], stats[256:320], stats[320:384]
-            torch._foreach_copy_(list(rm1.split(32)) + list(rv1.split(32)) + list(rm2.split(16)) + list(rv2.split(16)),
-                                 [b.running_mean for b in bn1] + [b.running_var for b in bn1] +
-                                 [b.running_mean for b in bn2] + [b.running_var for b in bn2])
+            if banks is None:
+                torch._foreach_copy_(list(rm1.split(32)) + list(rv1.split(32)) + list(rm2.split(16)) + list(rv2.split(16)), stat_list)
         cfg = dict(running_mean1=rm1, running_var1=rv1, running_mean2=rm2, running_var2=rv2, eps1=bn1[0].eps, eps2=bn2[0].eps,
                    momentum1=bn1[0].momentum, momentum2=bn2[0].momentum, p1=p1, p2=p2, seed1=seeds[0], seed2=seeds[1])
-        params = [p for hd in heads for p in _seq_params(hd)]
+        if banks is not None:
+            cfg["_param_bank"] = banks[0]
 
         def finish(more_counters=()):
             with torch.no_grad():
-                torch._foreach_copy_([b.running_mean for b in bn1] + [b.running_var for b in bn1] +
-                                     [b.running_mean for b in bn2] + [b.running_var for b in bn2],
-                                     list(rm1.split(32)) + list(rv1.split(32)) + list(rm2.split(16)) + list(rv2.split(16)))
+                if banks is None:
+                    torch._foreach_copy_(stat_list, list(rm1.split(32)) + list(rv1.split(32)) + list(rm2.split(16)) + list(rv2.split(16)))
                 torch._foreach_add_([b.num_batches_tracked for b in bn1 + bn2] + list(more_counters), 1)
         return cfg, params, finish
+
+    def _heads_in_place(self, params, stat_list, bn1, bn2):
+        """(parameter bank [4 * sum(_HEAD_SIZES)], statistics bank [384]) with the 40 head parameters and the 16 running-statistics
+        buffers living INSIDE them, in the stacked layout the kernels take -- or None (ROUTES.heads_state_in_place off, tensors that are
+        not CUDA float32, a stream capture under way).  Stacking them per step was three multi-tensor copy launches; here the tensors
+        are moved into the banks once (``p.data`` / the buffer re-pointed at its slice: same values, same Parameter objects, so
+        optimizers, state_dict() and load_state_dict() see no difference) and every later step only checks addresses.  Whatever
+        re-allocates them (``.to()``, a Parameter assigned by hand, copy.deepcopy of the model) is noticed by that check and they
+        are moved again."""
+        if not ROUTES.heads_state_in_place:
+            return None
+        offs_p = _head_param_offsets()
+        offs_s = [32 * k for k in range(4)] + [128 + 32 * k for k in range(4)] + [256 + 16 * k for k in range(4)] + [320 + 16 * k for k in range(4)]
+        banks = self.__dict__.get("_head_banks")
+        if banks is not None and _views_of(banks[0], params, offs_p) and _views_of(banks[1], stat_list, offs_s):
+            return banks
+        dev = params[0].device
+        if dev.type != "cuda" or any(t.dtype != torch.float32 or t.device != dev for t in list(params) + list(stat_list)) or \
+                torch.cuda.is_current_stream_capturing():
+            return None
+        pbank = torch.empty(4 * sum(_HEAD_SIZES), dtype=torch.float32, device=dev)
+        sbank = torch.empty(384, dtype=torch.float32, device=dev)
+
+        def set_param(i, view):
+            params[i].data = view
+
+        def set_stat(i, view):
+            kind, k = divmod(i, 4)
+            setattr((bn1 if kind < 2 else bn2)[k], "running_mean" if kind % 2 == 0 else "running_var", view)
+            stat_list[i] = view
+        _move_into(pbank, params, offs_p, set_param)
+        _move_into(sbank, stat_list, offs_s, set_stat)
+        banks = self.__dict__["_head_banks"] = (pbank, sbank)
+        return banks
 
     def _classifier_train(self, h: torch.Tensor, B: int, n: int, row_lo: int, n_valid: int) -> torch.Tensor:
         """models.py:363-377, :485-490 in train mode on the HIP kernels (_ClassifierTrainFn): the node-type filter is a row

@@ -84,8 +84,8 @@ extern "C" {
  * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_*, eg_elm_reduce, eg_coord_mlp_*_rows, eg_bilinear4_*_rows (round 5).
  * 134: eg_dropout_epoch_add / _set, eg_debug_dropout_epoch (round 5: a whole train step as one HIP graph).
  * 135: eg_gcn_layer_bwd_lower, eg_bilinear4_bwd_rows_sums, eg_avg_pool_pyramid_fwd / _bwd, eg_criteria_* (round 6).
- * 136: eg_classifier_train_fwd_act(h_sparse), eg_classifier_bwd_sums(layer_residual, recompute_h).  137, 138: eg_coord_update_fwd / _bwd. */
-#define EG_ABI_VERSION 138
+ * 136: eg_classifier_train_fwd_act(h_sparse), eg_classifier_bwd_sums(layer_residual, recompute_h).  137, 138: eg_coord_update_fwd / _bwd.  139: eg_adam_step. */
+#define EG_ABI_VERSION 139
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
 
@@ -499,6 +499,22 @@ int eg_coord_update_bwd(float* dx, int64_t n_per_frame, int64_t coord_base, int6
                         const float* dnew_coords, const float* lm, const float* coords, int batch, const eg_cls_train_params* params,
                         int frame, const float* z1, const float* z2, const float* bn, const float* pre, float* scratch, float* dbil,
                         const eg_lower_sums* lower, float* tap_sums, float* dcoords, float* grads, eg_stream_t stream);
+
+/* ---- the optimizer update of the training step (reference: torch.optim.Adam through src/engine.py's optimizer) as ONE launch ---
+ * torch's fused Adam arithmetic (ADAM_MODE::ORIGINAL, amsgrad off) on up to 96 tensors per call:
+ *   g = grad (maximize: -grad) + weight_decay * p;  m += (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g g
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = steps[k] + 1;   then steps[k] = t
+ * tensors: HOST array of `count` entries (device pointers; they travel in the kernel arguments, so a captured launch keeps them);
+ * steps: [count] device floats, the number of updates of each tensor so far.  EG_ERR_UNSUPPORTED (nothing launched) for count > 96. */
+typedef struct eg_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+} eg_adam_tensor;
+int eg_adam_step(const eg_adam_tensor* tensors, int count, float* steps, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 int maximize, eg_stream_t stream);
 
 /* ---- losses on the logits and landmark decode (the steps right after the hot path) ---------------------
  * Reference: src/core/criterion.py:13-27 (WeightedBCEWithLogitsLoss), :93-151 (ExpectedLandmarkMSE),

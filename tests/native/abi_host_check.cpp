@@ -65,6 +65,23 @@ int main() {
                                       dummy, nullptr, &ls, nullptr) == EG_ERR_ARG, "eg_gcn_layer_bwd_lower(g = NULL)");
         EXPECT(eg_bilinear4_bwd_rows_sums(dummy, 512, dummy, dummy, 1, 4, 100, 0, 8, dummy, dummy, &ls, dummy, nullptr) == EG_ERR_ARG,
                "eg_bilinear4_bwd_rows_sums(incomplete eg_lower_sums)");
+        eg_cls_train_params cp{};
+        EXPECT(eg_coord_update_fwd(nullptr, 100, 96, 0, dummy, 1, &cp, 1, 8, 1, dummy, dummy, dummy, dummy, dummy, dummy, dummy, nullptr) == EG_ERR_ARG,
+               "eg_coord_update_fwd(h = NULL)");
+        EXPECT(eg_coord_update_fwd(dummy, 100, 98, 0, dummy, 1, &cp, 1, 8, 1, dummy, dummy, dummy, dummy, dummy, dummy, dummy, nullptr) == EG_ERR_ARG,
+               "eg_coord_update_fwd(coordinate rows outside the frame)");
+        EXPECT(eg_coord_update_fwd(dummy, 100, 62, 0, dummy, 1, &cp, 1, 8, 1, dummy, dummy, dummy, dummy, dummy, dummy, dummy, nullptr) == EG_ERR_ARG,
+               "eg_coord_update_fwd(coordinate rows inside the main grid)");
+        EXPECT(eg_coord_update_bwd(dummy, 100, 96, 0, dummy, dummy, nullptr, dummy, dummy, 1, &cp, 8, dummy, dummy, dummy, dummy, dummy, nullptr, nullptr, nullptr,
+                                   dummy, dummy, nullptr) == EG_ERR_ARG, "eg_coord_update_bwd(dbil = NULL)");
+        EXPECT(eg_coord_update_bwd(dummy, 100, 96, 0, dummy, dummy, nullptr, dummy, dummy, 1, &cp, 8, dummy, dummy, dummy, dummy, dummy, dummy, &ls, nullptr,
+                                   dummy, dummy, nullptr) == EG_ERR_ARG, "eg_coord_update_bwd(incomplete eg_lower_sums)");
+        eg_adam_tensor at{dummy, dummy, dummy, nullptr, 16};
+        EXPECT(eg_adam_step(&at, 1, dummy, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_ARG, "eg_adam_step(exp_avg_sq = NULL)");
+        at.exp_avg_sq = dummy;
+        EXPECT(eg_adam_step(&at, 1, dummy, 1e-3f, 1.0f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_ARG, "eg_adam_step(beta1 = 1)");
+        EXPECT(eg_adam_step(&at, 97, dummy, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_UNSUPPORTED, "eg_adam_step(97 tensors)");
+        EXPECT(eg_adam_step(&at, 1, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_ARG, "eg_adam_step(steps = NULL)");
     }
     EXPECT(eg_workspace_bytes() > 0, "eg_workspace_bytes");
     EXPECT(std::strlen(eg_last_error()) > 0, "eg_last_error carries the last message");

@@ -227,3 +227,75 @@ def test_documented_graphed_loop_takes_new_batches_without_touching_the_graph_te
     fresh_static = data.to_device(copy.copy(data.collate([ds[0], ds[1]])), DEV)
     with pytest.raises(ValueError):
         data.copy_batch_(fresh_static, other)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd,maximize", [(0.0, False), (0.01, False), (0.0, True)])
+def test_one_launch_adam_equals_torch_adam(wd, maximize):
+    """echoglad_amd.optim.Adam (eg_adam_step: the whole parameter list in one launch, the step count a device float advanced by the kernel)
+    against torch.optim.Adam on the same gradients, 5 steps: parameters and both moments to a few ulps (the same formulas; torch's
+    foreach form orders two multiplications differently); state_dict round trip; more tensors than one call takes."""
+    from echoglad_amd.optim import Adam
+    rs = np.random.RandomState(3)
+    shapes = [(128, 128), (128,), (32, 136), (2, 16), (1,), (4097,)] + [(7,)] * 100          # 106 tensors: two calls per step
+    ours = [torch.nn.Parameter(torch.from_numpy(rs.standard_normal(s).astype(np.float32)).to(DEV)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    a = Adam(ours, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, maximize=maximize)
+    b = torch.optim.Adam(ref, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, maximize=maximize)
+    for it in range(5):
+        for p, q in zip(ours, ref):
+            g = torch.from_numpy(rs.standard_normal(tuple(p.shape)).astype(np.float32)).to(DEV) * (0.1 + it)
+            p.grad, q.grad = g.clone(), g.clone()
+        if it == 2:
+            ours[3].grad = None                       # a parameter without a gradient in one step: skipped by both
+            ref[3].grad = None
+        a.step()
+        b.step()
+        for k, (p, q) in enumerate(zip(ours, ref)):
+            assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max())), (it, k)
+    assert float(a.state[ours[0]]["step"]) == 5.0
+    for p, q in zip(ours, ref):
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert torch.allclose(a.state[p][key], b.state[q][key], rtol=1e-5, atol=1e-6), key
+    # state_dict round trip into a fresh optimizer (and torch's own state loads as well): the next step is the same step
+    import copy
+    sd = copy.deepcopy(a.state_dict())                 # (load_state_dict keeps tensors that need no cast: without the copy the two would share moments)
+    ours2 = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    a2 = Adam(ours2, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, maximize=maximize)
+    a2.load_state_dict(sd)
+    ours3 = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    a3 = Adam(ours3, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, maximize=maximize)
+    a3.load_state_dict(copy.deepcopy(b.state_dict()))
+    for p, p2, p3, q in zip(ours, ours2, ours3, ref):
+        g = torch.from_numpy(rs.standard_normal(tuple(p.shape)).astype(np.float32)).to(DEV)
+        p.grad, p2.grad, p3.grad, q.grad = g.clone(), g.clone(), g.clone(), g.clone()
+    a.step(); a2.step(); a3.step(); b.step()
+    for k, (p, p2, p3, q) in enumerate(zip(ours, ours2, ours3, ref)):
+        assert torch.equal(p, p2), k
+        assert float((p3 - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max())), k
+    assert float(a2.state[ours2[0]]["step"]) == 6.0 and float(a3.state[ours3[0]]["step"]) == 6.0
+    cpu = torch.nn.Parameter(torch.zeros(3))
+    cpu.grad = torch.ones(3)
+    with pytest.raises(RuntimeError):
+        Adam([cpu]).step()
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_with_the_one_launch_adam():
+    """engine.GraphedTrainStep with echoglad_amd.optim.Adam: the update is part of the captured graph and its step count advances with
+    every replay (bias corrections change from replay to replay)."""
+    from echoglad_amd.optim import Adam
+    w = torch.nn.Parameter(torch.ones(64, 64, device=DEV))
+    x = torch.randn(8, 64, device=DEV)
+    opt = Adam([w], lr=1e-2)
+    ref_w = torch.nn.Parameter(w.detach().clone())
+    ref_opt = torch.optim.Adam([ref_w], lr=1e-2)
+    step = engine.GraphedTrainStep(lambda: ((x @ w) ** 2).mean(), opt, warmup=2)
+    for _ in range(4):
+        step()
+    for _ in range(6):
+        ref_opt.zero_grad()
+        ((x @ ref_w) ** 2).mean().backward()
+        ref_opt.step()
+    assert float(opt.state[w]["step"]) == 6.0
+    assert float((w - ref_w).abs().max()) <= 1e-5

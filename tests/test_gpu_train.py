@@ -1141,3 +1141,66 @@ def test_batchnorm_backward_sums_handed_down_by_the_dx_launch(monkeypatch, frame
         worst = max(worst, err / (scale + 1e-30))
         assert torch.equal(a[2][k], a2[2][k]), k                # bit-reproducible
     print(f"sums handed down vs own sums pass: worst relative gradient difference {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_head_parameters_and_statistics_live_in_the_stacked_arrays(monkeypatch):
+    """nn.ROUTES.heads_state_in_place: after the first train-mode forward the 40 head parameters and 16 running-statistics buffers are
+    slices of two banks in the kernels' stacked layout (no per-step stacking copies); the same Parameter objects, the same values; a
+    step computes the same bits as with the per-step copies; state_dict round trips; tensors that get re-allocated are moved again."""
+    import copy
+    from echoglad_amd import nn as egnn
+    frame, naux, B = 32, 4, 2
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(egnn.ROUTES, "heads_state_in_place", on)
+        hip, _ = model_pair(frame, naux, 2, coord=True, seed=43)
+        hip.train()
+        topo, ei, nt, bi = graph_tensors(frame, naux, B, coord=True)
+        x = synthetic_node_feats(B * topo.num_nodes, 128, seed=3).to(DEV)
+        coords0 = initial_coords(B, frame).to(DEV)
+        heads = list(hip.node_classifiers)
+        objs = [p for hd in heads for p in hd.parameters()]
+        before = [p.detach().clone() for p in objs]
+        opt = torch.optim.Adam(hip.parameters(), lr=1e-3)
+        outs = []
+        for it in range(3):
+            torch.manual_seed(99 + it)
+            got, gc = hip.forward_nodes(x, ei.to(DEV), B, coords0)
+            opt.zero_grad()
+            ((got ** 2).mean() + (gc ** 2).mean() * 1e-3).backward()
+            if it == 0:
+                assert [id(p) for hd in heads for p in hd.parameters()] == [id(p) for p in objs]
+                for p, b0 in zip(objs, before):
+                    assert torch.equal(p.detach(), b0)                                   # moving them changed no value
+                banks = hip.__dict__.get("_head_banks")
+                assert (banks is not None) == on
+                if on:
+                    lo, hi = banks[0].data_ptr(), banks[0].data_ptr() + 4 * banks[0].numel()
+                    assert all(lo <= p.data_ptr() < hi for p in objs)
+                    assert all(banks[1].data_ptr() <= hd._modules[k].running_mean.data_ptr() < banks[1].data_ptr() + 4 * 384
+                               for hd in heads for k in ("1", "5"))
+            if it == 1 and on:
+                # somebody re-allocates a parameter and a buffer (what .to() / an assignment does): noticed, moved again
+                heads[2]._modules["4"].weight.data = heads[2]._modules["4"].weight.data.clone()
+                heads[1]._modules["1"].running_var = heads[1]._modules["1"].running_var.clone()
+            opt.step()
+            outs.append(got.detach().clone())
+        if on:
+            banks2 = hip.__dict__["_head_banks"]
+            assert banks2[0].data_ptr() <= heads[2]._modules["4"].weight.data_ptr() < banks2[0].data_ptr() + 4 * banks2[0].numel()
+        sd = copy.deepcopy(hip.state_dict())
+        hip2, _ = model_pair(frame, naux, 2, coord=True, seed=1)
+        hip2.load_state_dict(sd)
+        hip2.train()
+        hip.load_state_dict(sd)                                                       # (into the slices, in place)
+        torch.manual_seed(5)
+        a, _ = hip.forward_nodes(x, ei.to(DEV), B, coords0)
+        torch.manual_seed(5)
+        b, _ = hip2.forward_nodes(x, ei.to(DEV), B, coords0)
+        assert torch.equal(a, b)
+        res[on] = (outs, {k: v.clone() for k, v in hip.state_dict().items()})
+    for u, v in zip(res[True][0], res[False][0]):
+        assert torch.equal(u, v)
+    for k in res[True][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
