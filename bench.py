@@ -522,7 +522,8 @@ def cpu_baseline(args, kw, state_dict):
 
 DOMINANT_KERNEL_SOURCES = ("gcn_layer_ps.hip", "seg_wide.h", "tile.h", "common.h", "graph.hip", "conn.hip")
 TRAIN_KERNEL_SOURCES = ("gcn_layer.hip", "gcn_layer_ps.hip", "train.hip", "bn_act_tiles.hip", "cls_train.hip", "train_common.h",
-                        "seg_wide.h", "tile.h", "common.h", "graph.hip", "conn.hip", "coord.hip", "heatmap.hip")
+                        "seg_wide.h", "tile.h", "common.h", "graph.hip", "conn.hip", "coord.hip", "coord_common.h", "coord_mlp.hip", "heatmap.hip",
+                        "adam.hip")
 
 
 def kernel_source_digest(sources=DOMINANT_KERNEL_SOURCES) -> str:

@@ -827,7 +827,7 @@ def _fold_bn(bn: nn.BatchNorm1d, lin_bias: Optional[torch.Tensor]):
 
 def _versions(module: nn.Module) -> tuple:
     return tuple(t._version for t in list(module.parameters()) + list(module.buffers())) + \
-           tuple(t.data_ptr() for t in list(module.parameters()) + list(module.buffers()))
+           tuple(t.data_ptr() for t in module.parameters())
 
 
 def _mlp_head(in_f, hid, out_f, drop_p, last):
@@ -1404,8 +1404,10 @@ class HierarchicalPatchModel(nn.Module):
         # object with the same data_ptr is a view of the same storage), the graph handle the edge_index resolves to (an equal
         # edge_index in a fresh tensor replays too), and the parameter versions -- not on the identity of either input tensor
         graph, gb = self._resolver.resolve(edge_index, node_feats.shape[0])
+        banks = self.__dict__.get("_head_banks")          # (the heads' running statistics move when _heads_in_place re-banks them)
         key = (node_feats.data_ptr(), tuple(node_feats.shape), node_feats.device, id(graph), gb, B,
-               tuple(_versions(l) for l in self.gnn_layers), tuple(_versions(c) for c in self.node_classifiers))
+               tuple(_versions(l) for l in self.gnn_layers), tuple(_versions(c) for c in self.node_classifiers),
+               None if banks is None else banks[1].data_ptr())
         hit = self._hip_graphs.get(key)
         if hit is not None and hit[4][0] is not graph:
             hit = None
