@@ -102,7 +102,8 @@ __device__ inline void stage_inputs(const float* __restrict__ lm, long long lm_s
 
 __device__ inline float hidden_act(float z, float scale, float shift, unsigned long long seed, unsigned long long idx, float p,
                                    float ik, float* keep_out) {
-    const float y = z * scale + shift;
+    const float y = __builtin_fmaf(z, scale, shift);       // (explicit: the small and the general kernels must agree bit for bit -- frame f of a
+                                                            //  batch of 32 runs the one, the same frame alone the other -- whatever the compiler would contract)
     const float k = p > 0.f ? keep_scale(seed, idx, p, ik) : 1.0f;
     *keep_out = y > 0.f ? k : 0.f;              // d act / d y
     return y > 0.f ? y * k : 0.f;
@@ -211,7 +212,7 @@ __device__ inline void bn_setup(const float* __restrict__ z, int rows, int train
         bn_inv[c] = inv;
         const float sc = gamma[c] * inv;
         s_scale[c] = sc;
-        s_shift[c] = beta[c] - mean * sc;
+        s_shift[c] = __builtin_fmaf(-mean, sc, beta[c]);
     }
     __syncthreads();
 }
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd 
             const int r = (t >> 5) + 32 * half;
             float acc = b;
 #pragma unroll 8
-            for (int i = 0; i < CM_IN; ++i) acc += s_w1[o * CM_LDW1 + i] * s_in[r * CM_LDI + i];
+            for (int i = 0; i < CM_IN; ++i) acc = __builtin_fmaf(s_w1[o * CM_LDW1 + i], s_in[r * CM_LDI + i], acc);
             if (row0 + r < R) a.z1[(row0 + r) * CM_H1 + o] = acc;
         }
     }
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd 
         const int r = t >> 4, o = t & 15;
         float acc = a.w.b2[o];
 #pragma unroll
-        for (int i = 0; i < CM_H1; ++i) acc += s_w2[o * CM_LDW2 + i] * s_h1[r * CM_LDH + i];
+        for (int i = 0; i < CM_H1; ++i) acc = __builtin_fmaf(s_w2[o * CM_LDW2 + i], s_h1[r * CM_LDH + i], acc);
         if (row0 + r < R) a.z2[(row0 + r) * CM_H2 + o] = acc;
     }
     __syncthreads();
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd 
             float k;
             const float h = hidden_act(a.z2[r * CM_H2 + i], s_sc2[i], s_sh2[i], a.w.seed2, (unsigned long long)r * CM_H2 + i,
                                        a.w.p2, a.w.ik2, &k);
-            acc += s_w3[d * CM_H2 + i] * h;
+            acc = __builtin_fmaf(s_w3[d * CM_H2 + i], h, acc);
         }
         const float pre = coords[e] + acc;
         if (a.pre) a.pre[e] = pre;
@@ -346,7 +347,7 @@ __device__ inline void bn_setup_lds(const float* s_z, int rows, int train, const
         bn_inv[c] = inv;
         const float sc = s_gamma[c] * inv;
         s_scale[c] = sc;
-        s_shift[c] = s_beta[c] - mean * sc;
+        s_shift[c] = __builtin_fmaf(-mean, sc, s_beta[c]);
     }
     __syncthreads();
 }
@@ -376,33 +377,32 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_update_fwd_small(const Coo
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int r = (t >> 5) + 32 * half;
-            if (32 * half >= R) break;                  // (uniform)
+            if (r >= R) continue;                       // (rows past the end are nobody's operand: at batch 1 two waves of 16 have work)
             float acc = b;
             if (!(EG_CM_ABL & 1))
 #pragma unroll 8
-            for (int i = 0; i < CM_IN; ++i) acc += s_w1[o * CM_LDW1 + i] * s_in[r * CM_LDI + i];
+            for (int i = 0; i < CM_IN; ++i) acc = __builtin_fmaf(s_w1[o * CM_LDW1 + i], s_in[r * CM_LDI + i], acc);
             s_z1[r * CM_H1 + o] = acc;
-            if (r < R) a.z1[r * CM_H1 + o] = acc;
+            a.z1[r * CM_H1 + o] = acc;
         }
     }
     __syncthreads();
     bn_setup_lds<CM_H1>(s_z1, R, a.train, s_par + SP_G1, s_par + SP_BE1, s_par + SP_M1, s_par + SP_V1, a.eps1, a.mom1, a.rm1, a.rv1, a.bn,
                         a.bn + CM_H1, s_red, s_mean, s_var, s_sc1, s_sh1);
     // ---- z2 = h1 W2^T + b2: thread -> (row t >> 4, output channel t & 15)
-    for (int el = t; el < CM_TILE * CM_H1; el += CM_THREADS) {
+    for (int el = t; el < R * CM_H1; el += CM_THREADS) {
         const int r = el >> 5, i = el & 31;
-        float k, h = 0.f;
-        if (r < R) h = hidden_act(s_z1[r * CM_H1 + i], s_sc1[i], s_sh1[i], a.w.seed1, (unsigned long long)r * CM_H1 + i, a.w.p1, a.w.ik1, &k);
-        s_h1[r * CM_LDH + i] = h;
+        float k;
+        s_h1[r * CM_LDH + i] = hidden_act(s_z1[r * CM_H1 + i], s_sc1[i], s_sh1[i], a.w.seed1, (unsigned long long)r * CM_H1 + i, a.w.p1, a.w.ik1, &k);
     }
     __syncthreads();
-    {
+    if ((t >> 4) < R) {
         const int r = t >> 4, o = t & 15;
         float acc = s_par[SP_B2 + o];
 #pragma unroll
-        for (int i = 0; i < CM_H1; ++i) acc += s_w2[o * CM_LDW2 + i] * s_h1[r * CM_LDH + i];
+        for (int i = 0; i < CM_H1; ++i) acc = __builtin_fmaf(s_w2[o * CM_LDW2 + i], s_h1[r * CM_LDH + i], acc);
         s_z2[r * CM_H2 + o] = acc;
-        if (r < R) a.z2[r * CM_H2 + o] = acc;
+        a.z2[r * CM_H2 + o] = acc;
     }
     __syncthreads();
     bn_setup_lds<CM_H2>(s_z2, R, a.train, s_par + SP_G2, s_par + SP_BE2, s_par + SP_M2, s_par + SP_V2, a.eps2, a.mom2, a.rm2, a.rv2,
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_update_fwd_small(const Coo
         for (int i = 0; i < CM_H2; ++i) {
             float k;
             const float h = hidden_act(s_z2[r * CM_H2 + i], s_sc2[i], s_sh2[i], a.w.seed2, (unsigned long long)r * CM_H2 + i, a.w.p2, a.w.ik2, &k);
-            acc += s_w3[d * CM_H2 + i] * h;
+            acc = __builtin_fmaf(s_w3[d * CM_H2 + i], h, acc);
         }
         const float pre = c_own + acc;
         if (a.pre) a.pre[t] = pre;
@@ -603,18 +603,21 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
                 s_dz[r * CM_LDZ2 + o] = row0 + r < R ? scratch[(row0 + r) * CM_SCR + o] : 0.f;
             }
             __syncthreads();
+            const int rows_here = R - row0 < CM_TILE ? R - row0 : CM_TILE;      // (rows past the end are zeros in every operand: skipped)
+            const int r_hi = 32 * whalf + 32 < rows_here ? 32 * whalf + 32 : rows_here;
 #pragma unroll 8
-            for (int r = 32 * whalf; r < 32 * whalf + 32; ++r) dw2 += s_dz[r * CM_LDZ2 + wo] * s_h1[r * CM_LDH + wi];
+            for (int r = 32 * whalf; r < r_hi; ++r) dw2 += s_dz[r * CM_LDZ2 + wo] * s_h1[r * CM_LDH + wi];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int r = part + 32 * half;
+                if (r >= rows_here) continue;
                 float gp = 0.f;
 #pragma unroll
                 for (int o = 0; o < CM_H2; ++o) gp += s_dz[r * CM_LDZ2 + o] * s_w2[o * CM_LDW2 + c];
                 const float g = gp * s_k1[r * CM_LDH + c];
                 sg += g;
                 sgx += g * s_x1[r * CM_LDH + c];
-                if (row0 + r < R) scratch[(row0 + r) * CM_SCR + CM_H2 + c] = g;
+                scratch[(row0 + r) * CM_SCR + CM_H2 + c] = g;
             }
         }
         s_red[0][t] = sg; s_red[1][t] = sgx; s_red[2][t] = dw2;
@@ -652,8 +655,9 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
                 s_dz[r * CM_LDH + i] = row0 + r < R ? scratch[(row0 + r) * CM_SCR + CM_H2 + i] : 0.f;
             }
             __syncthreads();
+            const int rows_here = R - row0 < CM_TILE ? R - row0 : CM_TILE;
 #pragma unroll 4
-            for (int r = 0; r < CM_TILE; ++r) {
+            for (int r = 0; r < rows_here; ++r) {
                 acc0 += s_dz[r * CM_LDH + o0] * *reinterpret_cast<const f32x4*>(&s_in[r * CM_LDI + 4 * q0]);
                 if (two) acc1 += s_dz[r * CM_LDH + o1] * *reinterpret_cast<const f32x4*>(&s_in[r * CM_LDI + 4 * q1]);
             }
@@ -667,12 +671,12 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
                     *dp = a.dlm_acc ? *dp + acc : acc;
                 }
             }
-            if (t < CM_TILE * 8) {
+            if (t < rows_here * 8) {
                 const int r = t >> 3, i = C + (t & 7);
                 float acc = 0.f;
 #pragma unroll
                 for (int o = 0; o < CM_H1; ++o) acc += s_dz[r * CM_LDH + o] * s_w1[o * CM_LDW1 + i];
-                if (row0 + r < R) scratch[(row0 + r) * CM_SCR + CM_H2 + CM_H1 + (t & 7)] = acc;
+                scratch[(row0 + r) * CM_SCR + CM_H2 + CM_H1 + (t & 7)] = acc;
             }
         }
         *reinterpret_cast<f32x4*>(a.grads + CG_DW1 + o0 * CM_IN + 4 * q0) = acc0;

@@ -1204,3 +1204,36 @@ def test_head_parameters_and_statistics_live_in_the_stacked_arrays(monkeypatch):
         assert torch.equal(u, v)
     for k in res[True][1]:
         assert torch.equal(res[True][1][k], res[False][1][k]), k
+
+
+@pytest.mark.gpu
+def test_landmark_mlp_small_and_general_kernels_agree_bit_for_bit_in_eval_mode():
+    """Frame f of a batch of 32 runs the general landmark-MLP kernel (128 rows), the same frame alone the single-tile one (4 rows, everything
+    in LDS): with the statistics frozen the two must give the same bits (the eval-mode property "a frame of the batch == the frame alone"
+    of test_cfg4_train_full_batch_32_properties depends on it; the kernels spell their multiply-adds out for that)."""
+    from echoglad_amd.nn import _MLP_NAMES, _seq_params
+    hip, _ = model_pair(16, 3, 1, coord=True, seed=3)
+    mlp = hip.node_coordinate_mlp[0]
+    hip.eval()
+    bn1, bn2 = mlp[1], mlp[5]
+    rs = np.random.RandomState(0)
+    with torch.no_grad():
+        for b in (bn1, bn2):
+            b.running_mean.copy_(torch.from_numpy(rs.standard_normal(tuple(b.running_mean.shape)).astype(np.float32)))
+            b.running_var.copy_(torch.from_numpy(rs.uniform(0.5, 2.0, tuple(b.running_var.shape)).astype(np.float32)))
+    P = dict(eps1=bn1.eps, eps2=bn2.eps, p1=0.5, p2=0.5, seed1=0, seed2=0, running_mean1=bn1.running_mean, running_var1=bn1.running_var,
+             running_mean2=bn2.running_mean, running_var2=bn2.running_var, momentum1=None, momentum2=None)
+    P.update({k: p.detach().contiguous() for k, p in zip(_MLP_NAMES, _seq_params(mlp))})
+    B, frame = 32, 224
+    for trial in range(10):
+        lm = torch.from_numpy(rs.standard_normal((4 * B, 128)).astype(np.float32) * 3).to(DEV)
+        c = torch.from_numpy(rs.uniform(0, frame - 1, (4 * B, 2)).astype(np.float32)).to(DEV)
+        full, sf = ops.coord_mlp_fwd(lm, c, B, P, False, frame, True)
+        for f in (0, 5, 17, 31):
+            one, so = ops.coord_mlp_fwd(lm[4 * f:4 * f + 4].contiguous(), c[4 * f:4 * f + 4].contiguous(), 1, P, False, frame, True)
+            assert torch.equal(full[4 * f:4 * f + 4], one), (trial, f)
+            assert torch.equal(sf[0][4 * f:4 * f + 4], so[0]) and torch.equal(sf[1][4 * f:4 * f + 4], so[1]), (trial, f)
+        # ... and 16 frames (64 rows: still the single-tile kernel) against 17 (the general one)
+        a16, _ = ops.coord_mlp_fwd(lm[:64].contiguous(), c[:64].contiguous(), 16, P, False, frame, False)
+        a17, _ = ops.coord_mlp_fwd(lm[:68].contiguous(), c[:68].contiguous(), 17, P, False, frame, False)
+        assert torch.equal(a16, a17[:64]) and torch.equal(a17, full[:68])
