@@ -124,6 +124,7 @@ class GraphedTrainStep:
                              "(collectives fired from inside backward cannot be part of the captured graph)")
         self.loss_fn, self.optimizer, self.reducer = loss_fn, optimizer, reducer
         self.replays = 0
+        self._written = [p for g in optimizer.param_groups for p in g["params"]]
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
@@ -164,6 +165,10 @@ class GraphedTrainStep:
         self.graph.replay()
         if self.reducer is not None:
             self._update()
+        else:
+            # a replay runs no host code: the in-place version counters of what the captured update wrote stand still -- and whatever
+            # is cached on them (the model's folded inference parameters, its inference graphs) would not notice the step
+            torch.autograd.graph.increment_version(self._written)
         self.replays += 1
         return self.outputs
 

@@ -965,6 +965,17 @@ class HierarchicalPatchModel(nn.Module):
         topo = get_topology(self.topology_spec)
         return topo.num_nodes, topo.n_conn, topo.num_valid_nodes, topo.main.base, topo.coord_base
 
+    def train(self, mode: bool = True):
+        """nn.Module.train + a fresh start for everything cached on in-place version counters (folded inference parameters, captured
+        inference graphs): a training step replayed from a HIP graph (engine.GraphedTrainStep) runs no host code, so the running
+        statistics it updates on the device bump no counter -- the switch to eval() in front of an evaluation is where that shows."""
+        if bool(mode) != self.training:                # (a change of mode only: eval() in front of every batch keeps its graphs)
+            self.__dict__.get("_fold_cache", {}).clear()
+            graphs = self.__dict__.get("_hip_graphs")
+            if graphs:
+                graphs.clear()
+        return super().train(mode)
+
     # ---- folded inference parameters, cached on parameter versions -------------------------
     def _folded_layers(self):
         key = tuple(_versions(l) for l in self.gnn_layers)

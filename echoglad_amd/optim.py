@@ -74,6 +74,9 @@ class Adam(torch.optim.Optimizer):
                 _lib.check(lib.eg_adam_step(table, len(part), ct.c_void_p(counts.data_ptr()), float(group["lr"]), float(b1), float(b2),
                                             float(group["eps"]), float(group["weight_decay"]), int(bool(group["maximize"])), stream),
                            "eg_adam_step")
+                # the kernel wrote the parameters behind autograd's back: tell it (in-place version counters: what saved-tensor checks
+                # and the model's caches of folded inference parameters are keyed on)
+                torch.autograd.graph.increment_version(part)
         return loss
 
     def _counts_of(self, part):

@@ -299,3 +299,53 @@ def test_graphed_train_step_with_the_one_launch_adam():
         ref_opt.step()
     assert float(opt.state[w]["step"]) == 6.0
     assert float((w - ref_w).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_eval_after_graphed_training_sees_the_trained_state():
+    """A replayed training step runs no host code -- no in-place version counter moves -- and the one-launch Adam writes the parameters from
+    a kernel of its own: the model's caches of folded inference parameters must not survive either.  Inference after graphed training
+    (and after eager steps with echoglad_amd.optim.Adam) == inference of a fresh model loaded with the trained state."""
+    from echoglad_amd.optim import Adam
+    frame, naux, B = 16, 3, 2
+    hip, _, emb, _, ds = _setup(frame, naux, True, 5)
+    batch = data.to_device(data.collate([ds[i] for i in range(B)], ds.topology), DEV)
+    crit = {"bce": losses.WeightedBCEWithLogitsLoss("none", 9000, 1), "elm": losses.ExpectedLandmarkMSE(10, B, frame, naux), "coordinate": engine.MSE(1)}
+    for q in emb.parameters():
+        q.requires_grad_(False)
+    model = {"embedder": emb, "landmark": hip}
+
+    def infer(m):
+        m.eval()
+        with torch.no_grad():
+            return [t.clone() for t in engine.forward_batch({"embedder": emb, "landmark": m}, batch, True)]
+
+    first = infer(hip)                                   # (fills the caches of folded parameters / the inference graph)
+    hip.train()
+    opt = Adam(list(hip.parameters()), lr=1e-2)
+
+    def loss_fn():
+        preds, cp = engine.forward_batch(model, batch, True)
+        return engine.total_loss(engine.compute_loss(crit, preds, batch.y, cp, batch.node_coord_y, batch.valid_labels, B))
+    step = engine.GraphedTrainStep(loss_fn, opt, warmup=2)
+    for _ in range(3):
+        step()
+    got = infer(hip)
+    assert not torch.equal(got[0], first[0])             # five steps at lr 1e-2 moved it
+    fresh, _, _, _, _ = _setup(frame, naux, True, 6)
+    fresh.load_state_dict({k: v.clone() for k, v in hip.state_dict().items()})
+    want = infer(fresh)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # eager steps with the one-launch Adam, model left in eval mode in between (fine-tuning with frozen statistics)
+    hip.eval()
+    for q in hip.parameters():
+        q.requires_grad_(True)
+    before = infer(hip)
+    opt2 = Adam(list(hip.parameters()), lr=1e-2)
+    preds, cp = engine.forward_batch(model, batch, True)
+    engine.total_loss(engine.compute_loss(crit, preds, batch.y, cp, batch.node_coord_y, batch.valid_labels, B)).backward()
+    opt2.step()
+    after = infer(hip)
+    fresh.load_state_dict({k: v.clone() for k, v in hip.state_dict().items()})
+    want = infer(fresh)
+    assert not torch.equal(after[0], before[0]) and torch.equal(after[0], want[0])
