@@ -1235,8 +1235,7 @@ __global__ __launch_bounds__(RED_F32_THREADS) void k_cls_mid_final(const MidFina
     const float* __restrict__ partial = second ? a.partial_bn1 : a.partial2;
     const int n = second ? 2 * H1 : 4 * 16 * 32;
     const int col = (second ? blockIdx.x - NB2 : blockIdx.x) * 32 + (t & 31);
-    double s = 0.0;
-    for (int b = sl; b < a.gb; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * n + col];
+    const double s = strided_sum(partial + col, n, sl, a.gb, RED_F32_THREADS / 32);
     red[t] = s;
     __syncthreads();
 #pragma unroll

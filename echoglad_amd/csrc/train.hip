@@ -50,9 +50,7 @@ __device__ inline void column_partials(long long rows, double* __restrict__ part
 __global__ __launch_bounds__(RED_F32_THREADS) void k_reduce_f32_partials(const float* __restrict__ partial, int nblocks, int n, double* __restrict__ totals) {
     __shared__ double red[RED_F32_THREADS];
     const int t = threadIdx.x, col = blockIdx.x * 32 + (t & 31), sl = t >> 5;
-    double s = 0.0;
-    if (col < n)
-        for (int b = sl; b < nblocks; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * n + col];
+    const double s = col < n ? strided_sum(partial + col, n, sl, nblocks, RED_F32_THREADS / 32) : 0.0;
     red[t] = s;
     __syncthreads();
 #pragma unroll
@@ -92,9 +90,7 @@ __global__ __launch_bounds__(RED_F32_THREADS) void k_bn_reduce_finalize(const fl
     const int t = threadIdx.x, j = t & 31, sl = t >> 5;
     const int c = blockIdx.x * 16 + (j & 15);                     // channel; j >> 4: 0 = sum, 1 = sum of squares
     const int col = (j >> 4) * a.cc + c, n = 2 * a.cc;
-    double s = 0.0;
-    if (c < a.cc)
-        for (int b = sl; b < nblocks; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * n + col];
+    const double s = c < a.cc ? strided_sum(partial + col, n, sl, nblocks, RED_F32_THREADS / 32) : 0.0;
     red[t] = s;
     __syncthreads();
 #pragma unroll
@@ -315,9 +311,7 @@ __global__ __launch_bounds__(RED_F32_THREADS) void k_tile_sums_stage1(const floa
     __shared__ double red[RED_F32_THREADS];
     const int t = threadIdx.x, col = blockIdx.x * 32 + (t & 31), sl = t >> 5;
     const int lo = blockIdx.y * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
-    double s = 0.0;
-#pragma unroll 4
-    for (int b = lo + sl; b < hi; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * 2 * C + col];
+    const double s = strided_sum(partial + col, 2 * C, lo + sl, hi, RED_F32_THREADS / 32);
     red[t] = s;
     __syncthreads();
 #pragma unroll
@@ -355,9 +349,7 @@ __global__ __launch_bounds__(RED_F32_THREADS) void k_tile_sums_small(const float
     __shared__ double red[RED_F32_THREADS];
     const int t = threadIdx.x, j = t & 31, sl = t >> 5;
     const int c = blockIdx.x * 16 + (j & 15), col = (j >> 4) * C + c;          // j >> 4: 0 = sum g, 1 = sum g z
-    double s = 0.0;
-#pragma unroll 4
-    for (int b = sl; b < n_tiles; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * 2 * C + col];
+    const double s = strided_sum(partial + col, 2 * C, sl, n_tiles, RED_F32_THREADS / 32);
     red[t] = s;
     __syncthreads();
 #pragma unroll
@@ -463,9 +455,7 @@ __global__ __launch_bounds__(RED_F32_THREADS) void k_dweight_final(const float* 
     const int t = threadIdx.x, sl = t >> 5;
     if (blockIdx.x >= C * C / 32) {                          // the extra column reduction: k_reduce_f32_partials' arithmetic
         const int col = (blockIdx.x - C * C / 32) * 32 + (t & 31);
-        double s = 0.0;
-        if (col < extra.n)
-            for (int b = sl; b < extra.nblocks; b += RED_F32_THREADS / 32) s += (double)extra.partial[(size_t)b * extra.n + col];
+        const double s = col < extra.n ? strided_sum(extra.partial + col, extra.n, sl, extra.nblocks, RED_F32_THREADS / 32) : 0.0;
         red[t] = s;
         __syncthreads();
 #pragma unroll
@@ -477,8 +467,7 @@ __global__ __launch_bounds__(RED_F32_THREADS) void k_dweight_final(const float* 
         return;
     }
     const int idx = blockIdx.x * 32 + (t & 31);
-    double s = 0.0;
-    for (int b = sl; b < nblocks; b += RED_F32_THREADS / 32) s += (double)partial[(size_t)b * C * C + idx];
+    const double s = strided_sum(partial + idx, C * C, sl, nblocks, RED_F32_THREADS / 32);
     red[t] = s;
     __syncthreads();
 #pragma unroll

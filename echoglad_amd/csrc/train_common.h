@@ -122,6 +122,23 @@ __device__ inline long long map_row(const RowMap& m, long long r) {
     return f * m.stride + m.lo + (r - f * m.n_valid);
 }
 
+// sum of p[lo * stride], p[(lo + step) * stride], ... (indices < hi) in ascending order, fp64 -- the loads in batches of 8 in front of
+// their adds (a plain `for (...) s += p[...]` with a run-time trip count is one dependent memory round trip per iteration: the small
+// reduction kernels of a training step were 2 / 3 latency); the ORDER of the additions is the plain loop's, so are the bits
+__device__ inline double strided_sum(const float* __restrict__ p, long long stride, int lo, int hi, int step) {
+    double s = 0.0;
+    int b = lo;
+    for (; b + 7 * step < hi; b += 8 * step) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(b + k * step) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (double)v[k];
+    }
+    for (; b < hi; b += step) s += (double)p[(size_t)b * stride];
+    return s;
+}
+
 // stage 2 of every column reduction: partial float [nblocks][n] -> totals double [n], fixed order (bitwise reproducible)
 constexpr int RED_F32_THREADS = 1024;      // k_reduce_f32_partials, k_dweight_final: 32 columns x 32 slices of the partial list
 __global__ void k_reduce_f32_partials(const float* __restrict__ partial, int nblocks, int n, double* __restrict__ totals);
