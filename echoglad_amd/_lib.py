@@ -15,7 +15,7 @@ LIB_PATH = Path(os.environ.get("ECHOGLAD_LIB", _PKG / "lib" / "libechoglad_hip.s
 HEADER_PATH = _PKG.parent / "include" / "echoglad_hip.h"
 
 EG_OK, EG_ERR_ARG, EG_ERR_UNSUPPORTED, EG_ERR_HIP = 0, -1, -2, -3
-ABI_VERSION = 139          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
+ABI_VERSION = 140          # EG_ABI_VERSION of include/echoglad_hip.h that SIGNATURES below was written for
 
 _lib: Optional[ct.CDLL] = None
 
@@ -102,7 +102,7 @@ SIGNATURES: Dict[str, tuple] = {
     "eg_coord_mlp_bwd": (_i, [_p, _p, _p, _i, _pp, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "eg_coord_mlp_fwd_rows": (_i, [_p, _i64, _p, _p, _i, _pp, _i, _i, _p, _p, _p, _p, _p, _p]),
     "eg_coord_mlp_bwd_rows": (_i, [_p, _p, _p, _i, _pp, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),
-    "eg_adam_step": (_i, [_p, _i, _p, ct.c_float, ct.c_float, ct.c_float, ct.c_float, ct.c_float, _i, _p]),
+    "eg_adam_step": (_i, [_p, _i, _p, ct.c_float, _p, ct.c_float, ct.c_float, ct.c_float, ct.c_float, _i, _p]),
     "eg_coord_update_fwd": (_i, [_p, _i64, _i64, _i64, _p, _i, _pp, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "eg_coord_update_bwd": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i, _pp, _i, _p, _p, _p, _p, _p, _p, ct.POINTER(LowerSums), _p, _p, _p, _p]),
     "eg_bilinear4_fwd_rows": (_i, [_p, _p, _i, _i, _i64, _i64, _i, _p, _i64, _p]),

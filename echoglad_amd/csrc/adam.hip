@@ -33,6 +33,7 @@ static_assert(ADAM_MAX_TENSORS <= ADAM_THREADS, "one thread per tensor in the lo
 struct AdamScalars {
     float lr, beta1, beta2, eps, weight_decay;
     int maximize;
+    const float* lr_dev;            // nullable: the learning rate as a device scalar (a scheduler's changes reach a captured launch)
     unsigned* ticket;
 };
 
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_step(const AdamTable tb, 
     const int ti = s_ti, rest = s_rest;
     const float t_now = tb.steps[ti] + 1.0f;
     const double bc1 = 1.0 - pow((double)a.beta1, (double)t_now), bc2 = 1.0 - pow((double)a.beta2, (double)t_now);
-    const float step_size = (float)((double)a.lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float lr = a.lr_dev ? *a.lr_dev : a.lr;
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     // (a uniform run-time index into the kernel-argument segment: scalar loads)
     float* __restrict__ p = tb.p[ti]; const float* __restrict__ g = tb.g[ti]; float* __restrict__ m = tb.m[ti]; float* __restrict__ v = tb.v[ti];
     const int n = tb.n[ti];
@@ -92,8 +94,8 @@ using namespace eg;
 
 extern "C" {
 
-int eg_adam_step(const eg_adam_tensor* tensors, int count, float* steps, float lr, float beta1, float beta2, float eps, float weight_decay,
-                 int maximize, eg_stream_t stream) {
+int eg_adam_step(const eg_adam_tensor* tensors, int count, float* steps, float lr, const float* lr_device, float beta1, float beta2, float eps,
+                 float weight_decay, int maximize, eg_stream_t stream) {
     if (!tensors || !steps || count < 0) return set_error(EG_ERR_ARG, "NULL argument");
     if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f)) return set_error(EG_ERR_ARG, "betas must be in [0, 1), eps >= 0");
     if (count > ADAM_MAX_TENSORS) return set_error(EG_ERR_UNSUPPORTED, "more than 96 tensors per call: split the list");
@@ -111,7 +113,7 @@ int eg_adam_step(const eg_adam_tensor* tensors, int count, float* steps, float l
     if (blocks >= (1ll << 31)) return set_error(EG_ERR_ARG, "too many elements");
     unsigned* ticket = eg_ticket_ptr((void*)stream, 2);
     if (!ticket) return set_error(EG_ERR_HIP, "no device memory for a ticket word");
-    const AdamScalars a{lr, beta1, beta2, eps, weight_decay, maximize ? 1 : 0, ticket};
+    const AdamScalars a{lr, beta1, beta2, eps, weight_decay, maximize ? 1 : 0, lr_device, ticket};
     hipLaunchKernelGGL(k_adam_step, dim3((unsigned)blocks), dim3(ADAM_THREADS), 0, (hipStream_t)stream, tb, a);
     EG_HIP_TRY(hipGetLastError());
     return EG_OK;

@@ -7,7 +7,9 @@ per 96 tensors; the step counts are device floats (one per parameter, as in torc
 (``engine.GraphedTrainStep`` asks for ``capturable``: this optimizer always is).  State layout as torch's (``state[p]`` = ``step``,
 ``exp_avg``, ``exp_avg_sq``), so ``state_dict()`` / ``load_state_dict()`` round-trip and a ``torch.optim.Adam`` state loads.
 
-CUDA float32 parameters with dense gradients only; anything else raises (there is no CPU path)."""
+``lr`` may be a CUDA float32 scalar tensor (torch's convention for captured steps: the kernel reads it, so a scheduler's ``fill_`` reaches the
+replays); a float lr is frozen into a captured launch.  CUDA float32 parameters with dense gradients only; anything else raises (there
+is no CPU path)."""
 from __future__ import annotations
 
 import ctypes as ct
@@ -28,7 +30,7 @@ class _AdamTensor(ct.Structure):
 class Adam(torch.optim.Optimizer):
     def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  maximize: bool = False):
-        if not 0.0 <= lr:
+        if not torch.is_tensor(lr) and not 0.0 <= lr:
             raise ValueError(f"Invalid learning rate: {lr}")
         if not 0.0 <= eps:
             raise ValueError(f"Invalid epsilon value: {eps}")
@@ -71,7 +73,13 @@ class Adam(torch.optim.Optimizer):
                     st = self.state[p]
                     g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                     table[k] = _AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
-                _lib.check(lib.eg_adam_step(table, len(part), ct.c_void_p(counts.data_ptr()), float(group["lr"]), float(b1), float(b2),
+                lr = group["lr"]
+                lr_dev = None
+                if torch.is_tensor(lr):                 # (torch's convention for a captured step: schedulers fill_() a tensor lr)
+                    if not lr.is_cuda or lr.dtype != torch.float32 or lr.numel() != 1:
+                        raise RuntimeError("echoglad_amd.optim.Adam: a tensor lr must be a CUDA float32 scalar")
+                    lr_dev, lr = ct.c_void_p(lr.data_ptr()), 0.0
+                _lib.check(lib.eg_adam_step(table, len(part), ct.c_void_p(counts.data_ptr()), float(lr), lr_dev, float(b1), float(b2),
                                             float(group["eps"]), float(group["weight_decay"]), int(bool(group["maximize"])), stream),
                            "eg_adam_step")
                 # the kernel wrote the parameters behind autograd's back: tell it (in-place version counters: what saved-tensor checks

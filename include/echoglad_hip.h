@@ -84,8 +84,8 @@ extern "C" {
  * 132: eg_classifier_bwd_sums, eg_gcn_layer_bwd_presummed.  133: eg_graph_layer_launches, eg_debug_layer_timing_*, eg_elm_reduce, eg_coord_mlp_*_rows, eg_bilinear4_*_rows (round 5).
  * 134: eg_dropout_epoch_add / _set, eg_debug_dropout_epoch (round 5: a whole train step as one HIP graph).
  * 135: eg_gcn_layer_bwd_lower, eg_bilinear4_bwd_rows_sums, eg_avg_pool_pyramid_fwd / _bwd, eg_criteria_* (round 6).
- * 136: eg_classifier_train_fwd_act(h_sparse), eg_classifier_bwd_sums(layer_residual, recompute_h).  137, 138: eg_coord_update_fwd / _bwd.  139: eg_adam_step. */
-#define EG_ABI_VERSION 139
+ * 136: eg_classifier_train_fwd_act(h_sparse), eg_classifier_bwd_sums(layer_residual, recompute_h).  137, 138: eg_coord_update_fwd / _bwd.  139, 140: eg_adam_step. */
+#define EG_ABI_VERSION 140
 
 #define EG_CHANNELS 128 /* node_embedding_dim == node_hidden_dim (configs/default.yml:13-14) */
 
@@ -505,7 +505,9 @@ int eg_coord_update_bwd(float* dx, int64_t n_per_frame, int64_t coord_base, int6
  *   g = grad (maximize: -grad) + weight_decay * p;  m += (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g g
  *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = steps[k] + 1;   then steps[k] = t
  * tensors: HOST array of `count` entries (device pointers; they travel in the kernel arguments, so a captured launch keeps them);
- * steps: [count] device floats, the number of updates of each tensor so far.  EG_ERR_UNSUPPORTED (nothing launched) for count > 96. */
+ * steps: [count] device floats, the number of updates of each tensor so far.  lr_device (nullable): the learning rate as a device float,
+ * read by the kernel instead of `lr` -- what a scheduler changes between the replays of a captured step.  EG_ERR_UNSUPPORTED (nothing
+ * launched) for count > 96. */
 typedef struct eg_adam_tensor {
     float* param;
     const float* grad;
@@ -513,7 +515,7 @@ typedef struct eg_adam_tensor {
     float* exp_avg_sq;
     int64_t numel;
 } eg_adam_tensor;
-int eg_adam_step(const eg_adam_tensor* tensors, int count, float* steps, float lr, float beta1, float beta2, float eps, float weight_decay,
+int eg_adam_step(const eg_adam_tensor* tensors, int count, float* steps, float lr, const float* lr_device, float beta1, float beta2, float eps, float weight_decay,
                  int maximize, eg_stream_t stream);
 
 /* ---- losses on the logits and landmark decode (the steps right after the hot path) ---------------------

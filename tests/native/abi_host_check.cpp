@@ -77,11 +77,11 @@ int main() {
         EXPECT(eg_coord_update_bwd(dummy, 100, 96, 0, dummy, dummy, nullptr, dummy, dummy, 1, &cp, 8, dummy, dummy, dummy, dummy, dummy, dummy, &ls, nullptr,
                                    dummy, dummy, nullptr) == EG_ERR_ARG, "eg_coord_update_bwd(incomplete eg_lower_sums)");
         eg_adam_tensor at{dummy, dummy, dummy, nullptr, 16};
-        EXPECT(eg_adam_step(&at, 1, dummy, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_ARG, "eg_adam_step(exp_avg_sq = NULL)");
+        EXPECT(eg_adam_step(&at, 1, dummy, 1e-3f, nullptr, 0.9f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_ARG, "eg_adam_step(exp_avg_sq = NULL)");
         at.exp_avg_sq = dummy;
-        EXPECT(eg_adam_step(&at, 1, dummy, 1e-3f, 1.0f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_ARG, "eg_adam_step(beta1 = 1)");
-        EXPECT(eg_adam_step(&at, 97, dummy, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_UNSUPPORTED, "eg_adam_step(97 tensors)");
-        EXPECT(eg_adam_step(&at, 1, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_ARG, "eg_adam_step(steps = NULL)");
+        EXPECT(eg_adam_step(&at, 1, dummy, 1e-3f, nullptr, 1.0f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_ARG, "eg_adam_step(beta1 = 1)");
+        EXPECT(eg_adam_step(&at, 97, dummy, 1e-3f, nullptr, 0.9f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_UNSUPPORTED, "eg_adam_step(97 tensors)");
+        EXPECT(eg_adam_step(&at, 1, nullptr, 1e-3f, nullptr, 0.9f, 0.999f, 1e-8f, 0.f, 0, nullptr) == EG_ERR_ARG, "eg_adam_step(steps = NULL)");
     }
     EXPECT(eg_workspace_bytes() > 0, "eg_workspace_bytes");
     EXPECT(std::strlen(eg_last_error()) > 0, "eg_last_error carries the last message");

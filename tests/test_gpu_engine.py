@@ -299,6 +299,25 @@ def test_graphed_train_step_with_the_one_launch_adam():
         ref_opt.step()
     assert float(opt.state[w]["step"]) == 6.0
     assert float((w - ref_w).abs().max()) <= 1e-5
+    # a scheduler under the captured step: lr as a device scalar, changed between replays (the reference's default schedule is
+    # ReduceLROnPlateau, which fill_()s a tensor lr)
+    w2 = torch.nn.Parameter(torch.ones(64, 64, device=DEV))
+    ref2 = torch.nn.Parameter(w2.detach().clone())
+    lr = torch.tensor(1e-2, device=DEV)
+    opt2 = Adam([w2], lr=lr, weight_decay=1e-4)
+    ref_opt2 = torch.optim.Adam([ref2], lr=1e-2, weight_decay=1e-4)
+    step2 = engine.GraphedTrainStep(lambda: ((x @ w2) ** 2).mean(), opt2, warmup=1)
+    for k in range(5):
+        if k == 2:
+            lr.fill_(1e-3)
+            ref_opt2.param_groups[0]["lr"] = 1e-3
+        step2()
+    for k in range(6):
+        ref_opt2.param_groups[0]["lr"] = 1e-2 if k < 3 else 1e-3      # (1 warm-up step + replays 0, 1 at 1e-2; replays 2 - 4 at 1e-3)
+        ref_opt2.zero_grad()
+        ((x @ ref2) ** 2).mean().backward()
+        ref_opt2.step()
+    assert float((w2 - ref2).abs().max()) <= 1e-5
 
 
 @pytest.mark.gpu
