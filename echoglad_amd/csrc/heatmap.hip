@@ -71,6 +71,47 @@ __device__ inline GtMax wave_gtmax(GtMax a) {                      // max, min h
     }
     return a;
 }
+// ... N of them at once: the shuffles of one step are issued back to back (each is an LDS round trip of ~120 cycles; reduced one after
+// the other, 26 reductions x 6 steps were 10 us of dependent latency in a workgroup that lives 19 us)
+template <int N>
+__device__ inline void wave_sum_n(double (&v)[N]) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        double o[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) o[k] = __shfl_xor(v[k], s);
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += o[k];
+    }
+}
+__device__ inline void wave_argmax4(float (&v)[4], int (&idx)[4]) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        float o[4]; int oi[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { o[c] = __shfl_xor(v[c], s); oi[c] = __shfl_xor(idx[c], s); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool take = o[c] > v[c] || (o[c] == v[c] && oi[c] < idx[c]);
+            v[c] = take ? o[c] : v[c]; idx[c] = take ? oi[c] : idx[c];
+        }
+    }
+}
+__device__ inline void wave_gtmax4(float (&g)[4], int (&gh)[4], int (&gw)[4]) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        float o[4]; int oh[4], ow[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { o[c] = __shfl_xor(g[c], s); oh[c] = __shfl_xor(gh[c], s); ow[c] = __shfl_xor(gw[c], s); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool gt = o[c] > g[c], eq = o[c] == g[c];
+            gh[c] = gt ? oh[c] : (eq ? min(gh[c], oh[c]) : gh[c]);
+            gw[c] = gt ? ow[c] : (eq ? min(gw[c], ow[c]) : gw[c]);
+            g[c] = gt ? o[c] : g[c];
+        }
+    }
+}
 
 __device__ inline float bce_logits(float x, float y) { return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))); }
 
@@ -143,11 +184,11 @@ __global__ __launch_bounds__(HM_THREADS) void k_hm_partial(const float* __restri
             }
         }
     }
+    wave_argmax4(m, bi);
+    if (y) wave_gtmax4(g, gh, gw);
+    if (valid) wave_sum_n<4>(vs);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        { const ArgMax r = wave_argmax(ArgMax{m[c], bi[c]}); m[c] = r.v; bi[c] = r.i; }
-        if (y) { const GtMax r = wave_gtmax(GtMax{g[c], gh[c], gw[c]}); g[c] = r.g; gh[c] = r.h; gw[c] = r.w; }
-        if (valid) vs[c] = wave_sum(vs[c]);
         if (lane == 0) { s_m[wv][c] = m[c]; s_bi[wv][c] = bi[c]; s_g[wv][c] = g[c]; s_gh[wv][c] = gh[c]; s_gw[wv][c] = gw[c]; s_vs[wv][c] = vs[c]; }
     }
     __syncthreads();
@@ -180,15 +221,17 @@ __global__ __launch_bounds__(HM_THREADS) void k_hm_partial(const float* __restri
             s[c] += e; sh[c] += e * h; sw[c] += e * w;
         }
     }
+    {
+        double all[14] = {s[0], s[1], s[2], s[3], sh[0], sh[1], sh[2], sh[3], sw[0], sw[1], sw[2], sw[3], bce_a, bce_v};
+        wave_sum_n<14>(all);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        s[c] = wave_sum(s[c]); sh[c] = wave_sum(sh[c]); sw[c] = wave_sum(sw[c]);
+        for (int c = 0; c < 4; ++c) { s[c] = all[c]; sh[c] = all[4 + c]; sw[c] = all[8 + c]; }
+        bce_a = all[12]; bce_v = all[13];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
         if (lane == 0) { s_s[wv][c][0] = s[c]; s_s[wv][c][1] = sh[c]; s_s[wv][c][2] = sw[c]; }
-    }
-    if (BCE) {
-        bce_a = wave_sum(bce_a); bce_v = wave_sum(bce_v);
-        if (lane == 0) { s_b[wv][0] = bce_a; s_b[wv][1] = bce_v; }
-    }
+    if (BCE && lane == 0) { s_b[wv][0] = bce_a; s_b[wv][1] = bce_v; }
     __syncthreads();
     if (BCE && tid == 64) {
         double A = 0, V = 0;
