@@ -186,37 +186,6 @@ __device__ inline void column_stats(const float* __restrict__ z, int rows, float
     __syncthreads();
 }
 
-// BatchNorm1d bookkeeping of one layer: statistics -> (mean, invstd) saved in bn, affine (scale, shift) in LDS
-template <int W>
-__device__ inline void bn_setup(const float* __restrict__ z, int rows, int train, const float* gamma, const float* beta, float eps,
-                                float mom, float* rm, float* rv, float* bn_mean, float* bn_inv, float* s_red, float* s_mean,
-                                float* s_var, float* s_scale, float* s_shift) {
-    if (train) column_stats<W>(z, rows, s_red, s_mean, s_var);
-    if (threadIdx.x < W) {
-        const int c = threadIdx.x;
-        float mean, var;
-        if (train) {
-            mean = s_mean[c];
-            var = s_var[c];
-            if (rm && mom >= 0.f) {
-                const float unbiased = rows > 1 ? var * (float)rows / (float)(rows - 1) : var;
-                rm[c] = (1.0f - mom) * rm[c] + mom * mean;
-                rv[c] = (1.0f - mom) * rv[c] + mom * unbiased;
-            }
-        } else {
-            mean = rm[c];
-            var = rv[c];
-        }
-        const float inv = 1.0f / sqrtf(var + eps);
-        bn_mean[c] = mean;
-        bn_inv[c] = inv;
-        const float sc = gamma[c] * inv;
-        s_scale[c] = sc;
-        s_shift[c] = __builtin_fmaf(-mean, sc, beta[c]);
-    }
-    __syncthreads();
-}
-
 __device__ inline CoordMlpW resolved(const CoordMlpW& w) {
     CoordMlpW r = w;
     const unsigned long long e = epoch_now(w.epoch);
@@ -224,89 +193,6 @@ __device__ inline CoordMlpW resolved(const CoordMlpW& w) {
     r.seed2 = w.seed2 + e;
     return r;
 }
-
-__global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd a_) {
-    CoordMlpFwd a = a_;
-    a.w = resolved(a_.w);
-    __shared__ __attribute__((aligned(16))) float s_in[CM_TILE * CM_LDI];       // input tile, later the h1 tile
-    __shared__ float s_w1[CM_H1 * CM_LDW1], s_w2[CM_H2 * CM_LDW2], s_w3[CM_OUT * CM_H2];
-    __shared__ float s_red[CM_THREADS], s_mean[CM_H1], s_var[CM_H1], s_sc1[CM_H1], s_sh1[CM_H1], s_sc2[CM_H2], s_sh2[CM_H2];
-    const int t = threadIdx.x, R = a.rows;
-    const float* __restrict__ lm = a.lm;
-    const float* __restrict__ coords = a.coords;
-    load_weights(a.w, s_w1, s_w2, s_w3);
-    // ---- z1 = in W1^T + b1, 64 rows at a time: thread -> (row t >> 5 and +32, output channel t & 31)
-    for (int row0 = 0; row0 < R; row0 += CM_TILE) {
-        __syncthreads();
-        stage_inputs(lm, a.lm_stride, coords, row0, R, s_in, a.lm_copy);
-        __syncthreads();
-        const int o = t & 31;
-        const float b = a.w.b1[o];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int r = (t >> 5) + 32 * half;
-            float acc = b;
-#pragma unroll 8
-            for (int i = 0; i < CM_IN; ++i) acc = __builtin_fmaf(s_w1[o * CM_LDW1 + i], s_in[r * CM_LDI + i], acc);
-            if (row0 + r < R) a.z1[(row0 + r) * CM_H1 + o] = acc;
-        }
-    }
-    __syncthreads();
-    bn_setup<CM_H1>(a.z1, R, a.train, a.w.gamma1, a.w.beta1, a.eps1, a.mom1, a.rm1, a.rv1, a.bn, a.bn + CM_H1, s_red, s_mean, s_var,
-                    s_sc1, s_sh1);
-    // ---- z2 = h1 W2^T + b2: h1 tile [64][33] in LDS, thread -> (row t >> 4, output channel t & 15)
-    float* s_h1 = s_in;
-    for (int row0 = 0; row0 < R; row0 += CM_TILE) {
-        __syncthreads();
-        for (int e = t; e < CM_TILE * CM_H1; e += CM_THREADS) {
-            const int r = e >> 5, i = e & 31, row = row0 + r;
-            float k, h = 0.f;
-            if (row < R)
-                h = hidden_act(a.z1[row * CM_H1 + i], s_sc1[i], s_sh1[i], a.w.seed1, (unsigned long long)row * CM_H1 + i, a.w.p1,
-                               a.w.ik1, &k);
-            s_h1[r * CM_LDH + i] = h;
-        }
-        __syncthreads();
-        const int r = t >> 4, o = t & 15;
-        float acc = a.w.b2[o];
-#pragma unroll
-        for (int i = 0; i < CM_H1; ++i) acc = __builtin_fmaf(s_w2[o * CM_LDW2 + i], s_h1[r * CM_LDH + i], acc);
-        if (row0 + r < R) a.z2[(row0 + r) * CM_H2 + o] = acc;
-    }
-    __syncthreads();
-    bn_setup<CM_H2>(a.z2, R, a.train, a.w.gamma2, a.w.beta2, a.eps2, a.mom2, a.rm2, a.rv2, a.bn + 2 * CM_H1, a.bn + 2 * CM_H1 + CM_H2,
-                    s_red, s_mean, s_var, s_sc2, s_sh2);
-    // ---- delta = h2 W3^T + b3; coords <- clamp(coords + delta)
-    for (int e = t; e < R * CM_OUT; e += CM_THREADS) {
-        const int r = e >> 1, d = e & 1;
-        float acc = a.w.b3[d];
-#pragma unroll
-        for (int i = 0; i < CM_H2; ++i) {
-            float k;
-            const float h = hidden_act(a.z2[r * CM_H2 + i], s_sc2[i], s_sh2[i], a.w.seed2, (unsigned long long)r * CM_H2 + i,
-                                       a.w.p2, a.w.ik2, &k);
-            acc = __builtin_fmaf(s_w3[d * CM_H2 + i], h, acc);
-        }
-        const float pre = coords[e] + acc;
-        if (a.pre) a.pre[e] = pre;
-        a.newc[e] = fminf(fmaxf(pre, 0.f), a.cmax);
-        if (a.newc2) a.newc2[e] = a.newc[e];
-    }
-}
-
-// ---- up to 64 rows (batch <= 16): the whole update in LDS -----------------------------------------------------------------
-// The general kernel above round-trips z1 / z2 through global memory between its phases and fetches its small parameters where it
-// needs them: ~15 dependent global round trips, 20 us for a kernel with 70 KB of work -- and at batch 1, where a whole training step
-// is ~1 ms, there are three of them forward and three backward.  With R <= 64 everything fits one tile: every global load is issued
-// at the top, z1 / z2 stay in LDS (and go out to global once, for the backward), and the resampling of the coordinate rows
-// (k_bilinear4_fwd, a launch of its own otherwise) runs at the end on the coordinates still in LDS.  Same arithmetic, same order of
-// additions as the general kernel.
-struct CoordSample {            // resampling behind the MLP (h == NULL: none)
-    const float* h;             // [batch * n_per_frame, 128]
-    float* out;                 // row 0 of frame 0's sample rows; frame stride row_stride floats
-    long long n_per_frame, main_base, row_stride;
-    int frame;
-};
 
 // small parameters in LDS: b1 g1 be1 m1 v1 (32 each) | b2 g2 be2 m2 v2 (16 each) | b3 (2)
 constexpr int SP_B1 = 0, SP_G1 = 32, SP_BE1 = 64, SP_M1 = 96, SP_V1 = 128, SP_B2 = 160, SP_G2 = 176, SP_BE2 = 192, SP_M2 = 208, SP_V2 = 224,
@@ -351,6 +237,104 @@ __device__ inline void bn_setup_lds(const float* s_z, int rows, int train, const
     }
     __syncthreads();
 }
+
+// Any number of rows, 64 at a time.  Up to CM_KEEP rows (batch 32 -- BASELINE configs[3]'s batch per GPU) z1 / z2 also stay in LDS for the
+// phases behind them (the statistics, the next product): reading them back from global memory between the phases was four dependent
+// round trips; beyond, they come back from global memory.  The small parameters sit in LDS from the top in either case.
+constexpr int CM_KEEP = 128;
+__global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_fwd(const CoordMlpFwd a_) {
+    CoordMlpFwd a = a_;
+    a.w = resolved(a_.w);
+    __shared__ __attribute__((aligned(16))) float s_in[CM_TILE * CM_LDI];       // input tile, later the h1 tile
+    __shared__ float s_w1[CM_H1 * CM_LDW1], s_w2[CM_H2 * CM_LDW2], s_w3[CM_OUT * CM_H2], s_par[SP_TOTAL];
+    __shared__ float s_z1k[CM_KEEP * CM_H1], s_z2k[CM_KEEP * CM_H2];
+    __shared__ float s_red[CM_THREADS], s_mean[CM_H1], s_var[CM_H1], s_sc1[CM_H1], s_sh1[CM_H1], s_sc2[CM_H2], s_sh2[CM_H2];
+    const int t = threadIdx.x, R = a.rows;
+    const bool keep = R <= CM_KEEP;
+    const float* z1src = keep ? s_z1k : a.z1;          // (generic pointers: LDS or global)
+    const float* z2src = keep ? s_z2k : a.z2;
+    const float* __restrict__ lm = a.lm;
+    const float* __restrict__ coords = a.coords;
+    load_weights(a.w, s_w1, s_w2, s_w3);
+    load_small_params(a.w, a.rm1, a.rv1, a.rm2, a.rv2, s_par);
+    // ---- z1 = in W1^T + b1, 64 rows at a time: thread -> (row t >> 5 and +32, output channel t & 31)
+    for (int row0 = 0; row0 < R; row0 += CM_TILE) {
+        __syncthreads();
+        stage_inputs(lm, a.lm_stride, coords, row0, R, s_in, a.lm_copy);
+        __syncthreads();
+        const int o = t & 31;
+        const float b = s_par[SP_B1 + o];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int r = (t >> 5) + 32 * half;
+            if (row0 + r >= R) continue;
+            float acc = b;
+#pragma unroll 8
+            for (int i = 0; i < CM_IN; ++i) acc = __builtin_fmaf(s_w1[o * CM_LDW1 + i], s_in[r * CM_LDI + i], acc);
+            a.z1[(row0 + r) * CM_H1 + o] = acc;
+            if (keep) s_z1k[(row0 + r) * CM_H1 + o] = acc;
+        }
+    }
+    __syncthreads();
+    bn_setup_lds<CM_H1>(z1src, R, a.train, s_par + SP_G1, s_par + SP_BE1, s_par + SP_M1, s_par + SP_V1, a.eps1, a.mom1, a.rm1, a.rv1, a.bn,
+                        a.bn + CM_H1, s_red, s_mean, s_var, s_sc1, s_sh1);
+    // ---- z2 = h1 W2^T + b2: h1 tile [64][33] in LDS, thread -> (row t >> 4, output channel t & 15)
+    float* s_h1 = s_in;
+    for (int row0 = 0; row0 < R; row0 += CM_TILE) {
+        __syncthreads();
+        for (int e = t; e < CM_TILE * CM_H1; e += CM_THREADS) {
+            const int r = e >> 5, i = e & 31, row = row0 + r;
+            float k, h = 0.f;
+            if (row < R)
+                h = hidden_act(z1src[row * CM_H1 + i], s_sc1[i], s_sh1[i], a.w.seed1, (unsigned long long)row * CM_H1 + i, a.w.p1,
+                               a.w.ik1, &k);
+            s_h1[r * CM_LDH + i] = h;
+        }
+        __syncthreads();
+        const int r = t >> 4, o = t & 15;
+        if (row0 + r < R) {
+            float acc = s_par[SP_B2 + o];
+#pragma unroll
+            for (int i = 0; i < CM_H1; ++i) acc = __builtin_fmaf(s_w2[o * CM_LDW2 + i], s_h1[r * CM_LDH + i], acc);
+            a.z2[(row0 + r) * CM_H2 + o] = acc;
+            if (keep) s_z2k[(row0 + r) * CM_H2 + o] = acc;
+        }
+    }
+    __syncthreads();
+    bn_setup_lds<CM_H2>(z2src, R, a.train, s_par + SP_G2, s_par + SP_BE2, s_par + SP_M2, s_par + SP_V2, a.eps2, a.mom2, a.rm2, a.rv2,
+                        a.bn + 2 * CM_H1, a.bn + 2 * CM_H1 + CM_H2, s_red, s_mean, s_var, s_sc2, s_sh2);
+    // ---- delta = h2 W3^T + b3; coords <- clamp(coords + delta)
+    for (int e = t; e < R * CM_OUT; e += CM_THREADS) {
+        const int r = e >> 1, d = e & 1;
+        float acc = s_par[SP_B3 + d];
+#pragma unroll
+        for (int i = 0; i < CM_H2; ++i) {
+            float k;
+            const float h = hidden_act(z2src[r * CM_H2 + i], s_sc2[i], s_sh2[i], a.w.seed2, (unsigned long long)r * CM_H2 + i,
+                                       a.w.p2, a.w.ik2, &k);
+            acc = __builtin_fmaf(s_w3[d * CM_H2 + i], h, acc);
+        }
+        const float pre = coords[e] + acc;
+        if (a.pre) a.pre[e] = pre;
+        const float nc = fminf(fmaxf(pre, 0.f), a.cmax);
+        a.newc[e] = nc;
+        if (a.newc2) a.newc2[e] = nc;
+    }
+}
+
+// ---- up to 64 rows (batch <= 16): the whole update in LDS -----------------------------------------------------------------
+// The general kernel above round-trips z1 / z2 through global memory between its phases and fetches its small parameters where it
+// needs them: ~15 dependent global round trips, 20 us for a kernel with 70 KB of work -- and at batch 1, where a whole training step
+// is ~1 ms, there are three of them forward and three backward.  With R <= 64 everything fits one tile: every global load is issued
+// at the top, z1 / z2 stay in LDS (and go out to global once, for the backward), and the resampling of the coordinate rows
+// (k_bilinear4_fwd, a launch of its own otherwise) runs at the end on the coordinates still in LDS.  Same arithmetic, same order of
+// additions as the general kernel.
+struct CoordSample {            // resampling behind the MLP (h == NULL: none)
+    const float* h;             // [batch * n_per_frame, 128]
+    float* out;                 // row 0 of frame 0's sample rows; frame stride row_stride floats
+    long long n_per_frame, main_base, row_stride;
+    int frame;
+};
 
 __global__ __launch_bounds__(CM_THREADS) void k_coord_update_fwd_small(const CoordMlpFwd a_, const CoordSample sp) {
     CoordMlpFwd a = a_;
@@ -460,14 +444,15 @@ __global__ __launch_bounds__(CM_THREADS) void k_coord_mlp_bwd(const CoordMlpBwd 
     __shared__ float s_red[4][CM_THREADS], s_part[CM_WAVES];
     __shared__ float s_gm[CM_H1], s_gxm[CM_H1], s_sc1[CM_H1], s_sh1[CM_H1], s_sc2[CM_H2], s_sh2[CM_H2];
     __shared__ float s_bn[2 * CM_H1 + 2 * CM_H2], s_g1[CM_H1], s_g2[CM_H2];    // mean1 | invstd1 | mean2 | invstd2, gamma1, gamma2
-    __shared__ float s_z1l[SMALL ? CM_TILE * CM_H1 : 1], s_z2l[SMALL ? CM_TILE * CM_H2 : 1], s_scr[SMALL ? CM_TILE * CM_SCR : 1];
+    __shared__ float s_z1l[SMALL ? CM_TILE * CM_H1 : 1], s_z2l[SMALL ? CM_TILE * CM_H2 : 1], s_scr[SMALL ? CM_TILE * CM_SCR : CM_KEEP * CM_SCR];
     __shared__ float s_hkx[SMALL ? 3 * CM_TILE * CM_LDH : 1], s_dd[SMALL ? CM_TILE * 2 : 1];
     const int t = threadIdx.x, R = a.rows;
     const float* __restrict__ lm = a.lm;
     const float* __restrict__ coords = a.coords;
     const float* __restrict__ z1 = SMALL ? s_z1l : a.z1;
     const float* __restrict__ z2 = SMALL ? s_z2l : a.z2;
-    float* const scratch = SMALL ? s_scr : a.scratch;
+    // (the general form: up to CM_KEEP rows -- batch 32 -- the scratch lives in LDS as well; a generic pointer then)
+    float* const scratch = (SMALL || R <= CM_KEEP) ? s_scr : a.scratch;
     const float* mean1 = s_bn;
     const float* inv1 = s_bn + CM_H1;
     const float* mean2 = s_bn + 2 * CM_H1;
