@@ -50,35 +50,28 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         stream = ct.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
-            for p in ps:
-                if not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse or p.grad.dtype != torch.float32:
-                    raise RuntimeError("echoglad_amd.optim.Adam: CUDA float32 parameters with dense float32 gradients only")
-            for p in ps:
-                st = self.state[p]
-                if "exp_avg" not in st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                if not p.is_contiguous():
-                    raise RuntimeError("echoglad_amd.optim.Adam: parameters must be contiguous")
+            # the prepared launches of this group (pointer tables, step-count arrays) are kept while nothing moved: the same parameters with
+            # the same addresses and gradients at the same addresses (the caching allocator hands a step's gradients the same blocks
+            # again) -- checks and 82 ctypes structs per step were 0.2 ms of a batch-1 step the host is the bound of
+            key = (tuple(map(id, ps)), tuple(p.data_ptr() for p in ps), tuple(p.grad.data_ptr() for p in ps))
+            cache = self.__dict__.setdefault("_prepared", {}).setdefault(gi, {})
+            hit = cache.get(key)
+            if hit is None:                             # (the allocator cycles through a few sets of blocks for a step's gradients)
+                if len(cache) >= 4:
+                    cache.clear()
+                hit = cache[key] = (key, self._prepare(ps))
             b1, b2 = group["betas"]
-            for lo in range(0, len(ps), _MAX_TENSORS):
-                part = ps[lo:lo + _MAX_TENSORS]
-                counts = self._counts_of(part)
-                table = (_AdamTensor * len(part))()
-                for k, p in enumerate(part):
-                    st = self.state[p]
-                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                    table[k] = _AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
-                lr = group["lr"]
-                lr_dev = None
-                if torch.is_tensor(lr):                 # (torch's convention for a captured step: schedulers fill_() a tensor lr)
-                    if not lr.is_cuda or lr.dtype != torch.float32 or lr.numel() != 1:
-                        raise RuntimeError("echoglad_amd.optim.Adam: a tensor lr must be a CUDA float32 scalar")
-                    lr_dev, lr = ct.c_void_p(lr.data_ptr()), 0.0
+            lr = group["lr"]
+            lr_dev = None
+            if torch.is_tensor(lr):                     # (torch's convention for a captured step: schedulers fill_() a tensor lr)
+                if not lr.is_cuda or lr.dtype != torch.float32 or lr.numel() != 1:
+                    raise RuntimeError("echoglad_amd.optim.Adam: a tensor lr must be a CUDA float32 scalar")
+                lr_dev, lr = ct.c_void_p(lr.data_ptr()), 0.0
+            for part, table, counts, _keep in hit[1]:
                 _lib.check(lib.eg_adam_step(table, len(part), ct.c_void_p(counts.data_ptr()), float(lr), lr_dev, float(b1), float(b2),
                                             float(group["eps"]), float(group["weight_decay"]), int(bool(group["maximize"])), stream),
                            "eg_adam_step")
@@ -86,6 +79,37 @@ class Adam(torch.optim.Optimizer):
                 # and the model's caches of folded inference parameters are keyed on)
                 torch.autograd.graph.increment_version(part)
         return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__.pop("_prepared", None)            # (the moments and counts are new tensors)
+        self.__dict__.pop("_count_arrays", None)
+
+    def _prepare(self, ps):
+        """[(parameters, eg_adam_tensor table, step counts, tensors kept alive)] -- one entry per launch of up to 96 parameters."""
+        for p in ps:
+            if not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse or p.grad.dtype != torch.float32:
+                raise RuntimeError("echoglad_amd.optim.Adam: CUDA float32 parameters with dense float32 gradients only")
+            if not p.is_contiguous():
+                raise RuntimeError("echoglad_amd.optim.Adam: parameters must be contiguous")
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()            # (its address is not the key's: prepared again next step -- correct, just not cached)
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        out = []
+        for lo in range(0, len(ps), _MAX_TENSORS):
+            part = ps[lo:lo + _MAX_TENSORS]
+            counts = self._counts_of(part)
+            table = (_AdamTensor * len(part))()
+            keep = []
+            for k, p in enumerate(part):
+                st = self.state[p]
+                table[k] = _AdamTensor(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                keep += [st["exp_avg"], st["exp_avg_sq"]]
+            out.append((part, table, counts, keep))
+        return out
 
     def _counts_of(self, part):
         """The step counts of the parameters of one launch as ONE device array (the kernel takes steps[k]); ``state[p]["step"]`` are 0-d
