@@ -48,12 +48,16 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        lib = _lib.load()
-        stream = ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lib, stream = None, None
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
+            if not ps[0].is_cuda:
+                raise RuntimeError("echoglad_amd.optim.Adam: CUDA float32 parameters with dense float32 gradients only")
+            if lib is None:
+                lib = _lib.load()
+                stream = ct.c_void_p(torch.cuda.current_stream().cuda_stream)
             # the prepared launches of this group (pointer tables, step-count arrays) are kept while nothing moved: the same parameters with
             # the same addresses and gradients at the same addresses (the caching allocator hands a step's gradients the same blocks
             # again) -- checks and 82 ctypes structs per step were 0.2 ms of a batch-1 step the host is the bound of
